@@ -190,3 +190,267 @@ def volumetric_caustic(width=1280, height=720, spp=1024, g=0.5) -> Scene:
                    "2.18557e-008 -0.5 1.98 0 -0.002 -8.74228e-011 -0.03 "
                    "0 0 0 1"), light, med, med)
     return b.s
+
+
+# ---------------------------------------------------------------------------
+# Synthetic geometry and "kitchen sink" scenes for unit / parity coverage
+# ---------------------------------------------------------------------------
+def uv_sphere_mesh(n_lat=12, n_lon=24, radius=1.0, center=(0, 0, 0),
+                   with_normals=True, with_uv=True):
+    """Latitude/longitude sphere as an indexed triangle mesh (y up)."""
+    pos, nor, uv, idx = [], [], [], []
+    for i in range(n_lat + 1):
+        theta = np.pi * i / n_lat
+        for j in range(n_lon + 1):
+            phi = 2 * np.pi * j / n_lon
+            d = np.array([np.sin(theta) * np.cos(phi), np.cos(theta),
+                          np.sin(theta) * np.sin(phi)])
+            pos.append(np.asarray(center) + radius * d)
+            nor.append(d)
+            uv.append((j / n_lon, i / n_lat))
+    for i in range(n_lat):
+        for j in range(n_lon):
+            a = i * (n_lon + 1) + j
+            b = a + n_lon + 1
+            if i != 0:
+                idx.append((a, a + 1, b))
+            if i != n_lat - 1:
+                idx.append((a + 1, b + 1, b))
+    return dict(positions=np.array(pos, dtype=np.float32),
+                normals=np.array(nor, dtype=np.float32) if with_normals else None,
+                texcoords=np.array(uv, dtype=np.float32) if with_uv else None,
+                indices=np.array(idx, dtype=np.uint32))
+
+
+def bumpy_terrain_mesh(n=64, size=4.0, height=0.15, seed=7):
+    """Deterministic displaced grid (n x n quads) in the xz plane."""
+    rng = np.random.default_rng(seed)
+    xs = np.linspace(-size / 2, size / 2, n + 1)
+    zz, xx = np.meshgrid(xs, xs, indexing="ij")
+    yy = height * (np.sin(3.1 * xx) * np.cos(2.3 * zz) + 0.3 * rng.standard_normal(xx.shape))
+    pos = np.stack([xx, yy, zz], axis=-1).reshape(-1, 3).astype(np.float32)
+    idx = []
+    for i in range(n):
+        for j in range(n):
+            a = i * (n + 1) + j
+            idx.append((a, a + n + 1, a + 1))
+            idx.append((a + 1, a + n + 1, a + n + 2))
+    return dict(positions=pos, normals=None, texcoords=None,
+                indices=np.array(idx, dtype=np.uint32))
+
+
+def procedural_envmap(width=64, height=32, channel=3, seed=3):
+    """Smooth sky gradient + a bright blob; float32 [h, w, c] in [0, ~20]."""
+    rng = np.random.default_rng(seed)
+    v, u = np.meshgrid(np.linspace(0, 1, height), np.linspace(0, 1, width),
+                       indexing="ij")
+    base = np.stack([0.3 + 0.5 * (1 - v), 0.4 + 0.4 * (1 - v), 0.6 + 0.3 * (1 - v)], -1)
+    blob = 18.0 * np.exp(-((u - 0.3) ** 2 + (v - 0.25) ** 2) / 0.004)
+    img = base + blob[..., None] * np.array([1.0, 0.9, 0.7])
+    img += 0.02 * rng.random(img.shape)
+    if channel == 4:
+        img = np.concatenate([img, np.ones_like(img[..., :1])], -1)
+    return img.astype(np.float32)
+
+
+def look_at_camera(eye, target, up, fov_x, width, height, spp) -> Camera:
+    return Camera(spp=spp, width=width, height=height, fov_x=fov_x,
+                  eye=tuple(float(f32(x)) for x in eye),
+                  look_at=tuple(float(f32(x)) for x in target),
+                  up=tuple(float(f32(x)) for x in up))
+
+
+def translate_scale(t=(0, 0, 0), s=(1, 1, 1)) -> np.ndarray:
+    m = np.eye(4, dtype=np.float32)
+    m[0, 0], m[1, 1], m[2, 2] = s
+    m[:3, 3] = t
+    return m
+
+
+def rot_x(deg) -> np.ndarray:
+    a = np.deg2rad(deg)
+    m = np.eye(4, dtype=np.float32)
+    m[1, 1], m[1, 2], m[2, 1], m[2, 2] = np.cos(a), -np.sin(a), np.sin(a), np.cos(a)
+    return m
+
+
+MATERIALS = ("diffuse", "rough_diffuse_fast", "rough_diffuse_full",
+             "conductor", "rough_conductor", "rough_conductor_aniso",
+             "dielectric", "rough_dielectric", "thin_dielectric", "plastic",
+             "rough_plastic", "bumpy_diffuse", "masked_diffuse")
+LIGHTINGS = ("area", "point", "spot", "directional", "sun", "envmap",
+             "constant", "mixed")
+
+
+def material_preview(material="rough_conductor", lighting="envmap", shape="mesh",
+                     width=64, height=64, spp=8, integrator="path",
+                     depth_max=mcsd.INVALID, medium=False) -> Scene:
+    """A matpreview-like scene: checkerboard floor, one test object, one
+    lighting set-up.  Covers every BSDF / texture / emitter / primitive kind
+    of the hot path; used for oracle-vs-reference and GPU-vs-oracle parity."""
+    b = _Builder()
+    s = b.s
+    s.camera = look_at_camera((0.0, 1.6, 4.2), (0.0, 0.6, 0.0), (0, 1, 0), 38.0,
+                              width, height, spp)
+    s.integrator = Integrator(
+        type=mcsd.INTEGRATOR_VOLPATH if integrator == "volpath" else mcsd.INTEGRATOR_PATH,
+        depth_max=depth_max, depth_rr=5, pdf_rr=0.95)
+    med = mcsd.INVALID
+    if medium:
+        s.media.append(Medium(sigma_a=(0.02, 0.03, 0.05), sigma_s=(0.25, 0.2, 0.15),
+                              phase_type=mcsd.PHASE_HG, g=(0.3, 0.3, 0.3)))
+        med = 0
+
+    # floor: checkerboard diffuse
+    s.textures.append(Texture(type=mcsd.TEX_CHECKERBOARD, color0=(0.4, 0.4, 0.4),
+                              color1=(0.2, 0.2, 0.2),
+                              to_uv=translate_scale(s=(8, 8, 1))))
+    s.bsdfs.append(Bsdf(type=mcsd.BSDF_DIFFUSE, twosided=True,
+                        id_diffuse_reflectance=len(s.textures) - 1))
+    floor_bsdf = len(s.bsdfs) - 1
+    b.shape(mcsd.INST_RECTANGLE, (translate_scale(s=(5, 1, 5)) @ rot_x(-90)).astype(np.float32),
+            floor_bsdf, med, med)
+
+    def tex(v):
+        return b.const_tex((v,) * 3 if np.isscalar(v) else v)
+
+    m = material
+    if m == "diffuse":
+        bs = Bsdf(type=mcsd.BSDF_DIFFUSE, twosided=True,
+                  id_diffuse_reflectance=tex((0.7, 0.3, 0.2)))
+    elif m in ("rough_diffuse_fast", "rough_diffuse_full"):
+        bs = Bsdf(type=mcsd.BSDF_ROUGH_DIFFUSE, twosided=True,
+                  use_fast_approx=m.endswith("fast"),
+                  id_diffuse_reflectance=tex((0.6, 0.6, 0.3)), id_roughness=tex(0.4))
+    elif m in ("conductor", "rough_conductor", "rough_conductor_aniso"):
+        au, av = {"conductor": (0.001, 0.001), "rough_conductor": (0.1, 0.1),
+                  "rough_conductor_aniso": (0.05, 0.3)}[m]
+        tu = tex(au)
+        tv = tu if au == av else tex(av)
+        bs = Bsdf(type=mcsd.BSDF_CONDUCTOR, twosided=True, id_roughness_u=tu,
+                  id_roughness_v=tv, id_specular_reflectance=tex(1.0),
+                  reflectivity=(0.913, 0.922, 0.924), edgetint=(0.05, 0.06, 0.08))
+    elif m in ("dielectric", "rough_dielectric", "thin_dielectric"):
+        a = 0.1 if m == "rough_dielectric" else 0.001
+        tu = tex(a)
+        bs = Bsdf(type=mcsd.BSDF_THIN_DIELECTRIC if m == "thin_dielectric" else mcsd.BSDF_DIELECTRIC,
+                  twosided=True, id_roughness_u=tu, id_roughness_v=tu,
+                  id_specular_reflectance=tex(1.0), id_specular_transmittance=tex((0.9, 1.0, 0.95)),
+                  eta=float(f32(1.33) / f32(1.000277)))
+    elif m in ("plastic", "rough_plastic"):
+        bs = Bsdf(type=mcsd.BSDF_PLASTIC, twosided=True, eta=float(f32(1.5046) / f32(1.000277)),
+                  id_roughness=tex(0.1 if m == "rough_plastic" else 0.001),
+                  id_diffuse_reflectance=tex((0.2, 0.4, 0.7)), id_specular_reflectance=tex(1.0))
+    elif m == "bumpy_diffuse":
+        img = procedural_envmap(32, 32, 1 if False else 3, seed=11)
+        s.textures.append(Texture(type=mcsd.TEX_BITMAP, width=32, height=32, channel=3,
+                                  data=(img / img.max()).reshape(-1), to_uv=translate_scale(s=(3, 3, 1))))
+        bs = Bsdf(type=mcsd.BSDF_DIFFUSE, twosided=True, id_bump_map=len(s.textures) - 1,
+                  id_diffuse_reflectance=tex((0.6, 0.6, 0.6)))
+    elif m == "masked_diffuse":
+        img = procedural_envmap(16, 16, 4, seed=5)
+        img[..., 3] = (np.indices((16, 16)).sum(0) % 2) * 0.8 + 0.1
+        s.textures.append(Texture(type=mcsd.TEX_BITMAP, width=16, height=16, channel=4,
+                                  data=img.reshape(-1)))
+        bs = Bsdf(type=mcsd.BSDF_DIFFUSE, twosided=True, id_opacity=len(s.textures) - 1,
+                  id_diffuse_reflectance=tex((0.3, 0.7, 0.3)))
+    else:
+        raise ValueError(material)
+    s.bsdfs.append(bs)
+    obj_bsdf = len(s.bsdfs) - 1
+
+    obj_int = mcsd.INVALID
+    if shape == "mesh":
+        g = uv_sphere_mesh(10, 20, 0.6, (0, 0.6, 0))
+        b.shape(mcsd.INST_MESHES, mcsd.IDENTITY.copy(), obj_bsdf, obj_int, med,
+                positions=g["positions"], normals=g["normals"],
+                texcoords=g["texcoords"], indices=g["indices"])
+    elif shape == "flat_mesh":   # no normals / no uv -> synthesised
+        g = uv_sphere_mesh(8, 16, 0.6, (0, 0.6, 0), with_normals=False, with_uv=False)
+        b.shape(mcsd.INST_MESHES, mcsd.IDENTITY.copy(), obj_bsdf, obj_int, med,
+                positions=g["positions"], indices=g["indices"])
+    elif shape == "sphere":
+        b.shape(mcsd.INST_SPHERE, translate_scale(t=(0, 0.6, 0)), obj_bsdf, obj_int, med,
+                sphere_radius=0.6, sphere_center=(0.0, 0.0, 0.0))
+    elif shape == "cube":
+        b.shape(mcsd.INST_CUBE, translate_scale(t=(0, 0.5, 0), s=(0.5, 0.5, 0.5)), obj_bsdf, obj_int, med)
+    elif shape == "disk":
+        b.shape(mcsd.INST_DISK, (translate_scale(t=(0, 0.7, 0), s=(1.6, 1.6, 1.6)) @ rot_x(-60)).astype(np.float32),
+                obj_bsdf, obj_int, med)
+    elif shape == "cylinder":
+        b.shape(mcsd.INST_CYLINDER, mcsd.IDENTITY.copy(), obj_bsdf, obj_int, med,
+                cyl_radius=0.4, cyl_p0=(0.0, 0.05, 0.0), cyl_p1=(0.3, 1.2, 0.1))
+    else:
+        raise ValueError(shape)
+
+    lights = {"mixed": ("area", "point", "directional", "constant")}.get(lighting, (lighting,))
+    for l in lights:
+        if l == "area":
+            light = b.area_light((12, 11, 9))
+            b.shape(mcsd.INST_RECTANGLE,
+                    (translate_scale(t=(0.8, 2.6, 0.6), s=(0.5, 0.5, 0.5)) @ rot_x(90)).astype(np.float32),
+                    light, med, med)
+        elif l == "point":
+            s.emitters.append(Emitter(type=mcsd.EMIT_POINT, position=(-1.5, 2.5, 1.5),
+                                      intensity=(30, 30, 30)))
+        elif l == "spot":
+            tw = np.linalg.inv(_look_at_lh((1.5, 3.0, 1.5), (0, 0.5, 0), (0, 1, 0))).astype(np.float32)
+            s.emitters.append(Emitter(type=mcsd.EMIT_SPOT, intensity=(60, 55, 50), to_world=tw,
+                                      cutoff_angle=float(np.deg2rad(25)), beam_width=float(np.deg2rad(18))))
+        elif l == "directional":
+            d = np.array([0.3, -0.8, -0.5])
+            d = d / np.linalg.norm(d)
+            s.emitters.append(Emitter(type=mcsd.EMIT_DIRECTIONAL, direction=tuple(float(f32(x)) for x in d),
+                                      radiance=(3, 3, 2.8)))
+        elif l == "sun":
+            img = procedural_envmap(32, 16, 3, seed=9)
+            s.textures.append(Texture(type=mcsd.TEX_BITMAP, width=32, height=16, channel=3,
+                                      data=img.reshape(-1)))
+            d = np.array([-0.4, -0.7, -0.6])
+            d = d / np.linalg.norm(d)
+            s.emitters.append(Emitter(type=mcsd.EMIT_SUN, cos_cutoff_angle=float(np.cos(np.deg2rad(2.0))),
+                                      id_texture=len(s.textures) - 1,
+                                      direction=tuple(float(f32(x)) for x in d), radiance=(40, 38, 33)))
+        elif l == "envmap":
+            img = procedural_envmap(64, 32, 4, seed=3)
+            s.textures.append(Texture(type=mcsd.TEX_BITMAP, width=64, height=32, channel=4,
+                                      data=img.reshape(-1)))
+            s.emitters.append(Emitter(type=mcsd.EMIT_ENVMAP, id_radiance=len(s.textures) - 1,
+                                      to_world=rot_x(10)))
+        elif l == "constant":
+            s.emitters.append(Emitter(type=mcsd.EMIT_CONSTANT, radiance=(0.5, 0.6, 0.8)))
+        else:
+            raise ValueError(lighting)
+    return s
+
+
+def _look_at_lh(eye, target, up):
+    eye, target, up = (np.asarray(v, dtype=np.float64) for v in (eye, target, up))
+    front = (target - eye) / np.linalg.norm(target - eye)
+    right = np.cross(up, front)
+    right /= np.linalg.norm(right)
+    up = np.cross(front, right)
+    m = np.eye(4)
+    m[0, :3], m[1, :3], m[2, :3] = right, up, front
+    m[0, 3], m[1, 3], m[2, 3] = -right @ eye, -up @ eye, -front @ eye
+    return m
+
+
+def terrain_scene(n=96, width=96, height=64, spp=4) -> Scene:
+    """A mid-size mesh (2*n*n triangles) under a directional light: the
+    divergent-traversal stand-in for the dragon configuration."""
+    b = _Builder()
+    s = b.s
+    s.camera = look_at_camera((0.0, 2.2, 4.5), (0.0, 0.0, 0.0), (0, 1, 0), 40.0, width, height, spp)
+    s.integrator = Integrator(type=mcsd.INTEGRATOR_PATH, depth_max=17, depth_rr=5, pdf_rr=0.95)
+    g = bumpy_terrain_mesh(n)
+    bs = b.diffuse("ground", (0.6, 0.55, 0.5))
+    b.shape(mcsd.INST_MESHES, mcsd.IDENTITY.copy(), bs, positions=g["positions"], indices=g["indices"])
+    ball = b.diffuse("ball", (0.3, 0.5, 0.7))
+    sp = uv_sphere_mesh(24, 48, 0.5, (0.2, 0.8, 0.3))
+    b.shape(mcsd.INST_MESHES, mcsd.IDENTITY.copy(), ball, positions=sp["positions"],
+            normals=sp["normals"], texcoords=sp["texcoords"], indices=sp["indices"])
+    d = np.array([0.1886, -0.6923, -0.6965])
+    s.emitters.append(Emitter(type=mcsd.EMIT_DIRECTIONAL, direction=tuple(float(f32(x)) for x in d),
+                              radiance=(10, 10, 10)))
+    return s

@@ -14,12 +14,24 @@
 // `Renderer::Draw(float*)`.
 //
 // Nothing in this file restates reference code; it only calls it.
+#include <algorithm>
+#include <array>
 #include <chrono>
+#include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <exception>
+#include <limits>
+#include <sstream>
 #include <string>
 #include <vector>
 
+// The per-sample hook below needs the committed Camera / Integrator objects,
+// which csrt::Renderer keeps private; open them up for this test driver only.
+#define private public
+#include "csrt/renderer/renderer.hpp"
+#undef private
 #include "csrt/renderer/bsdfs/kulla_conty.hpp"
 #include "csrt/renderer/bsdfs/microfacet.hpp"
 #include "csrt/renderer/renderer.hpp"
@@ -284,6 +296,113 @@ int mcpt_ref_render(const char *mcsd_path, float *frame, double *render_seconds)
         g_error = e.what();
         return 1;
     }
+}
+
+// Per-sample trace of one pixel: runs the body of DrawPixel
+// (renderer.cpp:62-85) for pixel (i, j) and records, for every sample s, the
+// unclamped radiance returned by Integrator::Shade and the LCG state after it.
+int mcpt_ref_trace_pixel(const char *mcsd_path, uint32_t i, uint32_t j,
+                         float *radiance, uint32_t *seed_after)
+{
+    try
+    {
+        const mcsd::Scene scene = mcsd::Load(mcsd_path);
+        const csrt::RendererConfig cfg = ToConfig(scene);
+        csrt::Renderer renderer(cfg);
+        csrt::Camera *camera = renderer.camera_;
+        csrt::Integrator *integrator = renderer.integrator_;
+        const uint32_t pixel_offset = (j * camera->width() + i) * 3;
+        uint32_t seed = csrt::Tea<4>(pixel_offset, 0);
+        for (uint32_t s = 0; s < camera->spp(); ++s)
+        {
+            const float u = s * camera->spp_inv(),
+                        v = csrt::GetVanDerCorputSequence<2>(s + 1),
+                        x = 2.0f * (i + u) / camera->width() - 1.0f,
+                        y = 1.0f - 2.0f * (j + v) / camera->height();
+            const csrt::Vec3 look_dir = csrt::Normalize(
+                camera->front() + x * camera->view_dx() + y * camera->view_dy());
+            const csrt::Vec3 c = integrator->Shade(camera->eye(), look_dir, &seed);
+            radiance[3 * s + 0] = c.x, radiance[3 * s + 1] = c.y, radiance[3 * s + 2] = c.z;
+            seed_after[s] = seed;
+        }
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+// ---- unit hooks on a committed scene --------------------------------------
+// A "session" keeps one csrt::Renderer alive so that many unit calls can be
+// made against its committed tables.
+struct RefSession
+{
+    csrt::Renderer *renderer = nullptr;
+};
+
+void *mcpt_ref_open(const char *mcsd_path)
+{
+    try
+    {
+        const mcsd::Scene scene = mcsd::Load(mcsd_path);
+        RefSession *s = new RefSession;
+        s->renderer = new csrt::Renderer(ToConfig(scene));
+        return s;
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return nullptr;
+    }
+}
+
+void mcpt_ref_close(void *session)
+{
+    RefSession *s = static_cast<RefSession *>(session);
+    delete s->renderer;
+    delete s;
+}
+
+// BSDF unit call.  rec_in: wo[3], wi[3], normal[3], tangent[3], bitangent[3],
+// uv[2], inside (17 floats).  out: valid, pdf, attenuation[3], wi[3] (8
+// floats).  mode 0 = Evaluate (bsdf.cpp:213-236), 1 = Sample (bsdf.cpp:188-211).
+void mcpt_ref_bsdf(void *session, uint32_t id_bsdf, int mode, const float *rec_in,
+                   uint32_t *seed, float *out)
+{
+    csrt::Renderer *r = static_cast<RefSession *>(session)->renderer;
+    csrt::BsdfSampleRec rec;
+    rec.wo = V3(rec_in), rec.wi = V3(rec_in + 3), rec.normal = V3(rec_in + 6);
+    rec.tangent = V3(rec_in + 9), rec.bitangent = V3(rec_in + 12);
+    rec.texcoord = csrt::Vec2{rec_in[15], rec_in[16]};
+    rec.inside = rec_in[17] != 0.0f;
+    if (mode == 0)
+        r->bsdfs_[id_bsdf].Evaluate(&rec);
+    else
+        r->bsdfs_[id_bsdf].Sample(seed, &rec);
+    out[0] = rec.valid ? 1.0f : 0.0f, out[1] = rec.pdf;
+    out[2] = rec.attenuation.x, out[3] = rec.attenuation.y, out[4] = rec.attenuation.z;
+    out[5] = rec.wi.x, out[6] = rec.wi.y, out[7] = rec.wi.z;
+}
+
+// Closest-hit unit call (tlas.cpp:13-42).  out: valid, inside, id_instance,
+// id_primitive (as floats), t, uv[2], position[3], normal[3], tangent[3],
+// bitangent[3] (19 floats).
+void mcpt_ref_intersect(void *session, const float *origin, const float *dir,
+                        uint32_t *seed, float *out)
+{
+    csrt::Renderer *r = static_cast<RefSession *>(session)->renderer;
+    csrt::Ray ray(V3(origin), V3(dir));
+    csrt::Integrator *integ = r->integrator_;
+    const csrt::Hit hit = integ->data_.tlas->Intersect(
+        integ->data_.bsdfs, integ->data_.map_instance_bsdf, seed, &ray);
+    out[0] = hit.valid, out[1] = hit.inside, out[2] = static_cast<float>(hit.id_instance == csrt::kInvalidId ? -1.0 : hit.id_instance);
+    out[3] = static_cast<float>(hit.id_primitve == csrt::kInvalidId ? -1.0 : hit.id_primitve);
+    out[4] = ray.t_max, out[5] = hit.texcoord.u, out[6] = hit.texcoord.v;
+    const csrt::Vec3 v[4] = {hit.position, hit.normal, hit.tangent, hit.bitangent};
+    for (int k = 0; k < 4; ++k)
+        out[7 + 3 * k] = v[k].x, out[8 + 3 * k] = v[k].y, out[9 + 3 * k] = v[k].z;
 }
 
 // ---- known-answer hooks: thin calls into reference functions -------------

@@ -1,0 +1,48 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    from _pkg import load_package
+    return load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import checkers
+    checkers.build(ref=False)
+    return checkers.Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference():
+    """The compiled reference (oracle/_ref).  Built on demand where the
+    reference sources exist; tests that need it are skipped elsewhere."""
+    import checkers
+    if not checkers.reference_available():
+        if os.path.isdir(os.path.join(checkers.REFERENCE_DIR, "src")):
+            checkers.build(ref=True)
+    if not checkers.reference_available():
+        pytest.skip("compiled reference (oracle/_ref) not available here")
+    return checkers.Reference()
+
+
+@pytest.fixture()
+def mcsd_file(tmp_path, pkg):
+    def write(scene, name="scene.mcsd"):
+        path = tmp_path / name
+        pkg.mcsd.dump(scene, path)
+        return str(path)
+    return write

@@ -1,0 +1,92 @@
+"""Regenerates tests/golden/*.npz and tests/golden/kat.json by running the
+COMPILED REFERENCE (oracle/_ref, built from /root/reference by oracle/Makefile).
+
+Runs only in the authoring container (needs /root/reference).  The committed
+outputs are data: frames, per-sample traces and known-answer values the real
+reference produced for the scenes in tests/golden_cases.py.
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+
+import checkers  # noqa: E402
+from _pkg import load_package  # noqa: E402
+from golden_cases import TRACE_PIXELS, cases  # noqa: E402
+
+
+def main():
+    checkers.build(ref=True)
+    ref = checkers.Reference()
+    pkg = load_package()
+    manifest = {}
+    scenes = cases(pkg.scenes)
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = {}
+        for name, scene in scenes.items():
+            raw = pkg.mcsd.dumps(scene)
+            path = os.path.join(tmp, name + ".mcsd")
+            with open(path, "wb") as f:
+                f.write(raw)
+            paths[name] = path
+            frame, _ = ref.render(path, scene.camera.width, scene.camera.height)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), frame=frame)
+            manifest[name] = {
+                "mcsd_sha256": hashlib.sha256(raw).hexdigest(),
+                "frame_sha256": hashlib.sha256(frame.tobytes()).hexdigest(),
+                "mean": float(frame.mean()),
+                "shape": list(frame.shape),
+            }
+            print(name, manifest[name]["frame_sha256"][:16], manifest[name]["mean"])
+        traces = {}
+        for name, i, j in TRACE_PIXELS:
+            rad, state = ref.trace_pixel(paths[name], i, j, scenes[name].camera.spp)
+            traces[f"{name}:{i}:{j}:radiance"] = rad
+            traces[f"{name}:{i}:{j}:state"] = state
+        np.savez_compressed(os.path.join(HERE, "pixel_traces.npz"), **traces)
+
+    # scalar / table known answers straight from reference functions
+    kat = {}
+    kat["tea4"] = {f"{a},{b}": int(ref.lib.mcpt_ref_tea4(a, b))
+                   for a, b in [(0, 0), (3, 0), (786429, 0), (12345, 7)]}
+    vals, state = ref.lcg(3153161610, 8)
+    kat["lcg_from_3153161610"] = {"values": [float(np.float32(v)) for v in vals], "state": int(state)}
+    kat["vdc2"] = [float(np.float32(ref.lib.mcpt_ref_vdc2(i))) for i in range(0, 40)]
+    kat["vdc3"] = [float(np.float32(ref.lib.mcpt_ref_vdc3(i))) for i in range(0, 40)]
+    brdf, albedo = ref.kulla_conty()
+    np.savez_compressed(os.path.join(HERE, "kulla_conty_lut.npz"), brdf=brdf, albedo=albedo)
+    kat["kulla_conty"] = {"brdf_sum": float(brdf.astype(np.float64).sum()),
+                          "albedo_sum": float(albedo.astype(np.float64).sum()),
+                          "brdf_sha256": hashlib.sha256(brdf.tobytes()).hexdigest(),
+                          "albedo_sha256": hashlib.sha256(albedo.tobytes()).hexdigest()}
+    # LBVH builder on seeded random boxes
+    rng = np.random.default_rng(2024)
+    bvh = {}
+    for n in (1, 2, 3, 12, 100, 1000):
+        lo = rng.random((n, 3)).astype(np.float32) * 10
+        hi = lo + rng.random((n, 3)).astype(np.float32)
+        if n == 12:  # duplicate centres -> identical Morton codes
+            lo[6:] = lo[:6]
+            hi[6:] = hi[:6]
+        areas = rng.random(n).astype(np.float32)
+        out = ref.bvh_build(np.concatenate([lo, hi], 1), areas)
+        bvh[f"n{n}_in_boxes"] = np.concatenate([lo, hi], 1)
+        bvh[f"n{n}_in_areas"] = areas
+        for k, v in out.items():
+            bvh[f"n{n}_{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "lbvh.npz"), **bvh)
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump({"frames": manifest, "kat": kat}, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
