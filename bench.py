@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Benchmark of the render hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete render of the workload frame (all pixels, all spp)
+with the scene already resident in HBM.  At N=1 the workload is BASELINE.json
+configs[1]: cornell-box 512x512 spp=256 (diffuse + MIS area light).  For N>1
+(launched by torch.distributed.run, one rank per GPU) the frame's 8x8 tiles are
+dealt round-robin to the ranks, every rank renders its tiles into a packed
+device buffer and ONE RCCL gather brings them to rank 0, which scatters them
+into the frame — all inside the timed region.  Total work is fixed as N grows
+("strong" scaling).
+
+Rank 0 prints one JSON line: metric Msamples/s (W*H*spp / t / 1e6, whole job),
+plus `roofline` (algorithmic bytes of the dominant kernel / its HIP-event
+duration against the 8 TB/s HBM peak) and, at N=1, `cpu_baseline` (the compiled
+reference, or the oracle port, timed on this host's cores on a bounded spp) and
+`parity` (GPU vs that CPU image at the same spp).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def algorithmic_bytes_per_sample(counts, spp):
+    """32 B per node test, 36 B per primitive test, 132 B of
+    attributes per shaded hit, 12 B/spp for the pixel store; the streaming
+    kernel keeps path state in registers, so the wavefront-state term is 0."""
+    s = float(counts["samples"])
+    return (counts["node_tests"] * 32.0 + counts["prim_tests"] * 36.0 +
+            counts["shaded_hits"] * 132.0) / s + 12.0 / spp
+
+
+def cpu_baseline(pkg, width, height, budget_s=20.0):
+    """Times the CPU checker on a bounded sample of the same workload and
+    returns (record, scene_used, cpu_frame)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import checkers
+    use_ref = checkers.reference_available()
+    cores = os.cpu_count() or 1
+    with tempfile.TemporaryDirectory() as tmp:
+        def run(spp):
+            scene = pkg.scenes.cornell_box(width, height, spp)
+            path = os.path.join(tmp, f"c{spp}.mcsd")
+            pkg.mcsd.dump(scene, path)
+            if use_ref:
+                frame, info = checkers.Reference().render(path, width, height)
+            else:
+                frame, info = checkers.Oracle().render(path)
+            return scene, frame, info["seconds"]
+        _, _, t_probe = run(1)
+        rate = width * height / max(t_probe, 1e-6)          # samples/s
+        spp = int(max(1, min(256, budget_s * rate / (width * height))))
+        scene, frame, seconds = run(spp)
+    samples = width * height * spp
+    rec = {"value": samples / seconds / 1e6, "unit": "Msamples/s", "cores": cores,
+           "kind": "reference" if use_ref else "port",
+           "sample": f"cornell-box {width}x{height} spp={spp} ({samples / 1e6:.1f} Msamples, "
+                     f"{seconds:.1f} s, all host threads)"}
+    return rec, scene, frame
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from _pkg import load_package
+    pkg = load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    W, H, SPP = args.width, args.height, args.spp
+    cfg = pkg.capi.Config.builtin("cornell-box").set_film(W, H, SPP)
+    renderer = pkg.capi.Renderer(cfg, device=local_rank)
+    rng = pkg.capi.TileRange(rank, world, 0)
+    assert renderer.tiles_in(rng) == len(pkg.tiling.rank_tiles(rank, world, W, H))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    if world == 1:
+        frame = torch.zeros(H * W * 3, dtype=torch.float32, device=device)
+    else:
+        fg = pkg.tiling.FrameGather(world, rank, W, H, device)
+
+    def step():
+        if world == 1:
+            renderer.draw_device(frame.data_ptr(), rng, packed=False, stream=stream, blocking=False)
+        else:
+            renderer.draw_device(fg.packed.data_ptr(), rng, packed=True, stream=stream, blocking=False)
+            fg.gather()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # same stream as the launches
+
+    if rank == 0:
+        samples = W * H * SPP
+        value = samples * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Msamples/sec (W*H*spp/s)", "value": value, "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cornell-box {W}x{H} spp={SPP} (builtin scene = "
+                                   "resources/scene/cornell-box/scene_v0.6.xml, path integrator, "
+                                   "diffuse + MIS area light)",
+                       "rng": "reference stream (Tea + LCG per pixel)",
+                       "partition": f"8x8 tiles round-robin over {world} GPU(s)"
+                                    + (", one RCCL gather to rank 0" if world > 1 else "")},
+        }
+        # ---- roofline of the render kernel (counting mode, outside the timed region)
+        if world == 1:
+            count_spp = min(SPP, 16)
+            rc = pkg.capi.Renderer(pkg.capi.Config.builtin("cornell-box").set_film(W, H, count_spp),
+                                   device=local_rank)
+            _, counts = rc.draw(counted=True)
+            rc.close()
+            b_per_sample = algorithmic_bytes_per_sample(counts, SPP)
+            achieved = b_per_sample * samples / (kernel_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "mcpt::render_kernel", "kernel_ms": kernel_ms,
+                "bytes_per_sample": b_per_sample,
+                "per_sample": {k: counts[k] / counts["samples"] for k in
+                               ("closest_rays", "shadow_rays", "node_tests", "prim_tests", "shaded_hits")},
+                "note": "algorithmic bytes (32 B/node test, 36 B/triangle test, 132 B/shaded hit, "
+                        "12 B/pixel); the scene (79 nodes, 36 triangles) is cache resident, so HBM "
+                        "traffic is far below this figure",
+            }
+            if not args.no_cpu_baseline:
+                rec, scene, cpu_frame = cpu_baseline(pkg, W, H)
+                out["cpu_baseline"] = rec
+                rg = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=local_rank)
+                gpu_frame, _ = rg.draw()
+                rg.close()
+                d = gpu_frame.astype(np.float64) - cpu_frame.astype(np.float64)
+                l2 = np.sqrt((d ** 2).sum(axis=2))
+                out["parity"] = {"vs": rec["kind"], "spp": scene.camera.spp,
+                                 "rmse": float(np.sqrt((d ** 2).mean())), "mean_l2": float(l2.mean()),
+                                 "max_l2": float(l2.max()), "frac_gt_1e-3": float((l2 > 1e-3).mean()),
+                                 "frac_exact": float((l2 == 0).mean())}
+        else:
+            out["roofline"] = None
+        print(json.dumps(out))
+    renderer.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+/* mcpt — C ABI of the MI355X path tracer (libmcpt_hip.so).
+ *
+ * Drop-in boundary for the render path of zhiwei-c/Monte-Carlo-Path-Tracing.
+ * The reference has no FFI; its seam is the C++ class `csrt::Renderer`
+ * (reference include/csrt/renderer/renderer.hpp:30-81) constructed from a
+ * `csrt::RendererConfig` (renderer.hpp:18-28) and driven by
+ * `csrt::RayTracer` (src/ray_tracer.cpp:124-159) from `main`
+ * (apps/main.cpp:25-95).  Each entry point below names the reference
+ * interface it replaces.  Plain pointers and sizes only; no exceptions cross
+ * this boundary: every call returns 0 on success or a non-zero status, and
+ * `mcpt_last_error()` returns the message (the reference throws
+ * csrt::MyException with chained text, include/csrt/utils/misc.hpp:52-62).
+ *
+ * Threading: calls on one renderer must be serialised by the caller (the
+ * reference's Renderer is not reentrant either, renderer.cpp:17-22); different
+ * renderers may be used from different threads.
+ */
+#ifndef MCPT_H
+#define MCPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- renderer configuration (replaces csrt::RendererConfig) -------------- */
+
+typedef struct mcpt_config mcpt_config;
+
+/* Replaces csrt::LoadConfig(filename) (reference src/parser/parser.cpp:94-179)
+ * for scenes already converted to MCSD (include/mcsd_format.h). */
+int mcpt_config_load_mcsd(const char *path, mcpt_config **out);
+int mcpt_config_from_mcsd_bytes(const void *bytes, size_t size, mcpt_config **out);
+
+/* Replaces csrt::LoadConfig for Mitsuba-style XML scene files
+ * (parser.cpp:94-1617 + model_loader.cpp).  Supported subset: see DESIGN.md. */
+int mcpt_config_load_xml(const char *path, mcpt_config **out);
+
+/* Built-in scenes ("cornell-box"): the same records the XML front end produces
+ * for the reference's example scenes, available without any scene file. */
+int mcpt_config_builtin(const char *name, mcpt_config **out);
+
+/* Replaces the CLI overrides of apps/main.cpp:46-52 (`-w -h -s`): values <= 0
+ * keep the scene's own.  As in the reference, fov_x is NOT recomputed. */
+int mcpt_config_set_film(mcpt_config *cfg, int width, int height, int spp);
+int mcpt_config_get_film(const mcpt_config *cfg, int *width, int *height, int *spp);
+
+int mcpt_config_save_mcsd(const mcpt_config *cfg, const char *path);
+void mcpt_config_destroy(mcpt_config *cfg);
+
+/* ---- renderer (replaces csrt::Renderer) ---------------------------------- */
+
+typedef struct mcpt_renderer mcpt_renderer;
+
+/* Which pixels a draw call produces: 8x8 pixel tiles in row-major tile order,
+ * tile index t = tile_first + k * tile_stride for k in [0, tile_count).
+ * tile_count == 0 means "every tile from tile_first in steps of tile_stride".
+ * {0, 1, 0} is the whole frame; rank r of N GPUs uses {r, N, 0}. */
+typedef struct mcpt_tile_range
+{
+    uint32_t tile_first, tile_stride, tile_count;
+} mcpt_tile_range;
+
+typedef struct mcpt_stats
+{
+    double render_seconds;      /* wall time of the draw call (kernel + copies) */
+    double kernel_milliseconds; /* HIP-event time of the render kernel on its stream */
+    uint64_t samples;           /* pixels * spp produced by this call */
+    /* filled only by mcpt_renderer_draw_counted(): */
+    uint64_t closest_rays, shadow_rays, node_tests, prim_tests, shaded_hits;
+} mcpt_stats;
+
+/* Replaces Renderer::Renderer(const RendererConfig&) (reference
+ * src/renderer/renderer.cpp:259-348 incl. Scene::Scene, scene.cpp:118-141):
+ * commits the configuration into flat tables, builds the two-level LBVH and
+ * uploads everything to HBM of `device` (HIP device ordinal). */
+int mcpt_renderer_create(const mcpt_config *cfg, int device, mcpt_renderer **out);
+
+/* Replaces Renderer::Draw(float *frame) (renderer.cpp:678-721): blocking; fills
+ * the caller's HOST buffer of width*height*3 float32 (row 0 = top, linear RGB,
+ * mean over spp of per-sample-clamped radiance).  stats may be NULL. */
+int mcpt_renderer_draw(mcpt_renderer *r, float *frame, mcpt_stats *stats);
+
+/* Device-resident variant for multi-GPU tiling and benchmarking: renders the
+ * tiles of `range` into a DEVICE buffer on `stream` (a hipStream_t, NULL = the
+ * default stream) and returns after enqueueing when `blocking` is 0.
+ *   packed == 0: out is a full frame (width*height*3 floats), only this
+ *                range's pixels are written;
+ *   packed != 0: out holds the range's tiles back to back, 64 pixels * 3
+ *                floats per tile (pixels outside the image are left untouched). */
+int mcpt_renderer_draw_device(mcpt_renderer *r, float *out_device, const mcpt_tile_range *range,
+                              int packed, void *stream, int blocking, mcpt_stats *stats);
+
+/* Same as mcpt_renderer_draw but with the in-kernel counting mode on: ray,
+ * node-test and primitive-test totals for the roofline bookkeeping
+ * (SURVEY.md §8d).  Slower; the image is identical. */
+int mcpt_renderer_draw_counted(mcpt_renderer *r, float *frame, mcpt_stats *stats);
+
+/* Number of 8x8 tiles of the frame, and how many of them `range` selects. */
+int mcpt_renderer_tile_count(const mcpt_renderer *r, uint32_t *tiles_total);
+uint32_t mcpt_tile_range_size(uint32_t tiles_total, const mcpt_tile_range *range);
+
+/* Scatter packed tiles (host memory) back into a host frame. */
+int mcpt_unpack_tiles(const float *packed, const mcpt_tile_range *range, int width, int height, float *frame);
+
+/* Committed-table inspection (tests, tools).  `what`: "nodes" (float, 8 per
+ * node), "node_area", "tri_pos" (float, 12 per primitive), "tri_attr" (36 per
+ * primitive), "lut_brdf", "lut_albedo", "light_cdf", "env_tables".  Returns a
+ * pointer into renderer-owned HOST memory, valid until the renderer dies. */
+int mcpt_renderer_table(const mcpt_renderer *r, const char *what, const void **data, size_t *count);
+
+/* Scene statistics: nodes, TLAS nodes, primitives, instances, feature bits,
+ * bytes of geometry in HBM (6 x uint64). */
+int mcpt_renderer_info(const mcpt_renderer *r, uint64_t info[6]);
+
+/* Replaces Renderer::~Renderer / ReleaseData (renderer.cpp:350-369). */
+void mcpt_renderer_destroy(mcpt_renderer *r);
+
+/* ---- image output (replaces image_io::Write, src/utils/image_io.cpp:25-53) -- */
+
+/* Writes `frame` (width*height*3 float32) by file suffix: ".png" (sRGB 8-bit,
+ * the reference's transfer curve), ".exr" (linear float32 scanline OpenEXR),
+ * ".pfm", ".f32" (raw). */
+int mcpt_write_image(const char *path, const float *frame, int width, int height);
+
+/* Thread-local message of the last failed call on this thread. */
+const char *mcpt_last_error(void);
+
+/* Library / device identification string, e.g. "mcpt 0.1 hip gfx950". */
+const char *mcpt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MCPT_H */

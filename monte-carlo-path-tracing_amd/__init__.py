@@ -8,5 +8,6 @@ Sub-modules:
   mcsd     MCSD scene-description reader/writer (include/mcsd_format.h)
   scenes   programmatic test scenes (cornell box, volumetric caustic, ...)
   capi     ctypes binding of the C-ABI in include/mcpt.h (the HIP renderer)
+  tiling   multi-GPU image partition + the single gather of finished tiles
 """
-from . import mcsd, scenes  # noqa: F401
+from . import capi, mcsd, scenes, tiling  # noqa: F401

@@ -1,0 +1,220 @@
+"""ctypes binding of the C ABI in include/mcpt.h (libmcpt_hip.so).
+
+Mirrors the reference's host-side interface for the render path:
+`Config` stands for csrt::RendererConfig (+ csrt::LoadConfig), `Renderer` for
+csrt::Renderer with its `Draw(float *frame)`; errors surface as
+`McptError` carrying the library's message (the reference throws
+csrt::MyException).  The library renders on the GPU only: if the shared object
+or a HIP device is missing, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmcpt_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+
+class McptError(RuntimeError):
+    pass
+
+
+class TileRange(ctypes.Structure):
+    """8x8-pixel tiles t = first + k * stride, k < count (count 0 = all)."""
+    _fields_ = [("tile_first", ctypes.c_uint32), ("tile_stride", ctypes.c_uint32),
+                ("tile_count", ctypes.c_uint32)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("render_seconds", ctypes.c_double), ("kernel_milliseconds", ctypes.c_double),
+                ("samples", ctypes.c_uint64), ("closest_rays", ctypes.c_uint64),
+                ("shadow_rays", ctypes.c_uint64), ("node_tests", ctypes.c_uint64),
+                ("prim_tests", ctypes.c_uint64), ("shaded_hits", ctypes.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def build(quiet: bool = True) -> str:
+    """Compile libmcpt_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    subprocess.run(["make", "-s", "-j8", "-C", CSRC], check=True,
+                   stdout=subprocess.DEVNULL if quiet else None)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise McptError(f"{LIB_PATH} is not built (run __graft_entry__.build())")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, cp, i32, u32 = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32
+    L.mcpt_last_error.restype = cp
+    L.mcpt_version.restype = cp
+    for name in ("mcpt_config_load_mcsd", "mcpt_config_load_xml", "mcpt_config_builtin"):
+        getattr(L, name).argtypes = [cp, ctypes.POINTER(vp)]
+    L.mcpt_config_from_mcsd_bytes.argtypes = [cp, ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.mcpt_config_set_film.argtypes = [vp, i32, i32, i32]
+    L.mcpt_config_get_film.argtypes = [vp] + [ctypes.POINTER(i32)] * 3
+    L.mcpt_config_save_mcsd.argtypes = [vp, cp]
+    L.mcpt_config_destroy.argtypes = [vp]
+    L.mcpt_config_destroy.restype = None
+    L.mcpt_renderer_create.argtypes = [vp, i32, ctypes.POINTER(vp)]
+    L.mcpt_renderer_draw.argtypes = [vp, vp, ctypes.POINTER(Stats)]
+    L.mcpt_renderer_draw_counted.argtypes = [vp, vp, ctypes.POINTER(Stats)]
+    L.mcpt_renderer_draw_device.argtypes = [vp, vp, ctypes.POINTER(TileRange), i32, vp, i32,
+                                            ctypes.POINTER(Stats)]
+    L.mcpt_renderer_tile_count.argtypes = [vp, ctypes.POINTER(u32)]
+    L.mcpt_tile_range_size.argtypes = [u32, ctypes.POINTER(TileRange)]
+    L.mcpt_tile_range_size.restype = u32
+    L.mcpt_unpack_tiles.argtypes = [vp, ctypes.POINTER(TileRange), i32, i32, vp]
+    L.mcpt_renderer_table.argtypes = [vp, cp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
+    L.mcpt_renderer_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.mcpt_renderer_destroy.argtypes = [vp]
+    L.mcpt_renderer_destroy.restype = None
+    L.mcpt_write_image.argtypes = [cp, vp, i32, i32]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise McptError(lib().mcpt_last_error().decode(errors="replace"))
+
+
+EXPORTED_SYMBOLS = [
+    "mcpt_config_load_mcsd", "mcpt_config_from_mcsd_bytes", "mcpt_config_load_xml",
+    "mcpt_config_builtin", "mcpt_config_set_film", "mcpt_config_get_film",
+    "mcpt_config_save_mcsd", "mcpt_config_destroy", "mcpt_renderer_create",
+    "mcpt_renderer_draw", "mcpt_renderer_draw_device", "mcpt_renderer_draw_counted",
+    "mcpt_renderer_tile_count", "mcpt_tile_range_size", "mcpt_unpack_tiles",
+    "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_destroy",
+    "mcpt_write_image", "mcpt_last_error", "mcpt_version",
+]
+
+
+class Config:
+    """A renderer configuration (csrt::RendererConfig)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def _make(fn, *args):
+        h = ctypes.c_void_p()
+        _check(fn(*args, ctypes.byref(h)))
+        return Config(h)
+
+    @classmethod
+    def load_mcsd(cls, path):
+        return cls._make(lib().mcpt_config_load_mcsd, str(path).encode())
+
+    @classmethod
+    def from_mcsd_bytes(cls, raw: bytes):
+        return cls._make(lib().mcpt_config_from_mcsd_bytes, raw, len(raw))
+
+    @classmethod
+    def from_scene(cls, scene):
+        """From a mcsd.Scene built in Python."""
+        from . import mcsd
+        return cls.from_mcsd_bytes(mcsd.dumps(scene))
+
+    @classmethod
+    def load_xml(cls, path):
+        return cls._make(lib().mcpt_config_load_xml, str(path).encode())
+
+    @classmethod
+    def builtin(cls, name):
+        return cls._make(lib().mcpt_config_builtin, name.encode())
+
+    def set_film(self, width=0, height=0, spp=0):
+        _check(lib().mcpt_config_set_film(self._h, width, height, spp))
+        return self
+
+    def film(self):
+        w, h, s = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(lib().mcpt_config_get_film(self._h, ctypes.byref(w), ctypes.byref(h), ctypes.byref(s)))
+        return w.value, h.value, s.value
+
+    def save_mcsd(self, path):
+        _check(lib().mcpt_config_save_mcsd(self._h, str(path).encode()))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().mcpt_config_destroy(self._h)
+            self._h = None
+
+
+class Renderer:
+    """csrt::Renderer: commit once, draw many times."""
+
+    def __init__(self, config: Config, device: int = 0):
+        self.width, self.height, self.spp = config.film()
+        h = ctypes.c_void_p()
+        _check(lib().mcpt_renderer_create(config._h, device, ctypes.byref(h)))
+        self._h = h
+        self.device = device
+        n = ctypes.c_uint32()
+        _check(lib().mcpt_renderer_tile_count(self._h, ctypes.byref(n)))
+        self.tiles_total = n.value
+
+    def draw(self, counted=False):
+        """Renderer::Draw(float*): returns (frame[h, w, 3] float32, stats dict)."""
+        frame = np.empty((self.height, self.width, 3), dtype=np.float32)
+        st = Stats()
+        fn = lib().mcpt_renderer_draw_counted if counted else lib().mcpt_renderer_draw
+        _check(fn(self._h, frame.ctypes.data, ctypes.byref(st)))
+        return frame, st.as_dict()
+
+    def tiles_in(self, rng: TileRange) -> int:
+        return lib().mcpt_tile_range_size(self.tiles_total, ctypes.byref(rng))
+
+    def draw_device(self, out_ptr: int, rng: TileRange = None, packed=False, stream=None,
+                    blocking=True):
+        """Render into device memory (e.g. a torch tensor's data_ptr())."""
+        rng = rng or TileRange(0, 1, 0)
+        st = Stats()
+        _check(lib().mcpt_renderer_draw_device(self._h, ctypes.c_void_p(out_ptr), ctypes.byref(rng),
+                                               int(packed), ctypes.c_void_p(stream or 0),
+                                               int(blocking), ctypes.byref(st)))
+        return st.as_dict()
+
+    def table(self, what: str) -> np.ndarray:
+        data, count = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(lib().mcpt_renderer_table(self._h, what.encode(), ctypes.byref(data), ctypes.byref(count)))
+        buf = (ctypes.c_float * count.value).from_address(data.value)
+        return np.frombuffer(buf, dtype=np.float32).copy()
+
+    def info(self):
+        arr = (ctypes.c_uint64 * 6)()
+        _check(lib().mcpt_renderer_info(self._h, arr))
+        keys = ("nodes", "tlas_nodes", "primitives", "instances", "features", "geometry_bytes")
+        return dict(zip(keys, (int(v) for v in arr)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mcpt_renderer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def unpack_tiles(packed: np.ndarray, rng: TileRange, width: int, height: int, frame: np.ndarray):
+    packed = np.ascontiguousarray(packed, dtype=np.float32)
+    assert frame.dtype == np.float32 and frame.flags.c_contiguous
+    _check(lib().mcpt_unpack_tiles(packed.ctypes.data, ctypes.byref(rng), width, height, frame.ctypes.data))
+
+
+def write_image(path, frame: np.ndarray):
+    frame = np.ascontiguousarray(frame, dtype=np.float32)
+    _check(lib().mcpt_write_image(str(path).encode(), frame.ctypes.data, frame.shape[1], frame.shape[0]))

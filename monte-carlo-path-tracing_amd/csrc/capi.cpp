@@ -1,0 +1,492 @@
+// C-ABI layer of libmcpt_hip.so (include/mcpt.h): configuration handles,
+// renderer lifetime (commit -> upload to HBM), draw calls on HIP streams.
+// There is NO CPU rendering path in this library: without a HIP device every
+// renderer call fails with an error.
+#include "mcpt.h"
+
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "hip/render_kernel.h"
+#include "host/commit.hpp"
+#include "host/frontend.hpp"
+#include "mcsd_scene.hpp"
+
+struct mcpt_config
+{
+    mcsd::Scene scene;
+};
+
+namespace
+{
+
+thread_local std::string g_error;
+
+int Fail(const std::string &what)
+{
+    g_error = what;
+    return 1;
+}
+
+void Check(hipError_t err, const char *what)
+{
+    if (err != hipSuccess)
+        throw std::runtime_error(std::string("HIP error : \"") + hipGetErrorString(err) + "\" when " + what + ".");
+}
+
+// One device allocation holding a copy of a host vector.
+class DeviceArray
+{
+public:
+    DeviceArray() = default;
+    DeviceArray(const DeviceArray &) = delete;
+    DeviceArray &operator=(const DeviceArray &) = delete;
+    ~DeviceArray()
+    {
+        if (ptr_)
+            (void)hipFree(ptr_);
+    }
+    template <typename T>
+    const T *Upload(const std::vector<T> &host, const char *name)
+    {
+        const size_t bytes = host.size() * sizeof(T);
+        Check(hipMalloc(&ptr_, bytes ? bytes : sizeof(T)), name);
+        if (bytes)
+            Check(hipMemcpy(ptr_, host.data(), bytes, hipMemcpyHostToDevice), name);
+        bytes_ = bytes;
+        return static_cast<const T *>(ptr_);
+    }
+    size_t bytes() const { return bytes_; }
+
+private:
+    void *ptr_ = nullptr;
+    size_t bytes_ = 0;
+};
+
+} // namespace
+
+struct mcpt_renderer
+{
+    int device = 0;
+    uint32_t n_cus = 0;
+    mcpt::FlatScene flat;
+    mcpt::DeviceScene dev{};
+    DeviceArray arrays[16];
+    float *frame_dev = nullptr;            // scratch frame for mcpt_renderer_draw
+    mcpt::TraceCounters *counters_dev = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::string variant;
+
+    ~mcpt_renderer()
+    {
+        if (frame_dev)
+            (void)hipFree(frame_dev);
+        if (counters_dev)
+            (void)hipFree(counters_dev);
+        if (ev_begin)
+            (void)hipEventDestroy(ev_begin);
+        if (ev_end)
+            (void)hipEventDestroy(ev_end);
+    }
+
+    uint32_t TilesX() const { return (static_cast<uint32_t>(flat.camera.width) + 7u) / 8u; }
+    uint32_t TilesY() const { return (static_cast<uint32_t>(flat.camera.height) + 7u) / 8u; }
+    uint32_t Tiles() const { return TilesX() * TilesY(); }
+};
+
+namespace
+{
+
+uint32_t RangeSize(uint32_t tiles_total, const mcpt_tile_range &range)
+{
+    if (range.tile_stride == 0 || range.tile_first >= tiles_total)
+        return 0;
+    const uint32_t available = (tiles_total - range.tile_first + range.tile_stride - 1) / range.tile_stride;
+    return range.tile_count == 0 ? available : (range.tile_count < available ? range.tile_count : available);
+}
+
+// Enqueues one render launch; optionally waits and reports timings.
+void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, bool packed, hipStream_t stream,
+          bool blocking, bool counted, mcpt_stats *stats)
+{
+    Check(hipSetDevice(r->device), "select device");
+    const uint32_t n_tiles = RangeSize(r->Tiles(), range);
+    mcpt::RenderJob job{};
+    job.n_items = n_tiles * 64u;
+    job.tile_first = range.tile_first;
+    job.tile_stride = range.tile_stride;
+    job.tiles_x = r->TilesX();
+    job.packed = packed ? 1u : 0u;
+    mcpt::TraceCounters *counters = nullptr;
+    if (counted)
+    {
+        if (!r->counters_dev)
+            Check(hipMalloc(reinterpret_cast<void **>(&r->counters_dev), sizeof(mcpt::TraceCounters)), "allocate counters");
+        Check(hipMemsetAsync(r->counters_dev, 0, sizeof(mcpt::TraceCounters), stream), "clear counters");
+        counters = r->counters_dev;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool timed = stats != nullptr && blocking;
+    if (timed)
+        Check(hipEventRecord(r->ev_begin, stream), "record event");
+    const char *variant = "";
+    Check(mcpt::LaunchRender(r->dev, job, out_device, counters, stream, r->n_cus, &variant), "launch render kernel");
+    r->variant = variant;
+    if (timed)
+        Check(hipEventRecord(r->ev_end, stream), "record event");
+    if (blocking)
+        Check(hipStreamSynchronize(stream), "draw");
+    if (stats)
+    {
+        *stats = mcpt_stats{};
+        stats->render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (timed)
+        {
+            float ms = 0;
+            Check(hipEventElapsedTime(&ms, r->ev_begin, r->ev_end), "read event");
+            stats->kernel_milliseconds = ms;
+        }
+        // exact pixel count of the selected tiles (edge tiles are partial)
+        uint64_t pixels = 0;
+        const uint32_t tx = r->TilesX(), w = r->flat.camera.width, h = r->flat.camera.height;
+        for (uint32_t k = 0; k < n_tiles; ++k)
+        {
+            const uint32_t t = range.tile_first + k * range.tile_stride;
+            const uint32_t x0 = (t % tx) * 8u, y0 = (t / tx) * 8u;
+            pixels += static_cast<uint64_t>(std::min(8u, w - x0)) * std::min(8u, h - y0);
+        }
+        stats->samples = pixels * r->flat.camera.spp;
+        if (counted && blocking)
+        {
+            mcpt::TraceCounters c{};
+            Check(hipMemcpy(&c, r->counters_dev, sizeof(c), hipMemcpyDeviceToHost), "read counters");
+            stats->closest_rays = c.closest_rays, stats->shadow_rays = c.shadow_rays;
+            stats->node_tests = c.node_tests, stats->prim_tests = c.prim_tests;
+            stats->shaded_hits = c.shaded_hits;
+        }
+    }
+}
+
+int DrawToHost(mcpt_renderer *r, float *frame, mcpt_stats *stats, bool counted)
+{
+    if (!r || !frame)
+        return Fail("null argument");
+    try
+    {
+        Check(hipSetDevice(r->device), "select device");
+        const size_t n = static_cast<size_t>(r->flat.camera.width) * r->flat.camera.height * 3;
+        if (!r->frame_dev)
+            Check(hipMalloc(reinterpret_cast<void **>(&r->frame_dev), n * sizeof(float)), "allocate frame");
+        const auto t0 = std::chrono::steady_clock::now();
+        const mcpt_tile_range all{0, 1, 0};
+        mcpt_stats local{};
+        Draw(r, r->frame_dev, all, false, nullptr, true, counted, &local);
+        Check(hipMemcpy(frame, r->frame_dev, n * sizeof(float), hipMemcpyDeviceToHost), "copy frame to host");
+        local.render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (stats)
+            *stats = local;
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(std::string("error when draw.\n\t") + e.what());
+    }
+}
+
+} // namespace
+
+extern "C"
+{
+
+const char *mcpt_last_error(void) { return g_error.c_str(); }
+
+const char *mcpt_version(void) { return "mcpt 0.1 hip gfx950"; }
+
+int mcpt_config_load_mcsd(const char *path, mcpt_config **out)
+{
+    if (!path || !out)
+        return Fail("null argument");
+    try
+    {
+        std::unique_ptr<mcpt_config> cfg(new mcpt_config);
+        cfg->scene = mcsd::Load(path);
+        *out = cfg.release();
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(e.what());
+    }
+}
+
+int mcpt_config_from_mcsd_bytes(const void *bytes, size_t size, mcpt_config **out)
+{
+    if (!bytes || !out)
+        return Fail("null argument");
+    try
+    {
+        std::unique_ptr<mcpt_config> cfg(new mcpt_config);
+        cfg->scene = mcsd::Parse(static_cast<const uint8_t *>(bytes), size);
+        *out = cfg.release();
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(e.what());
+    }
+}
+
+int mcpt_config_load_xml(const char *path, mcpt_config **out)
+{
+    if (!path || !out)
+        return Fail("null argument");
+    try
+    {
+        std::unique_ptr<mcpt_config> cfg(new mcpt_config);
+        cfg->scene = mcpt::LoadXmlScene(path);
+        *out = cfg.release();
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(e.what());
+    }
+}
+
+int mcpt_config_builtin(const char *name, mcpt_config **out)
+{
+    if (!name || !out)
+        return Fail("null argument");
+    try
+    {
+        std::unique_ptr<mcpt_config> cfg(new mcpt_config);
+        cfg->scene = mcpt::BuiltinScene(name);
+        *out = cfg.release();
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(e.what());
+    }
+}
+
+int mcpt_config_set_film(mcpt_config *cfg, int width, int height, int spp)
+{
+    if (!cfg)
+        return Fail("null argument");
+    if (width > 0)
+        cfg->scene.camera.width = width;
+    if (height > 0)
+        cfg->scene.camera.height = height;
+    if (spp > 0)
+        cfg->scene.camera.spp = static_cast<uint32_t>(spp);
+    return 0;
+}
+
+int mcpt_config_get_film(const mcpt_config *cfg, int *width, int *height, int *spp)
+{
+    if (!cfg)
+        return Fail("null argument");
+    if (width)
+        *width = cfg->scene.camera.width;
+    if (height)
+        *height = cfg->scene.camera.height;
+    if (spp)
+        *spp = static_cast<int>(cfg->scene.camera.spp);
+    return 0;
+}
+
+int mcpt_config_save_mcsd(const mcpt_config *cfg, const char *path)
+{
+    if (!cfg || !path)
+        return Fail("null argument");
+    try
+    {
+        mcsd::Save(cfg->scene, path);
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(e.what());
+    }
+}
+
+void mcpt_config_destroy(mcpt_config *cfg) { delete cfg; }
+
+int mcpt_renderer_create(const mcpt_config *cfg, int device, mcpt_renderer **out)
+{
+    if (!cfg || !out)
+        return Fail("null argument");
+    try
+    {
+        int n_devices = 0;
+        if (hipGetDeviceCount(&n_devices) != hipSuccess || n_devices == 0)
+            throw std::runtime_error("no HIP device available: this library renders on the GPU only.");
+        if (device < 0 || device >= n_devices)
+            throw std::runtime_error("invalid HIP device ordinal " + std::to_string(device) + ".");
+        std::unique_ptr<mcpt_renderer> r(new mcpt_renderer);
+        r->device = device;
+        Check(hipSetDevice(device), "select device");
+        hipDeviceProp_t prop;
+        Check(hipGetDeviceProperties(&prop, device), "query device");
+        r->n_cus = static_cast<uint32_t>(prop.multiProcessorCount);
+        r->flat = mcpt::CommitScene(cfg->scene);
+        const mcpt::FlatScene &f = r->flat;
+        mcpt::DeviceScene &d = r->dev;
+        d.camera = f.camera, d.integrator = f.integrator, d.features = f.features;
+        int k = 0;
+        d.nodes = r->arrays[k++].Upload(f.nodes, "upload nodes");
+        d.node_area = r->arrays[k++].Upload(f.node_area, "upload node areas");
+        d.tri_pos = r->arrays[k++].Upload(f.tri_pos, "upload triangle positions");
+        d.tri_attr = r->arrays[k++].Upload(f.tri_attr, "upload triangle attributes");
+        d.instances = r->arrays[k++].Upload(f.instances, "upload instances");
+        d.analytic = r->arrays[k++].Upload(f.analytic, "upload analytic shapes");
+        d.light_inst = r->arrays[k++].Upload(f.light_inst, "upload light table");
+        d.light_cdf = r->arrays[k++].Upload(f.light_cdf, "upload light cdf");
+        d.textures = r->arrays[k++].Upload(f.textures, "upload textures");
+        d.texels = r->arrays[k++].Upload(f.texels, "upload texels");
+        d.bsdfs = r->arrays[k++].Upload(f.bsdfs, "upload BSDFs");
+        d.media = r->arrays[k++].Upload(f.media, "upload media");
+        d.emitters = r->arrays[k++].Upload(f.emitters, "upload emitters");
+        d.env_tables = r->arrays[k++].Upload(f.env_tables, "upload environment tables");
+        d.lut_brdf = r->arrays[k++].Upload(f.lut_brdf, "upload Kulla-Conty table");
+        d.lut_albedo = r->arrays[k++].Upload(f.lut_albedo, "upload Kulla-Conty table");
+        Check(hipEventCreate(&r->ev_begin), "create event");
+        Check(hipEventCreate(&r->ev_end), "create event");
+        *out = r.release();
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(std::string("error when commit renderer.\n\t") + e.what());
+    }
+}
+
+int mcpt_renderer_draw(mcpt_renderer *r, float *frame, mcpt_stats *stats) { return DrawToHost(r, frame, stats, false); }
+
+int mcpt_renderer_draw_counted(mcpt_renderer *r, float *frame, mcpt_stats *stats)
+{
+    return DrawToHost(r, frame, stats, true);
+}
+
+int mcpt_renderer_draw_device(mcpt_renderer *r, float *out_device, const mcpt_tile_range *range, int packed,
+                              void *stream, int blocking, mcpt_stats *stats)
+{
+    if (!r || !out_device || !range)
+        return Fail("null argument");
+    try
+    {
+        Draw(r, out_device, *range, packed != 0, static_cast<hipStream_t>(stream), blocking != 0, false, stats);
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(std::string("error when draw.\n\t") + e.what());
+    }
+}
+
+int mcpt_renderer_tile_count(const mcpt_renderer *r, uint32_t *tiles_total)
+{
+    if (!r || !tiles_total)
+        return Fail("null argument");
+    *tiles_total = r->Tiles();
+    return 0;
+}
+
+uint32_t mcpt_tile_range_size(uint32_t tiles_total, const mcpt_tile_range *range)
+{
+    return range ? RangeSize(tiles_total, *range) : 0;
+}
+
+int mcpt_unpack_tiles(const float *packed, const mcpt_tile_range *range, int width, int height, float *frame)
+{
+    if (!packed || !range || !frame || width <= 0 || height <= 0)
+        return Fail("invalid argument");
+    const uint32_t w = static_cast<uint32_t>(width), h = static_cast<uint32_t>(height);
+    const uint32_t tx = (w + 7u) / 8u, ty = (h + 7u) / 8u;
+    const uint32_t n = RangeSize(tx * ty, *range);
+    for (uint32_t k = 0; k < n; ++k)
+    {
+        const uint32_t t = range->tile_first + k * range->tile_stride;
+        const uint32_t x0 = (t % tx) * 8u, y0 = (t / tx) * 8u;
+        for (uint32_t r = 0; r < 64; ++r)
+        {
+            const uint32_t x = x0 + (r & 7u), y = y0 + (r >> 3);
+            if (x >= w || y >= h)
+                continue;
+            std::memcpy(frame + 3 * (static_cast<size_t>(y) * w + x), packed + 3 * (static_cast<size_t>(k) * 64 + r),
+                        3 * sizeof(float));
+        }
+    }
+    return 0;
+}
+
+int mcpt_renderer_table(const mcpt_renderer *r, const char *what, const void **data, size_t *count)
+{
+    if (!r || !what || !data || !count)
+        return Fail("null argument");
+    const mcpt::FlatScene &f = r->flat;
+    const std::string w = what;
+    auto set = [&](const void *p, size_t n)
+    {
+        *data = p, *count = n;
+        return 0;
+    };
+    if (w == "nodes")
+        return set(f.nodes.data(), f.nodes.size() * 4);
+    if (w == "node_area")
+        return set(f.node_area.data(), f.node_area.size());
+    if (w == "tri_pos")
+        return set(f.tri_pos.data(), f.tri_pos.size() * 4);
+    if (w == "tri_attr")
+        return set(f.tri_attr.data(), f.tri_attr.size() * 4);
+    if (w == "lut_brdf")
+        return set(f.lut_brdf.data(), f.lut_brdf.size());
+    if (w == "lut_albedo")
+        return set(f.lut_albedo.data(), f.lut_albedo.size());
+    if (w == "light_cdf")
+        return set(f.light_cdf.data(), f.light_cdf.size());
+    if (w == "env_tables")
+        return set(f.env_tables.data(), f.env_tables.size());
+    return Fail("unknown table '" + w + "'");
+}
+
+int mcpt_renderer_info(const mcpt_renderer *r, uint64_t info[6])
+{
+    if (!r || !info)
+        return Fail("null argument");
+    const mcpt::IntegratorRec &ig = r->flat.integrator;
+    info[0] = ig.n_nodes, info[1] = ig.n_tlas_nodes, info[2] = ig.n_prims, info[3] = ig.n_instances;
+    info[4] = r->flat.features, info[5] = r->flat.GeometryBytes();
+    return 0;
+}
+
+void mcpt_renderer_destroy(mcpt_renderer *r)
+{
+    if (r)
+        (void)hipSetDevice(r->device);
+    delete r;
+}
+
+int mcpt_write_image(const char *path, const float *frame, int width, int height)
+{
+    if (!path || !frame || width <= 0 || height <= 0)
+        return Fail("invalid argument");
+    try
+    {
+        mcpt::WriteImage(path, frame, width, height);
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(e.what());
+    }
+}
+
+} // extern "C"

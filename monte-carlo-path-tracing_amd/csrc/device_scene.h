@@ -1,0 +1,243 @@
+// Flat scene layout shared by the host commit (csrc/host/commit.cpp) and the
+// HIP kernels (csrc/hip/*.hip).  Everything the renderer reads on the GPU is
+// a plain array in HBM addressed by index; there are no pointers inside
+// records.  This replaces the reference's pointer graph of managed-memory
+// objects (Scene/TLAS/BLAS/Instance/Primitive/Bsdf/Texture/Emitter/Medium,
+// reference include/csrt/**) committed by Renderer::Renderer
+// (src/renderer/renderer.cpp:259-348).
+//
+// Geometry layout (what the traversal kernel streams):
+//   nodes      2 x float4 per BVH node (32 B):
+//                [0] = box.lo.xyz, bits(skip)
+//                [1] = box.hi.xyz, bits(object)   object = kNoObject for inner nodes
+//              All trees live in one array, [TLAS | BLAS 0 | BLAS 1 | ...]
+//              (reference scene.cpp:497-508), each tree numbered in PRE-ORDER
+//              exactly as the reference builder numbers it
+//              (bvh_builder.cpp:143-170), so `left child = index + 1` and the
+//              fixed left-first visiting order of the reference
+//              (blas.cpp:26-43, tlas.cpp:22-41) is reproduced WITHOUT a stack
+//              by following `skip` (the pre-order successor that leaves the
+//              subtree) on a miss or after a leaf.  kEndOfTree ends a tree.
+//              The right child of node i is skip(i + 1).
+//   tri_pos    3 x float4 per triangle: p0, p1, p2 (w unused)  -> 36 B useful
+//   tri_attr   9 x float4 per triangle: n0 n1 n2 | t0 t1 t2 | b0 b1 b2, the six
+//              texture coordinates ride in the w lanes (n0.w=u0 n1.w=v0
+//              n2.w=u1 t0.w=v1 t1.w=u2 t2.w=v2) -> 132 B useful, read once per
+//              shaded hit.
+#ifndef MCPT_DEVICE_SCENE_H
+#define MCPT_DEVICE_SCENE_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#else
+struct float4
+{
+    float x, y, z, w;
+};
+struct uint4
+{
+    uint32_t x, y, z, w;
+};
+#endif
+
+namespace mcpt
+{
+
+constexpr uint32_t kNoObject = 0xFFFFFFFFu;
+constexpr uint32_t kEndOfTree = 0xFFFFFFFFu;
+constexpr uint32_t kNone = 0xFFFFFFFFu; // reference kInvalidId (defs.hpp:22)
+constexpr int kLutRes = 128;            // kulla_conty.hpp:9
+
+struct Vec3f
+{
+    float x, y, z;
+};
+
+// Row-major 4x4.
+struct Mat4f
+{
+    float m[16];
+};
+
+enum InstanceKind : uint32_t
+{
+    kInstTriangles = 0,
+    kInstSphere = 1,
+    kInstDisk = 2,
+    kInstCylinder = 3,
+};
+
+// One record per instance.  blas_root and prim_base are GLOBAL indices.
+struct InstanceRec
+{
+    uint32_t blas_root;
+    uint32_t prim_base;
+    uint32_t kind;     // InstanceKind
+    uint32_t analytic; // index into analytic[] for non-triangle kinds
+    uint32_t bsdf;     // kNone = no BSDF (pass-through surface)
+    uint32_t medium_int, medium_ext;
+    uint32_t area_light; // index of the area light this instance is, or kNone
+    float pdf_area;      // 1 / instance "area" (reference scene.cpp:493-495)
+    uint32_t pad[3];
+};
+
+// Analytic quadric with the matrices the reference recomputes on every test
+// (sphere.cpp:21,47 etc.) precomputed once with the same inverse arithmetic.
+struct AnalyticRec
+{
+    float radius, length;
+    Vec3f center;
+    float pad[3];
+    Mat4f to_world, to_local, normal_to_world;
+};
+
+enum TextureKind : uint32_t
+{
+    kTexConstant = 1,
+    kTexChecker = 2,
+    kTexBitmap = 3,
+};
+
+struct TextureRec
+{
+    uint32_t kind;
+    int32_t width, height, channel;
+    Vec3f color;  // constant
+    Vec3f color0; // checkerboard
+    Vec3f color1;
+    uint32_t texel_base; // offset into texels[]
+    uint32_t pad[2];
+    Mat4f to_uv;
+};
+
+enum BsdfKind : uint32_t
+{
+    kBsdfAreaLight = 1,
+    kBsdfDiffuse = 2,
+    kBsdfRoughDiffuse = 3,
+    kBsdfConductor = 4,
+    kBsdfDielectric = 5,
+    kBsdfThinDielectric = 6,
+    kBsdfPlastic = 7,
+};
+
+struct BsdfRec
+{
+    uint32_t kind;
+    uint32_t twosided;
+    uint32_t opacity, bump;       // texture ids or kNone
+    uint32_t tex0, tex1, tex2, tex3;
+    // tex0..3 by kind:
+    //   area light     radiance
+    //   diffuse        reflectance
+    //   rough diffuse  reflectance, roughness
+    //   conductor      roughness_u, roughness_v, specular_reflectance
+    //   (thin) dielec. roughness_u, roughness_v, specular_reflectance, specular_transmittance
+    //   plastic        roughness, diffuse_reflectance, specular_reflectance
+    Vec3f reflectivity3; // conductor
+    Vec3f f_avg3;        // conductor: hemispherical average Fresnel
+    float reflectivity;  // dielectric / plastic: ((eta-1)/(eta+1))^2
+    float eta, eta_inv;
+    float f_avg, f_avg_inv;
+    uint32_t pad[1];
+};
+
+struct MediumRec
+{
+    float sampling_weight;
+    Vec3f sigma_s, sigma_t;
+    uint32_t hg; // 1 = Henyey-Greenstein, 0 = isotropic
+    Vec3f g;
+    uint32_t pad;
+};
+
+enum EmitterKind : uint32_t
+{
+    kEmitPoint = 1,
+    kEmitSpot = 2,
+    kEmitDirectional = 3,
+    kEmitSun = 4,
+    kEmitEnvMap = 5,
+    kEmitConstant = 6,
+};
+
+struct EmitterRec
+{
+    uint32_t kind;
+    uint32_t texture; // spot / sun / envmap
+    float cutoff, cos_cutoff, uv_factor, cos_beam, transition_rcp;
+    float normalization; // envmap
+    Vec3f position, intensity, direction, radiance;
+    int32_t width, height; // envmap
+    uint32_t cdf_cols, cdf_rows, weight_rows; // offsets into env_tables[] (Q7 pointer quirk)
+    uint32_t pad[3];
+    Mat4f to_world, to_local;
+};
+
+struct CameraRec // reference camera.cpp:26-37
+{
+    int32_t width, height;
+    uint32_t spp;
+    float spp_inv;
+    Vec3f eye, front, dx, dy;
+};
+
+struct IntegratorRec // reference integrator.hpp:31-69 (the scalar part)
+{
+    uint32_t volpath, hide_emitters;
+    float pdf_rr, rr_scale; // rr_scale == pdf_rr (renderer.cpp:634, quirk Q2)
+    uint32_t depth_rr, depth_max;
+    uint32_t n_emitters, n_area_lights;
+    uint32_t id_sun, id_envmap;
+    uint32_t n_tlas_nodes, n_nodes, n_instances, n_prims;
+};
+
+// Feature bits: which parts of the hot path a scene actually exercises.  The
+// launcher picks a kernel instantiation from them.
+enum SceneFeature : uint32_t
+{
+    kFeatVolPath = 1u << 0,     // volpath integrator / media
+    kFeatEmitters = 1u << 1,    // non-area emitters present
+    kFeatAnalytic = 1u << 2,    // sphere / disk / cylinder instances
+    kFeatTextures = 1u << 3,    // non-constant textures, bump or opacity maps
+    kFeatMicrofacet = 1u << 4,  // any BSDF other than diffuse / area light
+};
+
+// Device view: raw pointers into HBM + the scalar records.
+struct DeviceScene
+{
+    CameraRec camera;
+    IntegratorRec integrator;
+    uint32_t features;
+    uint32_t pad0;
+
+    const float4 *nodes;       // 2 per node
+    const float *node_area;    // 1 per node
+    const float4 *tri_pos;     // 3 per triangle slot (global primitive index)
+    const float4 *tri_attr;    // 9 per triangle slot
+    const InstanceRec *instances;
+    const AnalyticRec *analytic;
+    const uint32_t *light_inst; // area light k -> instance
+    const float *light_cdf;     // n_area_lights + 1, not normalised
+    const TextureRec *textures;
+    const float *texels;
+    const BsdfRec *bsdfs;
+    const MediumRec *media;
+    const EmitterRec *emitters;
+    const float *env_tables;
+    const float *lut_brdf;   // kLutRes * kLutRes
+    const float *lut_albedo; // kLutRes
+};
+
+// Counters of the measurement mode: totals over a launch.
+struct TraceCounters
+{
+    unsigned long long closest_rays, shadow_rays, node_tests, prim_tests,
+        shaded_hits, samples;
+};
+
+} // namespace mcpt
+
+#endif // MCPT_DEVICE_SCENE_H

@@ -1,0 +1,31 @@
+// Launch interface between the C-ABI layer (capi.cpp) and the HIP kernel.
+#ifndef MCPT_RENDER_KERNEL_H
+#define MCPT_RENDER_KERNEL_H
+
+#include <hip/hip_runtime_api.h>
+
+#include "../device_scene.h"
+
+namespace mcpt
+{
+
+constexpr int kBlockSize = 256;
+
+// Work description of one launch: pixels are enumerated tile by tile
+// (8x8 pixel tiles, row-major tile order); item q -> local tile q / 64, pixel
+// q % 64 inside it; global tile = tile_first + local_tile * tile_stride.
+struct RenderJob
+{
+    uint32_t n_items;     // 64 * number of tiles handled by this launch
+    uint32_t tile_first;  // first global tile
+    uint32_t tile_stride; // distance between consecutive tiles of this launch
+    uint32_t tiles_x;     // tiles per image row
+    uint32_t packed;      // 0: write frame layout, 1: write packed tile layout
+};
+
+hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
+                        hipStream_t stream, uint32_t n_cus, const char **variant);
+
+} // namespace mcpt
+
+#endif // MCPT_RENDER_KERNEL_H

@@ -1,0 +1,149 @@
+// HIP render kernel for gfx950 (MI355X): persistent lanes running the streaming
+// path-tracing state machine of path_core.h.
+//
+// Launch shape.  A workgroup is 256 lanes = 4 wavefronts of 64.  Work items are
+// pixels enumerated tile by tile (8x8 pixels per tile, so one wavefront starts
+// on one coherent tile); a lane processes item q, q + stride, ... where stride
+// is the total number of launched lanes, so the grid is sized to the machine
+// (CUs x resident workgroups) rather than to the image, and every lane keeps
+// regenerating paths until its pixels are exhausted.  No data is exchanged
+// between lanes: the per-pixel sequential RNG chain of the reference makes
+// the pixel the unit of parallelism.
+//
+// Memory.  All scene tables are read-only arrays in HBM (device_scene.h).  The
+// walk reads one 32-byte node (two float4 loads) per step and one 48-byte
+// triangle record per leaf; hit attributes (144 B) are read once per shaded
+// hit.  Path state lives in registers; the only writes are 12 B per finished
+// pixel.  There is no matrix-shaped work here: no MFMA, no LDS staging of
+// operands — the node/triangle arrays of small scenes sit in the per-CU L1 /
+// per-XCD L2, large ones stream from HBM through L2.
+#include <hip/hip_runtime.h>
+
+#include "../path_core.h"
+#include "render_kernel.h"
+
+namespace mcpt
+{
+
+template <uint32_t kFeatures, bool kCount>
+__global__ void __launch_bounds__(kBlockSize)
+render_kernel(const DeviceScene sc, const RenderJob job, float *__restrict__ out, TraceCounters *__restrict__ counters)
+{
+    using C = Config<kFeatures>;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t width = static_cast<uint32_t>(sc.camera.width), height = static_cast<uint32_t>(sc.camera.height);
+
+    LaneCounters local{0, 0, 0, 0, 0, 0};
+    LaneCounters *cnt = kCount ? &local : nullptr;
+
+    PathState st;
+    st.alive = false;
+    bool has_pixel = false;
+    uint32_t slot = 0; // where this pixel's result goes
+    for (;;)
+    {
+        if (!has_pixel)
+        {
+            if (q >= job.n_items)
+                break;
+            // item -> tile -> pixel
+            const uint32_t local_tile = q >> 6, r = q & 63u;
+            const uint32_t tile = job.tile_first + local_tile * job.tile_stride;
+            const uint32_t x = (tile % job.tiles_x) * 8u + (r & 7u), y = (tile / job.tiles_x) * 8u + (r >> 3);
+            const uint32_t item = q;
+            q += stride;
+            if (x >= width || y >= height)
+                continue; // padding of an edge tile
+            const uint32_t pixel = y * width + x;
+            start_pixel(st, pixel);
+            slot = job.packed ? item : pixel;
+            has_pixel = true;
+        }
+        if (!st.alive)
+        {
+            if (st.sample >= sc.camera.spp)
+            {
+                const V3 c = pixel_value(sc, st);
+                float *dst = out + 3 * static_cast<size_t>(slot);
+                dst[0] = c.x, dst[1] = c.y, dst[2] = c.z;
+                has_pixel = false;
+                continue;
+            }
+            start_sample(sc, st);
+            if (kCount)
+                ++local.samples;
+        }
+        path_step<C>(sc, st, cnt);
+    }
+
+    if (kCount)
+    {
+        atomicAdd(&counters->closest_rays, static_cast<unsigned long long>(local.closest_rays));
+        atomicAdd(&counters->shadow_rays, static_cast<unsigned long long>(local.shadow_rays));
+        atomicAdd(&counters->node_tests, static_cast<unsigned long long>(local.node_tests));
+        atomicAdd(&counters->prim_tests, static_cast<unsigned long long>(local.prim_tests));
+        atomicAdd(&counters->shaded_hits, static_cast<unsigned long long>(local.shaded_hits));
+        atomicAdd(&counters->samples, static_cast<unsigned long long>(local.samples));
+    }
+}
+
+namespace
+{
+
+constexpr uint32_t kAll = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
+
+template <uint32_t kFeatures, bool kCount>
+hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters, hipStream_t stream,
+                  uint32_t max_blocks)
+{
+    int per_cu = 0;
+    hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<kFeatures, kCount>,
+                                                                  kBlockSize, 0);
+    if (err != hipSuccess)
+        return err;
+    if (per_cu < 1)
+        per_cu = 1;
+    uint32_t blocks = (job.n_items + kBlockSize - 1) / kBlockSize;
+    const uint32_t resident = max_blocks * static_cast<uint32_t>(per_cu);
+    if (blocks > resident)
+        blocks = resident;
+    if (blocks == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL((render_kernel<kFeatures, kCount>), dim3(blocks), dim3(kBlockSize), 0, stream, sc, job, out,
+                       counters);
+    return hipGetLastError();
+}
+
+} // namespace
+
+// Picks the leanest instantiation that covers the scene's feature bits.
+hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
+                        hipStream_t stream, uint32_t n_cus, const char **variant)
+{
+    const uint32_t f = sc.features;
+    if (counters != nullptr)
+    {
+        *variant = "all+count";
+        return Launch<kAll, true>(sc, job, out, counters, stream, n_cus);
+    }
+    if (f == 0)
+    {
+        *variant = "diffuse-area";
+        return Launch<0, false>(sc, job, out, nullptr, stream, n_cus);
+    }
+    if ((f & ~kFeatEmitters) == 0)
+    {
+        *variant = "diffuse-emitters";
+        return Launch<kFeatEmitters, false>(sc, job, out, nullptr, stream, n_cus);
+    }
+    if ((f & ~(kFeatEmitters | kFeatTextures | kFeatMicrofacet)) == 0)
+    {
+        *variant = "surface-materials";
+        return Launch<kFeatEmitters | kFeatTextures | kFeatMicrofacet, false>(sc, job, out, nullptr, stream, n_cus);
+    }
+    *variant = "all";
+    return Launch<kAll, false>(sc, job, out, nullptr, stream, n_cus);
+}
+
+} // namespace mcpt

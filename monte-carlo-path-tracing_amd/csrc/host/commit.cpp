@@ -1,0 +1,1058 @@
+// Scene commit: flatten a renderer configuration into the HBM layout of
+// device_scene.h.  Runs once per scene on the host.
+//
+// What must agree with the reference (the kernels consume these tables and the
+// image depends on them): world-space baking of meshes and their tangent
+// frames (reference src/rtcore/scene.cpp:15-111,247-324), unit rectangle /
+// cube tessellation (scene.cpp:196-245), analytic shape constants
+// (scene.cpp:326-472), the LBVH topology — it fixes the traversal order and
+// the area-weighted light sampling (src/rtcore/accel/bvh_builder.cpp:74-207),
+// light tables (src/renderer/renderer.cpp:271-304), per-BSDF constants
+// (src/renderer/bsdfs/bsdf.cpp:112-186), medium constants
+// (src/renderer/medium/medium.cpp:6-39), emitter constants and env-map tables
+// (src/renderer/emitters/emitter.cpp:122-175, envmap.cpp:20-68,
+// renderer.cpp:597-606), the Kulla-Conty LUT (kulla_conty.cpp:12-80).
+#include "commit.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+
+#include "../textures.h"
+#include "../vecmath.h"
+
+namespace mcpt
+{
+namespace
+{
+
+// ---- host-only 4x4 helpers (reference src/tensor/mat4.cpp) -----------------
+Mat4f Identity()
+{
+    Mat4f r{};
+    r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0f;
+    return r;
+}
+
+Mat4f Load(const float *p)
+{
+    Mat4f r;
+    std::memcpy(r.m, p, sizeof(r.m));
+    return r;
+}
+
+Mat4f Transposed(const Mat4f &a)
+{
+    Mat4f r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            r.m[4 * i + j] = a.m[4 * j + i];
+    return r;
+}
+
+Mat4f Multiply(const Mat4f &a, const Mat4f &b) // mat4.cpp:196-211: row . column, left to right
+{
+    Mat4f r;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            r.m[4 * i + j] = a.m[4 * i + 0] * b.m[0 + j] + a.m[4 * i + 1] * b.m[4 + j] +
+                             a.m[4 * i + 2] * b.m[8 + j] + a.m[4 * i + 3] * b.m[12 + j];
+    return r;
+}
+
+// mat4.cpp:110-168 — cofactor inverse in the reference's term grouping: 18
+// 2x2 minors of rows 1..3, four cofactor columns built as a*b - c*d + e*f,
+// alternating signs, determinant from row 0 as (p0 + p1) + (p2 + p3).
+Mat4f Inverted(const Mat4f &a)
+{
+    const float *r0 = a.m, *r1 = a.m + 4, *r2 = a.m + 8, *r3 = a.m + 12;
+    enum { X, Y, Z, W };
+    auto minor2 = [](const float *p, const float *q, int c0, int c1)
+    { return p[c0] * q[c1] - q[c0] * p[c1]; };
+    // for each column pair, the minors over row pairs (2,3), (1,3), (1,2)
+    const float zw[3] = {minor2(r2, r3, Z, W), minor2(r1, r3, Z, W), minor2(r1, r2, Z, W)};
+    const float yw[3] = {minor2(r2, r3, Y, W), minor2(r1, r3, Y, W), minor2(r1, r2, Y, W)};
+    const float yz[3] = {minor2(r2, r3, Y, Z), minor2(r1, r3, Y, Z), minor2(r1, r2, Y, Z)};
+    const float xw[3] = {minor2(r2, r3, X, W), minor2(r1, r3, X, W), minor2(r1, r2, X, W)};
+    const float xz[3] = {minor2(r2, r3, X, Z), minor2(r1, r3, X, Z), minor2(r1, r2, X, Z)};
+    const float xy[3] = {minor2(r2, r3, X, Y), minor2(r1, r3, X, Y), minor2(r1, r2, X, Y)};
+    // lane k of the reference's fac vectors uses minor index {0,0,1,2}[k];
+    // lane k of its vec vectors uses row 1 for k = 0 and row 0 otherwise.
+    static const int pick[4] = {0, 0, 1, 2};
+    float adj[4][4];
+    for (int k = 0; k < 4; ++k)
+    {
+        const float *row = (k == 0) ? r1 : r0;
+        const int s = pick[k];
+        const float sign_a = (k % 2 == 0) ? 1.0f : -1.0f, sign_b = -sign_a;
+        adj[0][k] = (row[Y] * zw[s] - row[Z] * yw[s] + row[W] * yz[s]) * sign_a;
+        adj[1][k] = (row[X] * zw[s] - row[Z] * xw[s] + row[W] * xz[s]) * sign_b;
+        adj[2][k] = (row[X] * yw[s] - row[Y] * xw[s] + row[W] * xy[s]) * sign_a;
+        adj[3][k] = (row[X] * yz[s] - row[Y] * xz[s] + row[Z] * xy[s]) * sign_b;
+    }
+    const float p0 = r0[X] * adj[0][0], p1 = r0[Y] * adj[1][0], p2 = r0[Z] * adj[2][0],
+                p3 = r0[W] * adj[3][0];
+    const float rcp_det = 1.0f / ((p0 + p1) + (p2 + p3));
+    Mat4f out;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            out.m[4 * i + j] = rcp_det * adj[i][j];
+    return out;
+}
+
+Mat4f TranslationMatrix(V3 t) // mat4.cpp:229-235
+{
+    Mat4f r = Identity();
+    r.m[3] = t.x, r.m[7] = t.y, r.m[11] = t.z;
+    return r;
+}
+
+// math.cpp:148-166: frame with the given z axis, as a matrix (cylinders).
+Mat4f FrameAroundAxis(V3 up)
+{
+    V3 c;
+    if (std::sqrt(D(sqr(up.x) + sqr(up.z))) > D(kEpsFloat))
+    {
+        const float k = static_cast<float>(1.0 / std::sqrt(D(sqr(up.x) + sqr(up.z))));
+        c = V3{-up.z * k, 0, up.x * k};
+    }
+    else
+    {
+        const float k = static_cast<float>(1.0 / std::sqrt(D(sqr(up.y) + sqr(up.z))));
+        c = V3{0, -up.z * k, up.y * k};
+    }
+    const V3 b = normalize(cross(c, up));
+    Mat4f r = Identity();
+    r.m[0] = b.x, r.m[1] = b.y, r.m[2] = b.z;
+    r.m[4] = c.x, r.m[5] = c.y, r.m[6] = c.z;
+    r.m[8] = up.x, r.m[9] = up.y, r.m[10] = up.z;
+    return r;
+}
+
+V3 Load3(const float *p) { return V3{p[0], p[1], p[2]}; }
+Vec3f Store3(V3 v) { return Vec3f{v.x, v.y, v.z}; }
+float4 Pack(V3 v, float w) { return float4{v.x, v.y, v.z, w}; }
+float Bits(uint32_t u)
+{
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// ---- bounding boxes ---------------------------------------------------------
+struct Bounds
+{
+    V3 lo{kMaxFloat, kMaxFloat, kMaxFloat}, hi{kLowestFloat, kLowestFloat, kLowestFloat}; // aabb.cpp:8
+    void Add(V3 p) { lo = vmin(p, lo), hi = vmax(p, hi); }
+    void Add(const Bounds &b) { lo = vmin(b.lo, lo), hi = vmax(b.hi, hi); }
+};
+
+// ---- LBVH -------------------------------------------------------------------
+// Same keys, same sort, same split rule as bvh_builder.cpp, emitted directly in
+// the stackless layout: pre-order array + skip links instead of child links.
+struct TreeNode
+{
+    Bounds box;
+    float area = 0;
+    uint32_t object = kNoObject; // leaves only
+    uint32_t skip = kEndOfTree;  // tree-local
+};
+
+uint32_t Dilate10(uint32_t v) // bvh_builder.cpp:14-21
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+uint32_t MortonCode(V3 unit) // bvh_builder.cpp:38-48
+{
+    const float x = fminf(fmaxf(unit.x * 1024.0f, 0.0f), 1023.0f),
+                y = fminf(fmaxf(unit.y * 1024.0f, 0.0f), 1023.0f),
+                z = fminf(fmaxf(unit.z * 1024.0f, 0.0f), 1023.0f);
+    return Dilate10(static_cast<uint32_t>(x)) * 4 + Dilate10(static_cast<uint32_t>(y)) * 2 +
+           Dilate10(static_cast<uint32_t>(z));
+}
+
+int CommonPrefix(uint64_t a, uint64_t b) // clz(a ^ b), 64 when equal (bvh_builder.cpp:23-34)
+{
+    const uint64_t x = a ^ b;
+    return x == 0 ? 64 : __builtin_clzll(x);
+}
+
+class LinearBvh
+{
+public:
+    LinearBvh(const std::vector<Bounds> &boxes, const std::vector<float> &areas)
+        : boxes_(boxes), areas_(areas)
+    {
+        const uint32_t n = static_cast<uint32_t>(boxes.size());
+        Bounds all;
+        for (const Bounds &b : boxes)
+            all.Add(b);
+        const V3 extent = all.hi - all.lo;
+        keys_.resize(n);
+        order_.resize(n);
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            const V3 centre = (boxes[i].lo + boxes[i].hi) * 0.5f;
+            keys_[i] = (static_cast<uint64_t>(MortonCode((centre - all.lo) / extent)) << 32) | i;
+            order_[i] = i;
+        }
+        std::sort(order_.begin(), order_.end(),
+                  [&](uint32_t a, uint32_t b) { return keys_[a] < keys_[b]; });
+        nodes_.reserve(n ? 2 * static_cast<size_t>(n) - 1 : 0);
+        if (n)
+            Emit(0, n, kEndOfTree);
+    }
+
+    std::vector<TreeNode> nodes_;
+
+private:
+    // bvh_builder.cpp:172-206
+    uint32_t SplitPoint(uint32_t first, uint32_t last) const
+    {
+        const uint64_t a = keys_[order_[first]], z = keys_[order_[last - 1]];
+        if (a == z)
+            return (first + last) >> 1;
+        const int common = CommonPrefix(a, z);
+        uint32_t split = first, step = last - first;
+        do
+        {
+            step = (step + 1) >> 1;
+            const uint32_t probe = split + step;
+            if (probe < last && CommonPrefix(a, keys_[order_[probe]]) > common)
+                split = probe;
+        } while (step > 1);
+        return split;
+    }
+
+    // Pre-order emission (bvh_builder.cpp:143-170).  `skip` is where the
+    // traversal continues after this subtree: the right sibling for a left
+    // child, the parent's skip for a right child.
+    uint32_t Emit(uint32_t begin, uint32_t end, uint32_t skip)
+    {
+        const uint32_t id = static_cast<uint32_t>(nodes_.size());
+        nodes_.emplace_back();
+        nodes_[id].skip = skip;
+        if (begin + 1 == end)
+        {
+            const uint32_t obj = order_[begin];
+            nodes_[id].object = obj;
+            nodes_[id].box = boxes_[obj];
+            nodes_[id].area = areas_[obj];
+            return id;
+        }
+        const uint32_t mid = SplitPoint(begin, end) + 1;
+        // the left subtree has 2*(mid-begin)-1 nodes, so the right child's
+        // index is known before recursing
+        const uint32_t right_id = id + 1 + (2 * (mid - begin) - 1);
+        const uint32_t l = Emit(begin, mid, right_id);
+        const uint32_t r = Emit(mid, end, skip);
+        nodes_[id].area = nodes_[l].area + nodes_[r].area;
+        nodes_[id].box.lo = vmin(nodes_[l].box.lo, nodes_[r].box.lo); // aabb.cpp:50-53
+        nodes_[id].box.hi = vmax(nodes_[l].box.hi, nodes_[r].box.hi);
+        return id;
+    }
+
+    const std::vector<Bounds> &boxes_;
+    const std::vector<float> &areas_;
+    std::vector<uint64_t> keys_;
+    std::vector<uint32_t> order_;
+};
+
+// ---- meshes -----------------------------------------------------------------
+struct MeshSource
+{
+    std::vector<V2> uv;
+    std::vector<V3> pos, nrm, tan, bit;
+    std::vector<uint32_t> idx;
+};
+
+MeshSource RectangleSource() // scene.cpp:196-212
+{
+    MeshSource m;
+    m.uv = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+    m.pos = {{-1, -1, 0}, {1, -1, 0}, {1, 1, 0}, {-1, 1, 0}};
+    m.nrm = {{0, 0, 1}, {0, 0, 1}, {0, 0, 1}, {0, 0, 1}};
+    m.idx = {0, 1, 2, 2, 3, 0};
+    return m;
+}
+
+// scene.cpp:214-245.  24 vertices = 6 faces x 4 corners.  Corner signs per
+// face are generated from the face's axis triple instead of a literal table:
+// face order -y, +y, +x, +z, -x, -z.
+MeshSource CubeSource()
+{
+    struct Face
+    {
+        int axis;          // fixed axis
+        float side;        // its sign
+        float a[4], b[4];  // the two remaining coordinates, per corner
+    };
+    // remaining axes are taken in (x,y,z) order with the fixed one removed
+    static const Face faces[6] = {
+        {1, -1, {1, 1, -1, -1}, {-1, 1, 1, -1}},   // -y : (x, z)
+        {1, +1, {1, -1, -1, 1}, {-1, -1, 1, 1}},   // +y : (x, z)
+        {0, +1, {-1, 1, 1, -1}, {-1, -1, 1, 1}},   // +x : (y, z)
+        {2, +1, {1, 1, -1, -1}, {-1, 1, 1, -1}},   // +z : (x, y)
+        {0, -1, {-1, 1, 1, -1}, {1, 1, -1, -1}},   // -x : (y, z)
+        {2, -1, {1, 1, -1, -1}, {1, -1, -1, 1}},   // -z : (x, y)
+    };
+    static const float corner_uv[4][2] = {{0, 1}, {1, 1}, {1, 0}, {0, 0}};
+    MeshSource m;
+    for (int f = 0; f < 6; ++f)
+    {
+        const Face &F = faces[f];
+        for (int c = 0; c < 4; ++c)
+        {
+            float p[3];
+            int slot = 0;
+            for (int ax = 0; ax < 3; ++ax)
+                p[ax] = (ax == F.axis) ? F.side : (slot++ == 0 ? F.a[c] : F.b[c]);
+            float n[3] = {0, 0, 0};
+            n[F.axis] = F.side;
+            m.pos.push_back({p[0], p[1], p[2]});
+            m.nrm.push_back({n[0], n[1], n[2]});
+            m.uv.push_back({corner_uv[c][0], corner_uv[c][1]});
+        }
+        const uint32_t o = 4 * f;
+        const uint32_t tri[6] = {o, o + 1, o + 2, o + 3, o, o + 2};
+        m.idx.insert(m.idx.end(), tri, tri + 6);
+    }
+    return m;
+}
+
+MeshSource MeshFromRecord(const mcsd::Instance &in)
+{
+    MeshSource m;
+    for (size_t k = 0; k + 1 < in.texcoords.size(); k += 2)
+        m.uv.push_back({in.texcoords[k], in.texcoords[k + 1]});
+    auto load = [](const std::vector<float> &src, std::vector<V3> &dst)
+    {
+        for (size_t k = 0; k + 2 < src.size(); k += 3)
+            dst.push_back({src[k], src[k + 1], src[k + 2]});
+    };
+    load(in.positions, m.pos), load(in.normals, m.nrm), load(in.tangents, m.tan),
+        load(in.bitangents, m.bit);
+    m.idx = in.indices;
+    return m;
+}
+
+struct TriangleRecord
+{
+    V2 uv[3];
+    V3 p[3], n[3], t[3], b[3];
+};
+
+// Bake to world space (scene.cpp:247-284) and build per-triangle records with
+// the reference's tangent-frame rules (scene.cpp:15-111).  The "area" is
+// |e1 x e2|, i.e. twice the triangle area, exactly as the reference stores it
+// (scene.cpp:49) — light sampling and MIS use it consistently.
+void BakeTriangles(MeshSource m, const Mat4f &to_world, std::vector<TriangleRecord> &tris,
+                   std::vector<float> &areas)
+{
+    if (m.idx.empty())
+        throw std::runtime_error("cannot find vertex index info when adding instance to scene.");
+    if (m.pos.empty())
+        throw std::runtime_error("cannot find vertex position info when adding instance to scene.");
+    for (V3 &p : m.pos)
+        p = transform_point(to_world, p);
+    if (!m.nrm.empty())
+    {
+        const Mat4f normal_to_world = Inverted(Transposed(to_world));
+        for (V3 &n : m.nrm)
+            n = transform_dir(normal_to_world, n);
+    }
+    for (V3 &t : m.tan)
+        t = transform_dir(to_world, t);
+    for (V3 &b : m.bit)
+        b = transform_dir(to_world, b);
+
+    const size_t count = m.idx.size() / 3;
+    tris.resize(count);
+    areas.resize(count);
+    const size_t n_vert = m.pos.size();
+    for (size_t i = 0; i < count; ++i)
+    {
+        TriangleRecord &tri = tris[i];
+        const uint32_t *id = &m.idx[3 * i];
+        for (int j = 0; j < 3; ++j)
+            if (id[j] >= n_vert)
+                throw std::runtime_error("mesh index out of range.");
+        if (m.uv.empty())
+            tri.uv[0] = {0, 0}, tri.uv[1] = {1, 0}, tri.uv[2] = {1, 1};
+        else
+            for (int j = 0; j < 3; ++j)
+                tri.uv[j] = m.uv.at(id[j]);
+        for (int j = 0; j < 3; ++j)
+            tri.p[j] = m.pos[id[j]];
+        const V3 e1 = tri.p[1] - tri.p[0], e2 = tri.p[2] - tri.p[0];
+        const V3 ng = cross(e1, e2);
+        areas[i] = length(ng);
+        if (m.nrm.empty())
+        {
+            const V3 flat = normalize(ng);
+            tri.n[0] = tri.n[1] = tri.n[2] = flat;
+        }
+        else
+        {
+            for (int j = 0; j < 3; ++j)
+                tri.n[j] = m.nrm.at(id[j]);
+        }
+        if (m.tan.empty() && m.bit.empty())
+        {
+            const V2 d1 = tri.uv[1] - tri.uv[0], d2 = tri.uv[2] - tri.uv[0];
+            const float r = 1.0f / (d1.v * d2.u - d1.u * d2.v);
+            const V3 tangent = normalize((d1.v * e2 - d2.v * e1) * r);
+            for (int j = 0; j < 3; ++j)
+            {
+                tri.b[j] = normalize(cross(tri.n[j], tangent));
+                tri.t[j] = normalize(cross(tri.b[j], tri.n[j]));
+            }
+        }
+        else if (m.tan.empty())
+        {
+            for (int j = 0; j < 3; ++j)
+            {
+                tri.b[j] = m.bit.at(id[j]);
+                tri.t[j] = normalize(cross(tri.b[j], tri.n[j]));
+                tri.b[j] = normalize(cross(tri.n[j], tri.t[j]));
+            }
+        }
+        else
+        {
+            for (int j = 0; j < 3; ++j)
+            {
+                tri.t[j] = m.tan.at(id[j]);
+                tri.b[j] = normalize(cross(tri.n[j], tri.t[j]));
+                tri.t[j] = normalize(cross(tri.b[j], tri.n[j]));
+            }
+        }
+    }
+}
+
+// ---- Kulla-Conty ------------------------------------------------------------
+void ComputeKullaContyRow(int i, float *brdf, float *albedo)
+{
+    constexpr uint32_t kSamples = 1024;
+    constexpr float kSampleStep = 1.0f / kSamples;
+    const float step = 1.0f / kLutRes;
+    const V3 n = V3{0.0f, 0.0f, 1.0f};
+    float albedo_sum = 0.0f;
+    const float alpha = step * (static_cast<float>(i) + 0.5f);
+    for (int j = kLutRes - 1; j >= 0; --j)
+    {
+        const float mu = step * (static_cast<float>(j) + 0.5f);
+        const V3 view = V3{-sqrtf(1.f - mu * mu), 0.0f, -mu};
+        float acc = 0.0f; // directional albedo of the single-scatter lobe (kulla_conty.cpp:12-36)
+        for (uint32_t s = 0; s < kSamples; ++s)
+        {
+            V3 h;
+            float pdf_h;
+            ggx_sample_iso(s * kSampleStep, radical_inverse2(s), alpha, h, pdf_h);
+            const V3 l = reflect(view, h);
+            const float g = smith_g1_iso(alpha, -view, h) * smith_g1_iso(alpha, l, h);
+            const float n_v = dot(n, -view), n_l = dot(n, l), n_h = dot(n, h), h_v = dot(h, -view);
+            if (n_l > 0.0f && n_h > 0.0f && h_v > 0.0f)
+                acc += (h_v * g) / (n_v * n_h);
+        }
+        const float e = fminf(acc * kSampleStep, 1.0f);
+        brdf[i * kLutRes + j] = e;
+        float acc2 = 0.0f; // kulla_conty.cpp:38-58
+        for (uint32_t s = 0; s < kSamples; ++s)
+        {
+            V3 h;
+            float pdf_h;
+            ggx_sample_iso(s * kSampleStep, radical_inverse2(s), alpha, h, pdf_h);
+            const V3 l = reflect(view, h);
+            const float n_l = dot(n, l), n_h = dot(n, h), h_v = dot(-view, h);
+            if (n_l > 0.0f && n_h > 0.0f && h_v > 0.0f)
+                acc2 += e * n_l;
+        }
+        albedo_sum += acc2 * 2.0f * kSampleStep;
+    }
+    albedo[i] = albedo_sum * step;
+}
+
+// bsdf.cpp:12-38
+float AverageFresnelDielectric(float eta)
+{
+    if (eta < 1.0)
+        return -1.4399f * sqr(eta) + 0.7099f * eta + 0.6681f + 0.0636f / eta;
+    const float i1 = 1.0f / eta, i2 = i1 * i1, i3 = i2 * i1, i4 = i3 * i1, i5 = i4 * i1;
+    return 0.919317f - 3.4793f * i1 + 6.75335f * i2 - 7.80989f * i3 + 4.98554f * i4 - 1.36881f * i5;
+}
+
+// bsdf.cpp:40-52
+V3 AverageFresnelConductor(V3 r, V3 g)
+{
+    return splat(0.087237f) + 0.0230685f * g - 0.0864902f * g * g + 0.0774594f * g * g * g +
+           0.782654f * r - 0.136432f * r * r + 0.278708f * r * r * r + 0.19744f * g * r +
+           0.0360605f * g * g * r - 0.2586f * g * r * r;
+}
+
+std::string TextureError(uint32_t id) { return "cannot find texture (id " + std::to_string(id) + ")."; }
+
+} // namespace
+
+void KullaContyTables(const float **brdf, const float **albedo)
+{
+    static std::once_flag once;
+    static std::vector<float> s_brdf, s_albedo;
+    std::call_once(once, []()
+                   {
+                       s_brdf.assign(kLutRes * kLutRes, 0.0f);
+                       s_albedo.assign(kLutRes, 0.0f);
+                       unsigned workers = std::max(1u, std::thread::hardware_concurrency());
+                       std::vector<std::thread> pool;
+                       for (unsigned t = 0; t < workers; ++t)
+                           pool.emplace_back([t, workers]()
+                                             {
+                                                 for (int i = kLutRes - 1 - static_cast<int>(t); i >= 0;
+                                                      i -= static_cast<int>(workers))
+                                                     ComputeKullaContyRow(i, s_brdf.data(), s_albedo.data());
+                                             });
+                       for (std::thread &t : pool)
+                           t.join();
+                   });
+    *brdf = s_brdf.data();
+    *albedo = s_albedo.data();
+}
+
+DeviceScene FlatScene::HostView() const
+{
+    DeviceScene d{};
+    d.camera = camera, d.integrator = integrator, d.features = features;
+    d.nodes = nodes.data(), d.node_area = node_area.data();
+    d.tri_pos = tri_pos.data(), d.tri_attr = tri_attr.data();
+    d.instances = instances.data(), d.analytic = analytic.data();
+    d.light_inst = light_inst.data(), d.light_cdf = light_cdf.data();
+    d.textures = textures.data(), d.texels = texels.data();
+    d.bsdfs = bsdfs.data(), d.media = media.data(), d.emitters = emitters.data();
+    d.env_tables = env_tables.data();
+    d.lut_brdf = lut_brdf.data(), d.lut_albedo = lut_albedo.data();
+    return d;
+}
+
+size_t FlatScene::GeometryBytes() const
+{
+    return nodes.size() * sizeof(float4) + tri_pos.size() * sizeof(float4) +
+           tri_attr.size() * sizeof(float4);
+}
+
+FlatScene CommitScene(const mcsd::Scene &in)
+{
+    FlatScene fs;
+
+    // ---- camera (camera.cpp:26-37; fov_y is linear in the angle, quirk Q4) --
+    {
+        const mcsd::Camera &c = in.camera;
+        if (c.width <= 0 || c.height <= 0 || c.spp == 0)
+            throw std::runtime_error("invalid film size or sample count.");
+        fs.camera.width = c.width, fs.camera.height = c.height, fs.camera.spp = c.spp;
+        fs.camera.spp_inv = 1.0f / c.spp;
+        const V3 eye = Load3(c.eye), look_at = Load3(c.look_at), up0 = Load3(c.up);
+        const float fov_y = c.fov_x * c.height / c.width;
+        const V3 front = normalize(look_at - eye);
+        const V3 right = normalize(cross(front, up0));
+        const V3 up = normalize(cross(right, front));
+        fs.camera.eye = Store3(eye), fs.camera.front = Store3(front);
+        fs.camera.dx = Store3(right * tanf(c.fov_x * 0.5f * 0.01745329251994329576923690768489f));
+        fs.camera.dy = Store3(up * tanf(fov_y * 0.5f * 0.01745329251994329576923690768489f));
+    }
+    // ToRadians(0.5f * fov) = (0.5f * fov) * k; written above as fov * 0.5f * k,
+    // the same two roundings in the same order.
+
+    IntegratorRec &ig = fs.integrator;
+    ig.volpath = in.integrator.type == MCSD_INTEGRATOR_VOLPATH;
+    ig.hide_emitters = in.integrator.hide_emitters != 0;
+    ig.pdf_rr = in.integrator.pdf_rr;
+    ig.rr_scale = in.integrator.pdf_rr; // renderer.cpp:634: the "reciprocal" holds pdf_rr itself
+    ig.depth_rr = in.integrator.depth_rr;
+    ig.depth_max = in.integrator.depth_max;
+    ig.id_sun = ig.id_envmap = kNone;
+    if (ig.volpath)
+        fs.features |= kFeatVolPath;
+
+    // ---- geometry: one BLAS per instance ------------------------------------
+    const uint32_t n_inst = static_cast<uint32_t>(in.instances.size());
+    std::vector<std::vector<TreeNode>> blas(n_inst);
+    std::vector<uint32_t> prim_base(n_inst);
+    uint32_t n_prims = 0;
+    fs.instances.resize(n_inst);
+    for (uint32_t i = 0; i < n_inst; ++i)
+    {
+        const mcsd::Instance &s = in.instances[i];
+        InstanceRec &rec = fs.instances[i];
+        rec = InstanceRec{};
+        rec.analytic = kNone;
+        const Mat4f to_world = Load(s.to_world);
+        std::vector<Bounds> boxes;
+        std::vector<float> areas;
+        prim_base[i] = n_prims;
+        auto add_triangles = [&](MeshSource src)
+        {
+            std::vector<TriangleRecord> tris;
+            BakeTriangles(std::move(src), to_world, tris, areas);
+            boxes.resize(tris.size());
+            for (size_t k = 0; k < tris.size(); ++k)
+            {
+                const TriangleRecord &t = tris[k];
+                for (int j = 0; j < 3; ++j)
+                {
+                    boxes[k].Add(t.p[j]); // triangle.cpp:9-15
+                    fs.tri_pos.push_back(Pack(t.p[j], 0.0f));
+                }
+                const float w[9] = {t.uv[0].u, t.uv[0].v, t.uv[1].u, t.uv[1].v, t.uv[2].u, t.uv[2].v, 0, 0, 0};
+                for (int j = 0; j < 3; ++j)
+                    fs.tri_attr.push_back(Pack(t.n[j], w[j]));
+                for (int j = 0; j < 3; ++j)
+                    fs.tri_attr.push_back(Pack(t.t[j], w[3 + j]));
+                for (int j = 0; j < 3; ++j)
+                    fs.tri_attr.push_back(Pack(t.b[j], 0.0f));
+            }
+            rec.kind = kInstTriangles;
+            n_prims += static_cast<uint32_t>(tris.size());
+        };
+        auto add_analytic = [&](uint32_t kind, const AnalyticRec &a, const Bounds &box, float area)
+        {
+            rec.kind = kind;
+            rec.analytic = static_cast<uint32_t>(fs.analytic.size());
+            fs.analytic.push_back(a);
+            boxes = {box};
+            areas = {area};
+            // keep the global primitive numbering dense: one (unused) slot
+            for (int j = 0; j < 3; ++j)
+                fs.tri_pos.push_back(float4{0, 0, 0, 0});
+            for (int j = 0; j < 9; ++j)
+                fs.tri_attr.push_back(float4{0, 0, 0, 0});
+            n_prims += 1;
+            fs.features |= kFeatAnalytic;
+        };
+        switch (s.type)
+        {
+        case MCSD_INST_RECTANGLE:
+            add_triangles(RectangleSource());
+            break;
+        case MCSD_INST_CUBE:
+            add_triangles(CubeSource());
+            break;
+        case MCSD_INST_MESHES:
+            add_triangles(MeshFromRecord(s));
+            break;
+        case MCSD_INST_SPHERE: // scene.cpp:326-372, sphere.cpp:9-15
+        {
+            AnalyticRec a{};
+            a.radius = s.sphere_radius;
+            const V3 centre = Load3(s.sphere_center);
+            a.center = Store3(centre);
+            a.to_world = to_world, a.to_local = Inverted(to_world);
+            a.normal_to_world = Inverted(Transposed(to_world));
+            Bounds box;
+            box.Add(transform_point(to_world, centre + a.radius));
+            box.Add(transform_point(to_world, centre - a.radius));
+            const V3 cw = transform_point(to_world, centre),
+                     bw = transform_point(to_world, centre + V3{a.radius, 0.0f, 0.0f});
+            add_analytic(kInstSphere, a, box, 4.0f * kPi * sqr(length(cw - bw)));
+            break;
+        }
+        case MCSD_INST_DISK: // scene.cpp:374-416, disk.cpp:9-15
+        {
+            AnalyticRec a{};
+            a.to_world = to_world, a.to_local = Inverted(to_world);
+            a.normal_to_world = Inverted(Transposed(to_world));
+            Bounds box;
+            box.Add(transform_point(to_world, V3{-0.5f, -0.5f, 0}));
+            box.Add(transform_point(to_world, V3{0.5f, 0.5f, 0}));
+            const V3 cw = transform_point(to_world, V3{0, 0, 0}),
+                     bw = transform_point(to_world, V3{0.5f, 0, 0});
+            add_analytic(kInstDisk, a, box, kPi * sqr(length(cw - bw)));
+            break;
+        }
+        case MCSD_INST_CYLINDER: // scene.cpp:418-472, cylinder.cpp:9-19
+        {
+            AnalyticRec a{};
+            const V3 p0 = Load3(s.cyl_p0), p1 = Load3(s.cyl_p1);
+            Mat4f m = FrameAroundAxis(normalize(p1 - p0));
+            m = Multiply(TranslationMatrix(p0), m);
+            m = Multiply(to_world, m);
+            const V3 origin_w = transform_point(m, V3{0, 0, 0});
+            a.length = length(transform_point(m, V3{0, 0, length(p1 - p0)}) - origin_w);
+            a.radius = length(transform_point(m, V3{s.cyl_radius, 0, 0}) - origin_w);
+            a.to_world = m, a.to_local = Inverted(m), a.normal_to_world = Inverted(Transposed(m));
+            Bounds box;
+            box.Add(transform_point(m, V3{a.radius, a.radius, 0}));
+            box.Add(transform_point(m, V3{-a.radius, -a.radius, 0}));
+            box.Add(transform_point(m, V3{a.radius, a.radius, a.length}));
+            box.Add(transform_point(m, V3{-a.radius, -a.radius, a.length}));
+            add_analytic(kInstCylinder, a, box, k2Pi * sqr(a.radius));
+            break;
+        }
+        default:
+            throw std::runtime_error("unknow instance type.");
+        }
+        blas[i] = std::move(LinearBvh(boxes, areas).nodes_);
+        rec.prim_base = prim_base[i];
+        rec.bsdf = s.id_bsdf;
+        rec.medium_int = s.id_medium_int, rec.medium_ext = s.id_medium_ext;
+        rec.area_light = kNone;
+        if (s.id_medium_int != kNone || s.id_medium_ext != kNone)
+            fs.features |= kFeatVolPath;
+    }
+
+    // ---- TLAS in front, then the BLAS trees (scene.cpp:474-533) -------------
+    std::vector<TreeNode> tlas;
+    if (n_inst)
+    {
+        std::vector<Bounds> boxes(n_inst);
+        std::vector<float> areas(n_inst);
+        for (uint32_t i = 0; i < n_inst; ++i)
+        {
+            boxes[i] = blas[i][0].box;
+            areas[i] = blas[i][0].area;
+            fs.instances[i].pdf_area = 1.0f / areas[i];
+        }
+        tlas = std::move(LinearBvh(boxes, areas).nodes_);
+    }
+    auto append_tree = [&](const std::vector<TreeNode> &tree, uint32_t object_base)
+    {
+        const uint32_t base = static_cast<uint32_t>(fs.node_area.size());
+        for (const TreeNode &n : tree)
+        {
+            const uint32_t skip = n.skip == kEndOfTree ? kEndOfTree : n.skip + base;
+            const uint32_t object = n.object == kNoObject ? kNoObject : n.object + object_base;
+            fs.nodes.push_back(Pack(n.box.lo, Bits(skip)));
+            fs.nodes.push_back(Pack(n.box.hi, Bits(object)));
+            fs.node_area.push_back(n.area);
+        }
+        return base;
+    };
+    append_tree(tlas, 0);
+    ig.n_tlas_nodes = static_cast<uint32_t>(tlas.size());
+    for (uint32_t i = 0; i < n_inst; ++i)
+        fs.instances[i].blas_root = append_tree(blas[i], prim_base[i]);
+    ig.n_nodes = static_cast<uint32_t>(fs.node_area.size());
+    ig.n_instances = n_inst;
+    ig.n_prims = n_prims;
+
+    // ---- light tables (renderer.cpp:271-304): weights are NOT normalised ----
+    std::vector<float> weights;
+    for (uint32_t i = 0; i < n_inst; ++i)
+    {
+        const uint32_t b = in.instances[i].id_bsdf;
+        if (b < in.bsdfs.size() && in.bsdfs[b].type == MCSD_BSDF_AREA_LIGHT)
+        {
+            fs.instances[i].area_light = static_cast<uint32_t>(fs.light_inst.size());
+            fs.light_inst.push_back(i);
+            weights.push_back(in.bsdfs[b].weight);
+        }
+    }
+    fs.light_cdf.assign(weights.size() + 1, 0.0f);
+    for (size_t k = 0; k < weights.size(); ++k)
+        fs.light_cdf[k + 1] = weights[k] + fs.light_cdf[k];
+    ig.n_area_lights = static_cast<uint32_t>(weights.size());
+
+    // ---- textures (renderer.cpp:371-431): one shared texel pool -------------
+    for (const mcsd::Texture &t : in.textures)
+    {
+        TextureRec o{};
+        o.to_uv = Identity();
+        switch (t.type)
+        {
+        case MCSD_TEX_CONSTANT:
+            o.kind = kTexConstant;
+            o.color = Vec3f{t.color[0], t.color[1], t.color[2]};
+            break;
+        case MCSD_TEX_CHECKERBOARD:
+            o.kind = kTexChecker;
+            o.color0 = Vec3f{t.color0[0], t.color0[1], t.color0[2]};
+            o.color1 = Vec3f{t.color1[0], t.color1[1], t.color1[2]};
+            o.to_uv = Load(t.to_uv);
+            fs.features |= kFeatTextures;
+            break;
+        case MCSD_TEX_BITMAP:
+            o.kind = kTexBitmap;
+            o.width = t.width, o.height = t.height, o.channel = t.channel;
+            if (t.width <= 0 || t.height <= 0 || (t.channel != 1 && t.channel != 3 && t.channel != 4))
+                throw std::runtime_error("unsupported bitmap size or channel count.");
+            o.to_uv = Load(t.to_uv);
+            o.texel_base = static_cast<uint32_t>(fs.texels.size());
+            fs.texels.insert(fs.texels.end(), t.data.begin(), t.data.end());
+            fs.features |= kFeatTextures;
+            break;
+        default:
+            throw std::runtime_error("unknow texture type.");
+        }
+        fs.textures.push_back(o);
+    }
+    const size_t n_tex = fs.textures.size();
+    auto check = [&](uint32_t id, bool allow_none)
+    {
+        if (id == kNone && allow_none)
+            return;
+        if (id >= n_tex)
+            throw std::runtime_error(TextureError(id));
+    };
+
+    // ---- BSDF constants (bsdf.cpp:112-186) ----------------------------------
+    bool needs_lut = false;
+    for (const mcsd::Bsdf &b : in.bsdfs)
+    {
+        BsdfRec o{};
+        o.twosided = b.twosided != 0;
+        o.opacity = b.id_opacity, o.bump = b.id_bump_map;
+        o.tex0 = o.tex1 = o.tex2 = o.tex3 = kNone;
+        o.reflectivity = 1.0f, o.eta = 1.0f, o.eta_inv = 1.0f, o.f_avg = 1.0f, o.f_avg_inv = 1.0f;
+        check(o.opacity, true), check(o.bump, true);
+        if (o.opacity != kNone || o.bump != kNone)
+            fs.features |= kFeatTextures;
+        switch (b.type)
+        {
+        case MCSD_BSDF_AREA_LIGHT:
+            o.kind = kBsdfAreaLight;
+            o.tex0 = b.id_radiance;
+            check(o.tex0, false);
+            break;
+        case MCSD_BSDF_DIFFUSE:
+            o.kind = kBsdfDiffuse;
+            o.tex0 = b.id_diffuse_reflectance;
+            check(o.tex0, false);
+            break;
+        case MCSD_BSDF_ROUGH_DIFFUSE:
+            // use_fast_approx is parsed but never reaches the committed BSDF in
+            // the reference (bsdf.cpp:139-144): the full Oren-Nayar model runs.
+            o.kind = kBsdfRoughDiffuse;
+            o.tex0 = b.id_diffuse_reflectance, o.tex1 = b.id_roughness;
+            check(o.tex0, false), check(o.tex1, false);
+            fs.features |= kFeatMicrofacet;
+            break;
+        case MCSD_BSDF_CONDUCTOR:
+            o.kind = kBsdfConductor;
+            o.tex0 = b.id_roughness_u, o.tex1 = b.id_roughness_v, o.tex2 = b.id_specular_reflectance;
+            check(o.tex0, false), check(o.tex1, false), check(o.tex2, false);
+            o.reflectivity3 = Vec3f{b.reflectivity[0], b.reflectivity[1], b.reflectivity[2]};
+            o.f_avg3 = Store3(AverageFresnelConductor(Load3(b.reflectivity), Load3(b.edgetint)));
+            needs_lut = true;
+            fs.features |= kFeatMicrofacet;
+            break;
+        case MCSD_BSDF_DIELECTRIC:
+        case MCSD_BSDF_THIN_DIELECTRIC:
+            o.kind = b.type == MCSD_BSDF_DIELECTRIC ? kBsdfDielectric : kBsdfThinDielectric;
+            if (b.type == MCSD_BSDF_DIELECTRIC)
+            {
+                o.f_avg = AverageFresnelDielectric(b.eta);
+                o.f_avg_inv = AverageFresnelDielectric(1.0f / b.eta);
+                needs_lut = true;
+            }
+            o.twosided = 1;
+            o.tex0 = b.id_roughness_u, o.tex1 = b.id_roughness_v;
+            o.tex2 = b.id_specular_reflectance, o.tex3 = b.id_specular_transmittance;
+            check(o.tex0, false), check(o.tex1, false), check(o.tex2, false), check(o.tex3, false);
+            o.eta = b.eta, o.eta_inv = 1.0f / b.eta;
+            o.reflectivity = sqr(b.eta - 1.0f) / sqr(b.eta + 1.0f);
+            fs.features |= kFeatMicrofacet;
+            break;
+        case MCSD_BSDF_PLASTIC:
+            o.kind = kBsdfPlastic;
+            o.tex0 = b.id_roughness, o.tex1 = b.id_diffuse_reflectance, o.tex2 = b.id_specular_reflectance;
+            check(o.tex0, false), check(o.tex1, false), check(o.tex2, false);
+            o.reflectivity = sqr(b.eta - 1.0f) / sqr(b.eta + 1.0f);
+            o.f_avg = AverageFresnelDielectric(b.eta);
+            fs.features |= kFeatMicrofacet;
+            break;
+        default:
+            throw std::runtime_error("unknow BSDF type.");
+        }
+        fs.bsdfs.push_back(o);
+    }
+    for (const InstanceRec &rec : fs.instances)
+        if (rec.bsdf != kNone && rec.bsdf >= fs.bsdfs.size())
+            throw std::runtime_error("cannot find BSDF (id " + std::to_string(rec.bsdf) + ").");
+
+    // ---- Kulla-Conty LUT: only conductors and dielectrics read it -----------
+    fs.lut_brdf.assign(kLutRes * kLutRes, 0.0f);
+    fs.lut_albedo.assign(kLutRes, 0.0f);
+    if (needs_lut)
+    {
+        const float *b, *a;
+        KullaContyTables(&b, &a);
+        fs.lut_brdf.assign(b, b + kLutRes * kLutRes);
+        fs.lut_albedo.assign(a, a + kLutRes);
+    }
+
+    // ---- media (medium.cpp:6-39) --------------------------------------------
+    for (const mcsd::Medium &m : in.media)
+    {
+        MediumRec o{};
+        const V3 sa = Load3(m.sigma_a), ss = Load3(m.sigma_s);
+        o.sigma_s = Store3(ss);
+        const V3 st = sa + ss;
+        o.sigma_t = Store3(st);
+        const V3 albedo = ss / st;
+        for (int d = 0; d < 3; ++d)
+            if (comp(albedo, d) > o.sampling_weight && comp(st, d) > 0)
+                o.sampling_weight = comp(albedo, d);
+        if (o.sampling_weight > 0 && o.sampling_weight < 0.5f)
+            o.sampling_weight = 0.5f;
+        o.hg = m.phase_type == MCSD_PHASE_HG;
+        o.g = Vec3f{m.g[0], m.g[1], m.g[2]};
+        fs.media.push_back(o);
+    }
+    for (const InstanceRec &rec : fs.instances)
+        for (uint32_t id : {rec.medium_int, rec.medium_ext})
+            if (id != kNone && id >= fs.media.size())
+                throw std::runtime_error("cannot find medium (id " + std::to_string(id) + ").");
+
+    // ---- emitters (emitter.cpp:122-175, renderer.cpp:520-620) ---------------
+    for (size_t i = 0; i < in.emitters.size(); ++i)
+    {
+        const mcsd::Emitter &e = in.emitters[i];
+        EmitterRec o{};
+        o.texture = kNone;
+        o.to_world = Identity(), o.to_local = Identity();
+        switch (e.type)
+        {
+        case MCSD_EMIT_POINT:
+            o.kind = kEmitPoint;
+            o.position = Vec3f{e.position[0], e.position[1], e.position[2]};
+            o.intensity = Vec3f{e.intensity[0], e.intensity[1], e.intensity[2]};
+            break;
+        case MCSD_EMIT_SPOT:
+            o.kind = kEmitSpot;
+            o.cutoff = e.cutoff_angle;
+            o.cos_cutoff = cosf(e.cutoff_angle);
+            o.uv_factor = tanf(e.cutoff_angle);
+            o.cos_beam = cosf(e.beam_width);
+            o.transition_rcp = 1.0f / (e.cutoff_angle - e.beam_width);
+            o.intensity = Vec3f{e.intensity[0], e.intensity[1], e.intensity[2]};
+            o.texture = e.id_texture;
+            check(o.texture, true);
+            o.to_world = Load(e.to_world);
+            o.position = Store3(transform_point(o.to_world, V3{0, 0, 0}));
+            o.to_local = Inverted(o.to_world);
+            break;
+        case MCSD_EMIT_DIRECTIONAL:
+            o.kind = kEmitDirectional;
+            o.direction = Vec3f{e.direction[0], e.direction[1], e.direction[2]};
+            o.radiance = Vec3f{e.radiance[0], e.radiance[1], e.radiance[2]};
+            break;
+        case MCSD_EMIT_SUN:
+            o.kind = kEmitSun;
+            o.cos_cutoff = e.cos_cutoff_angle;
+            o.texture = e.id_texture;
+            check(o.texture, false);
+            o.direction = Vec3f{e.direction[0], e.direction[1], e.direction[2]};
+            o.radiance = Vec3f{e.radiance[0], e.radiance[1], e.radiance[2]};
+            ig.id_sun = static_cast<uint32_t>(i);
+            break;
+        case MCSD_EMIT_ENVMAP:
+        {
+            o.kind = kEmitEnvMap;
+            o.texture = e.id_radiance;
+            check(o.texture, false);
+            o.to_world = Load(e.to_world);
+            o.to_local = Inverted(o.to_world);
+            const TextureRec &tex = fs.textures[o.texture];
+            if (tex.kind != kTexBitmap)
+                throw std::runtime_error("radiance texture '" + std::to_string(o.texture) +
+                                         "' for emitter '" + std::to_string(i) + "' is not a bitmap.");
+            // envmap.cpp:20-68.  The tables are stored [row cdf | row weights |
+            // column cdfs] (renderer.cpp:597-606) but addressed through the
+            // offsets of emitter.cpp:166-175, which name them differently
+            // (quirk Q7): reproduce both halves of that.
+            const int w = tex.width, h = tex.height;
+            const float w_inv = 1.0f / w, h_inv = 1.0f / h;
+            std::vector<float> cdf_rows(h + 1), weight_rows(h), cdf_cols(static_cast<size_t>(w + 1) * h);
+            float sum_row = 0.0f;
+            for (int y = 0; y < h; ++y)
+            {
+                float sum_col = 0.0f;
+                float *col = &cdf_cols[static_cast<size_t>(y) * (w + 1)];
+                for (int x = 0; x < w; ++x)
+                {
+                    const V3 rgb = texture_color(fs.textures.data(), fs.texels.data(), o.texture,
+                                                 V2{x * w_inv, y * h_inv});
+                    sum_col += luminance(rgb);
+                    col[x + 1] = sum_col;
+                }
+                col[w] = 1.0f;
+                const float norm_col = 1.0f / sum_col;
+                for (int x = 1; x < w; ++x)
+                    col[w - x] *= norm_col;
+                const float weight = sinf((y + 0.5f) * kPi / h);
+                weight_rows[y] = weight;
+                sum_row += sum_col * weight;
+                cdf_rows[y + 1] = sum_row;
+            }
+            cdf_rows[h] = 1.0f;
+            const float norm_row = 1.0f / sum_row;
+            for (int y = 1; y < h; ++y)
+                cdf_rows[h - y] *= norm_row;
+            if (!std::isfinite(sum_row))
+                throw std::runtime_error("The environment map contains an invalid floating point value (nan/inf).");
+            o.normalization = static_cast<float>(1.0 / D(sum_row * (k2Pi * w_inv) * (kPi * h_inv)));
+            o.width = w, o.height = h;
+            const uint32_t base = static_cast<uint32_t>(fs.env_tables.size());
+            fs.env_tables.insert(fs.env_tables.end(), cdf_rows.begin(), cdf_rows.end());
+            fs.env_tables.insert(fs.env_tables.end(), weight_rows.begin(), weight_rows.end());
+            fs.env_tables.insert(fs.env_tables.end(), cdf_cols.begin(), cdf_cols.end());
+            o.cdf_cols = base;
+            o.cdf_rows = base + static_cast<uint32_t>(h) + 1;
+            o.weight_rows = base + static_cast<uint32_t>(h + 1) + static_cast<uint32_t>(h);
+            ig.id_envmap = static_cast<uint32_t>(i);
+            break;
+        }
+        case MCSD_EMIT_CONSTANT:
+            o.kind = kEmitConstant;
+            o.radiance = Vec3f{e.radiance[0], e.radiance[1], e.radiance[2]};
+            ig.id_envmap = static_cast<uint32_t>(i);
+            break;
+        default:
+            throw std::runtime_error("unknow emitter type.");
+        }
+        fs.emitters.push_back(o);
+    }
+    ig.n_emitters = static_cast<uint32_t>(fs.emitters.size());
+    if (ig.n_emitters)
+        fs.features |= kFeatEmitters;
+    if (ig.n_emitters)
+        for (const EmitterRec &e : fs.emitters)
+            if (e.texture != kNone)
+                fs.features |= kFeatTextures;
+
+    // never hand out null pointers for empty tables
+    if (fs.analytic.empty())
+        fs.analytic.push_back(AnalyticRec{});
+    if (fs.light_inst.empty())
+        fs.light_inst.push_back(kNone);
+    if (fs.textures.empty())
+        fs.textures.push_back(TextureRec{});
+    if (fs.texels.empty())
+        fs.texels.push_back(0.0f);
+    if (fs.bsdfs.empty())
+        fs.bsdfs.push_back(BsdfRec{});
+    if (fs.media.empty())
+        fs.media.push_back(MediumRec{});
+    if (fs.emitters.empty())
+        fs.emitters.push_back(EmitterRec{});
+    if (fs.env_tables.empty())
+        fs.env_tables.push_back(0.0f);
+    if (fs.nodes.empty())
+    {
+        fs.nodes.assign(2, float4{0, 0, 0, 0});
+        fs.node_area.push_back(0.0f);
+        fs.tri_pos.assign(3, float4{0, 0, 0, 0});
+        fs.tri_attr.assign(9, float4{0, 0, 0, 0});
+        fs.instances.push_back(InstanceRec{});
+    }
+    return fs;
+}
+
+} // namespace mcpt

@@ -1,0 +1,53 @@
+// Host-side scene commit: mcsd::Scene (the RendererConfig equivalent) ->
+// FlatScene (plain arrays in the layout of device_scene.h).  This is the work
+// the reference does in Renderer::Renderer / Scene::Scene
+// (reference src/renderer/renderer.cpp:259-348, src/rtcore/scene.cpp:118-533).
+#ifndef MCPT_HOST_COMMIT_HPP
+#define MCPT_HOST_COMMIT_HPP
+
+#include <vector>
+
+#include "../device_scene.h"
+#include "mcsd_scene.hpp"
+
+namespace mcpt
+{
+
+struct FlatScene
+{
+    CameraRec camera{};
+    IntegratorRec integrator{};
+    uint32_t features = 0;
+
+    std::vector<float4> nodes;     // 2 per node
+    std::vector<float> node_area;  // 1 per node
+    std::vector<float4> tri_pos;   // 3 per primitive slot
+    std::vector<float4> tri_attr;  // 9 per primitive slot
+    std::vector<InstanceRec> instances;
+    std::vector<AnalyticRec> analytic;
+    std::vector<uint32_t> light_inst;
+    std::vector<float> light_cdf;
+    std::vector<TextureRec> textures;
+    std::vector<float> texels;
+    std::vector<BsdfRec> bsdfs;
+    std::vector<MediumRec> media;
+    std::vector<EmitterRec> emitters;
+    std::vector<float> env_tables;
+    std::vector<float> lut_brdf, lut_albedo;
+
+    // A DeviceScene whose pointers address the host vectors (CPU inspection,
+    // tests) — the uploader rewrites them to HBM addresses.
+    DeviceScene HostView() const;
+    size_t GeometryBytes() const;
+};
+
+// Throws std::runtime_error with the reference's wording on invalid input.
+FlatScene CommitScene(const mcsd::Scene &scene);
+
+// The 128x128 + 128 Kulla-Conty tables (reference kulla_conty.cpp:62-80),
+// computed once per process (multi-threaded, ~0.5 s) and cached.
+void KullaContyTables(const float **brdf, const float **albedo);
+
+} // namespace mcpt
+
+#endif // MCPT_HOST_COMMIT_HPP

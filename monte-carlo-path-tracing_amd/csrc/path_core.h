@@ -1,0 +1,500 @@
+// The streaming path-tracing state machine executed by every GPU lane.
+//
+// One lane owns one pixel at a time and walks through its `spp` samples in
+// order, because the reference threads ONE LCG state through all samples of a
+// pixel (renderer.cpp:62-85): the number of draws per sample is data
+// dependent, so samples of a pixel cannot be computed out of order without
+// changing the image.  Parallelism therefore comes from pixels.
+//
+// Instead of the reference's recursive shape (Shade -> direct light -> any-hit
+// inside a per-depth loop), a lane runs a flat loop of STEPS.  Every step is
+//      [regenerate]  camera ray for the next sample / next pixel, if needed
+//      extend        closest-hit walk of the current ray
+//      resolve       miss / emitter / back face / medium event bookkeeping
+//      roulette      the reference's loop condition (path.cpp:57-59)
+//      connect       next-event estimation: one shadow walk per emitter + one
+//                    for the sampled area light
+//      scatter       BSDF or phase-function sample -> next ray
+// so all 64 lanes of a wavefront are in the same stage at the same time
+// (extend with extend, connect with connect) no matter how long their
+// individual paths are; a lane whose path ends simply regenerates at the top
+// of the next step while its neighbours extend.  The arithmetic and the order
+// of random draws inside each stage follow reference path.cpp:8-296 and
+// volpath.cpp:8-485.
+#ifndef MCPT_PATH_CORE_H
+#define MCPT_PATH_CORE_H
+
+#include "lights_media.h"
+#include "traversal.h"
+
+namespace mcpt
+{
+
+template <uint32_t kFeatures>
+struct Config
+{
+    static constexpr bool kVolPath = (kFeatures & kFeatVolPath) != 0;
+    static constexpr bool kEmitters = (kFeatures & kFeatEmitters) != 0;
+    static constexpr bool kAnalytic = (kFeatures & kFeatAnalytic) != 0;
+    static constexpr bool kTextures = (kFeatures & kFeatTextures) != 0;
+    static constexpr bool kMicrofacet = (kFeatures & kFeatMicrofacet) != 0;
+};
+
+struct LaneCounters
+{
+    uint32_t closest_rays, shadow_rays, node_tests, prim_tests, shaded_hits, samples;
+};
+
+// Per-lane path state that survives from one step to the next.
+struct PathState
+{
+    uint32_t rng;        // LCG state of the pixel
+    uint32_t pixel;      // row-major pixel index
+    uint32_t sample;     // next sample to start
+    uint32_t depth;      // reference loop counter
+    bool alive;          // a path is in flight
+    bool primary;        // the ray in flight is the camera ray
+    bool in_medium;      // current vertex is a medium scattering event
+    uint32_t medium;     // medium of the current medium vertex
+    float pdf_sample;    // pdf of the direction that produced the ray in flight
+    V3 origin, dir;      // ray in flight
+    V3 wo;               // direction towards the previous vertex
+    V3 wi;               // sampled direction (points into the vertex)
+    V3 throughput, L;    // path weight and radiance of the sample
+    V3 pixel_sum;        // sum of clamped samples
+};
+
+MCPT_HD ShadeTables shade_tables(const DeviceScene &sc)
+{
+    return ShadeTables{sc.textures, sc.texels, sc.lut_brdf, sc.lut_albedo};
+}
+MCPT_HD LightTables light_tables(const DeviceScene &sc)
+{
+    return LightTables{sc.textures, sc.texels, sc.env_tables};
+}
+
+MCPT_HD void start_pixel(PathState &st, uint32_t pixel)
+{
+    st.pixel = pixel;
+    st.rng = tea4(pixel * 3u, 0); // renderer.cpp:65-66
+    st.sample = 0;
+    st.alive = false;
+    st.pixel_sum = V3{0, 0, 0};
+}
+
+// renderer.cpp:68-76: stratified-in-x / van der Corput-in-y jitter, pinhole ray
+MCPT_HD void start_sample(const DeviceScene &sc, PathState &st)
+{
+    const CameraRec &cam = sc.camera;
+    const uint32_t i = st.pixel % static_cast<uint32_t>(cam.width), j = st.pixel / static_cast<uint32_t>(cam.width);
+    const uint32_t s = st.sample;
+    const float u = s * cam.spp_inv, v = radical_inverse2(s + 1), x = 2.0f * (i + u) / cam.width - 1.0f,
+                y = 1.0f - 2.0f * (j + v) / cam.height;
+    const V3 look = normalize(from(cam.front) + x * from(cam.dx) + y * from(cam.dy));
+    st.origin = from(cam.eye), st.dir = look;
+    st.wo = -look;
+    st.throughput = V3{1, 1, 1}, st.L = V3{0, 0, 0};
+    st.alive = true, st.primary = true, st.in_medium = false;
+    st.depth = 0;
+    st.pdf_sample = 0;
+    st.medium = kNone;
+    ++st.sample;
+}
+
+// renderer.cpp:77-80: clamp each sample to 1 BEFORE averaging (quirk Q3)
+MCPT_HD void finish_sample(PathState &st)
+{
+    st.pixel_sum += V3{fminf(st.L.x, 1.0f), fminf(st.L.y, 1.0f), fminf(st.L.z, 1.0f)};
+    st.alive = false;
+}
+
+MCPT_HD bool pixel_done(const DeviceScene &sc, const PathState &st) { return !st.alive && st.sample >= sc.camera.spp; }
+
+MCPT_HD V3 pixel_value(const DeviceScene &sc, const PathState &st) { return st.pixel_sum * sc.camera.spp_inv; }
+
+template <class C>
+MCPT_HD bool shadow_walk(const DeviceScene &sc, V3 origin, V3 dir, float t_max, uint32_t &rng, LaneCounters *cnt)
+{
+    Ray r = make_ray(origin, dir);
+    r.t_max = t_max;
+    HitRaw dummy;
+    TraceStats ts{0, 0};
+    const bool hit = cnt ? walk_scene<true, C::kAnalytic, C::kTextures, true>(sc, r, rng, dummy, ts)
+                         : walk_scene<true, C::kAnalytic, C::kTextures, false>(sc, r, rng, dummy, ts);
+    if (cnt)
+        ++cnt->shadow_rays, cnt->node_tests += ts.node_tests, cnt->prim_tests += ts.prim_tests;
+    return hit;
+}
+
+MCPT_HD BsdfQuery query_at(const Surface &s, V3 wo, V3 facing)
+{
+    BsdfQuery q;
+    q.valid = false, q.pdf = 0;
+    q.uv = s.uv, q.wo = wo, q.wi = V3{0, 0, 0};
+    q.inside = s.inside, q.normal = s.normal, q.tangent = s.tangent, q.bitangent = s.bitangent;
+    q.attenuation = V3{0, 0, 0};
+    if (dot(facing, s.normal) < 0.0f) // path.cpp:253-257, 282-286
+    {
+        q.inside = !q.inside;
+        q.normal = -q.normal;
+    }
+    return q;
+}
+
+// path.cpp:238-266.  has_bsdf == false: pass-through surface, weight 1.
+template <class C>
+MCPT_HD BsdfQuery eval_at(const DeviceScene &sc, const Surface &s, uint32_t bsdf, V3 wi, V3 wo)
+{
+    BsdfQuery q = query_at(s, wo, -wi);
+    q.wi = wi;
+    if (bsdf != kNone)
+        bsdf_eval<C::kMicrofacet>(shade_tables(sc), sc.bsdfs[bsdf], q);
+    else
+        q.pdf = 1, q.attenuation = V3{1, 1, 1}, q.valid = true;
+    return q;
+}
+
+MCPT_HD uint32_t medium_on_side(const DeviceScene &sc, const Surface &s, bool hit_valid, V3 w)
+{
+    // volpath.cpp:44-45: an invalid hit has a zero normal and invalid ids
+    if (!hit_valid)
+        return kNone;
+    const InstanceRec &rec = sc.instances[s.inst];
+    const bool inside = dot(w, s.normal) > 0 ? s.inside : !s.inside;
+    return inside ? rec.medium_int : rec.medium_ext;
+}
+
+MCPT_HD float area_light_pdf(const DeviceScene &sc, uint32_t light, uint32_t inst, float distance, float cos_light)
+{
+    const float pdf_area = (sc.light_cdf[light + 1] - sc.light_cdf[light]) * sc.instances[inst].pdf_area;
+    return pdf_area * sqr(distance) / cos_light;
+}
+
+// Next-event estimation at a surface vertex (path.cpp:138-236,
+// volpath.cpp:247-375) or at a medium vertex (volpath.cpp:377-485).
+template <class C>
+MCPT_HD V3 connect_lights(const DeviceScene &sc, bool at_medium, const Surface &s, V3 position, uint32_t medium_id,
+                          V3 wo, uint32_t &rng, LaneCounters *cnt)
+{
+    V3 L = V3{0, 0, 0};
+    const LightTables LT = light_tables(sc);
+    const uint32_t bsdf = at_medium ? kNone : sc.instances[s.inst].bsdf;
+    // medium the connection travels through
+    uint32_t conn_medium = kNone;
+    if (C::kVolPath)
+        conn_medium = at_medium ? medium_id : (sc.integrator.volpath ? medium_on_side(sc, s, true, wo) : kNone);
+
+    const bool vol = C::kVolPath && sc.integrator.volpath != 0;
+
+    // Transmittance `tr`, scattering value `att` and scattering pdf of a
+    // connection arriving along wi over `distance`; false = no contribution.
+    // Check order as in the reference: facing test, medium, BSDF (surface
+    // vertex) / medium, phase function (medium vertex).
+    auto weigh = [&](V3 wi, float distance, V3 &tr, V3 &att, float &pdf) -> bool
+    {
+        tr = V3{1.0f, 1.0f, 1.0f};
+        if (at_medium)
+        {
+            MediumEvent m = medium_event_init();
+            m.distance = distance;
+            medium_transmittance(sc.media[medium_id], m);
+            if (!m.valid)
+                return false;
+            tr = m.attenuation / m.pdf;
+            PhaseQuery p;
+            p.wi = wi, p.wo = wo;
+            phase_eval(sc.media[medium_id], p);
+            if (!p.valid)
+                return false;
+            att = p.attenuation, pdf = p.pdf;
+            return true;
+        }
+        if (dot(-wi, s.normal) < kEpsFloat)
+            return false;
+        if (C::kVolPath && conn_medium != kNone)
+        {
+            MediumEvent m = medium_event_init();
+            m.distance = distance;
+            medium_transmittance(sc.media[conn_medium], m);
+            if (!m.valid)
+                return false;
+            tr = m.attenuation / m.pdf;
+        }
+        const BsdfQuery q = eval_at<C>(sc, s, bsdf, wi, wo);
+        if (!q.valid)
+            return false;
+        att = q.attenuation, pdf = q.pdf;
+        return true;
+    };
+
+    if (C::kEmitters)
+    {
+        for (uint32_t k = 0; k < sc.integrator.n_emitters; ++k)
+        {
+            const EmitterRec &e = sc.emitters[k];
+            const float xi0 = lcg_next(rng), xi1 = lcg_next(rng);
+            const LightSample ls = emitter_sample(LT, e, position, xi0, xi1);
+            if (shadow_walk<C>(sc, position, -ls.wi, ls.distance - kEpsDistance, rng, cnt))
+                continue;
+            V3 tr, att;
+            float pdf;
+            if (!weigh(ls.wi, ls.distance, tr, att, pdf))
+                continue;
+            const V3 radiance = emitter_eval_sample(LT, e, ls);
+            if (ls.harsh)
+            {
+                // path.cpp:170 / volpath.cpp:297,413 (tr == 1 exactly without a medium)
+                L += vol ? radiance * tr * att : radiance * att;
+            }
+            else
+            {
+                const float pdf_direct = emitter_pdf(LT, e, -ls.wi);
+                if (pdf_direct > kEpsFloat)
+                {
+                    const float w = power_heuristic(pdf_direct, pdf);
+                    if (vol) // volpath.cpp:305-306, 421-422
+                        L += w * radiance * tr * att / pdf_direct;
+                    else // path.cpp:178
+                        L += w * radiance * (att / pdf_direct);
+                }
+            }
+        }
+    }
+
+    if (sc.integrator.n_area_lights != 0)
+    {
+        const float xi_pick = lcg_next(rng);
+        const uint32_t light = cdf_search(sc.integrator.n_area_lights + 1, sc.light_cdf, xi_pick) - 1;
+        const uint32_t inst = sc.light_inst[light];
+        const float xi0 = lcg_next(rng), xi1 = lcg_next(rng), xi2 = lcg_next(rng);
+        const LightPoint lp = sample_instance<C::kAnalytic>(sc, inst, xi0, xi1, xi2);
+        const V3 d = position - lp.position;
+        const float distance = length(d);
+        // the shadow ray starts ON THE LIGHT and travels to the shading point
+        if (shadow_walk<C>(sc, lp.position, normalize(d), distance - kEpsDistance, rng, cnt))
+            return L;
+        const V3 wi = normalize(d);
+        const float cos_light = dot(wi, lp.normal);
+        if (cos_light < kEpsFloat)
+            return L;
+        V3 tr, att;
+        float pdf;
+        if (!weigh(wi, distance, tr, att, pdf))
+            return L;
+        const float pdf_direct = area_light_pdf(sc, light, inst, distance, cos_light),
+                    w = power_heuristic(pdf_direct, pdf);
+        const V3 radiance = texture_color(sc.textures, sc.texels, sc.bsdfs[sc.instances[inst].bsdf].tex0, lp.uv);
+        if (vol) // volpath.cpp:371-372, 481-482
+            L += w * (radiance * tr * att / pdf_direct);
+        else // path.cpp:232
+            L += w * radiance * (att / pdf_direct);
+    }
+    return L;
+}
+
+// One step of a lane whose path is alive: extend the ray in flight, resolve
+// what it found, run the roulette, connect to the lights, scatter.  On return
+// either st.alive is still true (st.origin/st.dir hold the next ray) or the
+// sample has been finished (st.alive == false).
+template <class C>
+MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
+{
+    const IntegratorRec &ig = sc.integrator;
+    const bool vol = C::kVolPath && ig.volpath != 0;
+    const LightTables LT = light_tables(sc);
+
+    // ---- extend --------------------------------------------------------------
+    Ray ray = make_ray(st.origin, st.dir);
+    HitRaw raw;
+    TraceStats ts{0, 0};
+    const bool hit_valid = cnt ? walk_scene<false, C::kAnalytic, C::kTextures, true>(sc, ray, st.rng, raw, ts)
+                               : walk_scene<false, C::kAnalytic, C::kTextures, false>(sc, ray, st.rng, raw, ts);
+    if (cnt)
+        ++cnt->closest_rays, cnt->node_tests += ts.node_tests, cnt->prim_tests += ts.prim_tests;
+    Surface surf;
+    if (hit_valid)
+    {
+        surf = make_surface<C::kAnalytic, C::kTextures>(sc, ray, raw);
+        if (cnt)
+            ++cnt->shaded_hits;
+    }
+    else
+    {
+        surf.inside = false, surf.inst = 0, surf.uv = V2{0, 0};
+        surf.position = surf.normal = surf.tangent = surf.bitangent = V3{0, 0, 0};
+    }
+
+    // ---- resolve -------------------------------------------------------------
+    if (st.primary && !hit_valid)
+    {
+        // path.cpp:22-35 / volpath.cpp:22-35: environment AND sun on a primary miss
+        if (ig.id_envmap != kNone)
+            st.L += emitter_eval_dir(LT, sc.emitters[ig.id_envmap], st.dir);
+        if (ig.id_sun != kNone)
+            st.L += emitter_eval_dir(LT, sc.emitters[ig.id_sun], st.dir);
+        finish_sample(st);
+        return;
+    }
+
+    if (vol)
+    {
+        // free-flight sampling along the segment just traced (volpath.cpp:41-63,
+        // 115-139, 160-186)
+        const bool from_medium = st.in_medium;
+        const uint32_t id = from_medium ? st.medium : medium_on_side(sc, surf, hit_valid, st.primary ? st.wo : st.wi);
+        if (from_medium)
+            st.in_medium = false;
+        if (id != kNone)
+        {
+            MediumEvent m = medium_event_init();
+            medium_sample_distance(sc.media[id], ray.t_max, st.rng, m);
+            if (m.valid)
+            {
+                st.throughput *= m.attenuation / m.pdf;
+                if (m.scattered)
+                {
+                    st.in_medium = true;
+                    st.medium = id;
+                    st.origin = ray.origin + ray.dir * m.distance; // the medium vertex
+                }
+            }
+        }
+    }
+
+    const uint32_t bsdf = hit_valid ? sc.instances[surf.inst].bsdf : kNone;
+    if (!st.in_medium)
+    {
+        if (!hit_valid)
+        {
+            // secondary ray escaped: MIS-weighted environment only (path.cpp:79-94)
+            if (ig.id_envmap != kNone)
+            {
+                const EmitterRec &env = sc.emitters[ig.id_envmap];
+                const V3 radiance = emitter_eval_dir(LT, env, -st.wi);
+                const float pdf_direct = emitter_pdf(LT, env, -st.wi), w = power_heuristic(st.pdf_sample, pdf_direct);
+                st.L += w * st.throughput * radiance;
+            }
+            finish_sample(st);
+            return;
+        }
+        if (bsdf != kNone)
+        {
+            const BsdfRec &b = sc.bsdfs[bsdf];
+            if (surf.inside && !b.twosided)
+            {
+                // back of a one-sided surface absorbs (path.cpp:43-46, 101-104);
+                // for a primary ray the sample is black (L is still 0)
+                finish_sample(st);
+                return;
+            }
+            if (b.kind == kBsdfAreaLight)
+            {
+                const V3 radiance = texture_color(sc.textures, sc.texels, b.tex0, surf.uv);
+                if (st.primary)
+                {
+                    if (!ig.hide_emitters) // path.cpp:47-53
+                        st.L = radiance;
+                }
+                else
+                {
+                    const float cos_light = dot(st.wi, surf.normal); // path.cpp:105-124
+                    if (cos_light >= kEpsFloat)
+                    {
+                        const float pdf_direct = area_light_pdf(sc, sc.instances[surf.inst].area_light, surf.inst,
+                                                                ray.t_max, cos_light),
+                                    w = power_heuristic(st.pdf_sample, pdf_direct);
+                        st.L += w * st.throughput * radiance;
+                    }
+                }
+                finish_sample(st);
+                return;
+            }
+        }
+        if (!st.primary)
+        {
+            st.wo = st.wi; // path.cpp:127-132
+            if (st.depth >= ig.depth_rr)
+                st.throughput *= ig.rr_scale; // multiplies by pdf_rr: reference quirk Q2
+        }
+    }
+
+    // ---- roulette: the reference's for-loop header (path.cpp:57-59) -----------
+    st.depth = st.primary ? 1u : st.depth + 1u;
+    st.primary = false;
+    if (!(st.depth < ig.depth_rr || (st.depth < ig.depth_max && lcg_next(st.rng) < ig.pdf_rr)))
+    {
+        finish_sample(st);
+        return;
+    }
+
+    // ---- connect -------------------------------------------------------------
+    const V3 vertex = st.in_medium ? st.origin : surf.position;
+    st.L += st.throughput * connect_lights<C>(sc, st.in_medium, surf, vertex, st.medium, st.wo, st.rng, cnt);
+
+    // ---- scatter -------------------------------------------------------------
+    if (vol && st.in_medium)
+    {
+        PhaseQuery p; // volpath.cpp:96-110
+        p.wo = st.wo;
+        phase_sample(sc.media[st.medium], st.rng, p);
+        if (!p.valid)
+        {
+            finish_sample(st);
+            return;
+        }
+        st.wi = p.wi;
+        st.throughput *= p.attenuation / p.pdf;
+        st.pdf_sample = p.pdf;
+    }
+    else
+    {
+        BsdfQuery q = query_at(surf, st.wo, st.wo); // path.cpp:268-296
+        if (bsdf != kNone)
+        {
+            bsdf_sample<C::kMicrofacet>(shade_tables(sc), sc.bsdfs[bsdf], st.rng, q);
+        }
+        else
+        {
+            // a shape without BSDF is a pass-through surface (quirk Q8)
+            q.wi = st.wo, q.pdf = 1.0f, q.attenuation = V3{1.0f, 1.0f, 1.0f}, q.valid = true;
+        }
+        if (!q.valid)
+        {
+            finish_sample(st);
+            return;
+        }
+        st.wi = q.wi;
+        st.pdf_sample = q.pdf;
+        st.throughput *= q.attenuation / q.pdf;
+        st.origin = surf.position;
+    }
+    if (max_component(st.throughput) < kEps)
+    {
+        finish_sample(st);
+        return;
+    }
+    st.dir = -st.wi;
+}
+
+// Convenience for CPU-side emulation and unit tests: a whole pixel.
+template <class C>
+MCPT_HD V3 render_pixel(const DeviceScene &sc, uint32_t pixel, LaneCounters *cnt)
+{
+    PathState st;
+    start_pixel(st, pixel);
+    while (!pixel_done(sc, st))
+    {
+        if (!st.alive)
+        {
+            start_sample(sc, st);
+            if (cnt)
+                ++cnt->samples;
+        }
+        path_step<C>(sc, st, cnt);
+    }
+    return pixel_value(sc, st);
+}
+
+} // namespace mcpt
+
+#endif // MCPT_PATH_CORE_H

@@ -1,0 +1,494 @@
+// Ray / scene intersection on the flat scene of device_scene.h.
+//
+// * STACKLESS two-level traversal: nodes are stored in the reference
+//   builder's pre-order, so "descend" is `index + 1` and every other move is
+//   the node's precomputed `skip` link.  This visits nodes in exactly the
+//   reference's order (left child first, then right; tlas.cpp:22-41,
+//   blas.cpp:26-43) with one index register instead of two 65-entry stacks.
+//   A TLAS leaf jumps to the instance's BLAS root and remembers the TLAS skip
+//   link to resume from when the BLAS walk ends.
+// * Closest hit keeps shrinking t_max; a candidate with t == t_max is accepted
+//   (triangle.cpp:82: only t > t_max rejects), so among equal distances the
+//   LAST visited primitive wins — as in the reference.
+// * Triangles: Woop et al. watertight test with the double-precision edge
+//   fallback (triangle.cpp:23-87, ray.cpp:26-45).  Only the barycentrics are
+//   produced during the walk; the shading frame is interpolated once, for the
+//   final hit (same arithmetic as triangle.cpp:122-144).
+// * Quadrics (sphere/disk/cylinder.cpp) use matrices inverted once on the host
+//   with the reference's inverse arithmetic instead of per test.
+#ifndef MCPT_TRAVERSAL_H
+#define MCPT_TRAVERSAL_H
+
+#include "bsdfs.h"
+
+namespace mcpt
+{
+
+struct Ray // ray.hpp:9-27
+{
+    V3 origin, dir, dir_rcp, shear;
+    float t_max;
+    int kx, ky, kz;
+};
+
+MCPT_HD Ray make_ray(V3 origin, V3 dir) // ray.cpp:18-47
+{
+    Ray r;
+    r.origin = origin, r.dir = dir, r.t_max = kMaxFloat;
+    r.dir_rcp = V3{1.0f / (dir.x != 0 ? dir.x : kEpsDistance), 1.0f / (dir.y != 0 ? dir.y : kEpsDistance),
+                   1.0f / (dir.z != 0 ? dir.z : kEpsDistance)};
+    const float ax = fabsf(dir.x), ay = fabsf(dir.y), az = fabsf(dir.z);
+    r.kz = (ax > ay && ax > az) ? 0 : (ay > az ? 1 : 2);
+    r.kx = r.kz + 1 == 3 ? 0 : r.kz + 1;
+    r.ky = r.kx + 1 == 3 ? 0 : r.kx + 1;
+    const float dz = comp(dir, r.kz);
+    if (dz < 0.0f)
+    {
+        const int t = r.kx;
+        r.kx = r.ky;
+        r.ky = t;
+    }
+    r.shear = V3{comp(dir, r.kx) / dz, comp(dir, r.ky) / dz, 1.0f / dz};
+    return r;
+}
+
+// What the walk records about the closest primitive.  (a, b, c) are the
+// barycentrics u, v, w of a triangle or the object-space hit point of a quadric.
+struct HitRaw
+{
+    uint32_t inst, prim;
+    float a, b, c;
+    bool inside;
+};
+
+// Fully reconstructed surface point (hit.hpp:9-30).
+struct Surface
+{
+    bool inside;
+    uint32_t inst;
+    V2 uv;
+    V3 position, normal, tangent, bitangent;
+};
+
+struct TraceStats
+{
+    uint32_t node_tests, prim_tests;
+};
+
+MCPT_HD bool box_hit(const float4 &lo, const float4 &hi, const Ray &r) // aabb.cpp:29-48
+{
+    const V3 t0 = (xyz(lo) - r.origin) * r.dir_rcp, t1 = (xyz(hi) - r.origin) * r.dir_rcp;
+    float t_enter = kEpsDistance, t_exit = r.t_max;
+    t_enter = fmaxf(t_enter, r.dir_rcp.x > 0 ? t0.x : t1.x), t_exit = fminf(t_exit, r.dir_rcp.x > 0 ? t1.x : t0.x);
+    t_enter = fmaxf(t_enter, r.dir_rcp.y > 0 ? t0.y : t1.y), t_exit = fminf(t_exit, r.dir_rcp.y > 0 ? t1.y : t0.y);
+    t_enter = fmaxf(t_enter, r.dir_rcp.z > 0 ? t0.z : t1.z), t_exit = fminf(t_exit, r.dir_rcp.z > 0 ? t1.z : t0.z);
+    return t_enter <= t_exit;
+}
+
+MCPT_HD uint32_t as_uint(float f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(f);
+#else
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    return u;
+#endif
+}
+
+// Opacity mask of an instance's BSDF (bsdf.cpp:272-276): may draw one number.
+template <bool kTextures>
+MCPT_HD bool masked_out(const DeviceScene &sc, uint32_t bsdf, V2 uv, uint32_t &rng)
+{
+    if (!kTextures || bsdf == kNone)
+        return false;
+    const uint32_t opacity = sc.bsdfs[bsdf].opacity;
+    return opacity != kNone && texture_transparent(sc.textures, sc.texels, opacity, uv, rng);
+}
+
+MCPT_HD V2 triangle_uv(const float4 *attr, float u, float v, float w) // Lerp(texcoords, u, v, w)
+{
+    const V2 uv0 = V2{attr[0].w, attr[1].w}, uv1 = V2{attr[2].w, attr[3].w}, uv2 = V2{attr[4].w, attr[5].w};
+    return u * uv0 + v * uv1 + w * uv2;
+}
+
+// triangle.cpp:19-120 (WATERTIGHT_TRIANGLES branch)
+template <bool kTextures>
+MCPT_HD bool triangle_hit(const DeviceScene &sc, uint32_t prim, uint32_t bsdf, Ray &ray, uint32_t &rng, HitRaw &out)
+{
+    const float4 *p = sc.tri_pos + 3 * static_cast<size_t>(prim);
+    const V3 A = xyz(p[0]) - ray.origin, B = xyz(p[1]) - ray.origin, C = xyz(p[2]) - ray.origin;
+    const float Akz = comp(A, ray.kz), Bkz = comp(B, ray.kz), Ckz = comp(C, ray.kz);
+    const float Ax = comp(A, ray.kx) - ray.shear.x * Akz, Ay = comp(A, ray.ky) - ray.shear.y * Akz;
+    const float Bx = comp(B, ray.kx) - ray.shear.x * Bkz, By = comp(B, ray.ky) - ray.shear.y * Bkz;
+    const float Cx = comp(C, ray.kx) - ray.shear.x * Ckz, Cy = comp(C, ray.ky) - ray.shear.y * Ckz;
+    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f)
+    {
+        U = static_cast<float>(D(Cx) * D(By) - D(Cy) * D(Bx));
+        V = static_cast<float>(D(Ax) * D(Cy) - D(Ay) * D(Cx));
+        W = static_cast<float>(D(Bx) * D(Ay) - D(By) * D(Ax));
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f))
+        return false;
+    const float det = U + V + W;
+    if (det == 0.0f)
+        return false;
+    const float T = U * (ray.shear.z * Akz) + V * (ray.shear.z * Bkz) + W * (ray.shear.z * Ckz);
+    const float det_inv = 1.0f / det;
+    const float t = T * det_inv;
+    if (t > ray.t_max || t < kEpsDistance)
+        return false;
+    const float u = U * det_inv, v = V * det_inv, w = W * det_inv;
+    if (kTextures && masked_out<kTextures>(sc, bsdf, triangle_uv(sc.tri_attr + 9 * static_cast<size_t>(prim), u, v, w), rng))
+        return false;
+    ray.t_max = t;
+    out.prim = prim, out.a = u, out.b = v, out.c = w, out.inside = det_inv < 0;
+    return true;
+}
+
+MCPT_HD V2 sphere_uv(V3 p_local, float &theta, float &phi)
+{
+    to_spherical(p_local, theta, phi);
+    return V2{phi * k1Div2Pi, theta * k1DivPi};
+}
+
+// sphere.cpp:17-46
+template <bool kTextures>
+MCPT_HD bool sphere_hit(const DeviceScene &sc, const AnalyticRec &q, uint32_t prim, uint32_t bsdf, Ray &ray,
+                        uint32_t &rng, HitRaw &out)
+{
+    const V3 o = transform_point(q.to_local, ray.origin) - from(q.center), d = transform_dir(q.to_local, ray.dir);
+    const float a = dot(d, d), b = 2.0f * dot(d, o), c = dot(o, o) - sqr(q.radius);
+    float t_near = 0.0f, t_far = 0.0f;
+    if (!solve_quadratic(a, b, c, t_near, t_far) || t_far < kEpsDistance)
+        return false;
+    float t = t_near < kEpsDistance ? t_far : t_near;
+    const V3 p_local = o + t * d, position = transform_point(q.to_world, p_local + from(q.center));
+    t = length(position - ray.origin);
+    if (t > ray.t_max || t < kEpsDistance)
+        return false;
+    if (kTextures)
+    {
+        float theta, phi;
+        if (masked_out<kTextures>(sc, bsdf, sphere_uv(p_local, theta, phi), rng))
+            return false;
+    }
+    ray.t_max = t;
+    out.prim = prim, out.a = p_local.x, out.b = p_local.y, out.c = p_local.z, out.inside = c < 0.0f;
+    return true;
+}
+
+// disk.cpp:17-44
+template <bool kTextures>
+MCPT_HD bool disk_hit(const DeviceScene &sc, const AnalyticRec &q, uint32_t prim, uint32_t bsdf, Ray &ray,
+                      uint32_t &rng, HitRaw &out)
+{
+    const V3 o = transform_point(q.to_local, ray.origin), d = transform_dir(q.to_local, ray.dir);
+    const float t_z = -o.z / d.z;
+    if (t_z < kEpsFloat)
+        return false;
+    const V3 p_local = o + t_z * d;
+    if (length(p_local) > 0.5f)
+        return false;
+    const float t = length(transform_point(q.to_world, p_local) - ray.origin);
+    if (t > ray.t_max || t < kEpsDistance)
+        return false;
+    if (kTextures)
+    {
+        float theta, phi;
+        to_spherical(p_local, theta, phi);
+        if (masked_out<kTextures>(sc, bsdf, V2{length(p_local), phi * k1Div2Pi}, rng))
+            return false;
+    }
+    ray.t_max = t;
+    out.prim = prim, out.a = p_local.x, out.b = p_local.y, out.c = p_local.z, out.inside = d.z > 0;
+    return true;
+}
+
+// cylinder.cpp:21-59
+template <bool kTextures>
+MCPT_HD bool cylinder_hit(const DeviceScene &sc, const AnalyticRec &q, uint32_t prim, uint32_t bsdf, Ray &ray,
+                          uint32_t &rng, HitRaw &out)
+{
+    const V3 o = transform_point(q.to_local, ray.origin), d = transform_dir(q.to_local, ray.dir);
+    const float a = sqr(d.x) + sqr(d.y), b = 2.0f * (d.x * o.x + d.y * o.y), c = sqr(o.x) + sqr(o.y) - sqr(q.radius);
+    float t_near = 0.0f, t_far = 0.0f;
+    if (!solve_quadratic(a, b, c, t_near, t_far) || t_far < kEpsDistance)
+        return false;
+    const float z_near = o.z + d.z * t_near, z_far = o.z + d.z * t_far;
+    float t;
+    if (kEpsDistance < t_near && 0.0f <= z_near && z_near <= q.length)
+        t = t_near;
+    else if (0.0f <= z_far && z_far <= q.length)
+        t = t_far;
+    else
+        return false;
+    const V3 p_local = o + t * d;
+    if (kTextures &&
+        masked_out<kTextures>(sc, bsdf, V2{atan2f(p_local.y, p_local.x) * k1Div2Pi, p_local.z / q.length}, rng))
+        return false;
+    t = length(transform_point(q.to_world, p_local) - ray.origin);
+    if (t > ray.t_max || t < kEpsDistance)
+        return false;
+    ray.t_max = t;
+    out.prim = prim, out.a = p_local.x, out.b = p_local.y, out.c = p_local.z, out.inside = c < 0.0f;
+    return true;
+}
+
+// The walk.  kAny = shadow query: stop at the first accepted primitive.
+// Returns whether anything was hit; for closest queries `hit` describes it and
+// ray.t_max is its distance.
+template <bool kAny, bool kAnalytic, bool kTextures, bool kCount>
+MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &hit, TraceStats &stats)
+{
+    bool found = false;
+    uint32_t node = sc.integrator.n_tlas_nodes ? 0u : kEndOfTree;
+    uint32_t resume = kEndOfTree; // TLAS link to continue from once the current BLAS is exhausted
+    bool in_blas = false;
+    uint32_t inst = 0, inst_kind = 0, inst_bsdf = kNone, inst_analytic = 0;
+    for (;;)
+    {
+        if (node == kEndOfTree)
+        {
+            if (!in_blas)
+                break;
+            in_blas = false;
+            node = resume;
+            continue;
+        }
+        const float4 n0 = sc.nodes[2 * static_cast<size_t>(node)], n1 = sc.nodes[2 * static_cast<size_t>(node) + 1];
+        if (kCount)
+            ++stats.node_tests;
+        if (!box_hit(n0, n1, ray))
+        {
+            node = as_uint(n0.w);
+            continue;
+        }
+        const uint32_t object = as_uint(n1.w);
+        if (object == kNoObject)
+        {
+            ++node; // pre-order: the left child follows its parent
+            continue;
+        }
+        if (!in_blas)
+        {
+            const InstanceRec &rec = sc.instances[object];
+            inst = object, inst_kind = rec.kind, inst_bsdf = rec.bsdf, inst_analytic = rec.analytic;
+            resume = as_uint(n0.w);
+            node = rec.blas_root;
+            in_blas = true;
+            continue;
+        }
+        if (kCount)
+            ++stats.prim_tests;
+        bool accepted;
+        if (!kAnalytic || inst_kind == kInstTriangles)
+            accepted = triangle_hit<kTextures>(sc, object, inst_bsdf, ray, rng, hit);
+        else if (inst_kind == kInstSphere)
+            accepted = sphere_hit<kTextures>(sc, sc.analytic[inst_analytic], object, inst_bsdf, ray, rng, hit);
+        else if (inst_kind == kInstDisk)
+            accepted = disk_hit<kTextures>(sc, sc.analytic[inst_analytic], object, inst_bsdf, ray, rng, hit);
+        else
+            accepted = cylinder_hit<kTextures>(sc, sc.analytic[inst_analytic], object, inst_bsdf, ray, rng, hit);
+        if (accepted)
+        {
+            found = true;
+            hit.inst = inst;
+            if (kAny)
+                return true;
+        }
+        node = as_uint(n0.w);
+    }
+    return found;
+}
+
+// Shading frame of the closest hit (second half of the reference's primitive
+// tests: triangle.cpp:122-144, sphere.cpp:48-83, disk.cpp:46-108,
+// cylinder.cpp:61-86), including bump mapping and the back-face flip.
+template <bool kAnalytic, bool kTextures>
+MCPT_HD Surface make_surface(const DeviceScene &sc, const Ray &ray, const HitRaw &h)
+{
+    Surface s;
+    s.inst = h.inst, s.inside = h.inside;
+    const InstanceRec &rec = sc.instances[h.inst];
+    const uint32_t bsdf = rec.bsdf;
+    auto bump = [&](V3 &normal, V3 &tangent, V3 &bitangent)
+    {
+        if (bsdf == kNone)
+            return;
+        if (kTextures) // bsdf.cpp:238-253
+        {
+            const uint32_t map = sc.bsdfs[bsdf].bump;
+            if (map != kNone)
+            {
+                const V2 g = texture_gradient(sc.textures, sc.texels, map, s.uv);
+                normal = normalize(-g.u * tangent - g.v * bitangent + normal);
+            }
+        }
+        bitangent = normalize(cross(normal, tangent));
+        tangent = normalize(cross(bitangent, normal));
+    };
+    if (!kAnalytic || rec.kind == kInstTriangles)
+    {
+        const float4 *p = sc.tri_pos + 3 * static_cast<size_t>(h.prim);
+        const float4 *at = sc.tri_attr + 9 * static_cast<size_t>(h.prim);
+        const float u = h.a, v = h.b, w = h.c;
+        s.uv = triangle_uv(at, u, v, w);
+        s.position = u * xyz(p[0]) + v * xyz(p[1]) + w * xyz(p[2]);
+        s.normal = normalize(u * xyz(at[0]) + v * xyz(at[1]) + w * xyz(at[2]));
+        s.tangent = normalize(u * xyz(at[3]) + v * xyz(at[4]) + w * xyz(at[5]));
+        s.bitangent = normalize(u * xyz(at[6]) + v * xyz(at[7]) + w * xyz(at[8]));
+        bump(s.normal, s.tangent, s.bitangent);
+    }
+    else
+    {
+        const AnalyticRec &q = sc.analytic[rec.analytic];
+        const V3 p_local = V3{h.a, h.b, h.c};
+        if (rec.kind == kInstSphere)
+        {
+            float theta, phi;
+            s.uv = sphere_uv(p_local, theta, phi);
+            s.position = transform_point(q.to_world, p_local + from(q.center));
+            s.normal = transform_dir(q.normal_to_world, normalize(p_local));
+            constexpr float jitter = 0.01f * kPi;
+            float theta_p = theta + jitter;
+            const bool flip = theta_p > kPi;
+            if (flip)
+                theta_p = theta - jitter;
+            s.bitangent = normalize(transform_point(q.to_world, from_spherical(theta_p, phi, 1.0f)) - s.position);
+            if (flip)
+                s.bitangent = -s.bitangent;
+            s.tangent = normalize(cross(s.bitangent, s.normal));
+            s.bitangent = normalize(cross(s.normal, s.tangent));
+            bump(s.normal, s.tangent, s.bitangent);
+        }
+        else if (rec.kind == kInstDisk)
+        {
+            float theta, phi;
+            to_spherical(p_local, theta, phi);
+            const float r = length(p_local);
+            s.uv = V2{r, phi * k1Div2Pi};
+            s.position = transform_point(q.to_world, p_local);
+            constexpr float jitter = 0.01f * kPi;
+            float r_p = r + jitter;
+            const bool flip_b = r_p > r;
+            if (flip_b)
+                r_p = r - jitter;
+            float phi_p = phi + jitter;
+            const bool flip_t = phi_p > kPi;
+            if (flip_t)
+                phi_p = phi - jitter;
+            const V3 e1 = from_spherical(theta, phi, r_p) - p_local, e2 = from_spherical(theta, phi_p, r) - p_local;
+            const V2 duv1 = V2{r_p, s.uv.v} - s.uv, duv2 = V2{s.uv.u, phi_p * k1Div2Pi} - s.uv;
+            const float norm = 1.0f / (duv2.u * duv1.v - duv1.u * duv2.v);
+            V3 tangent = normalize((duv1.v * e2 - duv2.v * e1) * norm), normal = V3{0, 0, 1};
+            if (flip_t)
+                tangent = -tangent;
+            // the reference also derives a bitangent from the uv differentials
+            // (disk.cpp:76-79) but overwrites it before use (disk.cpp:85)
+            V3 bitangent = normalize(cross(normal, tangent));
+            tangent = normalize(cross(bitangent, normal));
+            bump(normal, tangent, bitangent);
+            s.normal = transform_dir(q.normal_to_world, normal);
+            s.tangent = transform_dir(q.to_world, tangent);
+            s.bitangent = transform_dir(q.to_world, bitangent);
+        }
+        else
+        {
+            s.uv = V2{atan2f(p_local.y, p_local.x) * k1Div2Pi, p_local.z / q.length};
+            s.position = transform_point(q.to_world, p_local);
+            s.normal = transform_dir(q.normal_to_world, normalize(V3{p_local.x, p_local.y, 0.0f}));
+            s.tangent = transform_dir(q.normal_to_world, V3{0, 0, 1});
+            s.bitangent = normalize(cross(s.normal, s.tangent));
+            bump(s.normal, s.tangent, s.bitangent);
+        }
+    }
+    if (h.inside)
+    {
+        s.normal = -s.normal;
+        s.bitangent = -s.bitangent;
+    }
+    return s;
+}
+
+// Uniform point on an instance for area-light sampling: area-weighted descent
+// (blas.cpp:79-98) — right child of node i is skip(i + 1) — then the
+// primitive's own sampler (triangle.cpp:150-160, sphere.cpp:88-105,
+// disk.cpp:113-141, cylinder.cpp:91-104).
+struct LightPoint
+{
+    V2 uv;
+    V3 position, normal;
+};
+
+template <bool kAnalytic>
+MCPT_HD LightPoint sample_instance(const DeviceScene &sc, uint32_t inst, float xi0, float xi1, float xi2)
+{
+    const InstanceRec &rec = sc.instances[inst];
+    uint32_t node = rec.blas_root;
+    float thresh = sc.node_area[node] * xi0;
+    uint32_t object;
+    while ((object = as_uint(sc.nodes[2 * static_cast<size_t>(node) + 1].w)) == kNoObject)
+    {
+        const uint32_t left = node + 1;
+        const float left_area = sc.node_area[left];
+        if (thresh < left_area)
+        {
+            node = left;
+        }
+        else
+        {
+            thresh -= left_area;
+            node = as_uint(sc.nodes[2 * static_cast<size_t>(left)].w);
+        }
+    }
+    LightPoint lp;
+    if (!kAnalytic || rec.kind == kInstTriangles)
+    {
+        const float4 *p = sc.tri_pos + 3 * static_cast<size_t>(object);
+        const float4 *at = sc.tri_attr + 9 * static_cast<size_t>(object);
+        const float s = sqrtf(1.0f - xi1);
+        const float u = 1.0f - s, v = s * xi2, w = 1.0f - u - v;
+        lp.uv = triangle_uv(at, w, u, v);
+        lp.position = w * xyz(p[0]) + u * xyz(p[1]) + v * xyz(p[2]);
+        lp.normal = normalize(w * xyz(at[0]) + u * xyz(at[1]) + v * xyz(at[2]));
+        return lp;
+    }
+    const AnalyticRec &q = sc.analytic[rec.analytic];
+    if (rec.kind == kInstSphere)
+    {
+        const float cos_t = 1.0f - 2.0f * xi1;
+        lp.uv = V2{xi2, acosf(cos_t) * k1DivPi};
+        const float sin_t = sqrtf(1.0f - sqr(cos_t)), phi = k2Pi * xi2;
+        const V3 n_local = V3{sin_t * cosf(phi), sin_t * sinf(phi), cos_t};
+        lp.position = transform_point(q.to_world, from(q.center) + q.radius * n_local);
+        lp.normal = transform_dir(q.normal_to_world, n_local);
+    }
+    else if (rec.kind == kInstDisk)
+    {
+        const float r1 = 2.0f * xi1 - 1.0f, r2 = 2.0f * xi2 - 1.0f;
+        float phi, r;
+        if (r1 == 0.0f && r2 == 0.0f)
+            r = phi = 0;
+        else if (sqr(r1) > sqr(r2))
+            r = r1, phi = kPiDiv4 * (r2 / r1);
+        else
+            r = r2, phi = kPiDiv2 - (r1 / r2) * kPiDiv4;
+        lp.uv = V2{r, phi * k1Div2Pi};
+        lp.position = transform_point(q.to_world, V3{(r * cosf(phi)) * 0.5f, (r * sinf(phi)) * 0.5f, 0});
+        lp.normal = transform_dir(q.normal_to_world, V3{0, 0, 1});
+    }
+    else
+    {
+        const float phi = k2Pi * xi1, z = xi2 * q.length;
+        lp.uv = V2{xi1, xi2};
+        lp.position = transform_point(q.to_world, V3{cosf(phi) * q.radius, sinf(phi) * q.radius, z});
+        lp.normal = transform_dir(q.normal_to_world, V3{cosf(phi), sinf(phi), 0});
+    }
+    return lp;
+}
+
+} // namespace mcpt
+
+#endif // MCPT_TRAVERSAL_H

@@ -1,0 +1,328 @@
+// Small vector / matrix / sampling vocabulary of the renderer, usable from
+// host code (scene commit) and from HIP device code (kernels).
+//
+// Numerical contract (it decides parity with the reference CPU integrator):
+//   * every operation is a single IEEE float32 operation in the order written;
+//     build with -ffp-contract=off, never with fast-math;
+//   * `v / s` and `v / w` multiply by reciprocals, normalisation is
+//     v * (1 / |v|), direction transforms normalise their result — as the
+//     reference's tensor library does (src/tensor/vec3.cpp:107-185,
+//     mat4.cpp:264-273, vec4.hpp:55);
+//   * where the reference evaluates a sub-expression in double because only
+//     the double libm overload is visible, the double is
+//     written out here too (see D(), the Pow3d/Pow5d helpers and callers).
+#ifndef MCPT_VECMATH_H
+#define MCPT_VECMATH_H
+
+#include <math.h>
+#include <stdint.h>
+
+#include "device_scene.h"
+
+#if defined(__HIPCC__)
+#define MCPT_HD __host__ __device__ __forceinline__
+#else
+#define MCPT_HD inline
+#endif
+
+namespace mcpt
+{
+
+constexpr float kEpsFloat = 1.1920928955078125e-07f; // FLT_EPSILON, defs.hpp:24
+constexpr float kEpsDistance = 1e-4f;                // defs.hpp:25
+constexpr float kEps = 0.01f;                        // defs.hpp:26
+constexpr float kMaxFloat = 3.402823466e+38f;
+constexpr float kLowestFloat = -3.402823466e+38f;
+
+constexpr float kPi = 3.141592653589793f; // math.hpp:17-23
+constexpr float k2Pi = 3.141592653589793f * 2.0f;
+constexpr float kPiDiv2 = 3.141592653589793f * 0.5f;
+constexpr float kPiDiv4 = 3.141592653589793f * 0.25f;
+constexpr float k1DivPi = 1.0f / kPi;
+constexpr float k1Div2Pi = 1.0f / k2Pi;
+constexpr float k1Div4Pi = 1.0f / (4.0f * kPi);
+
+MCPT_HD double D(float x) { return static_cast<double>(x); }
+
+struct V2
+{
+    float u, v;
+};
+MCPT_HD V2 mk2(float u, float v) { return V2{u, v}; }
+MCPT_HD V2 operator+(V2 a, V2 b) { return V2{a.u + b.u, a.v + b.v}; }
+MCPT_HD V2 operator-(V2 a, V2 b) { return V2{a.u - b.u, a.v - b.v}; }
+MCPT_HD V2 operator*(float t, V2 a) { return V2{t * a.u, t * a.v}; }
+
+struct V3
+{
+    float x, y, z;
+};
+MCPT_HD V3 mk3(float x, float y, float z) { return V3{x, y, z}; }
+MCPT_HD V3 splat(float s) { return V3{s, s, s}; }
+MCPT_HD V3 from(const Vec3f &v) { return V3{v.x, v.y, v.z}; }
+MCPT_HD V3 xyz(const float4 &v) { return V3{v.x, v.y, v.z}; }
+MCPT_HD float comp(V3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+
+MCPT_HD V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+MCPT_HD V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+MCPT_HD V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+MCPT_HD V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+MCPT_HD V3 operator/(V3 a, V3 b)
+{
+    const float k0 = 1.0f / b.x, k1 = 1.0f / b.y, k2 = 1.0f / b.z;
+    return V3{a.x * k0, a.y * k1, a.z * k2};
+}
+MCPT_HD V3 operator+(V3 a, float t) { return V3{a.x + t, a.y + t, a.z + t}; }
+MCPT_HD V3 operator-(V3 a, float t) { return V3{a.x - t, a.y - t, a.z - t}; }
+MCPT_HD V3 operator*(V3 a, float t) { return V3{a.x * t, a.y * t, a.z * t}; }
+MCPT_HD V3 operator/(V3 a, float t)
+{
+    const float k = 1.0f / t;
+    return V3{a.x * k, a.y * k, a.z * k};
+}
+MCPT_HD V3 operator+(float t, V3 a) { return V3{t + a.x, t + a.y, t + a.z}; }
+MCPT_HD V3 operator-(float t, V3 a) { return V3{t - a.x, t - a.y, t - a.z}; }
+MCPT_HD V3 operator*(float t, V3 a) { return V3{t * a.x, t * a.y, t * a.z}; }
+MCPT_HD void operator+=(V3 &a, V3 b) { a = a + b; }
+MCPT_HD void operator*=(V3 &a, V3 b) { a = a * b; }
+MCPT_HD void operator*=(V3 &a, float t) { a = a * t; }
+
+MCPT_HD float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+MCPT_HD float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+MCPT_HD V3 normalize(V3 a)
+{
+    const float k = 1.0f / length(a);
+    return a * k;
+}
+MCPT_HD V3 cross(V3 a, V3 b) // vec3.cpp:192-196, including its -x*z + z*x form
+{
+    return V3{a.y * b.z - a.z * b.y, -a.x * b.z + a.z * b.x, a.x * b.y - a.y * b.x};
+}
+MCPT_HD V3 vmin(V3 a, V3 b) { return V3{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)}; }
+MCPT_HD V3 vmax(V3 a, V3 b) { return V3{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)}; }
+MCPT_HD V3 vsqrt(V3 a) { return V3{sqrtf(a.x), sqrtf(a.y), sqrtf(a.z)}; }
+MCPT_HD float sqr(float t) { return t * t; }
+MCPT_HD V3 sqr(V3 t) { return t * t; }
+MCPT_HD float max_component(V3 a) { return fmaxf(fmaxf(a.x, a.y), a.z); }
+
+MCPT_HD float lerp(float a, float b, float t) { return (1.0f - t) * a + t * b; } // math.hpp:74-77
+MCPT_HD V3 lerp(V3 a, V3 b, float t) { return (1.0f - t) * a + t * b; }
+
+// ---- matrices -------------------------------------------------------------
+MCPT_HD float dot4(const float *a, float bx, float by, float bz, float bw) // vec4.cpp:164-167
+{
+    return a[0] * bx + a[1] * by + a[2] * bz + a[3] * bw;
+}
+
+MCPT_HD V3 transform_point(const Mat4f &a, V3 p) // mat4.cpp:264-267, vec4.cpp:93-97
+{
+    const float x = dot4(a.m + 0, p.x, p.y, p.z, 1.0f), y = dot4(a.m + 4, p.x, p.y, p.z, 1.0f),
+                z = dot4(a.m + 8, p.x, p.y, p.z, 1.0f), w = dot4(a.m + 12, p.x, p.y, p.z, 1.0f);
+    const float k = 1.0f / w;
+    return V3{x * k, y * k, z * k};
+}
+
+MCPT_HD V3 transform_dir(const Mat4f &a, V3 d) // mat4.cpp:270-273: normalised
+{
+    return normalize(V3{dot4(a.m + 0, d.x, d.y, d.z, 0.0f), dot4(a.m + 4, d.x, d.y, d.z, 0.0f),
+                        dot4(a.m + 8, d.x, d.y, d.z, 0.0f)});
+}
+
+// ---- RNG and low-discrepancy points (math.hpp:29-63) -----------------------
+MCPT_HD uint32_t tea4(uint32_t v0, uint32_t v1)
+{
+    uint32_t sum = 0;
+#pragma unroll
+    for (int round = 0; round < 4; ++round)
+    {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+
+MCPT_HD float lcg_next(uint32_t &state)
+{
+    state = state * 1664525u + 1013904223u;
+    return static_cast<float>(state & 0x00ffffffu) / static_cast<float>(0x01000000u);
+}
+
+// Base-2 radical inverse with the reference's float index update
+// (`index *= base_inv`, math.hpp:36-38).
+MCPT_HD float radical_inverse2(uint32_t index)
+{
+    float result = 0.0f, frac = 0.5f;
+    while (index > 0)
+    {
+        result += frac * static_cast<float>(index % 2u);
+        index = static_cast<uint32_t>(static_cast<float>(index) * 0.5f);
+        frac *= 0.5f;
+    }
+    return result;
+}
+
+MCPT_HD float power_heuristic(float a, float b) // math.cpp:8-13
+{
+    a *= a;
+    b *= b;
+    return a / (a + b);
+}
+
+// Exact integer powers in double standing in for the reference's
+// pow(float, int) calls (double libm pow).  x*x*x in double differs from a
+// correctly rounded pow by < 1 ulp(double); after the cast to float the two
+// agree except on ~1e-9 of inputs.
+MCPT_HD double pow2d(float x) { return D(x) * D(x); }
+MCPT_HD double pow3d(float x) { return D(x) * D(x) * D(x); }
+MCPT_HD double pow5d(float x)
+{
+    const double x2 = D(x) * D(x);
+    return x2 * x2 * D(x);
+}
+
+MCPT_HD void sample_hemisphere_cosine(float xi0, float xi1, V3 &dir, float &pdf) // math.cpp:31-38
+{
+    const float cos_t = sqrtf(xi0), phi = k2Pi * xi1;
+    const float sin_t = sqrtf(1.0f - sqr(cos_t)); // double sqrt -> float == sqrtf
+    dir = V3{sin_t * cosf(phi), sin_t * sinf(phi), cos_t};
+    pdf = k1DivPi * cos_t;
+}
+
+MCPT_HD V3 sample_sphere_uniform(float xi0, float xi1) // math.cpp:24-29
+{
+    const float cos_t = 1.0f - 2.0f * xi0, phi = k2Pi * xi1;
+    const float sin_t = sqrtf(1.0f - sqr(cos_t));
+    return V3{sin_t * cosf(phi), sin_t * sinf(phi), cos_t};
+}
+
+MCPT_HD V3 sample_cone_uniform(float cos_cutoff, float xi0, float xi1) // math.cpp:15-22
+{
+    const float cos_t = 1.0f - (1.0f - cos_cutoff) * xi0, phi = 2.0f * kPi * xi1;
+    const float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
+    return V3{sin_t * cosf(phi), sin_t * sinf(phi), cos_t};
+}
+
+MCPT_HD uint32_t cdf_search(uint32_t num, const float *cdf, float target) // math.cpp:40-55
+{
+    uint32_t lo = 0, hi = num;
+    while (lo + 1 != hi)
+    {
+        const uint32_t mid = (lo + hi) >> 1;
+        const float c = cdf[mid];
+        if (c < target)
+            lo = mid;
+        else if (c > target)
+            hi = mid;
+        else
+            return mid;
+    }
+    return hi;
+}
+
+MCPT_HD bool solve_quadratic(float a, float b, float c, float &x0, float &x1) // math.cpp:57-98
+{
+    if (a == 0.0f)
+    {
+        if (b != 0.0f)
+        {
+            x0 = x1 = -c / b;
+            return true;
+        }
+        return false;
+    }
+    const float disc = b * b - 4.0f * a * c;
+    if (disc < 0.0f)
+        return false;
+    const float root = sqrtf(disc);
+    const float q = (b < 0.0f) ? -0.5f * (b - root) : -0.5f * (b + root);
+    x0 = q / a;
+    x1 = c / q;
+    if (x0 > x1)
+    {
+        const float t = x0;
+        x0 = x1;
+        x1 = t;
+    }
+    return true;
+}
+
+// y-up spherical coordinates (math.cpp:101-128)
+MCPT_HD void to_spherical(V3 v, float &theta, float &phi)
+{
+    v = normalize(v);
+    theta = acosf(fminf(1.0f, fmaxf(-1.0f, v.y)));
+    if (v.z == 0 && v.x == 0)
+    {
+        phi = 0;
+    }
+    else
+    {
+        phi = atan2f(v.z, v.x);
+        if (phi < 0.0f)
+            phi += 2.0f * kPi;
+    }
+}
+
+MCPT_HD V3 from_spherical(float theta, float phi, float r)
+{
+    const float sin_t = sinf(theta);
+    return V3{r * sinf(phi) * sin_t, r * cosf(theta), r * cosf(phi) * sin_t};
+}
+
+// math.cpp:130-145; the reciprocal square roots are float / double-sqrt.
+MCPT_HD V3 frame_to_world(V3 local, V3 up)
+{
+    V3 c;
+    if (sqrt(D(sqr(up.x) + sqr(up.z))) > D(kEpsFloat))
+    {
+        const float k = static_cast<float>(1.0 / sqrt(D(sqr(up.x) + sqr(up.z))));
+        c = V3{up.z * k, 0, -up.x * k};
+    }
+    else
+    {
+        const float k = static_cast<float>(1.0 / sqrt(D(sqr(up.y) + sqr(up.z))));
+        c = V3{0, up.z * k, -up.y * k};
+    }
+    const V3 b = normalize(cross(c, up));
+    return normalize(local.x * b + local.y * c + local.z * up);
+}
+
+MCPT_HD V3 reflect(V3 wi, V3 n) // ray.cpp:49-52
+{
+    return normalize(wi - 2.0f * dot(wi, n) * n);
+}
+
+MCPT_HD bool refract(V3 wi, V3 n, float eta_inv, V3 &wt) // ray.cpp:54-68
+{
+    const float cos_t = fabsf(dot(wi, n));
+    const float k = 1.0f - sqr(eta_inv) * (1.0f - sqr(cos_t));
+    if (k < 0)
+        return false;
+    wt = normalize(eta_inv * wi + (eta_inv * cos_t - sqrtf(k)) * n);
+    return true;
+}
+
+// ---- GGX pieces shared by the LUT build (host) and the BSDFs (device) ------
+MCPT_HD void ggx_sample_iso(float xi0, float xi1, float alpha, V3 &h, float &pdf) // microfacet.cpp:8-19
+{
+    const float a2 = sqr(alpha);
+    const float tan2 = a2 * xi0 / (1.0f - xi0), phi = k2Pi * xi1;
+    const float cos_t = static_cast<float>(1.0 / sqrt(D(1.0f + tan2)));
+    const float sin_t = sqrtf(1.0f - sqr(cos_t));
+    h = V3{sin_t * cosf(phi), sin_t * sinf(phi), cos_t};
+    pdf = static_cast<float>(1.0 / (D(kPi * a2) * pow3d(cos_t) * D(sqr(1.0f + tan2 / a2))));
+}
+
+MCPT_HD float smith_g1_iso(float alpha, V3 v, V3 h) // microfacet.cpp:62-74
+{
+    const float n_dot_v = v.z;
+    if (n_dot_v * h.z <= 0)
+        return 0;
+    const float c2 = sqr(n_dot_v), tan2 = (1.0f - c2) / c2, a2 = sqr(alpha);
+    return 2.0f / (1.0f + sqrtf(static_cast<float>(1.0 + D(a2 * tan2))));
+}
+
+} // namespace mcpt
+
+#endif // MCPT_VECMATH_H

@@ -1,0 +1,47 @@
+"""TEST INFRASTRUCTURE — ctypes loader of tests/emu/libmcpt_emu.so (host build
+of the kernel body; see emulator.cpp)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libmcpt_emu.so")
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+
+
+class Emulator:
+    def __init__(self):
+        subprocess.run(["make", "-s", "-C", HERE], check=True)
+        lib = ctypes.CDLL(SO)
+        lib.mcpt_emu_last_error.restype = ctypes.c_char_p
+        lib.mcpt_emu_render.restype = ctypes.c_int
+        lib.mcpt_emu_render.argtypes = [ctypes.c_char_p, _f32p, ctypes.c_int, ctypes.c_void_p,
+                                        ctypes.POINTER(ctypes.c_uint32)]
+        lib.mcpt_emu_nodes.restype = ctypes.c_int
+        lib.mcpt_emu_nodes.argtypes = [ctypes.c_char_p, _u32p, _f32p, ctypes.c_uint32]
+        self.lib = lib
+
+    def render(self, mcsd_path, width, height, variant=-1, counted=False):
+        frame = np.zeros((height, width, 3), dtype=np.float32)
+        counters = np.zeros(6, dtype=np.uint32)
+        feat = ctypes.c_uint32()
+        rc = self.lib.mcpt_emu_render(str(mcsd_path).encode(), frame, variant,
+                                      counters.ctypes.data if counted else None, ctypes.byref(feat))
+        if rc != 0:
+            raise RuntimeError(self.lib.mcpt_emu_last_error().decode())
+        info = {"features": feat.value}
+        if counted:
+            info.update(zip(("closest_rays", "shadow_rays", "node_tests", "prim_tests", "shaded_hits", "samples"),
+                            (int(c) for c in counters)))
+        return frame, info
+
+    def nodes(self, mcsd_path, capacity=1 << 22):
+        links = np.zeros((capacity, 2), dtype=np.uint32)
+        geom = np.zeros((capacity, 7), dtype=np.float32)
+        n = self.lib.mcpt_emu_nodes(str(mcsd_path).encode(), links, geom, capacity)
+        if n < 0:
+            raise RuntimeError(self.lib.mcpt_emu_last_error().decode())
+        return links[:n], geom[:n]

@@ -1,0 +1,158 @@
+// TEST INFRASTRUCTURE — host emulation of the GPU lane state machine.
+//
+// Compiles the product's kernel body (csrc/path_core.h and everything it
+// includes) and the product's scene commit (csrc/host/commit.cpp) for the CPU
+// and runs one "lane" per pixel in a thread pool.  It exists so that the
+// logic of the HIP kernel (stackless traversal, stage ordering, draw order,
+// expression forms) can be checked bit-for-bit against the oracle in a
+// container without a GPU.  It is NOT part of libmcpt_hip.so, is never used by
+// the product path, bench.py or smoke(), and is not a fallback: the product has
+// no CPU rendering path.
+#include <atomic>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "host/commit.hpp"
+#include "path_core.h"
+
+namespace
+{
+
+using namespace mcpt;
+
+thread_local std::string g_error;
+
+template <uint32_t kFeatures>
+void RenderAll(const DeviceScene &sc, float *frame, LaneCounters *total)
+{
+    using C = Config<kFeatures>;
+    const uint32_t n = static_cast<uint32_t>(sc.camera.width) * sc.camera.height;
+    const unsigned workers = std::max(1u, std::thread::hardware_concurrency());
+    std::atomic<uint32_t> next{0};
+    std::vector<LaneCounters> counts(workers, LaneCounters{0, 0, 0, 0, 0, 0});
+    auto work = [&](unsigned tid)
+    {
+        for (;;)
+        {
+            const uint32_t begin = next.fetch_add(64);
+            if (begin >= n)
+                break;
+            for (uint32_t p = begin; p < std::min(begin + 64, n); ++p)
+            {
+                LaneCounters c{0, 0, 0, 0, 0, 0};
+                const V3 v = render_pixel<C>(sc, p, total ? &c : nullptr);
+                frame[3 * p] = v.x, frame[3 * p + 1] = v.y, frame[3 * p + 2] = v.z;
+                counts[tid].closest_rays += c.closest_rays, counts[tid].shadow_rays += c.shadow_rays;
+                counts[tid].node_tests += c.node_tests, counts[tid].prim_tests += c.prim_tests;
+                counts[tid].shaded_hits += c.shaded_hits, counts[tid].samples += c.samples;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < workers; ++t)
+        pool.emplace_back(work, t);
+    work(0);
+    for (std::thread &t : pool)
+        t.join();
+    if (total)
+        for (const LaneCounters &c : counts)
+        {
+            total->closest_rays += c.closest_rays, total->shadow_rays += c.shadow_rays;
+            total->node_tests += c.node_tests, total->prim_tests += c.prim_tests;
+            total->shaded_hits += c.shaded_hits, total->samples += c.samples;
+        }
+}
+
+} // namespace
+
+extern "C"
+{
+
+const char *mcpt_emu_last_error(void) { return g_error.c_str(); }
+
+// variant: -1 = pick like the GPU launcher does, otherwise a feature mask to
+// force (must be a superset of the scene's features).  counters: 6 x u32 or NULL.
+int mcpt_emu_render(const char *mcsd_path, float *frame, int variant, uint32_t *counters, uint32_t *features_out)
+{
+    try
+    {
+        const FlatScene flat = CommitScene(mcsd::Load(mcsd_path));
+        const DeviceScene sc = flat.HostView();
+        if (features_out)
+            *features_out = flat.features;
+        LaneCounters total{0, 0, 0, 0, 0, 0};
+        LaneCounters *cnt = counters ? &total : nullptr;
+        constexpr uint32_t kAll = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
+        uint32_t f = flat.features;
+        uint32_t pick;
+        if (variant >= 0)
+            pick = static_cast<uint32_t>(variant);
+        else if (f == 0)
+            pick = 0;
+        else if ((f & ~kFeatEmitters) == 0)
+            pick = kFeatEmitters;
+        else if ((f & ~(kFeatEmitters | kFeatTextures | kFeatMicrofacet)) == 0)
+            pick = kFeatEmitters | kFeatTextures | kFeatMicrofacet;
+        else
+            pick = kAll;
+        if ((f & ~pick) != 0)
+            throw std::runtime_error("forced variant does not cover the scene's features");
+        switch (pick)
+        {
+        case 0:
+            RenderAll<0>(sc, frame, cnt);
+            break;
+        case kFeatEmitters:
+            RenderAll<kFeatEmitters>(sc, frame, cnt);
+            break;
+        case kFeatEmitters | kFeatTextures | kFeatMicrofacet:
+            RenderAll<kFeatEmitters | kFeatTextures | kFeatMicrofacet>(sc, frame, cnt);
+            break;
+        default:
+            RenderAll<kAll>(sc, frame, cnt);
+            break;
+        }
+        if (counters)
+        {
+            counters[0] = total.closest_rays, counters[1] = total.shadow_rays, counters[2] = total.node_tests;
+            counters[3] = total.prim_tests, counters[4] = total.shaded_hits, counters[5] = total.samples;
+        }
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+// Committed tables of the product's host commit, for comparison with the
+// oracle's: nodes as (skip, object) u32 pairs + 6 box floats + area.
+int mcpt_emu_nodes(const char *mcsd_path, uint32_t *links, float *geom, uint32_t capacity)
+{
+    try
+    {
+        const FlatScene flat = CommitScene(mcsd::Load(mcsd_path));
+        const uint32_t n = static_cast<uint32_t>(flat.node_area.size());
+        if (n > capacity)
+            return static_cast<int>(n);
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            const float4 a = flat.nodes[2 * i], b = flat.nodes[2 * i + 1];
+            std::memcpy(&links[2 * i], &a.w, 4), std::memcpy(&links[2 * i + 1], &b.w, 4);
+            geom[7 * i] = flat.node_area[i];
+            geom[7 * i + 1] = a.x, geom[7 * i + 2] = a.y, geom[7 * i + 3] = a.z;
+            geom[7 * i + 4] = b.x, geom[7 * i + 5] = b.y, geom[7 * i + 6] = b.z;
+        }
+        return static_cast<int>(n);
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return -1;
+    }
+}
+
+} // extern "C"

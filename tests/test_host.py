@@ -1,0 +1,206 @@
+"""CPU-side checks of the product: C ABI surface, host commit tables, and the
+kernel body's logic through the host emulator (tests/emu) — all without a GPU."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from golden_cases import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+MANIFEST = json.load(open(os.path.join(GOLDEN, "manifest.json")))
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    pkg.capi.build()
+    return pkg.capi.lib()
+
+
+@pytest.fixture(scope="module")
+def emulator():
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import emu
+    return emu.Emulator()
+
+
+def test_library_exports_every_declared_symbol(pkg, lib):
+    header = open(os.path.join(ROOT, "include", "mcpt.h")).read()
+    declared = set(re.findall(r"\b(mcpt_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(pkg.capi.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_config_roundtrip_and_builtin(pkg, lib, tmp_path):
+    cfg = pkg.capi.Config.builtin("cornell-box")
+    assert cfg.film() == (1024, 1024, 256)
+    cfg.set_film(64, 0, 8)                     # 0 keeps the scene's own value
+    assert cfg.film() == (64, 1024, 8)
+    cfg.set_film(0, 64, 0)
+    out = tmp_path / "c.mcsd"
+    cfg.save_mcsd(out)
+    # the C++ built-in and the Python builder describe the same scene
+    assert out.read_bytes() == pkg.mcsd.dumps(pkg.scenes.cornell_box(64, 64, 8))
+    again = pkg.capi.Config.load_mcsd(out)
+    assert again.film() == (64, 64, 8)
+
+
+def test_no_cpu_fallback(pkg, lib):
+    """Without a HIP device the renderer refuses to exist."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(pkg.capi.McptError, match="GPU only|HIP"):
+        pkg.capi.Renderer(pkg.capi.Config.builtin("cornell-box").set_film(8, 8, 1))
+
+
+def test_bad_input_is_rejected(pkg, lib, tmp_path):
+    with pytest.raises(pkg.capi.McptError):
+        pkg.capi.Config.from_mcsd_bytes(b"not a scene")
+    with pytest.raises(pkg.capi.McptError):
+        pkg.capi.Config.load_mcsd(tmp_path / "missing.mcsd")
+    with pytest.raises(pkg.capi.McptError):
+        pkg.capi.Config.builtin("teapot")
+
+
+def test_image_writers(pkg, lib, tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    frame = rng.random((20, 30, 3)).astype(np.float32)
+    pkg.capi.write_image(tmp_path / "a.png", frame)
+    got = np.asarray(Image.open(tmp_path / "a.png"))
+    # reference transfer curve (image_io.cpp:25-53), truncated to 8 bit
+    lin = frame.astype(np.float32)
+    srgb = np.where(lin <= np.float32(0.0031308), np.float32(12.92) * lin,
+                    np.float32(1.055) * lin ** np.float32(1 / 2.4) - np.float32(0.055))
+    want = (np.clip(srgb, 0, 1) * 255).astype(np.uint8)
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    pkg.capi.write_image(tmp_path / "a.pfm", frame)
+    raw = (tmp_path / "a.pfm").read_bytes()
+    assert raw.startswith(b"PF\n30 20\n-1.0\n")
+    body = np.frombuffer(raw[len(b"PF\n30 20\n-1.0\n"):], dtype="<f4").reshape(20, 30, 3)
+    assert np.array_equal(body[::-1], frame)
+    pkg.capi.write_image(tmp_path / "a.exr", frame)
+    exr = (tmp_path / "a.exr").read_bytes()
+    assert exr[:4] == b"\x76\x2f\x31\x01"
+    # uncompressed scanlines: last line's R plane is the tail of the file
+    tail = np.frombuffer(exr[-30 * 4:], dtype="<f4")
+    assert np.array_equal(tail, frame[-1, :, 0])
+    with pytest.raises(pkg.capi.McptError):
+        pkg.capi.write_image(tmp_path / "a.bmp", frame)
+
+
+def test_tile_unpack(pkg, lib):
+    w, h = 21, 13
+    frame = np.zeros((h, w, 3), dtype=np.float32)
+    want = np.zeros((h, w, 3), dtype=np.float32)
+    tiles_x, tiles_y = 3, 2
+    for rank in range(4):
+        rng = pkg.capi.TileRange(rank, 4, 0)
+        n = lib.mcpt_tile_range_size(tiles_x * tiles_y, ctypes.byref(rng))
+        assert n == len(range(rank, tiles_x * tiles_y, 4))
+        packed = np.zeros((n, 64, 3), dtype=np.float32)
+        for k in range(n):
+            t = rank + 4 * k
+            for r in range(64):
+                x, y = (t % tiles_x) * 8 + r % 8, (t // tiles_x) * 8 + r // 8
+                packed[k, r] = (t, r, 1)
+                if x < w and y < h:
+                    want[y, x] = (t, r, 1)
+        pkg.capi.unpack_tiles(packed, rng, w, h, frame)
+    assert np.array_equal(frame, want) and (frame[..., 2] == 1).all()
+
+
+# ---- host commit vs oracle: same tree, expressed with skip links ------------
+def _skip_links_from_children(links):
+    """Oracle nodes (leaf, left, right, object; tree-local) of ONE tree ->
+    expected (skip, object) per node in the same (pre-order) numbering."""
+    n = len(links)
+    skip = np.full(n, 0xFFFFFFFF, dtype=np.uint64)
+    for i in range(n):
+        leaf, left, right, _ = links[i]
+        if not leaf:
+            assert left == i + 1
+            skip[left] = right
+            skip[right] = skip[i]
+    return skip
+
+
+@pytest.mark.parametrize("name", ["cornell_64_spp8", "volumetric_96x54_spp16", "terrain_directional",
+                                  "rough_plastic_constant_cyl"])
+def test_commit_matches_oracle_tables(name, pkg, oracle, emulator, mcsd_file):
+    scene = cases(pkg.scenes)[name]
+    path = mcsd_file(scene)
+    o_links, o_geom = oracle.nodes(path)
+    e_links, e_geom = emulator.nodes(path)
+    assert len(o_links) == len(e_links)
+    assert np.array_equal(o_geom, e_geom)            # areas and boxes, node for node
+    # split the oracle's array into trees: TLAS has 2*inst-1 nodes, then each BLAS
+    n_inst = len(scene.instances)
+    n_tlas = 2 * n_inst - 1
+    tlas_skip = _skip_links_from_children(o_links[:n_tlas])
+    assert np.array_equal(e_links[:n_tlas, 0].astype(np.uint64), tlas_skip)
+    # TLAS leaves name instances; BLAS leaves name GLOBAL primitive slots
+    leaves = o_links[:n_tlas, 0] == 1
+    assert np.array_equal(e_links[:n_tlas, 1][leaves], o_links[:n_tlas, 3][leaves])
+    assert (e_links[:n_tlas, 1][~leaves] == 0xFFFFFFFF).all()
+    # BLAS trees follow in instance order; a tree ends where a root's subtree ends
+    base, prim_base = n_tlas, 0
+    for _ in range(n_inst):
+        # size of this tree: walk the oracle's child links from its root
+        size, stack = 0, [0]
+        tree = o_links[base:]
+        while stack:
+            i = stack.pop()
+            size += 1
+            if not tree[i][0]:
+                stack += [tree[i][1], tree[i][2]]
+        tree = o_links[base:base + size]
+        want_skip = _skip_links_from_children(tree)
+        got_skip = e_links[base:base + size, 0].astype(np.uint64)
+        end = got_skip == 0xFFFFFFFF
+        assert np.array_equal(end, want_skip == 0xFFFFFFFF)
+        assert np.array_equal(got_skip[~end] - base, want_skip[~end])
+        lf = tree[:, 0] == 1
+        assert np.array_equal(e_links[base:base + size, 1][lf].astype(np.int64) - prim_base,
+                              tree[:, 3][lf].astype(np.int64))
+        base += size
+        prim_base += int(lf.sum())
+    assert base == len(o_links)
+
+
+# ---- kernel-body logic on CPU (bit-exact against reference goldens) ---------
+@pytest.mark.parametrize("name", sorted(MANIFEST["frames"]))
+def test_kernel_body_emulated_matches_golden(name, pkg, emulator, mcsd_file):
+    scene = cases(pkg.scenes)[name]
+    golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
+    frame, _ = emulator.render(mcsd_file(scene), scene.camera.width, scene.camera.height)
+    assert np.array_equal(frame, golden), f"max diff {np.abs(frame - golden).max():.3e}"
+
+
+def test_kernel_variants_agree(pkg, emulator, mcsd_file):
+    """The specialised kernel instantiations compute the same image as the
+    general one."""
+    scene = pkg.scenes.cornell_box(48, 48, 4)
+    path = mcsd_file(scene)
+    lean, info = emulator.render(path, 48, 48)
+    assert info["features"] == 0
+    for variant in (2, 26, 31):
+        other, _ = emulator.render(path, 48, 48, variant=variant)
+        assert np.array_equal(lean, other), variant
+
+
+def test_emulated_counters_match_oracle(pkg, oracle, emulator, mcsd_file):
+    scene = pkg.scenes.cornell_box(48, 48, 4)
+    path = mcsd_file(scene)
+    _, got = emulator.render(path, 48, 48, counted=True)
+    _, want = oracle.render(path, with_stats=True)
+    for key in ("closest_rays", "shadow_rays", "node_tests", "prim_tests"):
+        assert got[key] == want[key], key
+    assert got["samples"] == 48 * 48 * 4
