@@ -115,6 +115,19 @@ int mcpt_renderer_table(const mcpt_renderer *r, const char *what, const void **d
  * bytes of geometry in HBM (6 x uint64). */
 int mcpt_renderer_info(const mcpt_renderer *r, uint64_t info[6]);
 
+/* Unit-level GPU queries for diagnostics and parity tests (host pointers in and
+ * out; no reference counterpart — the reference has no tests).
+ *   intersect: rays = origin[3] dir[3] per query; out = 19 floats per query:
+ *     valid, inside, instance, primitive, t, uv[2], position[3], normal[3],
+ *     tangent[3], bitangent[3] (closest hit incl. bump / back-face handling).
+ *   bsdf: records = wo[3] wi[3] normal[3] tangent[3] bitangent[3] uv[2] inside
+ *     (18 floats); mode 0 = evaluate, 1 = sample; out = valid, pdf,
+ *     attenuation[3], wi[3].  seeds / seeds_out: the LCG state before / after. */
+int mcpt_debug_intersect(mcpt_renderer *r, uint32_t n, const float *rays, const uint32_t *seeds, float *out,
+                         uint32_t *seeds_out);
+int mcpt_debug_bsdf(mcpt_renderer *r, uint32_t id_bsdf, int mode, uint32_t n, const float *records,
+                    const uint32_t *seeds, float *out, uint32_t *seeds_out);
+
 /* Replaces Renderer::~Renderer / ReleaseData (renderer.cpp:350-369). */
 void mcpt_renderer_destroy(mcpt_renderer *r);
 

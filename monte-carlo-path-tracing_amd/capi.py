@@ -56,6 +56,14 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise McptError(f"{LIB_PATH} is not built (run __graft_entry__.build())")
+    # PyTorch wheels bundle their own libamdhip64.so.7; a process must hold ONE
+    # HIP runtime, otherwise the second one sees no devices and streams /
+    # tensors cannot be shared.  Importing torch first lets the loader satisfy
+    # this library's libamdhip64.so.7 dependency with the runtime torch loaded.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, cp, i32, u32 = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32
     L.mcpt_last_error.restype = cp
@@ -79,6 +87,8 @@ def lib():
     L.mcpt_unpack_tiles.argtypes = [vp, ctypes.POINTER(TileRange), i32, i32, vp]
     L.mcpt_renderer_table.argtypes = [vp, cp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
     L.mcpt_renderer_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.mcpt_debug_intersect.argtypes = [vp, u32, vp, vp, vp, vp]
+    L.mcpt_debug_bsdf.argtypes = [vp, u32, i32, u32, vp, vp, vp, vp]
     L.mcpt_renderer_destroy.argtypes = [vp]
     L.mcpt_renderer_destroy.restype = None
     L.mcpt_write_image.argtypes = [cp, vp, i32, i32]
@@ -98,6 +108,7 @@ EXPORTED_SYMBOLS = [
     "mcpt_renderer_draw", "mcpt_renderer_draw_device", "mcpt_renderer_draw_counted",
     "mcpt_renderer_tile_count", "mcpt_tile_range_size", "mcpt_unpack_tiles",
     "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_destroy",
+    "mcpt_debug_intersect", "mcpt_debug_bsdf",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
 ]
 
@@ -187,6 +198,27 @@ class Renderer:
                                                int(packed), ctypes.c_void_p(stream or 0),
                                                int(blocking), ctypes.byref(st)))
         return st.as_dict()
+
+    def debug_intersect(self, origins, dirs, seeds=None):
+        """Closest hit of n rays on the GPU: (out[n, 19], seeds_after[n])."""
+        rays = np.ascontiguousarray(np.concatenate([origins, dirs], axis=1), dtype=np.float32)
+        n = len(rays)
+        seeds = np.ones(n, dtype=np.uint32) if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint32)
+        out = np.zeros((n, 19), dtype=np.float32)
+        after = np.zeros(n, dtype=np.uint32)
+        _check(lib().mcpt_debug_intersect(self._h, n, rays.ctypes.data, seeds.ctypes.data,
+                                          out.ctypes.data, after.ctypes.data))
+        return out, after
+
+    def debug_bsdf(self, id_bsdf, mode, records, seeds):
+        records = np.ascontiguousarray(records, dtype=np.float32).reshape(-1, 18)
+        n = len(records)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        out = np.zeros((n, 8), dtype=np.float32)
+        after = np.zeros(n, dtype=np.uint32)
+        _check(lib().mcpt_debug_bsdf(self._h, id_bsdf, mode, n, records.ctypes.data, seeds.ctypes.data,
+                                     out.ctypes.data, after.ctypes.data))
+        return out, after
 
     def table(self, what: str) -> np.ndarray:
         data, count = ctypes.c_void_p(), ctypes.c_size_t()

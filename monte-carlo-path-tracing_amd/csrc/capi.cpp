@@ -5,6 +5,7 @@
 #include "mcpt.h"
 
 #include <chrono>
+#include <functional>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -465,6 +466,56 @@ int mcpt_renderer_info(const mcpt_renderer *r, uint64_t info[6])
     info[0] = ig.n_nodes, info[1] = ig.n_tlas_nodes, info[2] = ig.n_prims, info[3] = ig.n_instances;
     info[4] = r->flat.features, info[5] = r->flat.GeometryBytes();
     return 0;
+}
+
+// Runs `launch` with device copies of the host inputs and copies results back.
+static int RunUnit(mcpt_renderer *r, uint32_t n, const float *in, size_t in_per, const uint32_t *seeds, float *out,
+                   size_t out_per, uint32_t *seeds_out,
+                   const std::function<hipError_t(const float *, const uint32_t *, float *, uint32_t *)> &launch)
+{
+    if (!r || !in || !seeds || !out || !seeds_out)
+        return Fail("null argument");
+    float *d_in = nullptr, *d_out = nullptr;
+    uint32_t *d_seeds = nullptr, *d_seeds_out = nullptr;
+    int rc = 0;
+    try
+    {
+        Check(hipSetDevice(r->device), "select device");
+        Check(hipMalloc(reinterpret_cast<void **>(&d_in), std::max<size_t>(1, n * in_per) * 4), "allocate");
+        Check(hipMalloc(reinterpret_cast<void **>(&d_out), std::max<size_t>(1, n * out_per) * 4), "allocate");
+        Check(hipMalloc(reinterpret_cast<void **>(&d_seeds), std::max<size_t>(1, n) * 4), "allocate");
+        Check(hipMalloc(reinterpret_cast<void **>(&d_seeds_out), std::max<size_t>(1, n) * 4), "allocate");
+        Check(hipMemcpy(d_in, in, n * in_per * 4, hipMemcpyHostToDevice), "upload");
+        Check(hipMemcpy(d_seeds, seeds, n * 4ull, hipMemcpyHostToDevice), "upload");
+        Check(launch(d_in, d_seeds, d_out, d_seeds_out), "launch unit kernel");
+        Check(hipDeviceSynchronize(), "unit kernel");
+        Check(hipMemcpy(out, d_out, n * out_per * 4, hipMemcpyDeviceToHost), "download");
+        Check(hipMemcpy(seeds_out, d_seeds_out, n * 4ull, hipMemcpyDeviceToHost), "download");
+    }
+    catch (const std::exception &e)
+    {
+        rc = Fail(e.what());
+    }
+    (void)hipFree(d_in), (void)hipFree(d_out), (void)hipFree(d_seeds), (void)hipFree(d_seeds_out);
+    return rc;
+}
+
+int mcpt_debug_intersect(mcpt_renderer *r, uint32_t n, const float *rays, const uint32_t *seeds, float *out,
+                         uint32_t *seeds_out)
+{
+    return RunUnit(r, n, rays, 6, seeds, out, 19, seeds_out,
+                   [&](const float *a, const uint32_t *b, float *c, uint32_t *d)
+                   { return mcpt::LaunchIntersect(r->dev, n, a, b, c, d, nullptr); });
+}
+
+int mcpt_debug_bsdf(mcpt_renderer *r, uint32_t id_bsdf, int mode, uint32_t n, const float *records,
+                    const uint32_t *seeds, float *out, uint32_t *seeds_out)
+{
+    if (r && id_bsdf >= r->flat.bsdfs.size())
+        return Fail("BSDF id out of range");
+    return RunUnit(r, n, records, 18, seeds, out, 8, seeds_out,
+                   [&](const float *a, const uint32_t *b, float *c, uint32_t *d)
+                   { return mcpt::LaunchBsdf(r->dev, n, id_bsdf, mode, a, b, c, d, nullptr); });
 }
 
 void mcpt_renderer_destroy(mcpt_renderer *r)

@@ -26,6 +26,12 @@ struct RenderJob
 hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
                         hipStream_t stream, uint32_t n_cus, const char **variant);
 
+// Unit kernels for diagnostics and parity tests (one query per lane).
+hipError_t LaunchIntersect(const DeviceScene &sc, uint32_t n, const float *rays, const uint32_t *seeds, float *out,
+                           uint32_t *seeds_out, hipStream_t stream);
+hipError_t LaunchBsdf(const DeviceScene &sc, uint32_t n, uint32_t id_bsdf, int mode, const float *recs,
+                      const uint32_t *seeds, float *out, uint32_t *seeds_out, hipStream_t stream);
+
 } // namespace mcpt
 
 #endif // MCPT_RENDER_KERNEL_H

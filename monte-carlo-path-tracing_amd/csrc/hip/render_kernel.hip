@@ -88,6 +88,87 @@ render_kernel(const DeviceScene sc, const RenderJob job, float *__restrict__ out
     }
 }
 
+// ---- unit kernels (diagnostics / parity tests): one query per lane ----------
+constexpr uint32_t kAllFeatures = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
+
+// in: origin[3], dir[3] per ray.  out (19 floats per ray): valid, inside,
+// instance, primitive-in-instance, t, uv[2], position, normal, tangent, bitangent.
+__global__ void intersect_kernel(const DeviceScene sc, uint32_t n, const float *__restrict__ rays,
+                                 const uint32_t *__restrict__ seeds, float *__restrict__ out,
+                                 uint32_t *__restrict__ seeds_out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    Ray ray = make_ray(V3{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, V3{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]});
+    uint32_t rng = seeds[i];
+    HitRaw raw;
+    TraceStats ts{0, 0};
+    const bool hit = walk_scene<false, true, true, false>(sc, ray, rng, raw, ts);
+    float *o = out + 19 * static_cast<size_t>(i);
+    for (int k = 0; k < 19; ++k)
+        o[k] = 0.0f;
+    o[2] = o[3] = -1.0f;
+    o[4] = ray.t_max;
+    seeds_out[i] = rng;
+    if (!hit)
+        return;
+    const Surface s = make_surface<true, true>(sc, ray, raw);
+    o[0] = 1.0f, o[1] = s.inside ? 1.0f : 0.0f, o[2] = static_cast<float>(s.inst);
+    o[3] = static_cast<float>(raw.prim - sc.instances[s.inst].prim_base);
+    o[5] = s.uv.u, o[6] = s.uv.v;
+    const V3 v[4] = {s.position, s.normal, s.tangent, s.bitangent};
+    for (int k = 0; k < 4; ++k)
+        o[7 + 3 * k] = v[k].x, o[8 + 3 * k] = v[k].y, o[9 + 3 * k] = v[k].z;
+}
+
+// in (18 floats per query): wo, wi, normal, tangent, bitangent, uv, inside.
+// out (8 floats): valid, pdf, attenuation[3], wi[3].  mode 0 = evaluate, 1 = sample.
+__global__ void bsdf_kernel(const DeviceScene sc, uint32_t n, uint32_t id_bsdf, int mode,
+                            const float *__restrict__ recs, const uint32_t *__restrict__ seeds,
+                            float *__restrict__ out, uint32_t *__restrict__ seeds_out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float *r = recs + 18 * static_cast<size_t>(i);
+    BsdfQuery q;
+    q.valid = false, q.pdf = 0, q.attenuation = V3{0, 0, 0};
+    q.wo = V3{r[0], r[1], r[2]}, q.wi = V3{r[3], r[4], r[5]}, q.normal = V3{r[6], r[7], r[8]};
+    q.tangent = V3{r[9], r[10], r[11]}, q.bitangent = V3{r[12], r[13], r[14]};
+    q.uv = V2{r[15], r[16]}, q.inside = r[17] != 0.0f;
+    uint32_t rng = seeds[i];
+    const ShadeTables T = shade_tables(sc);
+    if (mode == 0)
+        bsdf_eval<true>(T, sc.bsdfs[id_bsdf], q);
+    else
+        bsdf_sample<true>(T, sc.bsdfs[id_bsdf], rng, q);
+    float *o = out + 8 * static_cast<size_t>(i);
+    o[0] = q.valid ? 1.0f : 0.0f, o[1] = q.pdf;
+    o[2] = q.attenuation.x, o[3] = q.attenuation.y, o[4] = q.attenuation.z;
+    o[5] = q.wi.x, o[6] = q.wi.y, o[7] = q.wi.z;
+    seeds_out[i] = rng;
+}
+
+hipError_t LaunchIntersect(const DeviceScene &sc, uint32_t n, const float *rays, const uint32_t *seeds, float *out,
+                           uint32_t *seeds_out, hipStream_t stream)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, n, rays, seeds, out, seeds_out);
+    return hipGetLastError();
+}
+
+hipError_t LaunchBsdf(const DeviceScene &sc, uint32_t n, uint32_t id_bsdf, int mode, const float *recs,
+                      const uint32_t *seeds, float *out, uint32_t *seeds_out, hipStream_t stream)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(bsdf_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, n, id_bsdf, mode, recs, seeds, out,
+                       seeds_out);
+    return hipGetLastError();
+}
+
 namespace
 {
 

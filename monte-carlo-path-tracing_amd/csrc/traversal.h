@@ -282,18 +282,25 @@ MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &
         }
         if (kCount)
             ++stats.prim_tests;
+        // Candidates are written to a local record and committed in ONE place:
+        // with four writers merging into `hit` across divergent branches hipcc
+        // -O2/-O3 (ROCm 7.2) dropped the disk path's store of `c` (found by the
+        // host-vs-device differential test, tests/test_gpu_units.py).
+        HitRaw cand;
+        cand.inst = inst, cand.prim = object, cand.a = cand.b = cand.c = 0.0f, cand.inside = false;
         bool accepted;
         if (!kAnalytic || inst_kind == kInstTriangles)
-            accepted = triangle_hit<kTextures>(sc, object, inst_bsdf, ray, rng, hit);
+            accepted = triangle_hit<kTextures>(sc, object, inst_bsdf, ray, rng, cand);
         else if (inst_kind == kInstSphere)
-            accepted = sphere_hit<kTextures>(sc, sc.analytic[inst_analytic], object, inst_bsdf, ray, rng, hit);
+            accepted = sphere_hit<kTextures>(sc, sc.analytic[inst_analytic], object, inst_bsdf, ray, rng, cand);
         else if (inst_kind == kInstDisk)
-            accepted = disk_hit<kTextures>(sc, sc.analytic[inst_analytic], object, inst_bsdf, ray, rng, hit);
+            accepted = disk_hit<kTextures>(sc, sc.analytic[inst_analytic], object, inst_bsdf, ray, rng, cand);
         else
-            accepted = cylinder_hit<kTextures>(sc, sc.analytic[inst_analytic], object, inst_bsdf, ray, rng, hit);
+            accepted = cylinder_hit<kTextures>(sc, sc.analytic[inst_analytic], object, inst_bsdf, ray, rng, cand);
         if (accepted)
         {
             found = true;
+            hit = cand;
             hit.inst = inst;
             if (kAny)
                 return true;

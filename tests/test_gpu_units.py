@@ -1,0 +1,124 @@
+"""Per-function parity on the GPU: closest-hit records and BSDF sample /
+evaluate outputs from the unit kernels vs the oracle on the same seeded inputs.
+Needs a real MI355X (`-m gpu`).
+
+Bars: discrete outputs (valid, inside, instance, primitive, LCG state) equal on
+all but a tiny fraction of queries (a last-ulp libm difference can flip a
+threshold test); continuous outputs within 2e-4 relative / 1e-5 absolute on
+the agreeing queries."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def differential_binary(tmp_path_factory):
+    """hipcc-built host-vs-device harness (tests/gpu_diff)."""
+    out = tmp_path_factory.mktemp("gpu_diff") / "host_vs_device_walk"
+    csrc = os.path.join(ROOT, "monte-carlo-path-tracing_amd", "csrc")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                    "-w", f"-I{csrc}", f"-I{os.path.join(ROOT, 'include')}",
+                    os.path.join(ROOT, "tests", "gpu_diff", "host_vs_device_walk.hip"),
+                    os.path.join(csrc, "host", "commit.cpp"), "-o", str(out)], check=True)
+    return str(out)
+
+
+@pytest.mark.parametrize("shape", ["mesh", "flat_mesh", "sphere", "disk", "cylinder", "cube"])
+def test_raw_hits_bit_exact_host_vs_device(shape, pkg, mcsd_file, differential_binary):
+    """The same traversal code on CPU and GPU: raw hit records identical."""
+    path = mcsd_file(pkg.scenes.material_preview("bumpy_diffuse", "area", shape, 8, 8, 1))
+    res = subprocess.run([differential_binary, path], check=True, capture_output=True, text=True).stdout
+    m = re.search(r"walk mismatch raw (\d+) surface (\d+) hits (\d+) of (\d+)", res)
+    assert m, res
+    raw, surface, hits, n = (int(g) for g in m.groups())
+    print(shape, res.strip().splitlines()[-1])
+    assert hits > n // 2
+    assert raw == 0
+    if shape in ("mesh", "flat_mesh", "cube"):   # no libm on the triangle path
+        assert surface == 0
+
+
+def _close(a, b, rtol=2e-4, atol=1e-5):
+    return np.abs(a - b) <= atol + rtol * np.abs(b)
+
+
+@pytest.mark.parametrize("shape", ["mesh", "flat_mesh", "sphere", "disk", "cylinder", "cube"])
+def test_intersection_records(shape, pkg, oracle, mcsd_file):
+    scene = pkg.scenes.material_preview("bumpy_diffuse", "area", shape, 8, 8, 1)
+    path = mcsd_file(scene)
+    rng = np.random.default_rng(17)
+    n = 20000
+    org = rng.normal(size=(n, 3)) * 1.5 + [0, 0.8, 0]
+    d = np.array([0, 0.6, 0]) + rng.normal(size=(n, 3)) * 0.5 - org
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    org, d = org.astype(np.float32), d.astype(np.float32)
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
+    got, _ = r.debug_intersect(org, d)
+    r.close()
+    want = np.zeros_like(got)
+    with oracle.open(path) as so:
+        for i in range(n):
+            want[i], _ = so.intersect(org[i], d[i])
+    disc = (got[:, :4] == want[:, :4]).all(axis=1)
+    print(shape, "discrete agreement", disc.mean(), "bit-exact rows", (got == want).all(axis=1).mean())
+    assert disc.mean() > 0.999
+    # distance, position: tight.  uv of quadrics comes from acosf/atan2f and the
+    # bump-mapped frame differentiates a bitmap over delta = 1e-4 in uv, which
+    # amplifies last-ulp differences ~1e4 times: looser bound on the frame.
+    tight = got[disc][:, [4, 7, 8, 9]], want[disc][:, [4, 7, 8, 9]]
+    assert _close(tight[0], tight[1], rtol=1e-5, atol=2e-6).all(axis=1).mean() > 0.999
+    ok = _close(got[disc], want[disc], rtol=5e-3, atol=5e-3)
+    bad = ~ok.all(axis=1)
+    if bad.any():
+        i = np.nonzero(disc)[0][np.nonzero(bad)[0][0]]
+        print("first mismatch", org[i], d[i], "\n", got[i], "\n", want[i])
+    assert bad.mean() < 0.001, bad.mean()
+
+
+@pytest.mark.parametrize("material", ["diffuse", "rough_diffuse_full", "rough_conductor_aniso", "conductor",
+                                      "dielectric", "rough_dielectric", "thin_dielectric", "plastic",
+                                      "rough_plastic"])
+def test_bsdf_records(material, pkg, oracle, mcsd_file):
+    scene = pkg.scenes.material_preview(material, "constant", "sphere", 8, 8, 1)
+    path = mcsd_file(scene)
+    rng = np.random.default_rng(23)
+    n = 8000
+
+    def unit(v):
+        return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+    nrm = unit(rng.normal(size=(n, 3)))
+    tan = unit(np.cross(nrm, rng.normal(size=(n, 3))))
+    bit = np.cross(nrm, tan)
+    wo = unit(nrm + 0.8 * rng.normal(size=(n, 3)))          # mostly on the normal's side
+    wi = unit(-nrm + 0.8 * rng.normal(size=(n, 3)))
+    recs = np.concatenate([wo, wi, nrm, tan, bit, rng.random((n, 2)), rng.integers(0, 2, (n, 1))], axis=1)
+    recs = recs.astype(np.float32)
+    seeds = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
+    for mode in (0, 1):
+        got, after = r.debug_bsdf(1, mode, recs, seeds)
+        want = np.zeros_like(got)
+        want_after = np.zeros_like(after)
+        with oracle.open(path) as so:
+            for i in range(n):
+                want[i], want_after[i] = so.bsdf(1, mode, recs[i], int(seeds[i]))
+        disc = (got[:, 0] == want[:, 0]) & (after == want_after)
+        print(material, "mode", mode, "discrete agreement", disc.mean(),
+              "bit-exact rows", (got == want).all(axis=1).mean())
+        assert disc.mean() > 0.998
+        sel = disc & (want[:, 0] == 1)
+        ok = _close(got[sel], want[sel], rtol=5e-4, atol=1e-5)
+        bad = ~ok.all(axis=1)
+        if bad.any():
+            i = np.nonzero(sel)[0][np.nonzero(bad)[0][0]]
+            print("first mismatch", recs[i], seeds[i], "\n", got[i], "\n", want[i])
+        assert bad.mean() < 0.002, bad.mean()
+    r.close()
