@@ -25,8 +25,18 @@
 namespace mcpt
 {
 
+// Register budget: the lean instantiations (no microfacet / volume code) are
+// held to 128 VGPRs = 4 wavefronts per SIMD = 4 workgroups of 256 per CU, so
+// that a 512x512 frame (262 144 pixels = 256 CUs x 1024 lanes) is resident in
+// one round; the full instantiation needs ~230 VGPRs and runs 2 per SIMD.
+template <uint32_t kFeatures>
+struct Budget
+{
+    static constexpr int kWavesPerSimd = (kFeatures & (kFeatMicrofacet | kFeatVolPath | kFeatAnalytic)) ? 2 : 4;
+};
+
 template <uint32_t kFeatures, bool kCount>
-__global__ void __launch_bounds__(kBlockSize)
+__global__ void __launch_bounds__(kBlockSize, Budget<kFeatures>::kWavesPerSimd)
 render_kernel(const DeviceScene sc, const RenderJob job, float *__restrict__ out, TraceCounters *__restrict__ counters)
 {
     using C = Config<kFeatures>;

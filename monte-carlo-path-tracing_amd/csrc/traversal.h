@@ -239,6 +239,13 @@ MCPT_HD bool cylinder_hit(const DeviceScene &sc, const AnalyticRec &q, uint32_t 
 // The walk.  kAny = shadow query: stop at the first accepted primitive.
 // Returns whether anything was hit; for closest queries `hit` describes it and
 // ray.t_max is its distance.
+//
+// Shape of the loop ("while-while"): an inner loop of pure node steps (one
+// 32-byte node fetch + slab test each) runs until the lane holds a primitive
+// candidate or has left the tree; only then is the (much longer) primitive
+// test executed.  Per lane the visiting order is unchanged; per wavefront the
+// 64 lanes run box tests together and primitive tests together instead of
+// paying for both in every iteration.
 template <bool kAny, bool kAnalytic, bool kTextures, bool kCount>
 MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &hit, TraceStats &stats)
 {
@@ -249,37 +256,48 @@ MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &
     uint32_t inst = 0, inst_kind = 0, inst_bsdf = kNone, inst_analytic = 0;
     for (;;)
     {
-        if (node == kEndOfTree)
+        // ---- node steps until a primitive candidate turns up ----------------
+        uint32_t object = kNoObject, after = kEndOfTree;
+        for (;;)
         {
+            if (node == kEndOfTree)
+            {
+                if (!in_blas)
+                    break;
+                in_blas = false;
+                node = resume;
+                continue;
+            }
+            const float4 n0 = sc.nodes[2 * static_cast<size_t>(node)], n1 = sc.nodes[2 * static_cast<size_t>(node) + 1];
+            if (kCount)
+                ++stats.node_tests;
+            if (!box_hit(n0, n1, ray))
+            {
+                node = as_uint(n0.w);
+                continue;
+            }
+            const uint32_t leaf_object = as_uint(n1.w);
+            if (leaf_object == kNoObject)
+            {
+                ++node; // pre-order: the left child follows its parent
+                continue;
+            }
             if (!in_blas)
-                break;
-            in_blas = false;
-            node = resume;
-            continue;
+            {
+                const InstanceRec &rec = sc.instances[leaf_object];
+                inst = leaf_object, inst_kind = rec.kind, inst_bsdf = rec.bsdf, inst_analytic = rec.analytic;
+                resume = as_uint(n0.w);
+                node = rec.blas_root;
+                in_blas = true;
+                continue;
+            }
+            object = leaf_object, after = as_uint(n0.w);
+            break;
         }
-        const float4 n0 = sc.nodes[2 * static_cast<size_t>(node)], n1 = sc.nodes[2 * static_cast<size_t>(node) + 1];
-        if (kCount)
-            ++stats.node_tests;
-        if (!box_hit(n0, n1, ray))
-        {
-            node = as_uint(n0.w);
-            continue;
-        }
-        const uint32_t object = as_uint(n1.w);
         if (object == kNoObject)
-        {
-            ++node; // pre-order: the left child follows its parent
-            continue;
-        }
-        if (!in_blas)
-        {
-            const InstanceRec &rec = sc.instances[object];
-            inst = object, inst_kind = rec.kind, inst_bsdf = rec.bsdf, inst_analytic = rec.analytic;
-            resume = as_uint(n0.w);
-            node = rec.blas_root;
-            in_blas = true;
-            continue;
-        }
+            break; // left the TLAS: done
+
+        // ---- primitive test ---------------------------------------------------
         if (kCount)
             ++stats.prim_tests;
         // Candidates are written to a local record and committed in ONE place:
@@ -305,7 +323,7 @@ MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &
             if (kAny)
                 return true;
         }
-        node = as_uint(n0.w);
+        node = after;
     }
     return found;
 }
