@@ -10,6 +10,9 @@ namespace mcpt
 {
 
 constexpr int kBlockSize = 256;
+// Traversal data (nodes + triangle positions) up to this size is staged in LDS:
+// 4 workgroups per CU x 32 KiB leaves room in the 160 KiB of a CU.
+constexpr size_t kLdsGeometryBytes = 32 * 1024;
 
 // Work description of one launch: pixels are enumerated tile by tile
 // (8x8 pixel tiles, row-major tile order); item q -> local tile q / 64, pixel

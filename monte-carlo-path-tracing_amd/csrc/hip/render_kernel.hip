@@ -35,11 +35,30 @@ struct Budget
     static constexpr int kWavesPerSimd = (kFeatures & (kFeatMicrofacet | kFeatVolPath | kFeatAnalytic)) ? 2 : 4;
 };
 
-template <uint32_t kFeatures, bool kCount>
+// kLdsGeometry: the node array and the triangle position array (the two streams
+// the walk reads) are copied into LDS by each workgroup before it starts and
+// the walk reads them from there (ds_read_b128) instead of through L1.  Used for
+// scenes whose traversal data fits kLdsGeometryBytes (cornell: 4.3 KB); the walk
+// is a chain of dependent loads, so the shorter LDS latency shortens every
+// node step.  Large scenes stream from HBM / L2 as before.
+template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
 __global__ void __launch_bounds__(kBlockSize, Budget<kFeatures>::kWavesPerSimd)
-render_kernel(const DeviceScene sc, const RenderJob job, float *__restrict__ out, TraceCounters *__restrict__ counters)
+render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ out, TraceCounters *__restrict__ counters)
 {
     using C = Config<kFeatures>;
+    extern __shared__ float4 lds_geometry[];
+    DeviceScene sc = sc_in;
+    if (kLdsGeometry)
+    {
+        const uint32_t n_node_vec = 2u * sc_in.integrator.n_nodes, n_tri_vec = 3u * sc_in.integrator.n_prims;
+        for (uint32_t i = threadIdx.x; i < n_node_vec; i += blockDim.x)
+            lds_geometry[i] = sc_in.nodes[i];
+        for (uint32_t i = threadIdx.x; i < n_tri_vec; i += blockDim.x)
+            lds_geometry[n_node_vec + i] = sc_in.tri_pos[i];
+        __syncthreads();
+        sc.nodes = lds_geometry;
+        sc.tri_pos = lds_geometry + n_node_vec;
+    }
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t width = static_cast<uint32_t>(sc.camera.width), height = static_cast<uint32_t>(sc.camera.height);
@@ -184,13 +203,15 @@ namespace
 
 constexpr uint32_t kAll = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
 
-template <uint32_t kFeatures, bool kCount>
+template <uint32_t kFeatures, bool kCount, bool kLdsGeometry = false>
 hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters, hipStream_t stream,
                   uint32_t max_blocks)
 {
+    const size_t lds_bytes =
+        kLdsGeometry ? (2ull * sc.integrator.n_nodes + 3ull * sc.integrator.n_prims) * sizeof(float4) : 0;
     int per_cu = 0;
-    hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<kFeatures, kCount>,
-                                                                  kBlockSize, 0);
+    hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &per_cu, render_kernel<kFeatures, kCount, kLdsGeometry>, kBlockSize, lds_bytes);
     if (err != hipSuccess)
         return err;
     if (per_cu < 1)
@@ -201,8 +222,8 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
         blocks = resident;
     if (blocks == 0)
         return hipSuccess;
-    hipLaunchKernelGGL((render_kernel<kFeatures, kCount>), dim3(blocks), dim3(kBlockSize), 0, stream, sc, job, out,
-                       counters);
+    hipLaunchKernelGGL((render_kernel<kFeatures, kCount, kLdsGeometry>), dim3(blocks), dim3(kBlockSize), lds_bytes,
+                       stream, sc, job, out, counters);
     return hipGetLastError();
 }
 
@@ -218,15 +239,19 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
         *variant = "all+count";
         return Launch<kAll, true>(sc, job, out, counters, stream, n_cus);
     }
+    const size_t geometry = (2ull * sc.integrator.n_nodes + 3ull * sc.integrator.n_prims) * sizeof(float4);
+    const bool lds = geometry <= kLdsGeometryBytes;
     if (f == 0)
     {
-        *variant = "diffuse-area";
-        return Launch<0, false>(sc, job, out, nullptr, stream, n_cus);
+        *variant = lds ? "diffuse-area+lds" : "diffuse-area";
+        return lds ? Launch<0, false, true>(sc, job, out, nullptr, stream, n_cus)
+                   : Launch<0, false>(sc, job, out, nullptr, stream, n_cus);
     }
     if ((f & ~kFeatEmitters) == 0)
     {
-        *variant = "diffuse-emitters";
-        return Launch<kFeatEmitters, false>(sc, job, out, nullptr, stream, n_cus);
+        *variant = lds ? "diffuse-emitters+lds" : "diffuse-emitters";
+        return lds ? Launch<kFeatEmitters, false, true>(sc, job, out, nullptr, stream, n_cus)
+                   : Launch<kFeatEmitters, false>(sc, job, out, nullptr, stream, n_cus);
     }
     if ((f & ~(kFeatEmitters | kFeatTextures | kFeatMicrofacet)) == 0)
     {

@@ -75,13 +75,18 @@ struct TraceStats
     uint32_t node_tests, prim_tests;
 };
 
-MCPT_HD bool box_hit(const float4 &lo, const float4 &hi, const Ray &r) // aabb.cpp:29-48
+// aabb.cpp:29-48.  The reference computes (lo - o) * rcp and (hi - o) * rcp and
+// then picks per axis by the sign of rcp; picking the plane first and
+// transforming only the picked one is the same arithmetic on the same operands
+// with half the subtract / multiply work.
+MCPT_HD bool box_hit(const float4 &lo, const float4 &hi, const Ray &r)
 {
-    const V3 t0 = (xyz(lo) - r.origin) * r.dir_rcp, t1 = (xyz(hi) - r.origin) * r.dir_rcp;
-    float t_enter = kEpsDistance, t_exit = r.t_max;
-    t_enter = fmaxf(t_enter, r.dir_rcp.x > 0 ? t0.x : t1.x), t_exit = fminf(t_exit, r.dir_rcp.x > 0 ? t1.x : t0.x);
-    t_enter = fmaxf(t_enter, r.dir_rcp.y > 0 ? t0.y : t1.y), t_exit = fminf(t_exit, r.dir_rcp.y > 0 ? t1.y : t0.y);
-    t_enter = fmaxf(t_enter, r.dir_rcp.z > 0 ? t0.z : t1.z), t_exit = fminf(t_exit, r.dir_rcp.z > 0 ? t1.z : t0.z);
+    const bool px = r.dir_rcp.x > 0, py = r.dir_rcp.y > 0, pz = r.dir_rcp.z > 0;
+    const float nx = ((px ? lo.x : hi.x) - r.origin.x) * r.dir_rcp.x, fx = ((px ? hi.x : lo.x) - r.origin.x) * r.dir_rcp.x;
+    const float ny = ((py ? lo.y : hi.y) - r.origin.y) * r.dir_rcp.y, fy = ((py ? hi.y : lo.y) - r.origin.y) * r.dir_rcp.y;
+    const float nz = ((pz ? lo.z : hi.z) - r.origin.z) * r.dir_rcp.z, fz = ((pz ? hi.z : lo.z) - r.origin.z) * r.dir_rcp.z;
+    const float t_enter = fmaxf(fmaxf(fmaxf(kEpsDistance, nx), ny), nz);
+    const float t_exit = fminf(fminf(fminf(r.t_max, fx), fy), fz);
     return t_enter <= t_exit;
 }
 
@@ -271,28 +276,25 @@ MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &
             const float4 n0 = sc.nodes[2 * static_cast<size_t>(node)], n1 = sc.nodes[2 * static_cast<size_t>(node) + 1];
             if (kCount)
                 ++stats.node_tests;
-            if (!box_hit(n0, n1, ray))
+            const bool inside_box = box_hit(n0, n1, ray);
+            const uint32_t skip = as_uint(n0.w), leaf_object = as_uint(n1.w);
+            if (inside_box && leaf_object != kNoObject)
             {
-                node = as_uint(n0.w);
-                continue;
-            }
-            const uint32_t leaf_object = as_uint(n1.w);
-            if (leaf_object == kNoObject)
-            {
-                ++node; // pre-order: the left child follows its parent
-                continue;
-            }
-            if (!in_blas)
-            {
+                if (in_blas)
+                {
+                    object = leaf_object, after = skip;
+                    break;
+                }
                 const InstanceRec &rec = sc.instances[leaf_object];
                 inst = leaf_object, inst_kind = rec.kind, inst_bsdf = rec.bsdf, inst_analytic = rec.analytic;
-                resume = as_uint(n0.w);
+                resume = skip;
                 node = rec.blas_root;
                 in_blas = true;
                 continue;
             }
-            object = leaf_object, after = as_uint(n0.w);
-            break;
+            // inner node: descend to the left child (pre-order successor) on a
+            // hit, otherwise leave the subtree
+            node = inside_box ? node + 1 : skip;
         }
         if (object == kNoObject)
             break; // left the TLAS: done
