@@ -1,0 +1,142 @@
+// mcpt_cli: command-line driver over the C ABI of include/mcpt.h.
+//
+// Same switches as the reference program (apps/main.cpp:98-199):
+//   [-g/--gpu] -i <scene> [-o <image>] [-w <width>] [-h <height>] [-s <spp>]
+// <scene> is a Mitsuba-style .xml file, a .mcsd configuration, or
+// "builtin:<name>".  Differences, all deliberate:
+//   * rendering always runs on the GPU; -c/--cpu is refused (the product has
+//     no CPU path) and -p/--preview (the GLUT viewer) is not part of it;
+//   * the output format follows the suffix (.png .exr .pfm .f32) instead of
+//     being forced to .png; the default stays "result.png";
+//   * the exit status is non-zero on failure (the reference always returns 0).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mcpt.h"
+
+namespace
+{
+
+void Usage()
+{
+    std::fprintf(stderr,
+                 "mcpt_cli (%s)\n\n"
+                 "  mcpt_cli [-g|--gpu] -i|--input <scene.xml | scene.mcsd | builtin:cornell-box>\n"
+                 "           [-o|--output <result.png|.exr|.pfm|.f32>] [-w|--width N] [-h|--height N]\n"
+                 "           [-s|--spp N] [-d|--device N] [--save-config <file.mcsd>]\n\n"
+                 "  --gpu        render with HIP on the selected device (the default and only backend)\n"
+                 "  --cpu        refused: this build has no CPU renderer\n",
+                 mcpt_version());
+}
+
+bool EndsWith(const std::string &s, const char *suffix)
+{
+    const size_t n = std::strlen(suffix);
+    return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
+}
+
+int Fail(const char *what)
+{
+    std::fprintf(stderr, "[error] %s\n\t%s\n", what, mcpt_last_error());
+    return 1;
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    std::string input, output = "result.png", save_config;
+    int width = 0, height = 0, spp = 0, device = 0;
+    for (int i = 1; i < argc; ++i)
+    {
+        const std::string a = argv[i];
+        const bool has_value = i + 1 < argc;
+        if (a == "--cpu" || a == "-c")
+        {
+            std::fprintf(stderr, "[error] --cpu: this program renders on the GPU only.\n");
+            return 2;
+        }
+        else if (a == "--preview" || a == "-p")
+        {
+            std::fprintf(stderr, "[error] --preview: the interactive viewer is not part of this program.\n");
+            return 2;
+        }
+        else if (a == "--gpu" || a == "-g")
+            ;
+        else if ((a == "--width" || a == "-w") && has_value)
+            width = std::atoi(argv[++i]);
+        else if ((a == "--height" || a == "-h") && has_value)
+            height = std::atoi(argv[++i]);
+        else if ((a == "--spp" || a == "-s") && has_value)
+            spp = std::atoi(argv[++i]);
+        else if ((a == "--device" || a == "-d") && has_value)
+            device = std::atoi(argv[++i]);
+        else if ((a == "--input" || a == "-i") && has_value)
+            input = argv[++i];
+        else if ((a == "--output" || a == "-o") && has_value)
+            output = argv[++i];
+        else if (a == "--save-config" && has_value)
+            save_config = argv[++i];
+        else if (a == "--help")
+        {
+            Usage();
+            return 0;
+        }
+        else
+        {
+            std::fprintf(stderr, "[error] unknown or incomplete option '%s'.\n", a.c_str());
+            Usage();
+            return 2;
+        }
+    }
+    if (input.empty())
+    {
+        Usage();
+        return 2;
+    }
+
+    mcpt_config *config = nullptr;
+    int rc;
+    if (input.rfind("builtin:", 0) == 0)
+        rc = mcpt_config_builtin(input.c_str() + 8, &config);
+    else if (EndsWith(input, ".mcsd"))
+        rc = mcpt_config_load_mcsd(input.c_str(), &config);
+    else
+        rc = mcpt_config_load_xml(input.c_str(), &config);
+    if (rc != 0)
+        return Fail("cannot load the scene.");
+    if (mcpt_config_set_film(config, width, height, spp) != 0)
+        return Fail("invalid film override.");
+    if (!save_config.empty() && mcpt_config_save_mcsd(config, save_config.c_str()) != 0)
+        return Fail("cannot save the configuration.");
+    mcpt_config_get_film(config, &width, &height, &spp);
+
+    const auto t0 = std::chrono::steady_clock::now();
+    mcpt_renderer *renderer = nullptr;
+    rc = mcpt_renderer_create(config, device, &renderer);
+    mcpt_config_destroy(config);
+    if (rc != 0)
+        return Fail("error when create renderer.");
+    const auto t1 = std::chrono::steady_clock::now();
+
+    std::vector<float> frame(static_cast<size_t>(width) * height * 3);
+    mcpt_stats stats;
+    if (mcpt_renderer_draw(renderer, frame.data(), &stats) != 0)
+    {
+        mcpt_renderer_destroy(renderer);
+        return Fail("error when draw.");
+    }
+    mcpt_renderer_destroy(renderer);
+    const double setup_s = std::chrono::duration<double>(t1 - t0).count();
+    std::fprintf(stderr, "[info] %d x %d, %d spp: scene commit %.3f s, draw %.3f s (%.1f Msamples/s)\n", width, height,
+                 spp, setup_s, stats.kernel_milliseconds * 1e-3,
+                 stats.kernel_milliseconds > 0 ? double(width) * height * spp / (stats.kernel_milliseconds * 1e3) : 0.0);
+    if (mcpt_write_image(output.c_str(), frame.data(), width, height) != 0)
+        return Fail("cannot write the image.");
+    std::fprintf(stderr, "[info] save result as image \"%s\".\n", output.c_str());
+    return 0;
+}
