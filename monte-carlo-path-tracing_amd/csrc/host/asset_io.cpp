@@ -1,6 +1,6 @@
 // Asset readers of the scene front end: Wavefront OBJ, Mitsuba ".serialized"
 // meshes (zlib), and float images for bitmap textures / environment maps
-// (PFM; OpenEXR scanline files with NONE / ZIPS / ZIP compression).
+// (PFM; OpenEXR scanline files with NONE / ZIPS / ZIP / PIZ compression).
 //
 // Reference counterparts: src/parser/model_loader.cpp (assimp for OBJ,
 // :426-504 for .serialized) and src/utils/image_io.cpp:55-158 (tinyexr, stb).
@@ -342,7 +342,7 @@ ImageData LoadPfm(const std::string &path)
     return img;
 }
 
-// OpenEXR, single-part scanline, compression NONE / ZIPS / ZIP, HALF or FLOAT
+// OpenEXR, single-part scanline, compression NONE / ZIPS / ZIP / PIZ (exr_piz.cpp), HALF or FLOAT
 // channels.  Output: RGBA float with alpha 1 when absent ("channel = 4", as the
 // reference's tinyexr path returns, image_io.cpp:75-98).
 ImageData LoadExr(const std::string &path)
@@ -436,9 +436,12 @@ ImageData LoadExr(const std::string &path)
     case 3: // ZIP
         lines_per_block = 16;
         break;
+    case 4: // PIZ
+        lines_per_block = 32;
+        break;
     default:
         throw std::runtime_error("EXR compression " + std::to_string(compression) +
-                                 " (only NONE / ZIPS / ZIP are supported) in '" + path + "'.");
+                                 " (only NONE / ZIPS / ZIP / PIZ are supported) in '" + path + "'.");
     }
     size_t bytes_per_pixel = 0;
     for (const Channel &c : channels)
@@ -464,6 +467,13 @@ ImageData LoadExr(const std::string &path)
         raw.resize(expect);
         if (compression == 0 || packed == expect)
             std::memcpy(raw.data(), &f[at], std::min<size_t>(packed, expect));
+        else if (compression == 4)
+        {
+            std::vector<int> words;
+            for (const Channel &c : channels)
+                words.push_back(c.type == 1 ? 1 : 2);
+            DecodePizBlock(&f[at], packed, words, w, lines, raw.data());
+        }
         else
         {
             tmp.resize(expect);

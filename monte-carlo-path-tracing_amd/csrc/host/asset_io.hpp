@@ -27,6 +27,11 @@ MeshData LoadObj(const std::string &path, bool flip_texcoords, bool face_normals
 MeshData LoadSerialized(const std::string &path, int shape_index);
 ImageData LoadFloatImage(const std::string &path);
 
+// One PIZ-compressed EXR block -> raw scanline bytes (exr_piz.cpp).  `words_per_sample`: per
+// channel in file order, 1 for HALF and 2 for FLOAT / UINT.
+void DecodePizBlock(const uint8_t *src, size_t n_src, const std::vector<int> &words_per_sample, int width, int lines,
+                    uint8_t *dst);
+
 } // namespace mcpt
 
 #endif // MCPT_HOST_ASSET_IO_HPP

@@ -530,6 +530,224 @@ def exr_bytes(channels, compression=0):
     return head + b"".join(struct.pack("<Q", o) for o in offsets) + b"".join(blocks)
 
 
+def _piz_forward_wavelet(a, nx, ox, ny, oy, narrow):
+    """Forward transform matching the PIZ scheme's two-point (average, difference) steps."""
+    def enc(x, y):
+        if narrow:
+            xs, ys = np.int16(np.uint16(x)), np.int16(np.uint16(y))
+            m = (int(xs) + int(ys)) >> 1
+            d = int(xs) - int(ys)
+            return m & 0xFFFF, d & 0xFFFF
+        ao = (int(x) + 0x8000) & 0xFFFF
+        m = (ao + int(y)) >> 1
+        d = ao - int(y)
+        if d < 0:
+            m = (m + 0x8000) & 0xFFFF
+        return m, d & 0xFFFF
+    n = min(nx, ny)
+    p, p2 = 1, 2
+    while p2 <= n:
+        oy1, oy2, ox1, ox2 = oy * p, oy * p2, ox * p, ox * p2
+        py, ey = 0, oy * (ny - p2)
+        while py <= ey:
+            px, ex = py, py + ox * (nx - p2)
+            while px <= ex:
+                p01, p10 = px + ox1, px + oy1
+                p11 = p10 + ox1
+                i00, i01 = enc(a[px], a[p01])
+                i10, i11 = enc(a[p10], a[p11])
+                a[px], a[p10] = enc(i00, i10)
+                a[p01], a[p11] = enc(i01, i11)
+                px += ox2
+            if nx & p:
+                p10 = px + oy1
+                a[px], a[p10] = enc(a[px], a[p10])
+            py += oy2
+        if ny & p:
+            px, ex = py, py + ox * (nx - p2)
+            while px <= ex:
+                p01 = px + ox1
+                a[px], a[p01] = enc(a[px], a[p01])
+                px += ox2
+        p, p2 = p2, p2 << 1
+
+
+def _piz_huffman(words):
+    """Canonical-Huffman stream in the PIZ layout (no run-length symbols used)."""
+    import heapq
+    freq = np.bincount(words, minlength=65537).astype(np.int64)
+    first = int(np.flatnonzero(freq)[0])
+    last = int(np.flatnonzero(freq)[-1]) + 1          # + the run-length pseudo symbol
+    freq[last] = 1
+    heap = [(int(f), i) for i, f in enumerate(freq) if f]
+    heapq.heapify(heap)
+    parent = {}
+    node = 70000
+    while len(heap) > 1:
+        f0, a = heapq.heappop(heap)
+        f1, b = heapq.heappop(heap)
+        parent[a] = parent[b] = node
+        heapq.heappush(heap, (f0 + f1, node))
+        node += 1
+    length = np.zeros(65537, np.int64)
+    for i in np.flatnonzero(freq):
+        d, n = 0, int(i)
+        while n in parent:
+            n, d = parent[n], d + 1
+        length[i] = max(d, 1)
+    assert length.max() <= 58
+    count = np.bincount(length, minlength=59).astype(object)
+    nxt, c = [0] * 59, 0
+    for l in range(58, 0, -1):
+        nc = (c + count[l]) >> 1
+        nxt[l], c = c, nc
+    code = {}
+    for i in range(65537):
+        if length[i]:
+            code[i] = nxt[length[i]]
+            nxt[length[i]] += 1
+    bits = "".join(format(int(length[i]), "06b") for i in range(first, last + 1))
+    table = int(bits + "0" * (-len(bits) % 8), 2).to_bytes((len(bits) + 7) // 8, "big")
+    data = "".join(format(code[int(w)], "0%db" % length[int(w)]) for w in words)
+    n_bits = len(data)
+    payload = int(data + "0" * (-n_bits % 8), 2).to_bytes((n_bits + 7) // 8, "big") if n_bits else b""
+    return struct.pack("<IIIII", first, last, len(table), n_bits, 0) + table + payload
+
+
+def piz_block(rows_by_channel):
+    """rows_by_channel: list (file channel order) of uint16 arrays (lines, width * words)."""
+    planes = [np.ascontiguousarray(r).astype(np.uint16).ravel().copy() for r in rows_by_channel]
+    used = np.zeros(65536, bool)
+    for pl in planes:
+        used[pl] = True
+    used[0] = False
+    nz = np.flatnonzero(used)
+    bitmap = np.packbits(used.astype(np.uint8), bitorder="little")
+    lo, hi = (int(nz[0]) >> 3, int(nz[-1]) >> 3) if len(nz) else (8191, 0)
+    forward = np.zeros(65536, np.uint16)
+    k = 0
+    for i in range(65536):
+        if i == 0 or used[i]:
+            forward[i] = k
+            k += 1
+    narrow = (k - 1) < (1 << 14)
+    coded = []
+    for pl, rows in zip(planes, rows_by_channel):
+        lines, row_words = rows.shape
+        words = row_words // WIDTH_OF[id(rows)]
+        a = [int(v) for v in forward[pl]]
+        for j in range(words):
+            view = _Strided(a, j)
+            _piz_forward_wavelet(view, WIDTH_OF[id(rows)], words, lines, row_words, narrow)
+        coded.append(np.asarray(a, np.int64))
+    stream = _piz_huffman(np.concatenate(coded))
+    head = struct.pack("<HH", lo, hi) + (bitmap[lo:hi + 1].tobytes() if lo <= hi else b"")
+    return head + struct.pack("<i", len(stream)) + stream
+
+
+class _Strided:
+    def __init__(self, a, off):
+        self.a, self.off = a, off
+
+    def __getitem__(self, i):
+        return self.a[self.off + i]
+
+    def __setitem__(self, i, v):
+        self.a[self.off + i] = v
+
+
+WIDTH_OF = {}
+
+
+def exr_piz_bytes(channels):
+    """Single-part scanline EXR with PIZ blocks; `channels`: {name: (array (h, w), 'half'|'float')}."""
+    names = sorted(channels)
+    h, w = channels[names[0]][0].shape
+
+    def attr(name, type_, raw):
+        return name.encode() + b"\0" + type_.encode() + b"\0" + struct.pack("<i", len(raw)) + raw
+
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", 1 if channels[n][1] == "half" else 2, 0, 0, 0, 0, 1, 1)
+                      for n in names) + b"\0"
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    header = (attr("channels", "chlist", chlist) + attr("compression", "compression", bytes([4])) +
+              attr("dataWindow", "box2i", box) + attr("displayWindow", "box2i", box) +
+              attr("lineOrder", "lineOrder", b"\0") + b"\0")
+    blocks = []
+    for y0 in range(0, h, 32):
+        rows = []
+        for n in names:
+            arr, kind = channels[n]
+            part = arr[y0:y0 + 32]
+            r = (part.astype(np.float16).view(np.uint16) if kind == "half"
+                 else np.ascontiguousarray(part.astype("<f4")).view(np.uint16).reshape(part.shape[0], -1))
+            r = np.ascontiguousarray(r)
+            WIDTH_OF[id(r)] = w
+            rows.append(r)
+        raw = piz_block(rows)
+        blocks.append(struct.pack("<ii", y0, len(raw)) + raw)
+    head = struct.pack("<II", 20000630, 2) + header
+    offsets, pos = [], len(head) + 8 * len(blocks)
+    for b in blocks:
+        offsets.append(pos)
+        pos += len(b)
+    return head + b"".join(struct.pack("<Q", o) for o in offsets) + b"".join(blocks)
+
+
+@pytest.mark.parametrize("w, h, wide", [(12, 20, False), (33, 37, False), (400, 40, True)])
+def test_exr_piz_reader(pkg, tmp_path, w, h, wide):
+    """PIZ blocks (the matpreview env map's compression): Huffman + wavelet + value
+    table, HALF and FLOAT channels, odd sizes, more than one 32-line block, both
+    the 14-bit and the 16-bit wavelet variants (`wide` uses > 16384 distinct values)."""
+    rng = np.random.default_rng(w * h)
+    yy, xx = np.mgrid[0:h, 0:w]
+    smooth = (np.sin(xx * 0.3) + np.cos(yy * 0.2) + 2.5).astype(np.float32)
+    r = (smooth + rng.random((h, w), dtype=np.float32) * 0.05).astype(np.float16).astype(np.float32)
+    g = (smooth * 0.5).astype(np.float16).astype(np.float32)
+    b = rng.random((h, w), dtype=np.float32) * (1000.0 if wide else 1.0)
+    if wide:
+        # enough distinct 16-bit words to leave the 14-bit variant
+        b = (rng.integers(0, 2 ** 31, (h, w)).astype(np.uint32) & 0x7F7FFFFF).view(np.float32)
+        b = np.nan_to_num(b, nan=1.0, posinf=1.0, neginf=1.0)
+    files = {"p.exr": exr_piz_bytes({"R": (r, "half"), "G": (g, "half"), "B": (b, "float")})}
+    body = '<texture type="bitmap" id="t"><string name="filename" value="p.exr"/></texture>'
+    s = translate(pkg, tmp_path, scene_xml(body), files=files)
+    t = s.textures[0]
+    assert (t.width, t.height, t.channel) == (w, h, 4)
+    words = np.concatenate([r[:32].astype(np.float16).view(np.uint16).ravel(),
+                            g[:32].astype(np.float16).view(np.uint16).ravel(), b[:32].view(np.uint16).ravel()])
+    assert (len(np.unique(words)) > (1 << 14)) == wide       # which wavelet variant the first block uses
+    rgba = np.asarray(t.data).reshape(h, w, 4)
+    np.testing.assert_array_equal(rgba[..., 0], r)
+    np.testing.assert_array_equal(rgba[..., 1], g)
+    np.testing.assert_array_equal(rgba[..., 2], b)
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_SCENES + "/matpreview/envmap.exr"), reason="reference scene files not present")
+def test_matpreview_scene_file(pkg, tmp_path):
+    """The reference's material-preview scene (BASELINE config 4): serialized
+    meshes + PIZ env map + named conductor translate; the env map is a natural
+    image (smooth, positive, finite) and carries the scene's scale of 3."""
+    cfg = pkg.capi.Config.load_xml(REF_SCENES + "/matpreview/rough_conductor.xml")
+    out = tmp_path / "mp.mcsd"
+    cfg.save_mcsd(out)
+    s = pkg.mcsd.load(out)
+    assert (s.camera.width, s.camera.height, s.camera.spp) == (1366, 1024, 256)
+    assert s.camera.fov_x == 38.0                        # "fov_axis" (snake case) is ignored
+    assert s.integrator.depth_max == 0xFFFFFFFF
+    assert [len(i.indices) for i in s.instances] == [512, 3936, 57152]
+    assert [i.id_bsdf for i in s.instances] == [1, 0, 2]
+    env = s.textures[s.emitters[0].id_radiance]
+    assert (env.width, env.height, env.channel) == (512, 256, 4)
+    img = np.asarray(env.data).reshape(256, 512, 4)
+    assert np.isfinite(img).all() and img[..., :3].min() > 0 and np.all(img[..., 3] == 3.0)
+    lum = np.log1p(img[..., :3].mean(-1))
+    assert np.abs(np.diff(lum, axis=1)).mean() < 0.1 * lum.std() * 2
+    al = s.bsdfs[2]
+    assert al.type == pkg.mcsd.BSDF_CONDUCTOR
+    np.testing.assert_allclose(s.textures[al.id_roughness_u].color, np.float32([0.1] * 3))
+
+
 @pytest.mark.parametrize("compression", [0, 2, 3])
 def test_bitmap_readers(pkg, tmp_path, compression):
     rng = np.random.default_rng(5)
