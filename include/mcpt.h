@@ -106,14 +106,24 @@ uint32_t mcpt_tile_range_size(uint32_t tiles_total, const mcpt_tile_range *range
 int mcpt_unpack_tiles(const float *packed, const mcpt_tile_range *range, int width, int height, float *frame);
 
 /* Committed-table inspection (tests, tools).  `what`: "nodes" (float, 8 per
- * node), "node_area", "tri_pos" (float, 12 per primitive), "tri_attr" (36 per
- * primitive), "lut_brdf", "lut_albedo", "light_cdf", "env_tables".  Returns a
+ * node), "node_area", "walk_nodes" (16 per node), "walk_prims" (12 per slot),
+ * "tri_pos" (float, 12 per primitive), "tri_attr" (36 per primitive),
+ * "lut_brdf", "lut_albedo", "light_cdf", "env_tables".  Returns a
  * pointer into renderer-owned HOST memory, valid until the renderer dies. */
 int mcpt_renderer_table(const mcpt_renderer *r, const char *what, const void **data, size_t *count);
 
-/* Scene statistics: nodes, TLAS nodes, primitives, instances, feature bits,
- * bytes of geometry in HBM (6 x uint64). */
-int mcpt_renderer_info(const mcpt_renderer *r, uint64_t info[6]);
+/* Scene statistics (9 x uint64): nodes and TLAS nodes of the reference-topology
+ * trees, primitives, instances, feature bits, bytes of geometry in HBM, nodes and
+ * depth of the ordered-walk hierarchy, whether opacity masks are present. */
+int mcpt_renderer_info(const mcpt_renderer *r, uint64_t info[9]);
+
+/* Which ray query later draws use.  0 (default): near-first walk of the SAH
+ * hierarchy — same image as the reference's traversal (reference
+ * src/rtcore/accel/tlas.cpp:22-41, blas.cpp:26-43), fewer node visits.
+ * 1: the reference's own trees in the reference's visiting order (validation;
+ * always used when a BSDF has an opacity map, whose test draws random numbers
+ * during the walk). */
+int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order);
 
 /* Unit-level GPU queries for diagnostics and parity tests (host pointers in and
  * out; no reference counterpart — the reference has no tests).

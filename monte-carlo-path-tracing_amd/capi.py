@@ -87,6 +87,7 @@ def lib():
     L.mcpt_unpack_tiles.argtypes = [vp, ctypes.POINTER(TileRange), i32, i32, vp]
     L.mcpt_renderer_table.argtypes = [vp, cp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
     L.mcpt_renderer_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    L.mcpt_renderer_set_walk.argtypes = [vp, ctypes.c_int]
     L.mcpt_debug_intersect.argtypes = [vp, u32, vp, vp, vp, vp]
     L.mcpt_debug_bsdf.argtypes = [vp, u32, i32, u32, vp, vp, vp, vp]
     L.mcpt_renderer_destroy.argtypes = [vp]
@@ -107,7 +108,7 @@ EXPORTED_SYMBOLS = [
     "mcpt_config_save_mcsd", "mcpt_config_destroy", "mcpt_renderer_create",
     "mcpt_renderer_draw", "mcpt_renderer_draw_device", "mcpt_renderer_draw_counted",
     "mcpt_renderer_tile_count", "mcpt_tile_range_size", "mcpt_unpack_tiles",
-    "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_destroy",
+    "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_set_walk", "mcpt_renderer_destroy",
     "mcpt_debug_intersect", "mcpt_debug_bsdf",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
 ]
@@ -227,10 +228,17 @@ class Renderer:
         return np.frombuffer(buf, dtype=np.float32).copy()
 
     def info(self):
-        arr = (ctypes.c_uint64 * 6)()
+        arr = (ctypes.c_uint64 * 9)()
         _check(lib().mcpt_renderer_info(self._h, arr))
-        keys = ("nodes", "tlas_nodes", "primitives", "instances", "features", "geometry_bytes")
+        keys = ("nodes", "tlas_nodes", "primitives", "instances", "features", "geometry_bytes",
+                "walk_nodes", "walk_depth", "has_masks")
         return dict(zip(keys, (int(v) for v in arr)))
+
+    def set_walk(self, reference_order: bool):
+        """False (default): ordered walk of the SAH hierarchy; True: the reference's
+        trees in the reference's order (validation mode)."""
+        _check(lib().mcpt_renderer_set_walk(self._h, 1 if reference_order else 0))
+        return self
 
     def close(self):
         if getattr(self, "_h", None):

@@ -78,7 +78,8 @@ struct mcpt_renderer
     uint32_t n_cus = 0;
     mcpt::FlatScene flat;
     mcpt::DeviceScene dev{};
-    DeviceArray arrays[16];
+    DeviceArray arrays[18];
+    bool reference_walk = false;           // mcpt_renderer_set_walk
     float *frame_dev = nullptr;            // scratch frame for mcpt_renderer_draw
     mcpt::TraceCounters *counters_dev = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -124,6 +125,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     job.tile_stride = range.tile_stride;
     job.tiles_x = r->TilesX();
     job.packed = packed ? 1u : 0u;
+    job.reference_walk = r->reference_walk ? 1u : 0u;
     mcpt::TraceCounters *counters = nullptr;
     if (counted)
     {
@@ -344,6 +346,8 @@ int mcpt_renderer_create(const mcpt_config *cfg, int device, mcpt_renderer **out
         int k = 0;
         d.nodes = r->arrays[k++].Upload(f.nodes, "upload nodes");
         d.node_area = r->arrays[k++].Upload(f.node_area, "upload node areas");
+        d.walk_nodes = r->arrays[k++].Upload(f.walk_nodes, "upload walk hierarchy");
+        d.walk_prims = r->arrays[k++].Upload(f.walk_prims, "upload walk primitives");
         d.tri_pos = r->arrays[k++].Upload(f.tri_pos, "upload triangle positions");
         d.tri_attr = r->arrays[k++].Upload(f.tri_attr, "upload triangle attributes");
         d.instances = r->arrays[k++].Upload(f.instances, "upload instances");
@@ -443,6 +447,10 @@ int mcpt_renderer_table(const mcpt_renderer *r, const char *what, const void **d
         return set(f.nodes.data(), f.nodes.size() * 4);
     if (w == "node_area")
         return set(f.node_area.data(), f.node_area.size());
+    if (w == "walk_nodes")
+        return set(f.walk_nodes.data(), f.walk_nodes.size() * 4);
+    if (w == "walk_prims")
+        return set(f.walk_prims.data(), f.walk_prims.size() * 4);
     if (w == "tri_pos")
         return set(f.tri_pos.data(), f.tri_pos.size() * 4);
     if (w == "tri_attr")
@@ -458,13 +466,22 @@ int mcpt_renderer_table(const mcpt_renderer *r, const char *what, const void **d
     return Fail("unknown table '" + w + "'");
 }
 
-int mcpt_renderer_info(const mcpt_renderer *r, uint64_t info[6])
+int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order)
+{
+    if (!r)
+        return Fail("null argument");
+    r->reference_walk = reference_order != 0;
+    return 0;
+}
+
+int mcpt_renderer_info(const mcpt_renderer *r, uint64_t info[9])
 {
     if (!r || !info)
         return Fail("null argument");
     const mcpt::IntegratorRec &ig = r->flat.integrator;
     info[0] = ig.n_nodes, info[1] = ig.n_tlas_nodes, info[2] = ig.n_prims, info[3] = ig.n_instances;
     info[4] = r->flat.features, info[5] = r->flat.GeometryBytes();
+    info[6] = ig.n_walk_nodes, info[7] = ig.walk_depth, info[8] = ig.has_masks;
     return 0;
 }
 
@@ -505,7 +522,7 @@ int mcpt_debug_intersect(mcpt_renderer *r, uint32_t n, const float *rays, const 
 {
     return RunUnit(r, n, rays, 6, seeds, out, 19, seeds_out,
                    [&](const float *a, const uint32_t *b, float *c, uint32_t *d)
-                   { return mcpt::LaunchIntersect(r->dev, n, a, b, c, d, nullptr); });
+                   { return mcpt::LaunchIntersect(r->dev, n, a, b, c, d, r->reference_walk, nullptr); });
 }
 
 int mcpt_debug_bsdf(mcpt_renderer *r, uint32_t id_bsdf, int mode, uint32_t n, const float *records,

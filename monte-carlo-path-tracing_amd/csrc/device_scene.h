@@ -19,6 +19,19 @@
 //              by following `skip` (the pre-order successor that leaves the
 //              subtree) on a miss or after a leaf.  kEndOfTree ends a tree.
 //              The right child of node i is skip(i + 1).
+//   walk_nodes 4 x float4 per node (64 B) of the ORDERED-walk hierarchy: a binary
+//              SAH tree over all primitives of all instances (one primitive per
+//              leaf, leaves have no record of their own):
+//                [0] = child0.lo.xyz, bits(ref0)   [1] = child0.hi.xyz, bits(ref1)
+//                [2] = child1.lo.xyz, -            [3] = child1.hi.xyz, -
+//              ref = node index, or kWalkLeaf | slot into walk_prims.  Node 0 is
+//              a top node whose child 0 is the whole scene (so the scene box is
+//              tested like the reference's TLAS root) and child 1 is empty.
+//              The boxes of leaves are bit-identical to the reference's leaf
+//              boxes, interior boxes are exact unions: a primitive is reachable
+//              here under exactly the conditions it is in the reference's tree.
+//   walk_prims 3 x float4 per slot: p0 | bits(global primitive), p1 | bits(instance),
+//              p2 | bits(rank of the primitive in the reference's visiting order)
 //   tri_pos    3 x float4 per triangle: p0, p1, p2 (w unused)  -> 36 B useful
 //   tri_attr   9 x float4 per triangle: n0 n1 n2 | t0 t1 t2 | b0 b1 b2, the six
 //              texture coordinates ride in the w lanes (n0.w=u0 n1.w=v0
@@ -48,6 +61,8 @@ namespace mcpt
 constexpr uint32_t kNoObject = 0xFFFFFFFFu;
 constexpr uint32_t kEndOfTree = 0xFFFFFFFFu;
 constexpr uint32_t kNone = 0xFFFFFFFFu; // reference kInvalidId (defs.hpp:22)
+constexpr uint32_t kWalkLeaf = 0x80000000u; // walk_nodes child reference: primitive slot, not a node
+constexpr uint32_t kWalkDepthMax = 56;      // bound on the ordered-walk tree depth (= stack entries)
 constexpr int kLutRes = 128;            // kulla_conty.hpp:9
 
 struct Vec3f
@@ -192,6 +207,10 @@ struct IntegratorRec // reference integrator.hpp:31-69 (the scalar part)
     uint32_t n_emitters, n_area_lights;
     uint32_t id_sun, id_envmap;
     uint32_t n_tlas_nodes, n_nodes, n_instances, n_prims;
+    uint32_t n_walk_nodes; // ordered-walk hierarchy (0 = empty scene)
+    uint32_t walk_depth;   // its depth = stack entries a lane needs
+    uint32_t has_masks;    // some BSDF carries an opacity map: the walk must keep the reference's order
+    uint32_t pad;
 };
 
 // Feature bits: which parts of the hot path a scene actually exercises.  The
@@ -203,6 +222,9 @@ enum SceneFeature : uint32_t
     kFeatAnalytic = 1u << 2,    // sphere / disk / cylinder instances
     kFeatTextures = 1u << 3,    // non-constant textures, bump or opacity maps
     kFeatMicrofacet = 1u << 4,  // any BSDF other than diffuse / area light
+    // not a property of the scene but of the launch: walk the SAH hierarchy
+    // near child first instead of the reference's tree in the reference's order
+    kFeatOrderedWalk = 1u << 5,
 };
 
 // Device view: raw pointers into HBM + the scalar records.
@@ -215,6 +237,8 @@ struct DeviceScene
 
     const float4 *nodes;       // 2 per node
     const float *node_area;    // 1 per node
+    const float4 *walk_nodes;  // 4 per node of the ordered-walk hierarchy
+    const float4 *walk_prims;  // 3 per slot
     const float4 *tri_pos;     // 3 per triangle slot (global primitive index)
     const float4 *tri_attr;    // 9 per triangle slot
     const InstanceRec *instances;

@@ -35,12 +35,14 @@ struct Budget
     static constexpr int kWavesPerSimd = (kFeatures & (kFeatMicrofacet | kFeatVolPath | kFeatAnalytic)) ? 2 : 4;
 };
 
-// kLdsGeometry: the node array and the triangle position array (the two streams
-// the walk reads) are copied into LDS by each workgroup before it starts and
-// the walk reads them from there (ds_read_b128) instead of through L1.  Used for
-// scenes whose traversal data fits kLdsGeometryBytes (cornell: 4.3 KB); the walk
-// is a chain of dependent loads, so the shorter LDS latency shortens every
-// node step.  Large scenes stream from HBM / L2 as before.
+// kLdsGeometry: the arrays the ray queries and the light sampler read (both
+// hierarchies, walk primitives, triangle positions) are copied into LDS by each
+// workgroup before it starts and read from there (ds_read_b128) instead of
+// through L1.  Used for scenes whose traversal data fits kLdsGeometryBytes
+// (cornell: 8 KB); a walk is a chain of dependent loads, so the shorter LDS
+// latency shortens every step.  Large scenes stream from HBM / L2.
+// The ordered walk's stacks always live in LDS: lane t of the workgroup owns the
+// words t, t + 256, t + 512, ... of the stack area.
 template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
 __global__ void __launch_bounds__(kBlockSize, Budget<kFeatures>::kWavesPerSimd)
 render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ out, TraceCounters *__restrict__ counters)
@@ -48,16 +50,29 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     using C = Config<kFeatures>;
     extern __shared__ float4 lds_geometry[];
     DeviceScene sc = sc_in;
+    uint32_t n_staged = 0;
     if (kLdsGeometry)
     {
         const uint32_t n_node_vec = 2u * sc_in.integrator.n_nodes, n_tri_vec = 3u * sc_in.integrator.n_prims;
+        const uint32_t n_walk_vec = C::kOrdered ? 4u * sc_in.integrator.n_walk_nodes : 0u;
+        const uint32_t n_slot_vec = C::kOrdered ? n_tri_vec : 0u;
         for (uint32_t i = threadIdx.x; i < n_node_vec; i += blockDim.x)
             lds_geometry[i] = sc_in.nodes[i];
         for (uint32_t i = threadIdx.x; i < n_tri_vec; i += blockDim.x)
             lds_geometry[n_node_vec + i] = sc_in.tri_pos[i];
+        for (uint32_t i = threadIdx.x; i < n_walk_vec; i += blockDim.x)
+            lds_geometry[n_node_vec + n_tri_vec + i] = sc_in.walk_nodes[i];
+        for (uint32_t i = threadIdx.x; i < n_slot_vec; i += blockDim.x)
+            lds_geometry[n_node_vec + n_tri_vec + n_walk_vec + i] = sc_in.walk_prims[i];
         __syncthreads();
         sc.nodes = lds_geometry;
         sc.tri_pos = lds_geometry + n_node_vec;
+        if (C::kOrdered)
+        {
+            sc.walk_nodes = lds_geometry + n_node_vec + n_tri_vec;
+            sc.walk_prims = lds_geometry + n_node_vec + n_tri_vec + n_walk_vec;
+        }
+        n_staged = n_node_vec + n_tri_vec + n_walk_vec + n_slot_vec;
     }
     const uint32_t stride = gridDim.x * blockDim.x;
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -68,6 +83,7 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
 
     PathState st;
     st.alive = false;
+    st.stack = reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + threadIdx.x;
     bool has_pixel = false;
     uint32_t slot = 0; // where this pixel's result goes
     for (;;)
@@ -122,10 +138,12 @@ constexpr uint32_t kAllFeatures = kFeatVolPath | kFeatEmitters | kFeatAnalytic |
 
 // in: origin[3], dir[3] per ray.  out (19 floats per ray): valid, inside,
 // instance, primitive-in-instance, t, uv[2], position, normal, tangent, bitangent.
+template <bool kOrdered>
 __global__ void intersect_kernel(const DeviceScene sc, uint32_t n, const float *__restrict__ rays,
                                  const uint32_t *__restrict__ seeds, float *__restrict__ out,
                                  uint32_t *__restrict__ seeds_out)
 {
+    extern __shared__ uint32_t lds_stack[];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
@@ -133,7 +151,8 @@ __global__ void intersect_kernel(const DeviceScene sc, uint32_t n, const float *
     uint32_t rng = seeds[i];
     HitRaw raw;
     TraceStats ts{0, 0};
-    const bool hit = walk_scene<false, true, true, false>(sc, ray, rng, raw, ts);
+    const bool hit = kOrdered ? walk_ordered<false, true, false>(sc, lds_stack + threadIdx.x, ray, raw, ts)
+                              : walk_scene<false, true, true, false>(sc, ray, rng, raw, ts);
     float *o = out + 19 * static_cast<size_t>(i);
     for (int k = 0; k < 19; ++k)
         o[k] = 0.0f;
@@ -180,11 +199,16 @@ __global__ void bsdf_kernel(const DeviceScene sc, uint32_t n, uint32_t id_bsdf, 
 }
 
 hipError_t LaunchIntersect(const DeviceScene &sc, uint32_t n, const float *rays, const uint32_t *seeds, float *out,
-                           uint32_t *seeds_out, hipStream_t stream)
+                           uint32_t *seeds_out, bool reference_walk, hipStream_t stream)
 {
     if (n == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, sc, n, rays, seeds, out, seeds_out);
+    if (reference_walk || sc.integrator.has_masks)
+        hipLaunchKernelGGL(intersect_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, stream, sc, n, rays, seeds,
+                           out, seeds_out);
+    else
+        hipLaunchKernelGGL(intersect_kernel<true>, dim3((n + 255) / 256), dim3(256),
+                           sc.integrator.walk_depth * 256 * sizeof(uint32_t), stream, sc, n, rays, seeds, out, seeds_out);
     return hipGetLastError();
 }
 
@@ -203,12 +227,21 @@ namespace
 
 constexpr uint32_t kAll = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
 
+size_t StagedBytes(const DeviceScene &sc, bool ordered)
+{
+    size_t vecs = 2ull * sc.integrator.n_nodes + 3ull * sc.integrator.n_prims;
+    if (ordered)
+        vecs += 4ull * sc.integrator.n_walk_nodes + 3ull * sc.integrator.n_prims;
+    return vecs * sizeof(float4);
+}
+
 template <uint32_t kFeatures, bool kCount, bool kLdsGeometry = false>
 hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters, hipStream_t stream,
                   uint32_t max_blocks)
 {
-    const size_t lds_bytes =
-        kLdsGeometry ? (2ull * sc.integrator.n_nodes + 3ull * sc.integrator.n_prims) * sizeof(float4) : 0;
+    constexpr bool kOrdered = (kFeatures & kFeatOrderedWalk) != 0;
+    const size_t lds_bytes = (kLdsGeometry ? StagedBytes(sc, kOrdered) : 0) +
+                             (kOrdered ? size_t(sc.integrator.walk_depth) * kBlockSize * sizeof(uint32_t) : 0);
     int per_cu = 0;
     hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &per_cu, render_kernel<kFeatures, kCount, kLdsGeometry>, kBlockSize, lds_bytes);
@@ -229,37 +262,46 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
 
 } // namespace
 
-// Picks the leanest instantiation that covers the scene's feature bits.
+// Picks the leanest instantiation that covers the scene's feature bits.  The
+// ordered walk is the default; opacity masks (or job.reference_walk) select the
+// reference-order walk, which exists only in the full instantiation.
 hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
                         hipStream_t stream, uint32_t n_cus, const char **variant)
 {
+    constexpr uint32_t kO = kFeatOrderedWalk;
     const uint32_t f = sc.features;
+    const bool ordered = !job.reference_walk && !sc.integrator.has_masks;
     if (counters != nullptr)
     {
-        *variant = "all+count";
-        return Launch<kAll, true>(sc, job, out, counters, stream, n_cus);
+        *variant = ordered ? "all+count" : "all+count, reference walk";
+        return ordered ? Launch<kAll | kO, true>(sc, job, out, counters, stream, n_cus)
+                       : Launch<kAll, true>(sc, job, out, counters, stream, n_cus);
     }
-    const size_t geometry = (2ull * sc.integrator.n_nodes + 3ull * sc.integrator.n_prims) * sizeof(float4);
-    const bool lds = geometry <= kLdsGeometryBytes;
+    if (!ordered)
+    {
+        *variant = "all, reference walk";
+        return Launch<kAll, false>(sc, job, out, nullptr, stream, n_cus);
+    }
+    const bool lds = StagedBytes(sc, true) <= kLdsGeometryBytes;
     if (f == 0)
     {
         *variant = lds ? "diffuse-area+lds" : "diffuse-area";
-        return lds ? Launch<0, false, true>(sc, job, out, nullptr, stream, n_cus)
-                   : Launch<0, false>(sc, job, out, nullptr, stream, n_cus);
+        return lds ? Launch<kO, false, true>(sc, job, out, nullptr, stream, n_cus)
+                   : Launch<kO, false>(sc, job, out, nullptr, stream, n_cus);
     }
     if ((f & ~kFeatEmitters) == 0)
     {
         *variant = lds ? "diffuse-emitters+lds" : "diffuse-emitters";
-        return lds ? Launch<kFeatEmitters, false, true>(sc, job, out, nullptr, stream, n_cus)
-                   : Launch<kFeatEmitters, false>(sc, job, out, nullptr, stream, n_cus);
+        return lds ? Launch<kFeatEmitters | kO, false, true>(sc, job, out, nullptr, stream, n_cus)
+                   : Launch<kFeatEmitters | kO, false>(sc, job, out, nullptr, stream, n_cus);
     }
     if ((f & ~(kFeatEmitters | kFeatTextures | kFeatMicrofacet)) == 0)
     {
         *variant = "surface-materials";
-        return Launch<kFeatEmitters | kFeatTextures | kFeatMicrofacet, false>(sc, job, out, nullptr, stream, n_cus);
+        return Launch<kFeatEmitters | kFeatTextures | kFeatMicrofacet | kO, false>(sc, job, out, nullptr, stream, n_cus);
     }
     *variant = "all";
-    return Launch<kAll, false>(sc, job, out, nullptr, stream, n_cus);
+    return Launch<kAll | kO, false>(sc, job, out, nullptr, stream, n_cus);
 }
 
 } // namespace mcpt

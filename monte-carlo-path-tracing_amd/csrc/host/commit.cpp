@@ -187,6 +187,187 @@ private:
     std::vector<uint32_t> order_;
 };
 
+
+// ---- ordered-walk hierarchy ---------------------------------------------------
+// A second tree over ALL primitives of ALL instances, used only for ray queries
+// (light sampling keeps the reference's LBVH above: its topology is part of the
+// sampling distribution).  Binned-SAH binary tree, one primitive per leaf, fat
+// nodes holding both children's boxes (device_scene.h).  Leaf boxes are the
+// reference's leaf boxes and interior boxes exact unions, so the slab test on
+// the path to a primitive succeeds exactly when it does in the reference's
+// TLAS/BLAS pair (the test is monotone in the box) — the two hierarchies accept
+// the same primitives, only the visiting order and the number of visited nodes
+// differ.  The depth is bounded (kWalkDepthMax) because it sizes the per-lane
+// traversal stack.
+class WalkTreeBuilder
+{
+public:
+    WalkTreeBuilder(const std::vector<Bounds> &boxes, std::vector<float4> &nodes, std::vector<uint32_t> &slot_prim)
+        : boxes_(boxes), nodes_(nodes), slot_prim_(slot_prim)
+    {
+        const uint32_t n = static_cast<uint32_t>(boxes.size());
+        order_.resize(n);
+        centre_.resize(n);
+        for (uint32_t i = 0; i < n; ++i)
+        {
+            order_[i] = i;
+            centre_[i] = (boxes[i].lo + boxes[i].hi) * 0.5f;
+        }
+    }
+
+    // Returns the depth of the tree (interior levels, top node included).
+    uint32_t Build()
+    {
+        nodes_.clear();
+        slot_prim_.clear();
+        if (order_.empty())
+            return 0;
+        nodes_.resize(4); // top node
+        Bounds all;
+        uint32_t depth = 0;
+        const uint32_t root = Emit(0, static_cast<uint32_t>(order_.size()), kWalkDepthMax - 1, all, depth);
+        Bounds none; // lo = +max, hi = -max: never entered
+        nodes_[0] = Pack(all.lo, Bits(root)), nodes_[1] = Pack(all.hi, Bits(root));
+        nodes_[2] = Pack(none.lo, 0.0f), nodes_[3] = Pack(none.hi, 0.0f);
+        return depth + 1;
+    }
+
+private:
+    static float4 Pack(V3 v, float w) { return float4{v.x, v.y, v.z, w}; }
+    static float Bits(uint32_t u)
+    {
+        float f;
+        std::memcpy(&f, &u, 4);
+        return f;
+    }
+    static uint32_t Log2Ceil(uint32_t n)
+    {
+        uint32_t l = 0;
+        while ((1ull << l) < n)
+            ++l;
+        return l;
+    }
+    static double HalfArea(const Bounds &b)
+    {
+        const double dx = double(b.hi.x) - b.lo.x, dy = double(b.hi.y) - b.lo.y, dz = double(b.hi.z) - b.lo.z;
+        return dx * dy + dy * dz + dz * dx;
+    }
+
+    // Splits order_[begin, end) in place; returns the first index of the right part.
+    uint32_t Split(uint32_t begin, uint32_t end, uint32_t budget)
+    {
+        const uint32_t count = end - begin;
+        Bounds cb;
+        for (uint32_t i = begin; i < end; ++i)
+            cb.Add(centre_[order_[i]]);
+        const V3 extent = cb.hi - cb.lo;
+        const int wide = (extent.x >= extent.y && extent.x >= extent.z) ? 0 : (extent.y >= extent.z ? 1 : 2);
+        auto median = [&]()
+        {
+            const uint32_t mid = begin + count / 2;
+            std::nth_element(order_.begin() + begin, order_.begin() + mid, order_.begin() + end,
+                             [&](uint32_t a, uint32_t b)
+                             {
+                                 const float ca = comp(centre_[a], wide), cb2 = comp(centre_[b], wide);
+                                 return ca < cb2 || (ca == cb2 && a < b);
+                             });
+            return mid;
+        };
+        if (count <= 2 || budget <= Log2Ceil(count))
+            return count == 2 ? begin + 1 : median();
+        constexpr int kBins = 16;
+        double best_cost = 1e300;
+        int best_axis = -1, best_bin = 0;
+        for (int axis = 0; axis < 3; ++axis)
+        {
+            const float lo = comp(cb.lo, axis), width = comp(extent, axis);
+            if (!(width > 0.0f))
+                continue;
+            Bounds bin_box[kBins];
+            uint32_t bin_count[kBins] = {};
+            const float scale = kBins / width;
+            for (uint32_t i = begin; i < end; ++i)
+            {
+                const uint32_t prim = order_[i];
+                int b = static_cast<int>((comp(centre_[prim], axis) - lo) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                bin_box[b].Add(boxes_[prim]);
+                ++bin_count[b];
+            }
+            double right_area[kBins];
+            uint32_t right_count[kBins];
+            Bounds acc;
+            uint32_t n = 0;
+            for (int b = kBins - 1; b > 0; --b)
+            {
+                if (bin_count[b])
+                    acc.Add(bin_box[b]);
+                n += bin_count[b];
+                right_area[b] = n ? HalfArea(acc) : 0.0;
+                right_count[b] = n;
+            }
+            acc = Bounds();
+            n = 0;
+            for (int b = 0; b + 1 < kBins; ++b)
+            {
+                if (bin_count[b])
+                    acc.Add(bin_box[b]);
+                n += bin_count[b];
+                if (n == 0 || right_count[b + 1] == 0)
+                    continue;
+                const double cost = HalfArea(acc) * n + right_area[b + 1] * right_count[b + 1];
+                if (cost < best_cost)
+                    best_cost = cost, best_axis = axis, best_bin = b;
+            }
+        }
+        if (best_axis < 0)
+            return median();
+        const float lo = comp(cb.lo, best_axis), scale = kBins / comp(extent, best_axis);
+        const auto first_right = std::partition(order_.begin() + begin, order_.begin() + end,
+                                                [&](uint32_t prim)
+                                                {
+                                                    int b = static_cast<int>((comp(centre_[prim], best_axis) - lo) * scale);
+                                                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                                                    return b <= best_bin;
+                                                });
+        const uint32_t mid = static_cast<uint32_t>(first_right - order_.begin());
+        const uint32_t larger = std::max(mid - begin, end - mid);
+        if (mid == begin || mid == end || Log2Ceil(larger) > budget - 1)
+            return median();
+        return mid;
+    }
+
+    uint32_t Emit(uint32_t begin, uint32_t end, uint32_t budget, Bounds &box, uint32_t &depth)
+    {
+        if (begin + 1 == end)
+        {
+            const uint32_t slot = static_cast<uint32_t>(slot_prim_.size());
+            slot_prim_.push_back(order_[begin]);
+            box = boxes_[order_[begin]];
+            depth = 0;
+            return kWalkLeaf | slot;
+        }
+        const uint32_t id = static_cast<uint32_t>(nodes_.size() / 4);
+        nodes_.resize(nodes_.size() + 4);
+        const uint32_t mid = Split(begin, end, budget);
+        Bounds b0, b1;
+        uint32_t d0 = 0, d1 = 0;
+        const uint32_t r0 = Emit(begin, mid, budget - 1, b0, d0);
+        const uint32_t r1 = Emit(mid, end, budget - 1, b1, d1);
+        nodes_[4 * size_t(id)] = Pack(b0.lo, Bits(r0)), nodes_[4 * size_t(id) + 1] = Pack(b0.hi, Bits(r1));
+        nodes_[4 * size_t(id) + 2] = Pack(b1.lo, 0.0f), nodes_[4 * size_t(id) + 3] = Pack(b1.hi, 0.0f);
+        box.lo = vmin(b0.lo, b1.lo), box.hi = vmax(b0.hi, b1.hi);
+        depth = 1 + std::max(d0, d1);
+        return id;
+    }
+
+    const std::vector<Bounds> &boxes_;
+    std::vector<float4> &nodes_;
+    std::vector<uint32_t> &slot_prim_;
+    std::vector<uint32_t> order_;
+    std::vector<V3> centre_;
+};
+
 // ---- meshes -----------------------------------------------------------------
 struct MeshSource
 {
@@ -451,6 +632,7 @@ DeviceScene FlatScene::HostView() const
     DeviceScene d{};
     d.camera = camera, d.integrator = integrator, d.features = features;
     d.nodes = nodes.data(), d.node_area = node_area.data();
+    d.walk_nodes = walk_nodes.data(), d.walk_prims = walk_prims.data();
     d.tri_pos = tri_pos.data(), d.tri_attr = tri_attr.data();
     d.instances = instances.data(), d.analytic = analytic.data();
     d.light_inst = light_inst.data(), d.light_cdf = light_cdf.data();
@@ -463,8 +645,8 @@ DeviceScene FlatScene::HostView() const
 
 size_t FlatScene::GeometryBytes() const
 {
-    return nodes.size() * sizeof(float4) + tri_pos.size() * sizeof(float4) +
-           tri_attr.size() * sizeof(float4);
+    return nodes.size() * sizeof(float4) + walk_nodes.size() * sizeof(float4) + walk_prims.size() * sizeof(float4) +
+           tri_pos.size() * sizeof(float4) + tri_attr.size() * sizeof(float4);
 }
 
 FlatScene CommitScene(const mcsd::Scene &in)
@@ -505,6 +687,8 @@ FlatScene CommitScene(const mcsd::Scene &in)
     const uint32_t n_inst = static_cast<uint32_t>(in.instances.size());
     std::vector<std::vector<TreeNode>> blas(n_inst);
     std::vector<uint32_t> prim_base(n_inst);
+    std::vector<Bounds> prim_box;    // by global primitive index: the reference's leaf boxes
+    std::vector<uint32_t> prim_inst; // owning instance
     uint32_t n_prims = 0;
     fs.instances.resize(n_inst);
     for (uint32_t i = 0; i < n_inst; ++i)
@@ -619,6 +803,8 @@ FlatScene CommitScene(const mcsd::Scene &in)
             throw std::runtime_error("unknow instance type.");
         }
         blas[i] = std::move(LinearBvh(boxes, areas).nodes_);
+        prim_box.insert(prim_box.end(), boxes.begin(), boxes.end());
+        prim_inst.insert(prim_inst.end(), boxes.size(), i);
         rec.prim_base = prim_base[i];
         rec.bsdf = s.id_bsdf;
         rec.medium_int = s.id_medium_int, rec.medium_ext = s.id_medium_ext;
@@ -661,6 +847,30 @@ FlatScene CommitScene(const mcsd::Scene &in)
     ig.n_nodes = static_cast<uint32_t>(fs.node_area.size());
     ig.n_instances = n_inst;
     ig.n_prims = n_prims;
+
+    // ---- ordered-walk hierarchy over all primitives ---------------------------
+    {
+        // rank = position in the reference's visiting order (TLAS pre-order, then the
+        // instance's BLAS pre-order): decides between primitives at equal distance
+        std::vector<uint32_t> rank(n_prims, 0);
+        uint32_t counter = 0;
+        for (const TreeNode &t : tlas)
+            if (t.object != kNoObject)
+                for (const TreeNode &b : blas[t.object])
+                    if (b.object != kNoObject)
+                        rank[prim_base[t.object] + b.object] = counter++;
+        std::vector<uint32_t> slot_prim;
+        ig.walk_depth = WalkTreeBuilder(prim_box, fs.walk_nodes, slot_prim).Build();
+        ig.n_walk_nodes = static_cast<uint32_t>(fs.walk_nodes.size() / 4);
+        fs.walk_prims.reserve(3 * slot_prim.size());
+        for (const uint32_t prim : slot_prim)
+        {
+            const float4 *p = &fs.tri_pos[3 * static_cast<size_t>(prim)];
+            fs.walk_prims.push_back(float4{p[0].x, p[0].y, p[0].z, Bits(prim)});
+            fs.walk_prims.push_back(float4{p[1].x, p[1].y, p[1].z, Bits(prim_inst[prim])});
+            fs.walk_prims.push_back(float4{p[2].x, p[2].y, p[2].z, Bits(rank[prim])});
+        }
+    }
 
     // ---- light tables (renderer.cpp:271-304): weights are NOT normalised ----
     std::vector<float> weights;
@@ -733,6 +943,8 @@ FlatScene CommitScene(const mcsd::Scene &in)
         check(o.opacity, true), check(o.bump, true);
         if (o.opacity != kNone || o.bump != kNone)
             fs.features |= kFeatTextures;
+        if (o.opacity != kNone)
+            ig.has_masks = 1; // the mask test draws random numbers DURING the walk (bsdf.cpp:272-276)
         switch (b.type)
         {
         case MCSD_BSDF_AREA_LIGHT:
@@ -972,6 +1184,10 @@ FlatScene CommitScene(const mcsd::Scene &in)
         fs.tri_attr.assign(9, float4{0, 0, 0, 0});
         fs.instances.push_back(InstanceRec{});
     }
+    if (fs.walk_nodes.empty())
+        fs.walk_nodes.assign(4, float4{0, 0, 0, 0});
+    if (fs.walk_prims.empty())
+        fs.walk_prims.assign(3, float4{0, 0, 0, 0});
     return fs;
 }
 

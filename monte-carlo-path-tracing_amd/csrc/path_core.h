@@ -38,6 +38,7 @@ struct Config
     static constexpr bool kAnalytic = (kFeatures & kFeatAnalytic) != 0;
     static constexpr bool kTextures = (kFeatures & kFeatTextures) != 0;
     static constexpr bool kMicrofacet = (kFeatures & kFeatMicrofacet) != 0;
+    static constexpr bool kOrdered = (kFeatures & kFeatOrderedWalk) != 0; // which ray query runs (traversal.h)
 };
 
 struct LaneCounters
@@ -62,6 +63,7 @@ struct PathState
     V3 wi;               // sampled direction (points into the vertex)
     V3 throughput, L;    // path weight and radiance of the sample
     V3 pixel_sum;        // sum of clamped samples
+    uint32_t *stack;     // this lane's traversal stack (ordered walk): entry k at stack[k * kWalkStackStride]
 };
 
 MCPT_HD ShadeTables shade_tables(const DeviceScene &sc)
@@ -112,15 +114,28 @@ MCPT_HD bool pixel_done(const DeviceScene &sc, const PathState &st) { return !st
 
 MCPT_HD V3 pixel_value(const DeviceScene &sc, const PathState &st) { return st.pixel_sum * sc.camera.spp_inv; }
 
+// One ray query: the ordered walk of the SAH hierarchy, or the reference-order
+// walk of the reference's own trees (needed when opacity masks draw random
+// numbers during the walk; also the validation mode).
+template <class C, bool kAny>
+MCPT_HD bool trace(const DeviceScene &sc, uint32_t *stack, Ray &r, uint32_t &rng, HitRaw &hit, TraceStats &ts, bool count)
+{
+    if (C::kOrdered)
+        return count ? walk_ordered<kAny, C::kAnalytic, true>(sc, stack, r, hit, ts)
+                     : walk_ordered<kAny, C::kAnalytic, false>(sc, stack, r, hit, ts);
+    return count ? walk_scene<kAny, C::kAnalytic, C::kTextures, true>(sc, r, rng, hit, ts)
+                 : walk_scene<kAny, C::kAnalytic, C::kTextures, false>(sc, r, rng, hit, ts);
+}
+
 template <class C>
-MCPT_HD bool shadow_walk(const DeviceScene &sc, V3 origin, V3 dir, float t_max, uint32_t &rng, LaneCounters *cnt)
+MCPT_HD bool shadow_walk(const DeviceScene &sc, uint32_t *stack, V3 origin, V3 dir, float t_max, uint32_t &rng,
+                         LaneCounters *cnt)
 {
     Ray r = make_ray(origin, dir);
     r.t_max = t_max;
     HitRaw dummy;
     TraceStats ts{0, 0};
-    const bool hit = cnt ? walk_scene<true, C::kAnalytic, C::kTextures, true>(sc, r, rng, dummy, ts)
-                         : walk_scene<true, C::kAnalytic, C::kTextures, false>(sc, r, rng, dummy, ts);
+    const bool hit = trace<C, true>(sc, stack, r, rng, dummy, ts, cnt != nullptr);
     if (cnt)
         ++cnt->shadow_rays, cnt->node_tests += ts.node_tests, cnt->prim_tests += ts.prim_tests;
     return hit;
@@ -173,7 +188,7 @@ MCPT_HD float area_light_pdf(const DeviceScene &sc, uint32_t light, uint32_t ins
 // Next-event estimation at a surface vertex (path.cpp:138-236,
 // volpath.cpp:247-375) or at a medium vertex (volpath.cpp:377-485).
 template <class C>
-MCPT_HD V3 connect_lights(const DeviceScene &sc, bool at_medium, const Surface &s, V3 position, uint32_t medium_id,
+MCPT_HD V3 connect_lights(const DeviceScene &sc, uint32_t *stack, bool at_medium, const Surface &s, V3 position, uint32_t medium_id,
                           V3 wo, uint32_t &rng, LaneCounters *cnt)
 {
     V3 L = V3{0, 0, 0};
@@ -234,7 +249,7 @@ MCPT_HD V3 connect_lights(const DeviceScene &sc, bool at_medium, const Surface &
             const EmitterRec &e = sc.emitters[k];
             const float xi0 = lcg_next(rng), xi1 = lcg_next(rng);
             const LightSample ls = emitter_sample(LT, e, position, xi0, xi1);
-            if (shadow_walk<C>(sc, position, -ls.wi, ls.distance - kEpsDistance, rng, cnt))
+            if (shadow_walk<C>(sc, stack, position, -ls.wi, ls.distance - kEpsDistance, rng, cnt))
                 continue;
             V3 tr, att;
             float pdf;
@@ -271,7 +286,7 @@ MCPT_HD V3 connect_lights(const DeviceScene &sc, bool at_medium, const Surface &
         const V3 d = position - lp.position;
         const float distance = length(d);
         // the shadow ray starts ON THE LIGHT and travels to the shading point
-        if (shadow_walk<C>(sc, lp.position, normalize(d), distance - kEpsDistance, rng, cnt))
+        if (shadow_walk<C>(sc, stack, lp.position, normalize(d), distance - kEpsDistance, rng, cnt))
             return L;
         const V3 wi = normalize(d);
         const float cos_light = dot(wi, lp.normal);
@@ -307,8 +322,7 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
     Ray ray = make_ray(st.origin, st.dir);
     HitRaw raw;
     TraceStats ts{0, 0};
-    const bool hit_valid = cnt ? walk_scene<false, C::kAnalytic, C::kTextures, true>(sc, ray, st.rng, raw, ts)
-                               : walk_scene<false, C::kAnalytic, C::kTextures, false>(sc, ray, st.rng, raw, ts);
+    const bool hit_valid = trace<C, false>(sc, st.stack, ray, st.rng, raw, ts, cnt != nullptr);
     if (cnt)
         ++cnt->closest_rays, cnt->node_tests += ts.node_tests, cnt->prim_tests += ts.prim_tests;
     Surface surf;
@@ -429,7 +443,7 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
 
     // ---- connect -------------------------------------------------------------
     const V3 vertex = st.in_medium ? st.origin : surf.position;
-    st.L += st.throughput * connect_lights<C>(sc, st.in_medium, surf, vertex, st.medium, st.wo, st.rng, cnt);
+    st.L += st.throughput * connect_lights<C>(sc, st.stack, st.in_medium, surf, vertex, st.medium, st.wo, st.rng, cnt);
 
     // ---- scatter -------------------------------------------------------------
     if (vol && st.in_medium)
@@ -481,6 +495,8 @@ template <class C>
 MCPT_HD V3 render_pixel(const DeviceScene &sc, uint32_t pixel, LaneCounters *cnt)
 {
     PathState st;
+    uint32_t stack[kWalkDepthMax * kWalkStackStride];
+    st.stack = stack;
     start_pixel(st, pixel);
     while (!pixel_done(sc, st))
     {

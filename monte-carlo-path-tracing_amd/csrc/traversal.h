@@ -330,6 +330,171 @@ MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &
     return found;
 }
 
+
+// ---- ordered walk -------------------------------------------------------------
+// The production ray query: near-child-first traversal of the SAH hierarchy
+// (walk_nodes / walk_prims, device_scene.h) with a small per-lane stack of
+// postponed far children.  One step loads ONE 64-byte node and tests BOTH
+// children, so a ray touches roughly half as many records as in the
+// one-box-per-node walk above, and the shrinking t_max prunes most of the far
+// side — the reference's fixed left-then-right order cannot do that.
+//
+// Same answers as walk_scene (see commit.cpp, WalkTreeBuilder, for why the
+// same primitives are reachable):
+//   * shadow queries: t_max is fixed, acceptance of a primitive does not depend
+//     on the order, the result is the same boolean;
+//   * closest queries: the minimum distance is order independent; among
+//     primitives at EQUAL distance the reference keeps the one it visits last
+//     (triangle.cpp:82 accepts t == t_max) — reproduced by comparing the
+//     primitives' ranks in the reference's visiting order.
+// Not usable when a BSDF carries an opacity map: that test draws random numbers
+// during the walk, so the order of visits is part of the image
+// (IntegratorRec::has_masks selects walk_scene then).
+//
+// Stack: `stack[level * kWalkStackStride]`; on the GPU the lanes of a workgroup
+// interleave their stacks in LDS (stride = workgroup size, conflict free), the
+// host build uses a plain array.
+#if defined(__HIP_DEVICE_COMPILE__)
+constexpr uint32_t kWalkStackStride = 256;
+#else
+constexpr uint32_t kWalkStackStride = 1;
+#endif
+
+// Slab test of box_hit, also returning the entry distance.
+MCPT_HD bool box_enter(const float4 &lo, const float4 &hi, const Ray &r, float &t_enter)
+{
+    const bool px = r.dir_rcp.x > 0, py = r.dir_rcp.y > 0, pz = r.dir_rcp.z > 0;
+    const float nx = ((px ? lo.x : hi.x) - r.origin.x) * r.dir_rcp.x, fx = ((px ? hi.x : lo.x) - r.origin.x) * r.dir_rcp.x;
+    const float ny = ((py ? lo.y : hi.y) - r.origin.y) * r.dir_rcp.y, fy = ((py ? hi.y : lo.y) - r.origin.y) * r.dir_rcp.y;
+    const float nz = ((pz ? lo.z : hi.z) - r.origin.z) * r.dir_rcp.z, fz = ((pz ? hi.z : lo.z) - r.origin.z) * r.dir_rcp.z;
+    t_enter = fmaxf(fmaxf(fmaxf(kEpsDistance, nx), ny), nz);
+    const float t_exit = fminf(fminf(fminf(r.t_max, fx), fy), fz);
+    return t_enter <= t_exit;
+}
+
+// Watertight triangle test of triangle_hit on a walk_prims record (no mask).
+MCPT_HD bool triangle_hit_slot(const float4 *p, Ray &ray, HitRaw &out)
+{
+    const V3 A = xyz(p[0]) - ray.origin, B = xyz(p[1]) - ray.origin, C = xyz(p[2]) - ray.origin;
+    const float Akz = comp(A, ray.kz), Bkz = comp(B, ray.kz), Ckz = comp(C, ray.kz);
+    const float Ax = comp(A, ray.kx) - ray.shear.x * Akz, Ay = comp(A, ray.ky) - ray.shear.y * Akz;
+    const float Bx = comp(B, ray.kx) - ray.shear.x * Bkz, By = comp(B, ray.ky) - ray.shear.y * Bkz;
+    const float Cx = comp(C, ray.kx) - ray.shear.x * Ckz, Cy = comp(C, ray.ky) - ray.shear.y * Ckz;
+    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f)
+    {
+        U = static_cast<float>(D(Cx) * D(By) - D(Cy) * D(Bx));
+        V = static_cast<float>(D(Ax) * D(Cy) - D(Ay) * D(Cx));
+        W = static_cast<float>(D(Bx) * D(Ay) - D(By) * D(Ax));
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f))
+        return false;
+    const float det = U + V + W;
+    if (det == 0.0f)
+        return false;
+    const float T = U * (ray.shear.z * Akz) + V * (ray.shear.z * Bkz) + W * (ray.shear.z * Ckz);
+    const float det_inv = 1.0f / det;
+    const float t = T * det_inv;
+    if (t > ray.t_max || t < kEpsDistance)
+        return false;
+    ray.t_max = t;
+    out.a = U * det_inv, out.b = V * det_inv, out.c = W * det_inv, out.inside = det_inv < 0;
+    return true;
+}
+
+template <bool kAny, bool kAnalytic, bool kCount>
+MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitRaw &hit, TraceStats &stats)
+{
+    if (sc.integrator.n_walk_nodes == 0)
+        return false;
+    bool found = false;
+    uint32_t best_rank = 0;
+    uint32_t depth = 0; // entries on the stack
+    uint32_t cur = 0;   // the top node
+    for (;;)
+    {
+        // ---- node steps until the lane holds a primitive or runs out of work ----
+        bool exhausted = false;
+        while (!(cur & kWalkLeaf))
+        {
+            const float4 *n = sc.walk_nodes + 4 * static_cast<size_t>(cur);
+            const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            if (kCount)
+                stats.node_tests += 2;
+            float enter0, enter1;
+            const bool hit0 = box_enter(n0, n1, ray, enter0), hit1 = box_enter(n2, n3, ray, enter1);
+            const uint32_t ref0 = as_uint(n0.w), ref1 = as_uint(n1.w);
+            if (hit0 && hit1)
+            {
+                const bool first0 = enter0 <= enter1;
+                stack[depth * kWalkStackStride] = first0 ? ref1 : ref0;
+                ++depth;
+                cur = first0 ? ref0 : ref1;
+            }
+            else if (hit0 || hit1)
+            {
+                cur = hit0 ? ref0 : ref1;
+            }
+            else
+            {
+                if (depth == 0)
+                {
+                    exhausted = true;
+                    break;
+                }
+                --depth;
+                cur = stack[depth * kWalkStackStride];
+            }
+        }
+        if (exhausted)
+            break;
+
+        // ---- primitive test ---------------------------------------------------------
+        if (kCount)
+            ++stats.prim_tests;
+        const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(cur & ~kWalkLeaf);
+        const uint32_t prim = as_uint(p[0].w), inst = as_uint(p[1].w), rank = as_uint(p[2].w);
+        const float t_before = ray.t_max;
+        HitRaw cand;
+        cand.inst = inst, cand.prim = prim, cand.a = cand.b = cand.c = 0.0f, cand.inside = false;
+        bool accepted;
+        uint32_t unused_rng = 0;
+        if (!kAnalytic)
+        {
+            accepted = triangle_hit_slot(p, ray, cand);
+        }
+        else
+        {
+            const InstanceRec &rec = sc.instances[inst];
+            if (rec.kind == kInstTriangles)
+                accepted = triangle_hit_slot(p, ray, cand);
+            else if (rec.kind == kInstSphere)
+                accepted = sphere_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, ray, unused_rng, cand);
+            else if (rec.kind == kInstDisk)
+                accepted = disk_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, ray, unused_rng, cand);
+            else
+                accepted = cylinder_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, ray, unused_rng, cand);
+        }
+        // equal distance: the reference keeps whichever it visits later
+        if (accepted && !kAny && found && ray.t_max == t_before && rank < best_rank)
+            accepted = false;
+        if (accepted)
+        {
+            found = true;
+            hit = cand;
+            hit.inst = inst, hit.prim = prim;
+            best_rank = rank;
+            if (kAny)
+                return true;
+        }
+        if (depth == 0)
+            break;
+        --depth;
+        cur = stack[depth * kWalkStackStride];
+    }
+    return found;
+}
+
 // Shading frame of the closest hit (second half of the reference's primitive
 // tests: triangle.cpp:122-144, sphere.cpp:48-83, disk.cpp:46-108,
 // cylinder.cpp:61-86), including bump mapping and the back-face flip.

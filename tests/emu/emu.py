@@ -22,6 +22,8 @@ class Emulator:
                                         ctypes.POINTER(ctypes.c_uint32)]
         lib.mcpt_emu_nodes.restype = ctypes.c_int
         lib.mcpt_emu_nodes.argtypes = [ctypes.c_char_p, _u32p, _f32p, ctypes.c_uint32]
+        lib.mcpt_emu_walk.restype = ctypes.c_int
+        lib.mcpt_emu_walk.argtypes = [ctypes.c_char_p, _f32p, _f32p, ctypes.c_uint32, ctypes.c_uint32, _u32p]
         self.lib = lib
 
     def render(self, mcsd_path, width, height, variant=-1, counted=False):
@@ -37,6 +39,21 @@ class Emulator:
             info.update(zip(("closest_rays", "shadow_rays", "node_tests", "prim_tests", "shaded_hits", "samples"),
                             (int(c) for c in counters)))
         return frame, info
+
+    ORDERED = 32      # feature bit of the ordered walk in a forced `variant`
+    REFERENCE = -2    # `variant`: the launcher's pick, but with the reference-order walk
+
+    def walk(self, mcsd_path, capacity=1 << 21):
+        """The ordered-walk hierarchy: (nodes[n, 4, 4] float32 with bit-pattern links,
+        prims[m, 3, 4], info dict)."""
+        nodes = np.zeros((capacity, 4, 4), dtype=np.float32)
+        prims = np.zeros((capacity, 3, 4), dtype=np.float32)
+        counts = np.zeros(4, dtype=np.uint32)
+        rc = self.lib.mcpt_emu_walk(str(mcsd_path).encode(), nodes.reshape(-1), prims.reshape(-1), capacity, capacity,
+                                    counts)
+        if rc != 0:
+            raise RuntimeError(self.lib.mcpt_emu_last_error().decode() if rc == -1 else "capacity too small")
+        return nodes[:counts[0]], prims[:counts[1]], {"depth": int(counts[2]), "has_masks": bool(counts[3])}
 
     def nodes(self, mcsd_path, capacity=1 << 22):
         links = np.zeros((capacity, 2), dtype=np.uint32)

@@ -73,7 +73,10 @@ extern "C"
 const char *mcpt_emu_last_error(void) { return g_error.c_str(); }
 
 // variant: -1 = pick like the GPU launcher does, otherwise a feature mask to
-// force (must be a superset of the scene's features).  counters: 6 x u32 or NULL.
+// force (must be a superset of the scene's features).  Bit kFeatOrderedWalk of a
+// forced mask selects the ordered walk; -1 uses it whenever the launcher would
+// (no opacity masks), -2 = launcher's pick but with the reference-order walk.
+// counters: 6 x u32 or NULL.
 int mcpt_emu_render(const char *mcsd_path, float *frame, int variant, uint32_t *counters, uint32_t *features_out)
 {
     try
@@ -87,8 +90,12 @@ int mcpt_emu_render(const char *mcsd_path, float *frame, int variant, uint32_t *
         constexpr uint32_t kAll = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
         uint32_t f = flat.features;
         uint32_t pick;
+        bool ordered = variant == -1 && flat.integrator.has_masks == 0;
         if (variant >= 0)
-            pick = static_cast<uint32_t>(variant);
+        {
+            ordered = (static_cast<uint32_t>(variant) & kFeatOrderedWalk) != 0;
+            pick = static_cast<uint32_t>(variant) & ~kFeatOrderedWalk;
+        }
         else if (f == 0)
             pick = 0;
         else if ((f & ~kFeatEmitters) == 0)
@@ -99,19 +106,34 @@ int mcpt_emu_render(const char *mcsd_path, float *frame, int variant, uint32_t *
             pick = kAll;
         if ((f & ~pick) != 0)
             throw std::runtime_error("forced variant does not cover the scene's features");
-        switch (pick)
+        if (ordered && flat.integrator.has_masks)
+            throw std::runtime_error("the ordered walk cannot be used with opacity masks");
+        constexpr uint32_t kO = kFeatOrderedWalk;
+        switch (pick | (ordered ? kO : 0u))
         {
         case 0:
             RenderAll<0>(sc, frame, cnt);
             break;
+        case kO:
+            RenderAll<kO>(sc, frame, cnt);
+            break;
         case kFeatEmitters:
             RenderAll<kFeatEmitters>(sc, frame, cnt);
+            break;
+        case kFeatEmitters | kO:
+            RenderAll<kFeatEmitters | kO>(sc, frame, cnt);
             break;
         case kFeatEmitters | kFeatTextures | kFeatMicrofacet:
             RenderAll<kFeatEmitters | kFeatTextures | kFeatMicrofacet>(sc, frame, cnt);
             break;
+        case kFeatEmitters | kFeatTextures | kFeatMicrofacet | kO:
+            RenderAll<kFeatEmitters | kFeatTextures | kFeatMicrofacet | kO>(sc, frame, cnt);
+            break;
         default:
-            RenderAll<kAll>(sc, frame, cnt);
+            if (ordered)
+                RenderAll<kAll | kO>(sc, frame, cnt);
+            else
+                RenderAll<kAll>(sc, frame, cnt);
             break;
         }
         if (counters)
@@ -125,6 +147,32 @@ int mcpt_emu_render(const char *mcsd_path, float *frame, int variant, uint32_t *
     {
         g_error = e.what();
         return 1;
+    }
+}
+
+// The ordered-walk hierarchy of the product's host commit: 16 floats per node,
+// 12 per primitive slot (bit patterns preserved), and (n_nodes, n_slots, depth,
+// has_masks) in `counts`.  Returns 0, or the required capacities in counts on -2.
+int mcpt_emu_walk(const char *mcsd_path, float *nodes, float *prims, uint32_t node_capacity, uint32_t slot_capacity,
+                  uint32_t *counts)
+{
+    try
+    {
+        const FlatScene flat = CommitScene(mcsd::Load(mcsd_path));
+        const uint32_t n_nodes = flat.integrator.n_walk_nodes;
+        const uint32_t n_slots = n_nodes ? flat.integrator.n_prims : 0;
+        counts[0] = n_nodes, counts[1] = n_slots, counts[2] = flat.integrator.walk_depth;
+        counts[3] = flat.integrator.has_masks;
+        if (n_nodes > node_capacity || n_slots > slot_capacity)
+            return -2;
+        std::memcpy(nodes, flat.walk_nodes.data(), size_t(n_nodes) * 64);
+        std::memcpy(prims, flat.walk_prims.data(), size_t(n_slots) * 48);
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return -1;
     }
 }
 

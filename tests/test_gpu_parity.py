@@ -55,9 +55,10 @@ def scenes(pkg):
     return cases(pkg.scenes)
 
 
-def gpu_render(pkg, scene, counted=False):
+def gpu_render(pkg, scene, counted=False, reference_walk=False):
     r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
     try:
+        r.set_walk(reference_walk)
         return r.draw(counted=counted)
     finally:
         r.close()
@@ -99,9 +100,27 @@ def test_counted_mode_same_image_and_counts(pkg, oracle, mcsd_file):
     _, info = oracle.render(mcsd_file(scene), with_stats=True)
     n = 96 * 96 * 8
     assert st["samples"] == n
-    # same algorithm -> same work, up to the rare decision flips
-    for key in ("closest_rays", "shadow_rays", "node_tests", "prim_tests"):
+    # the image is the same, so the rays are the same (up to the rare decision flips);
+    # node / primitive test counts are the ordered walk's own
+    for key in ("closest_rays", "shadow_rays"):
         assert abs(st[key] - info[key]) / info[key] < 0.01, (key, st[key], info[key])
+    assert st["node_tests"] > 0 and st["prim_tests"] > 0
+    # the reference-order walk does the reference's work
+    ref_frame, ref_st = gpu_render(pkg, scene, counted=True, reference_walk=True)
+    for key in ("closest_rays", "shadow_rays", "node_tests", "prim_tests"):
+        assert abs(ref_st[key] - info[key]) / info[key] < 0.01, (key, ref_st[key], info[key])
+    assert np.array_equal(ref_frame, plain)
+
+
+@pytest.mark.parametrize("name", ["cornell_64_spp8", "rough_dielectric_envmap", "conductor_aniso_mixed",
+                                  "volpath_medium_mixed", "terrain_directional"])
+def test_ordered_walk_equals_reference_walk(name, pkg, scenes):
+    """The production ray query (near-first walk of the SAH hierarchy) and the
+    reference-order walk of the reference's trees give the same frame on the GPU,
+    bit for bit."""
+    ordered, _ = gpu_render(pkg, scenes[name])
+    reference, _ = gpu_render(pkg, scenes[name], reference_walk=True)
+    assert np.array_equal(ordered, reference), np.abs(ordered - reference).max()
 
 
 def test_deterministic(pkg):

@@ -49,8 +49,9 @@ def _close(a, b, rtol=2e-4, atol=1e-5):
     return np.abs(a - b) <= atol + rtol * np.abs(b)
 
 
+@pytest.mark.parametrize("walk", ["ordered", "reference"])
 @pytest.mark.parametrize("shape", ["mesh", "flat_mesh", "sphere", "disk", "cylinder", "cube"])
-def test_intersection_records(shape, pkg, oracle, mcsd_file):
+def test_intersection_records(shape, walk, pkg, oracle, mcsd_file):
     scene = pkg.scenes.material_preview("bumpy_diffuse", "area", shape, 8, 8, 1)
     path = mcsd_file(scene)
     rng = np.random.default_rng(17)
@@ -60,6 +61,7 @@ def test_intersection_records(shape, pkg, oracle, mcsd_file):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     org, d = org.astype(np.float32), d.astype(np.float32)
     r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
+    r.set_walk(walk == "reference")
     got, _ = r.debug_intersect(org, d)
     r.close()
     want = np.zeros_like(got)

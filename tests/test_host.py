@@ -175,32 +175,136 @@ def test_commit_matches_oracle_tables(name, pkg, oracle, emulator, mcsd_file):
     assert base == len(o_links)
 
 
+# ---- the ordered-walk hierarchy ------------------------------------------------
+@pytest.mark.parametrize("name", ["cornell_64_spp8", "rough_conductor_envmap", "conductor_aniso_mixed",
+                                  "rough_diffuse_point_disk", "terrain_directional"])
+def test_walk_hierarchy_is_sound(name, pkg, emulator, mcsd_file):
+    """Every primitive is exactly one leaf; leaf boxes are the reference's leaf
+    boxes; interior boxes are the exact unions of their children; the depth bound
+    that sizes the traversal stack holds; ranks enumerate the reference's visiting
+    order."""
+    scene = cases(pkg.scenes)[name]
+    path = mcsd_file(scene)
+    nodes, prims, info = emulator.walk(path)
+    links, geom = emulator.nodes(path)
+    refs = nodes[:, :2, 3].copy().view(np.uint32)          # (n, 2): child references
+    slot_prim = prims[:, 0, 3].copy().view(np.uint32)
+    slot_rank = prims[:, 2, 3].copy().view(np.uint32)
+    n_prims = len(prims)
+    assert sorted(slot_prim) == list(range(n_prims))
+    assert sorted(slot_rank) == list(range(n_prims))
+    # reference leaf box and visiting rank of every primitive, from the reference-topology trees
+    leaf_box, order = {}, []
+    n_tlas = int(np.flatnonzero(links[:, 0] == 0xFFFFFFFF)[0]) + 1 if len(links) else 0
+    # (the TLAS is the first tree: it ends at the first node whose skip link is "end" and
+    #  that is a leaf or whose subtree is complete; simpler: BLAS leaves carry prim ids)
+    for i, (skip, obj) in enumerate(links):
+        if obj != 0xFFFFFFFF:
+            leaf_box.setdefault(("node", i), (geom[i, 1:4], geom[i, 4:7], obj))
+    LEAF = 0x80000000
+    seen, max_depth = set(), 0
+
+    def visit(ref, depth):
+        nonlocal max_depth
+        if ref & LEAF:
+            seen.add(ref & ~LEAF)
+            p = prims[ref & ~LEAF]
+            return None  # box comes from the parent
+        max_depth = max(max_depth, depth + 1)
+        boxes = []
+        for c in range(2):
+            lo, hi = nodes[ref, 2 * c, :3], nodes[ref, 2 * c + 1, :3]
+            child = int(refs[ref, c])
+            if ref == 0 and c == 1:
+                assert (lo > hi).all()                   # the empty child of the top node
+                continue
+            if child & LEAF:
+                seen.add(child & ~LEAF)
+                tri = prims[child & ~LEAF][:, :3]
+                boxes.append((lo, hi))
+                if name in ("cornell_64_spp8", "rough_conductor_envmap", "terrain_directional"):
+                    # triangle meshes only: leaf box = bounds of the vertices (triangle.cpp:9-15)
+                    np.testing.assert_array_equal(lo, tri.min(0))
+                    np.testing.assert_array_equal(hi, tri.max(0))
+            else:
+                sub = visit(child, depth + 1)
+                np.testing.assert_array_equal(lo, sub[0])
+                np.testing.assert_array_equal(hi, sub[1])
+                boxes.append((lo, hi))
+        los, his = np.array([b[0] for b in boxes]), np.array([b[1] for b in boxes])
+        return los.min(0), his.max(0)
+
+    import sys
+    sys.setrecursionlimit(10000)
+    visit(0, 0)
+    assert seen == set(range(n_prims))
+    assert max_depth == info["depth"] <= 56
+    # ranks: primitives in the order the reference-topology trees are walked
+    # (TLAS pre-order, BLAS pre-order): rank r belongs to the r-th leaf visited
+    tlas_leaves = []
+    i = 0
+    tlas_end = None
+    # the TLAS occupies the front of the array; its size is the first BLAS root,
+    # which is the smallest index no TLAS node links to... take it from the oracle-checked
+    # layout: a tree's nodes are contiguous and its last node has skip == end.
+    tree_end = [k + 1 for k in range(len(links)) if links[k, 0] == 0xFFFFFFFF and links[k, 1] != 0xFFFFFFFF]
+    n_tlas = tree_end[0] if len(tree_end) > 1 else 0
+    if n_tlas:
+        inst_order = [int(obj) for skip, obj in links[:n_tlas] if obj != 0xFFFFFFFF]
+        starts = [n_tlas] + tree_end[1:-1]
+        per_inst = []
+        for a, b in zip(starts, tree_end[1:]):
+            per_inst.append([int(obj) for skip, obj in links[a:b] if obj != 0xFFFFFFFF])
+        want = [p for inst in inst_order for p in per_inst[inst]]
+        got = [int(p) for p in slot_prim[np.argsort(slot_rank)]]
+        assert got == want
+
+
 # ---- kernel-body logic on CPU (bit-exact against reference goldens) ---------
+@pytest.mark.parametrize("walk", ["ordered", "reference"])
 @pytest.mark.parametrize("name", sorted(MANIFEST["frames"]))
-def test_kernel_body_emulated_matches_golden(name, pkg, emulator, mcsd_file):
+def test_kernel_body_emulated_matches_golden(name, walk, pkg, emulator, mcsd_file):
+    """Both ray queries — the production ordered walk of the SAH hierarchy and the
+    reference-order walk — reproduce the compiled reference's frames bit for bit
+    (scenes with opacity masks always take the reference-order walk)."""
     scene = cases(pkg.scenes)[name]
     golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
-    frame, _ = emulator.render(mcsd_file(scene), scene.camera.width, scene.camera.height)
+    frame, _ = emulator.render(mcsd_file(scene), scene.camera.width, scene.camera.height,
+                               variant=-1 if walk == "ordered" else emulator.REFERENCE)
     assert np.array_equal(frame, golden), f"max diff {np.abs(frame - golden).max():.3e}"
 
 
 def test_kernel_variants_agree(pkg, emulator, mcsd_file):
     """The specialised kernel instantiations compute the same image as the
-    general one."""
+    general one, with either walk."""
     scene = pkg.scenes.cornell_box(48, 48, 4)
     path = mcsd_file(scene)
     lean, info = emulator.render(path, 48, 48)
     assert info["features"] == 0
-    for variant in (2, 26, 31):
+    for variant in (0, 2, 26, 31, 32, 34, 58, 63):
         other, _ = emulator.render(path, 48, 48, variant=variant)
         assert np.array_equal(lean, other), variant
 
 
+def test_masks_force_the_reference_walk(pkg, emulator, mcsd_file):
+    scene = cases(pkg.scenes)["masked_area_flat"]
+    path = mcsd_file(scene)
+    assert emulator.walk(path)[2]["has_masks"]
+    with pytest.raises(RuntimeError, match="opacity masks"):
+        emulator.render(path, 48, 48, variant=31 | emulator.ORDERED)
+
+
 def test_emulated_counters_match_oracle(pkg, oracle, emulator, mcsd_file):
+    """Reference-order walk: the same rays AND the same node / primitive tests as the
+    oracle.  Ordered walk: the same rays (the image is the same), its own test counts."""
     scene = pkg.scenes.cornell_box(48, 48, 4)
     path = mcsd_file(scene)
-    _, got = emulator.render(path, 48, 48, counted=True)
     _, want = oracle.render(path, with_stats=True)
+    _, got = emulator.render(path, 48, 48, variant=emulator.REFERENCE, counted=True)
     for key in ("closest_rays", "shadow_rays", "node_tests", "prim_tests"):
         assert got[key] == want[key], key
     assert got["samples"] == 48 * 48 * 4
+    _, ordered = emulator.render(path, 48, 48, counted=True)
+    for key in ("closest_rays", "shadow_rays", "shaded_hits", "samples"):
+        assert ordered[key] == got[key], key
+    assert 0 < ordered["prim_tests"] and ordered["node_tests"] % 2 == 0
