@@ -34,12 +34,26 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
 def algorithmic_bytes_per_sample(counts, spp):
-    """32 B per node test, 36 B per primitive test, 132 B of
-    attributes per shaded hit, 12 B/spp for the pixel store; the streaming
-    kernel keeps path state in registers, so the wavefront-state term is 0."""
+    """32 B per node (box) test — the ordered walk reads one
+    64-byte record per visit and tests its two boxes —, 36 B per primitive test,
+    132 B of attributes per shaded hit, 12 B/spp for the pixel store; the
+    streaming kernel keeps path state in registers, so the wavefront-state term
+    is 0."""
     s = float(counts["samples"])
     return (counts["node_tests"] * 32.0 + counts["prim_tests"] * 36.0 +
             counts["shaded_hits"] * 132.0) / s + 12.0 / spp
+
+
+def measured_traffic_bytes():
+    """HBM bytes per launch of the render kernel, from the committed counter
+    summary (tools/pmc_profile.py run on the GPU box; bench.py cannot run the
+    profiler on itself).  None when no summary is present."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_cornell.json")
+    try:
+        c = json.load(open(path))["counters"]
+        return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(pkg, width, height, budget_s=20.0):
@@ -80,6 +94,9 @@ def main():
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="take the multi-GPU code path (RCCL process group, packed tiles, gather, scatter) "
+                         "even with one rank: lets a 1-GPU box exercise it")
     args = ap.parse_args()
 
     import torch
@@ -95,7 +112,10 @@ def main():
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_gather = world > 1 or args.force_gather
+    if use_gather:
+        if "MASTER_ADDR" not in os.environ:   # plain `python bench.py --force-gather`
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
 
     W, H, SPP = args.width, args.height, args.spp
@@ -105,20 +125,20 @@ def main():
     assert renderer.tiles_in(rng) == len(pkg.tiling.rank_tiles(rank, world, W, H))
     stream = torch.cuda.current_stream().cuda_stream
 
-    if world == 1:
+    if not use_gather:
         frame = torch.zeros(H * W * 3, dtype=torch.float32, device=device)
     else:
         fg = pkg.tiling.FrameGather(world, rank, W, H, device)
 
     def step():
-        if world == 1:
+        if not use_gather:
             renderer.draw_device(frame.data_ptr(), rng, packed=False, stream=stream, blocking=False)
         else:
             renderer.draw_device(fg.packed.data_ptr(), rng, packed=True, stream=stream, blocking=False)
             fg.gather()
 
     def sync():
-        if world > 1:
+        if use_gather:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -160,19 +180,23 @@ def main():
             rc = pkg.capi.Renderer(pkg.capi.Config.builtin("cornell-box").set_film(W, H, count_spp),
                                    device=local_rank)
             _, counts = rc.draw(counted=True)
+            scene_info = rc.info()
             rc.close()
             b_per_sample = algorithmic_bytes_per_sample(counts, SPP)
             achieved = b_per_sample * samples / (kernel_ms * 1e-3) / 1e9
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(),
                 "kernel": "mcpt::render_kernel", "kernel_ms": kernel_ms,
                 "bytes_per_sample": b_per_sample,
                 "per_sample": {k: counts[k] / counts["samples"] for k in
                                ("closest_rays", "shadow_rays", "node_tests", "prim_tests", "shaded_hits")},
-                "note": "algorithmic bytes (32 B/node test, 36 B/triangle test, 132 B/shaded hit, "
-                        "12 B/pixel); the scene (79 nodes, 36 triangles) is cache resident, so HBM "
-                        "traffic is far below this figure",
+                "note": "algorithmic bytes (32 B/box test, 36 B/triangle test, 132 B/shaded hit, "
+                        "12 B/pixel) over the kernel time; the scene (%d two-box nodes, %d triangles) is "
+                        "staged in LDS, so HBM traffic (`traffic`: bytes per launch from the rocprofv3 "
+                        "PMC passes in profiles/, FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE) is "
+                        "far below this figure and the kernel is VALU-issue bound, not HBM bound"
+                        % (scene_info["walk_nodes"], scene_info["primitives"]),
             }
             if not args.no_cpu_baseline:
                 rec, scene, cpu_frame = cpu_baseline(pkg, W, H)
@@ -189,8 +213,15 @@ def main():
         else:
             out["roofline"] = None
         print(json.dumps(out))
+    if rank == 0 and args.force_gather:
+        # the gathered frame must be the plain full-frame draw, bit for bit
+        plain, _ = renderer.draw()
+        same = bool(np.array_equal(fg.frame.cpu().numpy().reshape(H, W, 3), plain))
+        print(json.dumps({"force_gather_frame_equals_plain_draw": same}), file=sys.stderr)
+        if not same:
+            sys.exit(3)
     renderer.close()
-    if world > 1:
+    if use_gather:
         dist.destroy_process_group()
 
 

@@ -70,6 +70,10 @@ typedef struct mcpt_stats
     uint64_t samples;           /* pixels * spp produced by this call */
     /* filled only by mcpt_renderer_draw_counted(): */
     uint64_t closest_rays, shadow_rays, node_tests, prim_tests, shaded_hits;
+    /* ordered walk: wavefront-level steps of the node and primitive phases (each step
+     * runs for all 64 lanes whether or not they have work): lane utilisation of the
+     * node phase = (node_tests / 2) / (64 * wave_node_steps) */
+    uint64_t wave_node_steps, wave_prim_steps;
 } mcpt_stats;
 
 /* Replaces Renderer::Renderer(const RendererConfig&) (reference

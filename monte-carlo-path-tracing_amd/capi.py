@@ -34,7 +34,8 @@ class Stats(ctypes.Structure):
     _fields_ = [("render_seconds", ctypes.c_double), ("kernel_milliseconds", ctypes.c_double),
                 ("samples", ctypes.c_uint64), ("closest_rays", ctypes.c_uint64),
                 ("shadow_rays", ctypes.c_uint64), ("node_tests", ctypes.c_uint64),
-                ("prim_tests", ctypes.c_uint64), ("shaded_hits", ctypes.c_uint64)]
+                ("prim_tests", ctypes.c_uint64), ("shaded_hits", ctypes.c_uint64),
+                ("wave_node_steps", ctypes.c_uint64), ("wave_prim_steps", ctypes.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

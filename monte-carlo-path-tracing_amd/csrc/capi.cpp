@@ -6,6 +6,7 @@
 
 #include <chrono>
 #include <functional>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -171,6 +172,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             Check(hipMemcpy(&c, r->counters_dev, sizeof(c), hipMemcpyDeviceToHost), "read counters");
             stats->closest_rays = c.closest_rays, stats->shadow_rays = c.shadow_rays;
             stats->node_tests = c.node_tests, stats->prim_tests = c.prim_tests;
+            stats->wave_node_steps = c.wave_node_steps, stats->wave_prim_steps = c.wave_prim_steps;
             stats->shaded_hits = c.shaded_hits;
         }
     }

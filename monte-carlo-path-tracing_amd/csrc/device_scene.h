@@ -259,7 +259,7 @@ struct DeviceScene
 struct TraceCounters
 {
     unsigned long long closest_rays, shadow_rays, node_tests, prim_tests,
-        shaded_hits, samples;
+        shaded_hits, samples, wave_node_steps, wave_prim_steps;
 };
 
 } // namespace mcpt

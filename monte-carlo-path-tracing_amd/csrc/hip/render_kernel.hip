@@ -78,7 +78,7 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t width = static_cast<uint32_t>(sc.camera.width), height = static_cast<uint32_t>(sc.camera.height);
 
-    LaneCounters local{0, 0, 0, 0, 0, 0};
+    LaneCounters local{0, 0, 0, 0, 0, 0, 0, 0};
     LaneCounters *cnt = kCount ? &local : nullptr;
 
     PathState st;
@@ -130,6 +130,10 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         atomicAdd(&counters->prim_tests, static_cast<unsigned long long>(local.prim_tests));
         atomicAdd(&counters->shaded_hits, static_cast<unsigned long long>(local.shaded_hits));
         atomicAdd(&counters->samples, static_cast<unsigned long long>(local.samples));
+        if (local.wave_node_steps)
+            atomicAdd(&counters->wave_node_steps, static_cast<unsigned long long>(local.wave_node_steps));
+        if (local.wave_prim_steps)
+            atomicAdd(&counters->wave_prim_steps, static_cast<unsigned long long>(local.wave_prim_steps));
     }
 }
 
@@ -150,7 +154,7 @@ __global__ void intersect_kernel(const DeviceScene sc, uint32_t n, const float *
     Ray ray = make_ray(V3{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, V3{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]});
     uint32_t rng = seeds[i];
     HitRaw raw;
-    TraceStats ts{0, 0};
+    TraceStats ts{0, 0, 0, 0};
     const bool hit = kOrdered ? walk_ordered<false, true, false>(sc, lds_stack + threadIdx.x, ray, raw, ts)
                               : walk_scene<false, true, true, false>(sc, ray, rng, raw, ts);
     float *o = out + 19 * static_cast<size_t>(i);

@@ -44,6 +44,7 @@ struct Config
 struct LaneCounters
 {
     uint32_t closest_rays, shadow_rays, node_tests, prim_tests, shaded_hits, samples;
+    uint32_t wave_node_steps, wave_prim_steps;
 };
 
 // Per-lane path state that survives from one step to the next.
@@ -134,10 +135,13 @@ MCPT_HD bool shadow_walk(const DeviceScene &sc, uint32_t *stack, V3 origin, V3 d
     Ray r = make_ray(origin, dir);
     r.t_max = t_max;
     HitRaw dummy;
-    TraceStats ts{0, 0};
+    TraceStats ts{0, 0, 0, 0};
     const bool hit = trace<C, true>(sc, stack, r, rng, dummy, ts, cnt != nullptr);
     if (cnt)
+    {
         ++cnt->shadow_rays, cnt->node_tests += ts.node_tests, cnt->prim_tests += ts.prim_tests;
+        cnt->wave_node_steps += ts.wave_node_steps, cnt->wave_prim_steps += ts.wave_prim_steps;
+    }
     return hit;
 }
 
@@ -321,10 +325,13 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
     // ---- extend --------------------------------------------------------------
     Ray ray = make_ray(st.origin, st.dir);
     HitRaw raw;
-    TraceStats ts{0, 0};
+    TraceStats ts{0, 0, 0, 0};
     const bool hit_valid = trace<C, false>(sc, st.stack, ray, st.rng, raw, ts, cnt != nullptr);
     if (cnt)
+    {
         ++cnt->closest_rays, cnt->node_tests += ts.node_tests, cnt->prim_tests += ts.prim_tests;
+        cnt->wave_node_steps += ts.wave_node_steps, cnt->wave_prim_steps += ts.wave_prim_steps;
+    }
     Surface surf;
     if (hit_valid)
     {

@@ -31,7 +31,7 @@ void RenderAll(const DeviceScene &sc, float *frame, LaneCounters *total)
     const uint32_t n = static_cast<uint32_t>(sc.camera.width) * sc.camera.height;
     const unsigned workers = std::max(1u, std::thread::hardware_concurrency());
     std::atomic<uint32_t> next{0};
-    std::vector<LaneCounters> counts(workers, LaneCounters{0, 0, 0, 0, 0, 0});
+    std::vector<LaneCounters> counts(workers, LaneCounters{});
     auto work = [&](unsigned tid)
     {
         for (;;)
@@ -41,7 +41,7 @@ void RenderAll(const DeviceScene &sc, float *frame, LaneCounters *total)
                 break;
             for (uint32_t p = begin; p < std::min(begin + 64, n); ++p)
             {
-                LaneCounters c{0, 0, 0, 0, 0, 0};
+                LaneCounters c{};
                 const V3 v = render_pixel<C>(sc, p, total ? &c : nullptr);
                 frame[3 * p] = v.x, frame[3 * p + 1] = v.y, frame[3 * p + 2] = v.z;
                 counts[tid].closest_rays += c.closest_rays, counts[tid].shadow_rays += c.shadow_rays;
@@ -85,7 +85,7 @@ int mcpt_emu_render(const char *mcsd_path, float *frame, int variant, uint32_t *
         const DeviceScene sc = flat.HostView();
         if (features_out)
             *features_out = flat.features;
-        LaneCounters total{0, 0, 0, 0, 0, 0};
+        LaneCounters total{};
         LaneCounters *cnt = counters ? &total : nullptr;
         constexpr uint32_t kAll = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
         uint32_t f = flat.features;

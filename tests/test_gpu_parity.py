@@ -171,3 +171,22 @@ def test_errors_are_reported(pkg):
         pkg.capi.Config.builtin("no-such-scene")
     with pytest.raises(pkg.capi.McptError):
         pkg.capi.Renderer(pkg.capi.Config.builtin("cornell-box").set_film(32, 32, 1), device=99)
+
+
+def test_rccl_gather_path_on_one_gpu():
+    """The multi-GPU step (RCCL process group, packed tile buffer, one gather, scatter
+    into the frame) run with a single rank on this box's GPU: the gathered frame must be
+    the plain full-frame draw bit for bit (bench.py exits 3 otherwise)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-gather", "--width", "200", "--height",
+                        "120", "--spp", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert '"force_gather_frame_equals_plain_draw": true' in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, r.stdout[-2000:]
+    line = json.loads(lines[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0

@@ -179,85 +179,60 @@ def test_commit_matches_oracle_tables(name, pkg, oracle, emulator, mcsd_file):
 @pytest.mark.parametrize("name", ["cornell_64_spp8", "rough_conductor_envmap", "conductor_aniso_mixed",
                                   "rough_diffuse_point_disk", "terrain_directional"])
 def test_walk_hierarchy_is_sound(name, pkg, emulator, mcsd_file):
-    """Every primitive is exactly one leaf; leaf boxes are the reference's leaf
-    boxes; interior boxes are the exact unions of their children; the depth bound
-    that sizes the traversal stack holds; ranks enumerate the reference's visiting
-    order."""
+    """Every primitive is exactly one leaf; triangle leaf boxes are the bounds of
+    the vertices (the reference's leaf boxes, triangle.cpp:9-15); interior boxes
+    are the exact unions of their children; the depth that sizes the traversal
+    stack is the real depth and within the bound; ranks enumerate the reference's
+    visiting order (TLAS pre-order, then each instance's BLAS pre-order)."""
     scene = cases(pkg.scenes)[name]
     path = mcsd_file(scene)
     nodes, prims, info = emulator.walk(path)
-    links, geom = emulator.nodes(path)
+    links, _ = emulator.nodes(path)
     refs = nodes[:, :2, 3].copy().view(np.uint32)          # (n, 2): child references
     slot_prim = prims[:, 0, 3].copy().view(np.uint32)
+    slot_inst = prims[:, 1, 3].copy().view(np.uint32)
     slot_rank = prims[:, 2, 3].copy().view(np.uint32)
     n_prims = len(prims)
-    assert sorted(slot_prim) == list(range(n_prims))
-    assert sorted(slot_rank) == list(range(n_prims))
-    # reference leaf box and visiting rank of every primitive, from the reference-topology trees
-    leaf_box, order = {}, []
-    n_tlas = int(np.flatnonzero(links[:, 0] == 0xFFFFFFFF)[0]) + 1 if len(links) else 0
-    # (the TLAS is the first tree: it ends at the first node whose skip link is "end" and
-    #  that is a leaf or whose subtree is complete; simpler: BLAS leaves carry prim ids)
-    for i, (skip, obj) in enumerate(links):
-        if obj != 0xFFFFFFFF:
-            leaf_box.setdefault(("node", i), (geom[i, 1:4], geom[i, 4:7], obj))
+    assert sorted(slot_prim) == list(range(n_prims)) and sorted(slot_rank) == list(range(n_prims))
+    triangle_instances = {i for i, inst in enumerate(scene.instances) if inst.type in
+                          (pkg.mcsd.INST_MESHES, pkg.mcsd.INST_CUBE, pkg.mcsd.INST_RECTANGLE)}
     LEAF = 0x80000000
-    seen, max_depth = set(), 0
+    seen, depths = [], []
 
-    def visit(ref, depth):
-        nonlocal max_depth
-        if ref & LEAF:
-            seen.add(ref & ~LEAF)
-            p = prims[ref & ~LEAF]
-            return None  # box comes from the parent
-        max_depth = max(max_depth, depth + 1)
+    def visit(node, depth):
+        depths.append(depth + 1)
         boxes = []
         for c in range(2):
-            lo, hi = nodes[ref, 2 * c, :3], nodes[ref, 2 * c + 1, :3]
-            child = int(refs[ref, c])
-            if ref == 0 and c == 1:
-                assert (lo > hi).all()                   # the empty child of the top node
+            lo, hi = nodes[node, 2 * c, :3], nodes[node, 2 * c + 1, :3]
+            child = int(refs[node, c])
+            if node == 0 and c == 1:
+                assert (lo > hi).all()                       # the empty child of the top node
                 continue
             if child & LEAF:
-                seen.add(child & ~LEAF)
-                tri = prims[child & ~LEAF][:, :3]
-                boxes.append((lo, hi))
-                if name in ("cornell_64_spp8", "rough_conductor_envmap", "terrain_directional"):
-                    # triangle meshes only: leaf box = bounds of the vertices (triangle.cpp:9-15)
+                slot = child & ~LEAF
+                seen.append(slot)
+                if int(slot_inst[slot]) in triangle_instances:
+                    tri = prims[slot][:, :3]
                     np.testing.assert_array_equal(lo, tri.min(0))
                     np.testing.assert_array_equal(hi, tri.max(0))
             else:
-                sub = visit(child, depth + 1)
-                np.testing.assert_array_equal(lo, sub[0])
-                np.testing.assert_array_equal(hi, sub[1])
-                boxes.append((lo, hi))
-        los, his = np.array([b[0] for b in boxes]), np.array([b[1] for b in boxes])
-        return los.min(0), his.max(0)
+                sub_lo, sub_hi = visit(child, depth + 1)
+                np.testing.assert_array_equal(lo, sub_lo)
+                np.testing.assert_array_equal(hi, sub_hi)
+            boxes.append((lo, hi))
+        return np.min([b[0] for b in boxes], axis=0), np.max([b[1] for b in boxes], axis=0)
 
-    import sys
-    sys.setrecursionlimit(10000)
     visit(0, 0)
-    assert seen == set(range(n_prims))
-    assert max_depth == info["depth"] <= 56
-    # ranks: primitives in the order the reference-topology trees are walked
-    # (TLAS pre-order, BLAS pre-order): rank r belongs to the r-th leaf visited
-    tlas_leaves = []
-    i = 0
-    tlas_end = None
-    # the TLAS occupies the front of the array; its size is the first BLAS root,
-    # which is the smallest index no TLAS node links to... take it from the oracle-checked
-    # layout: a tree's nodes are contiguous and its last node has skip == end.
+    assert sorted(seen) == list(range(n_prims))
+    assert max(depths) == info["depth"] <= 56
+    # a tree's nodes are contiguous and only its last node is a leaf whose skip link is "end"
     tree_end = [k + 1 for k in range(len(links)) if links[k, 0] == 0xFFFFFFFF and links[k, 1] != 0xFFFFFFFF]
-    n_tlas = tree_end[0] if len(tree_end) > 1 else 0
-    if n_tlas:
-        inst_order = [int(obj) for skip, obj in links[:n_tlas] if obj != 0xFFFFFFFF]
-        starts = [n_tlas] + tree_end[1:-1]
-        per_inst = []
-        for a, b in zip(starts, tree_end[1:]):
-            per_inst.append([int(obj) for skip, obj in links[a:b] if obj != 0xFFFFFFFF])
-        want = [p for inst in inst_order for p in per_inst[inst]]
-        got = [int(p) for p in slot_prim[np.argsort(slot_rank)]]
-        assert got == want
+    n_tlas = tree_end[0]
+    inst_order = [int(obj) for _, obj in links[:n_tlas] if obj != 0xFFFFFFFF]
+    per_inst = [[int(obj) for _, obj in links[a:b] if obj != 0xFFFFFFFF] for a, b in zip(tree_end[:-1], tree_end[1:])]
+    assert len(per_inst) == len(scene.instances)
+    want = [p for inst in inst_order for p in per_inst[inst]]
+    assert [int(p) for p in slot_prim[np.argsort(slot_rank)]] == want
 
 
 # ---- kernel-body logic on CPU (bit-exact against reference goldens) ---------

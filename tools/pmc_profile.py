@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Collects hardware counters for the render kernel with rocprofv3, one pass per
+counter group (the groups cannot share a pass), and writes one JSON summary.
+
+    python tools/pmc_profile.py --out gpurun_out/pmc.json [--spp 32] [-- extra bench.py args]
+
+Runs `python bench.py --spp N --steps 1 --warmup 0 --no-cpu-baseline` under
+`rocprofv3 --kernel-trace --pmc <group>` and sums each counter over the dispatches
+whose kernel name contains "render_kernel".  Only --kernel-trace is combined with
+--pmc (see the MI355X guide's profiling section)."""
+import argparse
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+
+GROUPS = [   # SQ has 8 slots per pass, TCC 4 (FETCH_SIZE takes 3, WRITE_SIZE 2), GRBM 2
+    ["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU",
+     "SQ_ACTIVE_INST_ANY", "SQ_INSTS_SALU"],
+    ["SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_BRANCH", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT",
+     "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS"],
+    ["SQ_INSTS_SMEM", "SQ_INSTS_VALU_TRANS_F32", "SQ_INST_CYCLES_VMEM_RD", "SQ_ACTIVE_INST_SCA", "GRBM_GUI_ACTIVE",
+     "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum"],
+    ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum"],
+    ["FETCH_SIZE"],
+    ["WRITE_SIZE"],
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--spp", type=int, default=32)
+    ap.add_argument("--workdir", default="gpurun_out/pmc_passes")
+    ap.add_argument("rest", nargs="*")
+    a = ap.parse_args()
+    env = dict(os.environ, TMPDIR="/tmp")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    counters, kernels, failed = {}, set(), []
+    for gi, group in enumerate(GROUPS):
+        d = os.path.join(a.workdir, f"pass{gi}")
+        os.makedirs(d, exist_ok=True)
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", *group, "--output-format", "csv", "-d", d, "-o", "p", "--",
+               sys.executable, os.path.join(root, "bench.py"), "--spp", str(a.spp), "--steps", "1", "--warmup", "0",
+               "--no-cpu-baseline", *a.rest]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            failed.append({"group": group, "rc": r.returncode, "stderr": r.stderr[-400:]})
+            continue
+        for row in csv.DictReader(open(files[0])):
+            # the plain render kernel only: bench.py also launches the counting
+            # instantiation (second template argument true) for its bookkeeping
+            if "render_kernel" not in row["Kernel_Name"] or ", true, " in row["Kernel_Name"]:
+                continue
+            kernels.add(row["Kernel_Name"][:120])
+            counters[row["Counter_Name"]] = counters.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+    c = counters
+    derived = {}
+    if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_THREAD_CYCLES_VALU"):
+        # thread-cycles / (instruction-cycles * 64 lanes)
+        derived["valu_lane_utilization"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+    if c.get("SQ_WAVE_CYCLES"):
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_LDS",
+                  "SQ_ACTIVE_INST_LDS"):
+            if k in c:
+                derived[k.lower() + "_per_wave_cycle"] = c[k] / c["SQ_WAVE_CYCLES"]
+    if c.get("SQ_INSTS_VALU"):
+        for k in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_BRANCH"):
+            if k in c:
+                derived[k.lower() + "_per_valu"] = c[k] / c["SQ_INSTS_VALU"]
+    if "FETCH_SIZE" in c:
+        derived["hbm_read_bytes_note"] = "FETCH_SIZE/WRITE_SIZE are in KiB; apply the guide's gfx950 correction"
+        derived["fetch_kib"] = c["FETCH_SIZE"]
+        derived["write_kib"] = c.get("WRITE_SIZE")
+    out = {"command": "rocprofv3 --kernel-trace --pmc <group> -- python bench.py --spp %d --steps 1 --warmup 0 "
+                      "--no-cpu-baseline %s (one pass per group)" % (a.spp, " ".join(a.rest)),
+           "kernels": sorted(kernels), "counters": counters, "derived": derived, "failed_groups": failed}
+    os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+    json.dump(out, open(a.out, "w"), indent=1)
+    print(json.dumps({"derived": derived, "failed": [f["group"] for f in failed]}))
+
+
+if __name__ == "__main__":
+    main()
