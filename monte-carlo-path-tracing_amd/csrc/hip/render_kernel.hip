@@ -78,7 +78,7 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t width = static_cast<uint32_t>(sc.camera.width), height = static_cast<uint32_t>(sc.camera.height);
 
-    LaneCounters local{0, 0, 0, 0, 0, 0, 0, 0};
+    LaneCounters local{};
     LaneCounters *cnt = kCount ? &local : nullptr;
 
     PathState st;
@@ -275,6 +275,13 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     constexpr uint32_t kO = kFeatOrderedWalk;
     const uint32_t f = sc.features;
     const bool ordered = !job.reference_walk && !sc.integrator.has_masks;
+#if defined(MCPT_EXPERIMENT_LEAN_ONLY)
+    // developer builds for kernel experiments: only the cornell instantiation (fast to compile)
+    *variant = "diffuse-area+lds (experiment build)";
+    if (counters != nullptr || !ordered || f != 0 || StagedBytes(sc, true) > kLdsGeometryBytes)
+        return hipErrorNotSupported;
+    return Launch<kO, false, true>(sc, job, out, nullptr, stream, n_cus);
+#endif
     if (counters != nullptr)
     {
         *variant = ordered ? "all+count" : "all+count, reference walk";

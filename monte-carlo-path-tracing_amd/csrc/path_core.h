@@ -45,6 +45,8 @@ struct LaneCounters
 {
     uint32_t closest_rays, shadow_rays, node_tests, prim_tests, shaded_hits, samples;
     uint32_t wave_node_steps, wave_prim_steps;
+    // work of the walks of the LAST path_step (model studies on the host build)
+    uint32_t last_closest_nodes, last_closest_prims, last_shadow_nodes, last_shadow_prims;
 };
 
 // Per-lane path state that survives from one step to the next.
@@ -141,6 +143,7 @@ MCPT_HD bool shadow_walk(const DeviceScene &sc, uint32_t *stack, V3 origin, V3 d
     {
         ++cnt->shadow_rays, cnt->node_tests += ts.node_tests, cnt->prim_tests += ts.prim_tests;
         cnt->wave_node_steps += ts.wave_node_steps, cnt->wave_prim_steps += ts.wave_prim_steps;
+        cnt->last_shadow_nodes += ts.node_tests, cnt->last_shadow_prims += ts.prim_tests;
     }
     return hit;
 }
@@ -331,6 +334,8 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
     {
         ++cnt->closest_rays, cnt->node_tests += ts.node_tests, cnt->prim_tests += ts.prim_tests;
         cnt->wave_node_steps += ts.wave_node_steps, cnt->wave_prim_steps += ts.wave_prim_steps;
+        cnt->last_closest_nodes = ts.node_tests, cnt->last_closest_prims = ts.prim_tests;
+        cnt->last_shadow_nodes = cnt->last_shadow_prims = 0;
     }
     Surface surf;
     if (hit_valid)

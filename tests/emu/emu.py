@@ -22,6 +22,8 @@ class Emulator:
                                         ctypes.POINTER(ctypes.c_uint32)]
         lib.mcpt_emu_nodes.restype = ctypes.c_int
         lib.mcpt_emu_nodes.argtypes = [ctypes.c_char_p, _u32p, _f32p, ctypes.c_uint32]
+        lib.mcpt_emu_wave_model.restype = ctypes.c_int
+        lib.mcpt_emu_wave_model.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
         lib.mcpt_emu_walk.restype = ctypes.c_int
         lib.mcpt_emu_walk.argtypes = [ctypes.c_char_p, _f32p, _f32p, ctypes.c_uint32, ctypes.c_uint32, _u32p]
         self.lib = lib
@@ -42,6 +44,16 @@ class Emulator:
 
     ORDERED = 32      # feature bit of the ordered walk in a forced `variant`
     REFERENCE = -2    # `variant`: the launcher's pick, but with the reference-order walk
+
+    def wave_model(self, mcsd_path):
+        """Lock-step 64-lane model of the walks (see emulator.cpp): what a wavefront pays
+        when the shadow walk runs on its own vs paired with the next closest walk."""
+        out = (ctypes.c_double * 6)()
+        if self.lib.mcpt_emu_wave_model(str(mcsd_path).encode(), out) != 0:
+            raise RuntimeError(self.lib.mcpt_emu_last_error().decode())
+        keys = ("lane_node_steps", "wave_node_steps_separate", "wave_node_steps_paired",
+                "lane_prim_tests", "wave_prim_phases_separate", "wave_prim_phases_paired")
+        return dict(zip(keys, out))
 
     def walk(self, mcsd_path, capacity=1 << 21):
         """The ordered-walk hierarchy: (nodes[n, 4, 4] float32 with bit-pattern links,

@@ -10,6 +10,7 @@
 // no CPU rendering path.
 #include <atomic>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -141,6 +142,107 @@ int mcpt_emu_render(const char *mcsd_path, float *frame, int variant, uint32_t *
             counters[0] = total.closest_rays, counters[1] = total.shadow_rays, counters[2] = total.node_tests;
             counters[3] = total.prim_tests, counters[4] = total.shaded_hits, counters[5] = total.samples;
         }
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+// Wavefront model: runs the 64 pixels of each 8x8 tile in lock step, one path_step per
+// lane per round like the GPU kernel, and accumulates what a wavefront pays for the
+// walks under two schedules: "separate" = closest walk then shadow walk, each lasting
+// as long as its slowest lane; "paired" = the shadow walk of a round runs in the same
+// loop as the NEXT round's closest walk (a lane does one after the other), lasting as
+// long as the largest per-lane sum.  out: {lane node steps, separate wave node steps,
+// paired wave node steps, lane prim tests, separate wave prim phases, paired wave prim phases}.
+int mcpt_emu_wave_model(const char *mcsd_path, double *out)
+{
+    try
+    {
+        const FlatScene flat = CommitScene(mcsd::Load(mcsd_path));
+        const DeviceScene sc = flat.HostView();
+        if (flat.integrator.has_masks)
+            throw std::runtime_error("masked scene");
+        using C = Config<kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet | kFeatOrderedWalk>;
+        const uint32_t w = sc.camera.width, h = sc.camera.height;
+        const uint32_t tx = (w + 7) / 8, ty = (h + 7) / 8;
+        std::vector<double> acc(6, 0.0);
+        std::mutex mu;
+        std::atomic<uint32_t> next{0};
+        auto work = [&]()
+        {
+            std::vector<double> a(6, 0.0);
+            for (;;)
+            {
+                const uint32_t tile = next.fetch_add(1);
+                if (tile >= tx * ty)
+                    break;
+                PathState st[64];
+                LaneCounters cnt[64];
+                std::vector<uint32_t> stacks(64 * kWalkDepthMax);
+                bool has[64];
+                for (uint32_t l = 0; l < 64; ++l)
+                {
+                    const uint32_t x = (tile % tx) * 8 + (l & 7), y = (tile / tx) * 8 + (l >> 3);
+                    has[l] = x < w && y < h;
+                    cnt[l] = LaneCounters{};
+                    st[l].stack = &stacks[l * kWalkDepthMax];
+                    if (has[l])
+                        start_pixel(st[l], y * w + x);
+                }
+                uint32_t carry_nodes[64] = {}, carry_prims[64] = {}; // previous round's shadow walk
+                for (;;)
+                {
+                    bool any = false;
+                    uint32_t cn[64] = {}, cp[64] = {}, sn[64] = {}, sp[64] = {};
+                    for (uint32_t l = 0; l < 64; ++l)
+                    {
+                        if (!has[l])
+                            continue;
+                        if (!st[l].alive)
+                        {
+                            if (st[l].sample >= sc.camera.spp)
+                            {
+                                has[l] = false;
+                                continue;
+                            }
+                            start_sample(sc, st[l]);
+                        }
+                        any = true;
+                        path_step<C>(sc, st[l], &cnt[l]);
+                        cn[l] = cnt[l].last_closest_nodes / 2, cp[l] = cnt[l].last_closest_prims;
+                        sn[l] = cnt[l].last_shadow_nodes / 2, sp[l] = cnt[l].last_shadow_prims;
+                    }
+                    uint32_t mcn = 0, mcp = 0, msn = 0, msp = 0, mpn = 0, mpp = 0;
+                    for (uint32_t l = 0; l < 64; ++l)
+                    {
+                        a[0] += cn[l] + sn[l], a[3] += cp[l] + sp[l];
+                        mcn = std::max(mcn, cn[l]), mcp = std::max(mcp, cp[l]);
+                        msn = std::max(msn, sn[l]), msp = std::max(msp, sp[l]);
+                        mpn = std::max(mpn, cn[l] + carry_nodes[l]), mpp = std::max(mpp, cp[l] + carry_prims[l]);
+                        carry_nodes[l] = sn[l], carry_prims[l] = sp[l];
+                    }
+                    a[1] += mcn + msn, a[4] += mcp + msp;
+                    a[2] += mpn, a[5] += mpp;
+                    if (!any)
+                        break;
+                }
+            }
+            std::lock_guard<std::mutex> lock(mu);
+            for (int i = 0; i < 6; ++i)
+                acc[i] += a[i];
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < std::max(1u, std::thread::hardware_concurrency()); ++t)
+            pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool)
+            t.join();
+        for (int i = 0; i < 6; ++i)
+            out[i] = acc[i];
         return 0;
     }
     catch (const std::exception &e)
