@@ -62,7 +62,9 @@ constexpr uint32_t kNoObject = 0xFFFFFFFFu;
 constexpr uint32_t kEndOfTree = 0xFFFFFFFFu;
 constexpr uint32_t kNone = 0xFFFFFFFFu; // reference kInvalidId (defs.hpp:22)
 constexpr uint32_t kWalkLeaf = 0x80000000u; // walk_nodes child reference: primitive slot, not a node
-constexpr uint32_t kWalkDepthMax = 56;      // bound on the ordered-walk tree depth (= stack entries)
+constexpr uint32_t kWalkDone = 0xFFFFFFFFu; // bottom-of-stack sentinel of the ordered walk
+constexpr uint32_t kWalkDepthMax = 56;      // bound on the ordered-walk tree depth
+constexpr uint32_t kWalkStackMax = kWalkDepthMax + 1; // stack entries: one per level + the sentinel
 constexpr int kLutRes = 128;            // kulla_conty.hpp:9
 
 struct Vec3f
@@ -208,7 +210,7 @@ struct IntegratorRec // reference integrator.hpp:31-69 (the scalar part)
     uint32_t id_sun, id_envmap;
     uint32_t n_tlas_nodes, n_nodes, n_instances, n_prims;
     uint32_t n_walk_nodes; // ordered-walk hierarchy (0 = empty scene)
-    uint32_t walk_depth;   // its depth = stack entries a lane needs
+    uint32_t walk_depth;   // stack entries a lane needs: the tree's depth + 1 (sentinel)
     uint32_t has_masks;    // some BSDF carries an opacity map: the walk must keep the reference's order
     uint32_t pad;
 };

@@ -860,7 +860,7 @@ FlatScene CommitScene(const mcsd::Scene &in)
                     if (b.object != kNoObject)
                         rank[prim_base[t.object] + b.object] = counter++;
         std::vector<uint32_t> slot_prim;
-        ig.walk_depth = WalkTreeBuilder(prim_box, fs.walk_nodes, slot_prim).Build();
+        ig.walk_depth = WalkTreeBuilder(prim_box, fs.walk_nodes, slot_prim).Build() + 1; // + sentinel entry
         ig.n_walk_nodes = static_cast<uint32_t>(fs.walk_nodes.size() / 4);
         fs.walk_prims.reserve(3 * slot_prim.size());
         for (const uint32_t prim : slot_prim)

@@ -507,7 +507,7 @@ template <class C>
 MCPT_HD V3 render_pixel(const DeviceScene &sc, uint32_t pixel, LaneCounters *cnt)
 {
     PathState st;
-    uint32_t stack[kWalkDepthMax * kWalkStackStride];
+    uint32_t stack[kWalkStackMax * kWalkStackStride];
     st.stack = stack;
     start_pixel(st, pixel);
     while (!pixel_done(sc, st))

@@ -428,12 +428,14 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
         return false;
     bool found = false;
     uint32_t best_rank = 0;
-    uint32_t depth = 0; // entries on the stack
+    // entry 0 of the stack is a sentinel that reads as "no more work": popping never
+    // has to test for an empty stack
+    stack[0] = kWalkDone;
+    uint32_t depth = 1; // entries on the stack
     uint32_t cur = 0;   // the top node
     for (;;)
     {
         // ---- node steps until the lane holds a primitive or runs out of work ----
-        bool exhausted = false;
         while (!(cur & kWalkLeaf))
         {
             const float4 *n = sc.walk_nodes + 4 * static_cast<size_t>(cur);
@@ -447,29 +449,20 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
             float enter0, enter1;
             const bool hit0 = box_enter(n0, n1, ray, enter0), hit1 = box_enter(n2, n3, ray, enter1);
             const uint32_t ref0 = as_uint(n0.w), ref1 = as_uint(n1.w);
-            if (hit0 && hit1)
-            {
-                const bool first0 = enter0 <= enter1;
-                stack[depth * kWalkStackStride] = first0 ? ref1 : ref0;
-                ++depth;
-                cur = first0 ? ref0 : ref1;
-            }
-            else if (hit0 || hit1)
-            {
-                cur = hit0 ? ref0 : ref1;
-            }
-            else
-            {
-                if (depth == 0)
-                {
-                    exhausted = true;
-                    break;
-                }
-                --depth;
-                cur = stack[depth * kWalkStackStride];
-            }
+            // both hit: continue with the nearer child, postpone the other; one hit: go
+            // there; none: take the most recently postponed reference.  Branch free: the
+            // postponed reference is ALWAYS stored at the top (it only becomes part of the
+            // stack when `both` advances depth) and the entry below the top is ALWAYS
+            // loaded (depth >= 1 here: entry 0 is the sentinel) — two unconditional LDS
+            // accesses cost less than the exec-mask regions of a three-way branch.
+            const bool first0 = enter0 <= enter1, both = hit0 && hit1, none = !(hit0 || hit1);
+            const uint32_t toward = (hit0 && (first0 || !hit1)) ? ref0 : ref1;
+            const uint32_t postponed = stack[(depth - 1) * kWalkStackStride];
+            stack[depth * kWalkStackStride] = first0 ? ref1 : ref0;
+            depth = depth + (both ? 1u : 0u) - (none ? 1u : 0u);
+            cur = none ? postponed : toward;
         }
-        if (exhausted)
+        if (cur == kWalkDone)
             break;
 
         // ---- primitive test ---------------------------------------------------------
@@ -514,8 +507,6 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
             if (kAny)
                 return true;
         }
-        if (depth == 0)
-            break;
         --depth;
         cur = stack[depth * kWalkStackStride];
     }

@@ -182,14 +182,14 @@ int mcpt_emu_wave_model(const char *mcsd_path, double *out)
                     break;
                 PathState st[64];
                 LaneCounters cnt[64];
-                std::vector<uint32_t> stacks(64 * kWalkDepthMax);
+                std::vector<uint32_t> stacks(64 * kWalkStackMax);
                 bool has[64];
                 for (uint32_t l = 0; l < 64; ++l)
                 {
                     const uint32_t x = (tile % tx) * 8 + (l & 7), y = (tile / tx) * 8 + (l >> 3);
                     has[l] = x < w && y < h;
                     cnt[l] = LaneCounters{};
-                    st[l].stack = &stacks[l * kWalkDepthMax];
+                    st[l].stack = &stacks[l * kWalkStackMax];
                     if (has[l])
                         start_pixel(st[l], y * w + x);
                 }
