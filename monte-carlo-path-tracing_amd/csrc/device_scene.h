@@ -212,7 +212,8 @@ struct IntegratorRec // reference integrator.hpp:31-69 (the scalar part)
     uint32_t n_walk_nodes; // ordered-walk hierarchy (0 = empty scene)
     uint32_t walk_depth;   // stack entries a lane needs: the tree's depth + 1 (sentinel)
     uint32_t has_masks;    // some BSDF carries an opacity map: the walk must keep the reference's order
-    uint32_t pad;
+    uint32_t walk_break;   // wavefront scheduling of the ordered walk (traversal.h, walk_ordered_vote): leave
+                           // the node phase when fewer lanes than this are searching; 0 = wait for all
 };
 
 // Feature bits: which parts of the hot path a scene actually exercises.  The
@@ -227,6 +228,8 @@ enum SceneFeature : uint32_t
     // not a property of the scene but of the launch: walk the SAH hierarchy
     // near child first instead of the reference's tree in the reference's order
     kFeatOrderedWalk = 1u << 5,
+    // the ordered walk schedules its phases by wavefront vote (large scenes)
+    kFeatVoteWalk = 1u << 6,
 };
 
 // Device view: raw pointers into HBM + the scalar records.

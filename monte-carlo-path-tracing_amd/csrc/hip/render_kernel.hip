@@ -268,11 +268,13 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
 
 // Picks the leanest instantiation that covers the scene's feature bits.  The
 // ordered walk is the default; opacity masks (or job.reference_walk) select the
-// reference-order walk, which exists only in the full instantiation.
+// reference-order walk, which exists only in the full instantiation.  The two
+// LDS-resident instantiations (tiny scenes) use the plain ordered walk, all others
+// the vote-scheduled one (its threshold comes from the commit: 0 for small scenes).
 hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
                         hipStream_t stream, uint32_t n_cus, const char **variant)
 {
-    constexpr uint32_t kO = kFeatOrderedWalk;
+    constexpr uint32_t kO = kFeatOrderedWalk, kV = kFeatOrderedWalk | kFeatVoteWalk;
     const uint32_t f = sc.features;
     const bool ordered = !job.reference_walk && !sc.integrator.has_masks;
 #if defined(MCPT_EXPERIMENT_LEAN_ONLY)
@@ -285,7 +287,7 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     if (counters != nullptr)
     {
         *variant = ordered ? "all+count" : "all+count, reference walk";
-        return ordered ? Launch<kAll | kO, true>(sc, job, out, counters, stream, n_cus)
+        return ordered ? Launch<kAll | kV, true>(sc, job, out, counters, stream, n_cus)
                        : Launch<kAll, true>(sc, job, out, counters, stream, n_cus);
     }
     if (!ordered)
@@ -298,21 +300,21 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     {
         *variant = lds ? "diffuse-area+lds" : "diffuse-area";
         return lds ? Launch<kO, false, true>(sc, job, out, nullptr, stream, n_cus)
-                   : Launch<kO, false>(sc, job, out, nullptr, stream, n_cus);
+                   : Launch<kV, false>(sc, job, out, nullptr, stream, n_cus);
     }
     if ((f & ~kFeatEmitters) == 0)
     {
         *variant = lds ? "diffuse-emitters+lds" : "diffuse-emitters";
         return lds ? Launch<kFeatEmitters | kO, false, true>(sc, job, out, nullptr, stream, n_cus)
-                   : Launch<kFeatEmitters | kO, false>(sc, job, out, nullptr, stream, n_cus);
+                   : Launch<kFeatEmitters | kV, false>(sc, job, out, nullptr, stream, n_cus);
     }
     if ((f & ~(kFeatEmitters | kFeatTextures | kFeatMicrofacet)) == 0)
     {
         *variant = "surface-materials";
-        return Launch<kFeatEmitters | kFeatTextures | kFeatMicrofacet | kO, false>(sc, job, out, nullptr, stream, n_cus);
+        return Launch<kFeatEmitters | kFeatTextures | kFeatMicrofacet | kV, false>(sc, job, out, nullptr, stream, n_cus);
     }
     *variant = "all";
-    return Launch<kAll | kO, false>(sc, job, out, nullptr, stream, n_cus);
+    return Launch<kAll | kV, false>(sc, job, out, nullptr, stream, n_cus);
 }
 
 } // namespace mcpt

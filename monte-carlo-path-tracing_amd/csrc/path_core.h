@@ -39,6 +39,7 @@ struct Config
     static constexpr bool kTextures = (kFeatures & kFeatTextures) != 0;
     static constexpr bool kMicrofacet = (kFeatures & kFeatMicrofacet) != 0;
     static constexpr bool kOrdered = (kFeatures & kFeatOrderedWalk) != 0; // which ray query runs (traversal.h)
+    static constexpr bool kVote = (kFeatures & kFeatVoteWalk) != 0;       // ... scheduled by wavefront vote
 };
 
 struct LaneCounters
@@ -124,8 +125,13 @@ template <class C, bool kAny>
 MCPT_HD bool trace(const DeviceScene &sc, uint32_t *stack, Ray &r, uint32_t &rng, HitRaw &hit, TraceStats &ts, bool count)
 {
     if (C::kOrdered)
+    {
+        if (C::kVote)
+            return count ? walk_ordered_vote<kAny, C::kAnalytic, true>(sc, stack, r, hit, ts)
+                         : walk_ordered_vote<kAny, C::kAnalytic, false>(sc, stack, r, hit, ts);
         return count ? walk_ordered<kAny, C::kAnalytic, true>(sc, stack, r, hit, ts)
                      : walk_ordered<kAny, C::kAnalytic, false>(sc, stack, r, hit, ts);
+    }
     return count ? walk_scene<kAny, C::kAnalytic, C::kTextures, true>(sc, r, rng, hit, ts)
                  : walk_scene<kAny, C::kAnalytic, C::kTextures, false>(sc, r, rng, hit, ts);
 }

@@ -109,7 +109,9 @@ int mcpt_emu_render(const char *mcsd_path, float *frame, int variant, uint32_t *
             throw std::runtime_error("forced variant does not cover the scene's features");
         if (ordered && flat.integrator.has_masks)
             throw std::runtime_error("the ordered walk cannot be used with opacity masks");
-        constexpr uint32_t kO = kFeatOrderedWalk;
+        // like the launcher: plain ordered walk in the two lean instantiations, vote-scheduled
+        // (a no-op on the one-lane "wavefronts" of the host build) in the others
+        constexpr uint32_t kO = kFeatOrderedWalk, kV = kFeatOrderedWalk | kFeatVoteWalk;
         switch (pick | (ordered ? kO : 0u))
         {
         case 0:
@@ -128,11 +130,11 @@ int mcpt_emu_render(const char *mcsd_path, float *frame, int variant, uint32_t *
             RenderAll<kFeatEmitters | kFeatTextures | kFeatMicrofacet>(sc, frame, cnt);
             break;
         case kFeatEmitters | kFeatTextures | kFeatMicrofacet | kO:
-            RenderAll<kFeatEmitters | kFeatTextures | kFeatMicrofacet | kO>(sc, frame, cnt);
+            RenderAll<kFeatEmitters | kFeatTextures | kFeatMicrofacet | kV>(sc, frame, cnt);
             break;
         default:
             if (ordered)
-                RenderAll<kAll | kO>(sc, frame, cnt);
+                RenderAll<kAll | kV>(sc, frame, cnt);
             else
                 RenderAll<kAll>(sc, frame, cnt);
             break;
@@ -166,7 +168,7 @@ int mcpt_emu_wave_model(const char *mcsd_path, double *out)
         const DeviceScene sc = flat.HostView();
         if (flat.integrator.has_masks)
             throw std::runtime_error("masked scene");
-        using C = Config<kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet | kFeatOrderedWalk>;
+        using C = Config<kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet | kFeatOrderedWalk | kFeatVoteWalk>;
         const uint32_t w = sc.camera.width, h = sc.camera.height;
         const uint32_t tx = (w + 7) / 8, ty = (h + 7) / 8;
         std::vector<double> acc(6, 0.0);
