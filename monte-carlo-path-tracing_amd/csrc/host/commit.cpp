@@ -15,6 +15,7 @@
 #include "commit.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -652,6 +653,9 @@ size_t FlatScene::GeometryBytes() const
 FlatScene CommitScene(const mcsd::Scene &in)
 {
     FlatScene fs;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto seconds_since = [](std::chrono::steady_clock::time_point t)
+    { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); };
 
     // ---- camera (camera.cpp:26-37; fov_y is linear in the angle, quirk Q4) --
     {
@@ -684,6 +688,7 @@ FlatScene CommitScene(const mcsd::Scene &in)
         fs.features |= kFeatVolPath;
 
     // ---- geometry: one BLAS per instance ------------------------------------
+    const auto t_geometry = std::chrono::steady_clock::now();
     const uint32_t n_inst = static_cast<uint32_t>(in.instances.size());
     std::vector<std::vector<TreeNode>> blas(n_inst);
     std::vector<uint32_t> prim_base(n_inst);
@@ -848,8 +853,11 @@ FlatScene CommitScene(const mcsd::Scene &in)
     ig.n_instances = n_inst;
     ig.n_prims = n_prims;
 
+    fs.seconds_lbvh = seconds_since(t_geometry);
+
     // ---- ordered-walk hierarchy over all primitives ---------------------------
     {
+        const auto t_walk = std::chrono::steady_clock::now();
         // rank = position in the reference's visiting order (TLAS pre-order, then the
         // instance's BLAS pre-order): decides between primitives at equal distance
         std::vector<uint32_t> rank(n_prims, 0);
@@ -873,6 +881,7 @@ FlatScene CommitScene(const mcsd::Scene &in)
             fs.walk_prims.push_back(float4{p[1].x, p[1].y, p[1].z, Bits(prim_inst[prim])});
             fs.walk_prims.push_back(float4{p[2].x, p[2].y, p[2].z, Bits(rank[prim])});
         }
+        fs.seconds_walk = seconds_since(t_walk);
     }
 
     // ---- light tables (renderer.cpp:271-304): weights are NOT normalised ----
@@ -1191,6 +1200,7 @@ FlatScene CommitScene(const mcsd::Scene &in)
         fs.walk_nodes.assign(4, float4{0, 0, 0, 0});
     if (fs.walk_prims.empty())
         fs.walk_prims.assign(3, float4{0, 0, 0, 0});
+    fs.seconds_total = seconds_since(t_begin);
     return fs;
 }
 

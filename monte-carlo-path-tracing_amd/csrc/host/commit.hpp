@@ -37,6 +37,10 @@ struct FlatScene
     std::vector<float> env_tables;
     std::vector<float> lut_brdf, lut_albedo;
 
+    // host seconds spent in the commit: baking + reference-topology LBVHs, the
+    // ordered-walk hierarchy, everything
+    double seconds_lbvh = 0, seconds_walk = 0, seconds_total = 0;
+
     // A DeviceScene whose pointers address the host vectors (CPU inspection,
     // tests) — the uploader rewrites them to HBM addresses.
     DeviceScene HostView() const;

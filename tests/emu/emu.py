@@ -60,12 +60,14 @@ class Emulator:
         prims[m, 3, 4], info dict)."""
         nodes = np.zeros((capacity, 4, 4), dtype=np.float32)
         prims = np.zeros((capacity, 3, 4), dtype=np.float32)
-        counts = np.zeros(4, dtype=np.uint32)
+        counts = np.zeros(8, dtype=np.uint32)
         rc = self.lib.mcpt_emu_walk(str(mcsd_path).encode(), nodes.reshape(-1), prims.reshape(-1), capacity, capacity,
                                     counts)
         if rc != 0:
             raise RuntimeError(self.lib.mcpt_emu_last_error().decode() if rc == -1 else "capacity too small")
-        return nodes[:counts[0]], prims[:counts[1]], {"depth": int(counts[2]), "has_masks": bool(counts[3])}
+        return nodes[:counts[0]], prims[:counts[1]], {"depth": int(counts[2]), "has_masks": bool(counts[3]),
+                                                        "commit_ms": {"geometry+lbvh": int(counts[4]), "walk_tree": int(counts[5]),
+                                                                      "total": int(counts[6])}}
 
     def nodes(self, mcsd_path, capacity=1 << 22):
         links = np.zeros((capacity, 2), dtype=np.uint32)

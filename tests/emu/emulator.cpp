@@ -267,6 +267,8 @@ int mcpt_emu_walk(const char *mcsd_path, float *nodes, float *prims, uint32_t no
         const uint32_t n_slots = n_nodes ? flat.integrator.n_prims : 0;
         counts[0] = n_nodes, counts[1] = n_slots, counts[2] = flat.integrator.walk_depth;
         counts[3] = flat.integrator.has_masks;
+        counts[4] = static_cast<uint32_t>(flat.seconds_lbvh * 1e3), counts[5] = static_cast<uint32_t>(flat.seconds_walk * 1e3);
+        counts[6] = static_cast<uint32_t>(flat.seconds_total * 1e3);
         if (n_nodes > node_capacity || n_slots > slot_capacity)
             return -2;
         std::memcpy(nodes, flat.walk_nodes.data(), size_t(n_nodes) * 64);

@@ -850,3 +850,25 @@ def test_cli_renders_like_the_library(pkg, tmp_path):
     got = np.frombuffer(raw[header_end:], "<f4").reshape(48, 48, 3)[::-1]
     frame, _ = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene)).draw()
     np.testing.assert_array_equal(got, frame)
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_SCENES + "/cornell-box/TungstenRender.exr"), reason="reference files not present")
+@pytest.mark.parametrize("scene", ["cornell-box", "volumetric-caustic", "dragon"])
+def test_piz_reader_on_the_reference_renders(pkg, tmp_path, scene):
+    """The PIZ decoder on three more real files: each TungstenRender.exr
+    has a tone-mapped PNG twin; a monotone tone curve preserves ranks, so the decoded
+    channels must be rank-correlated with the PNG's almost perfectly."""
+    from PIL import Image
+    from scipy.stats import spearmanr
+    os.symlink(f"{REF_SCENES}/{scene}/TungstenRender.exr", tmp_path / "t.exr")
+    body = '<texture type="bitmap" id="t"><string name="filename" value="t.exr"/></texture>'
+    t = translate(pkg, tmp_path, scene_xml(body)).textures[0]
+    img = np.asarray(t.data).reshape(t.height, t.width, t.channel)
+    png = np.asarray(Image.open(f"{REF_SCENES}/{scene}/TungstenRender.png").convert("RGB"), dtype=np.float32)
+    assert img.shape[:2] == png.shape[:2] and t.channel == 4
+    assert np.isfinite(img).all() and img[..., :3].min() >= 0 and np.all(img[..., 3] == 1.0)
+    if scene == "cornell-box":
+        assert img[..., 0].max() == 17.0                       # the light's radiance (17, 12, 4)
+    for c in range(3):
+        rho = spearmanr(img[..., c].ravel()[::97], png[..., c].ravel()[::97]).statistic
+        assert rho > 0.98, (scene, c, rho)
