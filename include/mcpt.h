@@ -129,6 +129,16 @@ int mcpt_renderer_info(const mcpt_renderer *r, uint64_t info[9]);
  * during the walk). */
 int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order);
 
+/* The reference-topology LBVH (reference src/rtcore/accel/bvh_builder.cpp:74-207) of n
+ * boxes (6 floats each: lo.xyz, hi.xyz) with areas, built by the host builder
+ * (on_device == 0, no GPU needed) or by the HIP builder.
+ * Output, 2n-1 nodes in pre-order: links[2k] = skip, links[2k+1] = object (box index
+ * or 0xFFFFFFFF), geom[7k] = area, geom[7k+1..3] = lo, geom[7k+4..6] = hi.
+ * seconds (may be NULL): build time; for the device builder it includes the copies
+ * to and from the GPU. */
+int mcpt_debug_lbvh_build(uint32_t n, const float *boxes, const float *areas, int on_device, uint32_t *links,
+                          float *geom, double *seconds);
+
 /* Unit-level GPU queries for diagnostics and parity tests (host pointers in and
  * out; no reference counterpart — the reference has no tests).
  *   intersect: rays = origin[3] dir[3] per query; out = 19 floats per query:

@@ -89,6 +89,7 @@ def lib():
     L.mcpt_renderer_table.argtypes = [vp, cp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
     L.mcpt_renderer_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.mcpt_renderer_set_walk.argtypes = [vp, ctypes.c_int]
+    L.mcpt_debug_lbvh_build.argtypes = [u32, vp, vp, i32, vp, vp, ctypes.POINTER(ctypes.c_double)]
     L.mcpt_debug_intersect.argtypes = [vp, u32, vp, vp, vp, vp]
     L.mcpt_debug_bsdf.argtypes = [vp, u32, i32, u32, vp, vp, vp, vp]
     L.mcpt_renderer_destroy.argtypes = [vp]
@@ -110,9 +111,24 @@ EXPORTED_SYMBOLS = [
     "mcpt_renderer_draw", "mcpt_renderer_draw_device", "mcpt_renderer_draw_counted",
     "mcpt_renderer_tile_count", "mcpt_tile_range_size", "mcpt_unpack_tiles",
     "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_set_walk", "mcpt_renderer_destroy",
-    "mcpt_debug_intersect", "mcpt_debug_bsdf",
+    "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
 ]
+
+
+def lbvh_build(boxes, areas, on_device=False):
+    """Reference-topology LBVH of boxes[n, 6] / areas[n] by the host builder or the HIP
+    builder: (links[2n-1, 2] uint32 = (skip, object), geom[2n-1, 7] = (area, lo, hi), seconds)."""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32).reshape(-1, 6)
+    areas = np.ascontiguousarray(areas, dtype=np.float32)
+    n = len(boxes)
+    n_nodes = max(2 * n - 1, 0)
+    links = np.zeros((max(n_nodes, 1), 2), dtype=np.uint32)
+    geom = np.zeros((max(n_nodes, 1), 7), dtype=np.float32)
+    sec = ctypes.c_double()
+    _check(lib().mcpt_debug_lbvh_build(n, boxes.ctypes.data, areas.ctypes.data, 1 if on_device else 0,
+                                       links.ctypes.data, geom.ctypes.data, ctypes.byref(sec)))
+    return links[:n_nodes], geom[:n_nodes], sec.value
 
 
 class Config:

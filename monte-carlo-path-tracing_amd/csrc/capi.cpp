@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include "hip/lbvh_build.h"
 #include "hip/render_kernel.h"
 #include "host/commit.hpp"
 #include "host/frontend.hpp"
@@ -69,6 +70,27 @@ public:
 private:
     void *ptr_ = nullptr;
     size_t bytes_ = 0;
+};
+
+// The HIP LBVH builder behind the host commit's accelerator hook.
+struct DeviceLbvh : mcpt::LbvhAccelerator
+{
+    void Build(uint32_t n, const float *boxes, const float *areas, std::vector<float4> &nodes,
+               std::vector<float> &node_area) override
+    {
+        const size_t n_nodes = 2 * size_t(n) - 1;
+        DeviceArray d_boxes, d_areas, d_nodes, d_area;
+        const float *boxes_dev = d_boxes.Upload(std::vector<float>(boxes, boxes + 6 * size_t(n)), "upload boxes");
+        const float *areas_dev = d_areas.Upload(std::vector<float>(areas, areas + n), "upload areas");
+        nodes.assign(2 * n_nodes, float4{0, 0, 0, 0});
+        node_area.assign(n_nodes, 0.0f);
+        float4 *nodes_dev = const_cast<float4 *>(d_nodes.Upload(nodes, "allocate nodes"));
+        float *area_dev = const_cast<float *>(d_area.Upload(node_area, "allocate node areas"));
+        Check(mcpt::BuildLbvhOnDevice(n, boxes_dev, areas_dev, nodes_dev, area_dev, nullptr), "device LBVH build");
+        Check(hipMemcpy(nodes.data(), nodes_dev, nodes.size() * sizeof(float4), hipMemcpyDeviceToHost), "download nodes");
+        Check(hipMemcpy(node_area.data(), area_dev, node_area.size() * sizeof(float), hipMemcpyDeviceToHost),
+              "download node areas");
+    }
 };
 
 } // namespace
@@ -341,7 +363,8 @@ int mcpt_renderer_create(const mcpt_config *cfg, int device, mcpt_renderer **out
         hipDeviceProp_t prop;
         Check(hipGetDeviceProperties(&prop, device), "query device");
         r->n_cus = static_cast<uint32_t>(prop.multiProcessorCount);
-        r->flat = mcpt::CommitScene(cfg->scene);
+        DeviceLbvh device_lbvh; // large meshes: reference-topology LBVH on the GPU (bit-identical)
+        r->flat = mcpt::CommitScene(cfg->scene, &device_lbvh);
         const mcpt::FlatScene &f = r->flat;
         mcpt::DeviceScene &d = r->dev;
         d.camera = f.camera, d.integrator = f.integrator, d.features = f.features;
@@ -466,6 +489,49 @@ int mcpt_renderer_table(const mcpt_renderer *r, const char *what, const void **d
     if (w == "env_tables")
         return set(f.env_tables.data(), f.env_tables.size());
     return Fail("unknown table '" + w + "'");
+}
+
+int mcpt_debug_lbvh_build(uint32_t n, const float *boxes, const float *areas, int on_device, uint32_t *links,
+                          float *geom, double *seconds)
+{
+    if (!boxes || !areas || !links || !geom)
+        return Fail("null argument");
+    try
+    {
+        std::vector<float4> nodes;
+        std::vector<float> node_area;
+        const auto t0 = std::chrono::steady_clock::now();
+        double elapsed = 0;
+        if (!on_device)
+        {
+            mcpt::BuildReferenceLbvh(n, boxes, areas, nodes, node_area);
+            elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+        else if (n)
+        {
+            int n_devices = 0;
+            if (hipGetDeviceCount(&n_devices) != hipSuccess || n_devices == 0)
+                throw std::runtime_error("no HIP device available.");
+            // (the timing includes the copies here; the kernels alone are timed by rocprofv3)
+            const auto t1 = std::chrono::steady_clock::now();
+            DeviceLbvh().Build(n, boxes, areas, nodes, node_area);
+            elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        }
+        for (size_t k = 0; k < node_area.size(); ++k)
+        {
+            std::memcpy(&links[2 * k], &nodes[2 * k].w, 4), std::memcpy(&links[2 * k + 1], &nodes[2 * k + 1].w, 4);
+            geom[7 * k] = node_area[k];
+            geom[7 * k + 1] = nodes[2 * k].x, geom[7 * k + 2] = nodes[2 * k].y, geom[7 * k + 3] = nodes[2 * k].z;
+            geom[7 * k + 4] = nodes[2 * k + 1].x, geom[7 * k + 5] = nodes[2 * k + 1].y, geom[7 * k + 6] = nodes[2 * k + 1].z;
+        }
+        if (seconds)
+            *seconds = elapsed;
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(e.what());
+    }
 }
 
 int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order)

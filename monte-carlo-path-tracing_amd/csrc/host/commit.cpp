@@ -650,7 +650,27 @@ size_t FlatScene::GeometryBytes() const
            tri_pos.size() * sizeof(float4) + tri_attr.size() * sizeof(float4);
 }
 
-FlatScene CommitScene(const mcsd::Scene &in)
+void BuildReferenceLbvh(uint32_t n, const float *boxes, const float *areas, std::vector<float4> &nodes,
+                        std::vector<float> &node_area)
+{
+    std::vector<Bounds> b(n);
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        b[i].lo = V3{boxes[6 * i], boxes[6 * i + 1], boxes[6 * i + 2]};
+        b[i].hi = V3{boxes[6 * i + 3], boxes[6 * i + 4], boxes[6 * i + 5]};
+    }
+    const std::vector<float> a(areas, areas + n);
+    const LinearBvh tree(b, a);
+    nodes.clear(), node_area.clear();
+    for (const TreeNode &t : tree.nodes_)
+    {
+        nodes.push_back(Pack(t.box.lo, Bits(t.skip)));
+        nodes.push_back(Pack(t.box.hi, Bits(t.object)));
+        node_area.push_back(t.area);
+    }
+}
+
+FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
 {
     FlatScene fs;
     const auto t_begin = std::chrono::steady_clock::now();
@@ -807,7 +827,32 @@ FlatScene CommitScene(const mcsd::Scene &in)
         default:
             throw std::runtime_error("unknow instance type.");
         }
-        blas[i] = std::move(LinearBvh(boxes, areas).nodes_);
+        if (lbvh && boxes.size() >= lbvh->min_prims)
+        {
+            std::vector<float> flat_boxes(6 * boxes.size());
+            for (size_t k = 0; k < boxes.size(); ++k)
+            {
+                float *b = &flat_boxes[6 * k];
+                b[0] = boxes[k].lo.x, b[1] = boxes[k].lo.y, b[2] = boxes[k].lo.z;
+                b[3] = boxes[k].hi.x, b[4] = boxes[k].hi.y, b[5] = boxes[k].hi.z;
+            }
+            std::vector<float4> tree_nodes;
+            std::vector<float> tree_area;
+            lbvh->Build(static_cast<uint32_t>(boxes.size()), flat_boxes.data(), areas.data(), tree_nodes, tree_area);
+            blas[i].resize(tree_area.size());
+            for (size_t k = 0; k < tree_area.size(); ++k)
+            {
+                TreeNode &t = blas[i][k];
+                const float4 a = tree_nodes[2 * k], b = tree_nodes[2 * k + 1];
+                t.box.lo = V3{a.x, a.y, a.z}, t.box.hi = V3{b.x, b.y, b.z};
+                t.area = tree_area[k];
+                std::memcpy(&t.skip, &a.w, 4), std::memcpy(&t.object, &b.w, 4);
+            }
+        }
+        else
+        {
+            blas[i] = std::move(LinearBvh(boxes, areas).nodes_);
+        }
         prim_box.insert(prim_box.end(), boxes.begin(), boxes.end());
         prim_inst.insert(prim_inst.end(), boxes.size(), i);
         rec.prim_base = prim_base[i];

@@ -47,8 +47,26 @@ struct FlatScene
     size_t GeometryBytes() const;
 };
 
+// Optional accelerator for the reference-topology LBVH of large instances: same
+// contract as BuildReferenceLbvh (bit-identical output), e.g. the HIP builder of
+// hip/lbvh_build.hip.  Instances with fewer than `min_prims` primitives are built on
+// the host.
+struct LbvhAccelerator
+{
+    virtual ~LbvhAccelerator() = default;
+    uint32_t min_prims = 1u << 16;
+    virtual void Build(uint32_t n, const float *boxes, const float *areas, std::vector<float4> &nodes,
+                       std::vector<float> &node_area) = 0;
+};
+
 // Throws std::runtime_error with the reference's wording on invalid input.
-FlatScene CommitScene(const mcsd::Scene &scene);
+FlatScene CommitScene(const mcsd::Scene &scene, LbvhAccelerator *lbvh = nullptr);
+
+// The reference-topology LBVH of one set of boxes (bvh_builder.cpp:74-207) in the
+// layout of device_scene.h: 2 float4 + 1 area per node, 2n-1 nodes, tree-local
+// links, object = box index.  boxes: 6 floats each (lo.xyz, hi.xyz).
+void BuildReferenceLbvh(uint32_t n, const float *boxes, const float *areas, std::vector<float4> &nodes,
+                        std::vector<float> &node_area);
 
 // The 128x128 + 128 Kulla-Conty tables (reference kulla_conty.cpp:62-80),
 // computed once per process (multi-threaded, ~0.5 s) and cached.

@@ -123,6 +123,32 @@ def test_ordered_walk_equals_reference_walk(name, pkg, scenes):
     assert np.array_equal(ordered, reference), np.abs(ordered - reference).max()
 
 
+def test_large_mesh_uses_the_device_lbvh_and_matches(pkg, oracle, mcsd_file):
+    """A mesh above the device-builder threshold (73 728 triangles >= 65 536): the
+    renderer's reference-topology tables, built by the HIP LBVH builder, equal the host
+    builder's word for word; the frame matches the oracle; both walks agree bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    import emu
+    scene = pkg.scenes.terrain_scene(192, 96, 64, 4)
+    path = mcsd_file(scene)
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
+    assert r.info()["primitives"] >= 65536
+    host_links, host_geom = emu.Emulator().nodes(path)
+    nodes = r.table("nodes").reshape(-1, 8)
+    assert np.array_equal(nodes[:, 3].copy().view(np.uint32), host_links[:, 0])
+    assert np.array_equal(nodes[:, 7].copy().view(np.uint32), host_links[:, 1])
+    assert np.array_equal(nodes[:, [0, 1, 2, 4, 5, 6]].view(np.uint32), host_geom[:, 1:].view(np.uint32))
+    assert np.array_equal(r.table("node_area").view(np.uint32), host_geom[:, 0].copy().view(np.uint32))
+    frame, _ = r.draw()
+    r.set_walk(True)
+    reference_order, _ = r.draw()
+    r.close()
+    assert np.array_equal(frame, reference_order)
+    want, _ = oracle.render(path)
+    assert_parity(frame, want, "terrain 73k triangles", spp=4)
+
+
 def test_deterministic(pkg):
     scene = pkg.scenes.cornell_box(64, 64, 8)
     a, _ = gpu_render(pkg, scene)

@@ -124,3 +124,30 @@ def test_bsdf_records(material, pkg, oracle, mcsd_file):
             print("first mismatch", recs[i], seeds[i], "\n", got[i], "\n", want[i])
         assert bad.mean() < 0.002, bad.mean()
     r.close()
+
+
+@pytest.mark.parametrize("n, kind", [(1, "random"), (2, "random"), (3, "random"), (37, "planar"), (1000, "duplicates"),
+                                     (4000, "clustered"), (65537, "random"), (300000, "random")])
+def test_device_lbvh_builder_is_bit_identical(n, kind, pkg):
+    """the HIP builder (Morton keys, radix sort, Karras topology,
+    pre-order emission, bottom-up fit) produces the host builder's arrays word for
+    word — links, boxes and areas."""
+    from test_host import _lbvh_inputs
+    boxes, areas = _lbvh_inputs(n, 100 + n, kind)
+    h_links, h_geom, h_sec = pkg.capi.lbvh_build(boxes, areas, on_device=False)
+    d_links, d_geom, d_sec = pkg.capi.lbvh_build(boxes, areas, on_device=True)
+    print(f"n={n} {kind}: host {h_sec * 1e3:.2f} ms, device {d_sec * 1e3:.2f} ms")
+    assert np.array_equal(h_links, d_links)
+    assert np.array_equal(h_geom.view(np.uint32), d_geom.view(np.uint32))
+
+
+def test_device_lbvh_builder_on_a_mesh(pkg):
+    """Boxes of a real triangle set (flat, thin, shared edges): 131k terrain triangles."""
+    mesh = pkg.scenes.bumpy_terrain_mesh(n=256)
+    tri = mesh["positions"][mesh["indices"].reshape(-1, 3)]
+    boxes = np.concatenate([tri.min(1), tri.max(1)], 1).astype(np.float32)
+    areas = np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1).astype(np.float32)
+    h_links, h_geom, h_sec = pkg.capi.lbvh_build(boxes, areas, on_device=False)
+    d_links, d_geom, d_sec = pkg.capi.lbvh_build(boxes, areas, on_device=True)
+    print(f"terrain {len(boxes)} triangles: host {h_sec * 1e3:.1f} ms, device {d_sec * 1e3:.2f} ms")
+    assert np.array_equal(h_links, d_links) and np.array_equal(h_geom.view(np.uint32), d_geom.view(np.uint32))

@@ -175,6 +175,44 @@ def test_commit_matches_oracle_tables(name, pkg, oracle, emulator, mcsd_file):
     assert base == len(o_links)
 
 
+def _lbvh_inputs(n, seed, kind):
+    rng = np.random.default_rng(seed)
+    lo = (rng.random((n, 3)) * 4 - 2).astype(np.float32)
+    hi = lo + (rng.random((n, 3)) * 0.5).astype(np.float32)
+    if kind == "planar":
+        hi[:, 2] = lo[:, 2] = 1.0                       # zero extent -> NaN Morton input
+    elif kind == "duplicates":
+        lo[n // 2:] = lo[:n - n // 2]                   # equal Morton codes: the index breaks ties
+        hi[n // 2:] = hi[:n - n // 2]
+    elif kind == "clustered":
+        lo = (lo * 0.001).astype(np.float32)            # many primitives per Morton cell
+        hi = (lo + 1e-4).astype(np.float32)
+    return np.concatenate([lo, hi], 1), rng.random(n).astype(np.float32)
+
+
+def _check_against_oracle_tree(links, geom, tree):
+    """(skip, object) + (area, box) of the product's builder against the oracle's
+    child-link tree (same pre-order numbering)."""
+    n = len(tree["leaf"])
+    assert len(links) == n
+    o_links = np.stack([tree["leaf"], tree["left"], tree["right"], tree["object"]], 1)
+    want_skip = _skip_links_from_children(o_links)
+    assert np.array_equal(links[:, 0].astype(np.uint64), want_skip)
+    leaf = tree["leaf"] == 1
+    assert np.array_equal(links[:, 1][leaf], tree["object"][leaf]) and (links[:, 1][~leaf] == 0xFFFFFFFF).all()
+    assert np.array_equal(geom[:, 0], tree["area"]) and np.array_equal(geom[:, 1:], tree["box"])
+
+
+@pytest.mark.parametrize("n, kind", [(1, "random"), (2, "random"), (3, "random"), (37, "planar"), (500, "random"),
+                                     (1000, "duplicates"), (4000, "clustered")])
+def test_host_lbvh_builder_matches_oracle(n, kind, pkg, lib, oracle):
+    """mcpt_debug_lbvh_build with the host builder (no GPU needed) == the oracle's
+    restatement of bvh_builder.cpp, which is pinned to the compiled reference."""
+    boxes, areas = _lbvh_inputs(n, 100 + n, kind)
+    links, geom, _ = pkg.capi.lbvh_build(boxes, areas, on_device=False)
+    _check_against_oracle_tree(links, geom, oracle.bvh_build(boxes, areas))
+
+
 # ---- the ordered-walk hierarchy ------------------------------------------------
 @pytest.mark.parametrize("name", ["cornell_64_spp8", "rough_conductor_envmap", "conductor_aniso_mixed",
                                   "rough_diffuse_point_disk", "terrain_directional"])
