@@ -454,3 +454,55 @@ def terrain_scene(n=96, width=96, height=64, spp=4) -> Scene:
     s.emitters.append(Emitter(type=mcsd.EMIT_DIRECTIONAL, direction=tuple(float(f32(x)) for x in d),
                               radiance=(10, 10, 10)))
     return s
+
+
+def blob_mesh(n_lat=128, n_lon=256, radius=1.0, center=(0, 0, 0), bumps=0.18, seed=1):
+    """A lumpy closed surface: a latitude/longitude sphere displaced along its normals
+    by a few spherical waves (vectorised: these go up to hundreds of thousands of
+    triangles).  No normals / uv: the flat-shaded path, like the dragon OBJ files."""
+    rng = np.random.default_rng(seed)
+    theta = np.pi * np.arange(n_lat + 1)[:, None] / n_lat
+    phi = 2 * np.pi * np.arange(n_lon + 1)[None, :] / n_lon
+    d = np.stack([np.sin(theta) * np.cos(phi), np.cos(theta) * np.ones_like(phi), np.sin(theta) * np.sin(phi)], -1)
+    r = np.ones(d.shape[:2])
+    for _ in range(6):
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        freq, phase = rng.integers(3, 14), rng.random() * 6.28
+        r += bumps / 6 * np.sin(freq * np.arccos(np.clip(d @ axis, -1, 1)) + phase) * (1 + rng.random())
+    pos = (np.asarray(center) + radius * r[..., None] * d).reshape(-1, 3).astype(np.float32)
+    i, j = np.meshgrid(np.arange(n_lat), np.arange(n_lon), indexing="ij")
+    a = (i * (n_lon + 1) + j).ravel()
+    b = a + n_lon + 1
+    upper = np.stack([a, a + 1, b], 1)[i.ravel() != 0]
+    lower = np.stack([a + 1, b + 1, b], 1)[i.ravel() != n_lat - 1]
+    return dict(positions=pos, normals=None, texcoords=None,
+                indices=np.concatenate([upper, lower]).astype(np.uint32))
+
+
+def blob_field_scene(n_blobs=12, n_lat=128, n_lon=256, width=1280, height=720, spp=256) -> Scene:
+    """Stand-in for BASELINE config 3 (dragon/scene.xml, whose large OBJ files are not
+    shipped with the reference): the same integrator settings (path, max depth 17),
+    diffuse materials and directional light (direction 0.1886 -0.6923 -0.6965,
+    irradiance 10) over a ground mesh and `n_blobs` lumpy closed meshes of
+    2*n_lat*n_lon - 2*n_lon triangles each (12 x 65 024 + ground = 0.8 M triangles by
+    default): deep, overlapping geometry with high depth complexity."""
+    b = _Builder()
+    s = b.s
+    s.camera = look_at_camera((0.0, 3.2, 7.5), (0.0, 0.6, 0.0), (0, 1, 0), 35.0, width, height, spp)
+    s.integrator = Integrator(type=mcsd.INTEGRATOR_PATH, depth_max=17, depth_rr=5, pdf_rr=0.95)
+    ground = b.diffuse("ground", (0.456263,) * 3)
+    g = bumpy_terrain_mesh(96, size=14.0, height=0.05)
+    b.shape(mcsd.INST_MESHES, mcsd.IDENTITY.copy(), ground, positions=g["positions"], indices=g["indices"])
+    body = b.diffuse("body", (0.79311,) * 3)
+    rng = np.random.default_rng(42)
+    for k in range(n_blobs):
+        ang = 2 * np.pi * k / max(n_blobs, 1) + 0.3 * rng.random()
+        dist = 0.0 if k == 0 else 1.4 + 1.9 * (k % 3) * 0.5 + 0.4 * rng.random()
+        centre = (dist * np.cos(ang), 0.55 + 0.5 * rng.random(), dist * np.sin(ang))
+        m = blob_mesh(n_lat, n_lon, radius=0.45 + 0.35 * rng.random(), center=centre, seed=100 + k)
+        b.shape(mcsd.INST_MESHES, mcsd.IDENTITY.copy(), body, positions=m["positions"], indices=m["indices"])
+    d = np.array([0.1886, -0.6923, -0.6965])
+    s.emitters.append(Emitter(type=mcsd.EMIT_DIRECTIONAL, direction=tuple(float(f32(x)) for x in d),
+                              radiance=(10, 10, 10)))
+    return s

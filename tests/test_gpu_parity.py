@@ -76,7 +76,8 @@ def test_against_oracle_larger(pkg, oracle, mcsd_file):
     for scene in (pkg.scenes.cornell_box(160, 160, 32),
                   pkg.scenes.volumetric_caustic(160, 90, 32),
                   pkg.scenes.material_preview("rough_conductor", "envmap", "mesh", 128, 128, 16),
-                  pkg.scenes.terrain_scene(96, 160, 96, 8)):
+                  pkg.scenes.terrain_scene(96, 160, 96, 8),
+                  pkg.scenes.blob_field_scene(12, 128, 256, 160, 90, 16)):   # 0.8 M triangles (config 3 stand-in)
         want, _ = oracle.render(mcsd_file(scene))
         frame, _ = gpu_render(pkg, scene)
         assert_parity(frame, want, "oracle", spp=scene.camera.spp)

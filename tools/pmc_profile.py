@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--spp", type=int, default=32)
     ap.add_argument("--workdir", default="gpurun_out/pmc_passes")
+    ap.add_argument("--command", default=None,
+                    help="profile this command instead of bench.py (e.g. 'python tools/render_scene.py standin:blob-field')")
     ap.add_argument("rest", nargs="*")
     a = ap.parse_args()
     env = dict(os.environ, TMPDIR="/tmp")
@@ -42,9 +44,10 @@ def main():
     for gi, group in enumerate(GROUPS):
         d = os.path.join(a.workdir, f"pass{gi}")
         os.makedirs(d, exist_ok=True)
-        cmd = ["rocprofv3", "--kernel-trace", "--pmc", *group, "--output-format", "csv", "-d", d, "-o", "p", "--",
-               sys.executable, os.path.join(root, "bench.py"), "--spp", str(a.spp), "--steps", "1", "--warmup", "0",
-               "--no-cpu-baseline", *a.rest]
+        target = (a.command.split() if a.command else
+                  [sys.executable, os.path.join(root, "bench.py"), "--spp", str(a.spp), "--steps", "1", "--warmup", "0",
+                   "--no-cpu-baseline", *a.rest])
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", *group, "--output-format", "csv", "-d", d, "-o", "p", "--", *target]
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if r.returncode != 0 or not files:
@@ -75,8 +78,10 @@ def main():
         derived["hbm_read_bytes_note"] = "FETCH_SIZE/WRITE_SIZE are in KiB; apply the guide's gfx950 correction"
         derived["fetch_kib"] = c["FETCH_SIZE"]
         derived["write_kib"] = c.get("WRITE_SIZE")
-    out = {"command": "rocprofv3 --kernel-trace --pmc <group> -- python bench.py --spp %d --steps 1 --warmup 0 "
-                      "--no-cpu-baseline %s (one pass per group)" % (a.spp, " ".join(a.rest)),
+    out = {"command": "rocprofv3 --kernel-trace --pmc <group> -- %s (one pass per group; counters summed over "
+                      "the dispatches of the plain render kernel)" %
+                      (a.command or "python bench.py --spp %d --steps 1 --warmup 0 --no-cpu-baseline %s"
+                       % (a.spp, " ".join(a.rest))),
            "kernels": sorted(kernels), "counters": counters, "derived": derived, "failed_groups": failed}
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
     json.dump(out, open(a.out, "w"), indent=1)
