@@ -138,7 +138,6 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
 }
 
 // ---- unit kernels (diagnostics / parity tests): one query per lane ----------
-constexpr uint32_t kAllFeatures = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
 
 // in: origin[3], dir[3] per ray.  out (19 floats per ray): valid, inside,
 // instance, primitive-in-instance, t, uv[2], position, normal, tangent, bitangent.
