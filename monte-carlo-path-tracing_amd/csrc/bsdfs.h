@@ -39,9 +39,13 @@ struct ShadeTables
     const TextureRec *textures;
     const float *texels;
     const float *lut_brdf, *lut_albedo;
+    bool all_constant; // every texture is a constant (compile-time constant in the lean kernels)
 };
 
-MCPT_HD V3 tex(const ShadeTables &T, uint32_t id, V2 uv) { return texture_color(T.textures, T.texels, id, uv); }
+MCPT_HD V3 tex(const ShadeTables &T, uint32_t id, V2 uv)
+{
+    return texture_color(T.textures, T.texels, id, uv, T.all_constant);
+}
 
 // ---- GGX --------------------------------------------------------------------
 MCPT_HD void ggx_sample_aniso(float xi0, float xi1, float au, float av, V3 &h, float &pdf) // microfacet.cpp:21-35

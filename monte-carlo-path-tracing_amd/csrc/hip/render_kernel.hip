@@ -189,7 +189,7 @@ __global__ void bsdf_kernel(const DeviceScene sc, uint32_t n, uint32_t id_bsdf, 
     q.tangent = V3{r[9], r[10], r[11]}, q.bitangent = V3{r[12], r[13], r[14]};
     q.uv = V2{r[15], r[16]}, q.inside = r[17] != 0.0f;
     uint32_t rng = seeds[i];
-    const ShadeTables T = shade_tables(sc);
+    const ShadeTables T = ShadeTables{sc.textures, sc.texels, sc.lut_brdf, sc.lut_albedo, false};
     if (mode == 0)
         bsdf_eval<true>(T, sc.bsdfs[id_bsdf], q);
     else

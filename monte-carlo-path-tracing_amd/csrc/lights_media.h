@@ -28,6 +28,7 @@ struct LightTables
     const TextureRec *textures;
     const float *texels;
     const float *env_tables;
+    bool all_constant; // see ShadeTables
 };
 
 MCPT_HD V3 latlong_lookup(const LightTables &T, uint32_t texture, V3 dir, float &theta, V2 &uv)
@@ -35,7 +36,7 @@ MCPT_HD V3 latlong_lookup(const LightTables &T, uint32_t texture, V3 dir, float 
     float phi;
     to_spherical(dir, theta, phi);
     uv = V2{phi * k1Div2Pi, theta * k1DivPi};
-    return texture_color(T.textures, T.texels, texture, uv);
+    return texture_color(T.textures, T.texels, texture, uv, T.all_constant);
 }
 
 // emitter.cpp:177-204.  xi0/xi1 are always drawn by the caller, also for the
@@ -95,7 +96,7 @@ MCPT_HD V3 emitter_eval_sample(const LightTables &T, const EmitterRec &e, const 
         if (e.texture != kNone)
         {
             const V2 uv = V2{0.5f + 0.5f * d.x / (d.z * e.uv_factor), 0.5f + 0.5f * d.y / (d.z * e.uv_factor)};
-            fall *= texture_color(T.textures, T.texels, e.texture, uv);
+            fall *= texture_color(T.textures, T.texels, e.texture, uv, T.all_constant);
         }
         if (d.z < e.cos_beam)
             fall *= (e.cutoff - acosf(d.z)) * e.transition_rcp;

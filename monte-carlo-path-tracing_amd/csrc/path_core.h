@@ -70,13 +70,15 @@ struct PathState
     uint32_t *stack;     // this lane's traversal stack (ordered walk): entry k at stack[k * kWalkStackStride]
 };
 
+template <class C>
 MCPT_HD ShadeTables shade_tables(const DeviceScene &sc)
 {
-    return ShadeTables{sc.textures, sc.texels, sc.lut_brdf, sc.lut_albedo};
+    return ShadeTables{sc.textures, sc.texels, sc.lut_brdf, sc.lut_albedo, !C::kTextures};
 }
+template <class C>
 MCPT_HD LightTables light_tables(const DeviceScene &sc)
 {
-    return LightTables{sc.textures, sc.texels, sc.env_tables};
+    return LightTables{sc.textures, sc.texels, sc.env_tables, !C::kTextures};
 }
 
 MCPT_HD void start_pixel(PathState &st, uint32_t pixel)
@@ -176,7 +178,7 @@ MCPT_HD BsdfQuery eval_at(const DeviceScene &sc, const Surface &s, uint32_t bsdf
     BsdfQuery q = query_at(s, wo, -wi);
     q.wi = wi;
     if (bsdf != kNone)
-        bsdf_eval<C::kMicrofacet>(shade_tables(sc), sc.bsdfs[bsdf], q);
+        bsdf_eval<C::kMicrofacet>(shade_tables<C>(sc), sc.bsdfs[bsdf], q);
     else
         q.pdf = 1, q.attenuation = V3{1, 1, 1}, q.valid = true;
     return q;
@@ -205,7 +207,7 @@ MCPT_HD V3 connect_lights(const DeviceScene &sc, uint32_t *stack, bool at_medium
                           V3 wo, uint32_t &rng, LaneCounters *cnt)
 {
     V3 L = V3{0, 0, 0};
-    const LightTables LT = light_tables(sc);
+    const LightTables LT = light_tables<C>(sc);
     const uint32_t bsdf = at_medium ? kNone : sc.instances[s.inst].bsdf;
     // medium the connection travels through
     uint32_t conn_medium = kNone;
@@ -311,7 +313,7 @@ MCPT_HD V3 connect_lights(const DeviceScene &sc, uint32_t *stack, bool at_medium
             return L;
         const float pdf_direct = area_light_pdf(sc, light, inst, distance, cos_light),
                     w = power_heuristic(pdf_direct, pdf);
-        const V3 radiance = texture_color(sc.textures, sc.texels, sc.bsdfs[sc.instances[inst].bsdf].tex0, lp.uv);
+        const V3 radiance = texture_color(sc.textures, sc.texels, sc.bsdfs[sc.instances[inst].bsdf].tex0, lp.uv, !C::kTextures);
         if (vol) // volpath.cpp:371-372, 481-482
             L += w * (radiance * tr * att / pdf_direct);
         else // path.cpp:232
@@ -329,7 +331,7 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
 {
     const IntegratorRec &ig = sc.integrator;
     const bool vol = C::kVolPath && ig.volpath != 0;
-    const LightTables LT = light_tables(sc);
+    const LightTables LT = light_tables<C>(sc);
 
     // ---- extend --------------------------------------------------------------
     Ray ray = make_ray(st.origin, st.dir);
@@ -421,7 +423,7 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
             }
             if (b.kind == kBsdfAreaLight)
             {
-                const V3 radiance = texture_color(sc.textures, sc.texels, b.tex0, surf.uv);
+                const V3 radiance = texture_color(sc.textures, sc.texels, b.tex0, surf.uv, !C::kTextures);
                 if (st.primary)
                 {
                     if (!ig.hide_emitters) // path.cpp:47-53
@@ -483,7 +485,7 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
         BsdfQuery q = query_at(surf, st.wo, st.wo); // path.cpp:268-296
         if (bsdf != kNone)
         {
-            bsdf_sample<C::kMicrofacet>(shade_tables(sc), sc.bsdfs[bsdf], st.rng, q);
+            bsdf_sample<C::kMicrofacet>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
         }
         else
         {

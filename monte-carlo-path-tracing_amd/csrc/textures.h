@@ -71,10 +71,15 @@ MCPT_HD V3 checker_color(const TextureRec &t, V2 uv) // checkboard.cpp:6-21
     return (x * y == 1) ? from(t.color0) : from(t.color1);
 }
 
-MCPT_HD V3 texture_color(const TextureRec *textures, const float *texels, uint32_t id, V2 uv) // texture.cpp:63-78
+// `all_constant`: the caller knows (scene feature bits) that every texture of the
+// scene is a constant; passed as a compile-time constant from the kernel
+// instantiations for such scenes so that the checkerboard / bitmap code (with its
+// wrap-around loops) is not compiled into them at every call site.
+MCPT_HD V3 texture_color(const TextureRec *textures, const float *texels, uint32_t id, V2 uv,
+                         bool all_constant = false) // texture.cpp:63-78
 {
     const TextureRec &t = textures[id];
-    if (t.kind == kTexConstant)
+    if (all_constant || t.kind == kTexConstant)
         return from(t.color);
     if (t.kind == kTexChecker)
         return checker_color(t, uv);
