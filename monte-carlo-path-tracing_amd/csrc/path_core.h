@@ -48,6 +48,9 @@ struct LaneCounters
     uint32_t wave_node_steps, wave_prim_steps;
     // work of the walks of the LAST path_step (model studies on the host build)
     uint32_t last_closest_nodes, last_closest_prims, last_shadow_nodes, last_shadow_prims;
+    // ... and the rays themselves (origin, direction, t_max); last_shadow_count of them
+    float last_closest_ray[7], last_shadow_ray[7];
+    uint32_t last_shadow_count;
 };
 
 // Per-lane path state that survives from one step to the next.
@@ -144,6 +147,13 @@ MCPT_HD bool shadow_walk(const DeviceScene &sc, uint32_t *stack, V3 origin, V3 d
 {
     Ray r = make_ray(origin, dir);
     r.t_max = t_max;
+    if (cnt)
+    {
+        const float rec[7] = {origin.x, origin.y, origin.z, dir.x, dir.y, dir.z, t_max};
+        for (int k = 0; k < 7; ++k)
+            cnt->last_shadow_ray[k] = rec[k];
+        ++cnt->last_shadow_count;
+    }
     HitRaw dummy;
     TraceStats ts{0, 0, 0, 0};
     const bool hit = trace<C, true>(sc, stack, r, rng, dummy, ts, cnt != nullptr);
@@ -344,6 +354,10 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
         cnt->wave_node_steps += ts.wave_node_steps, cnt->wave_prim_steps += ts.wave_prim_steps;
         cnt->last_closest_nodes = ts.node_tests, cnt->last_closest_prims = ts.prim_tests;
         cnt->last_shadow_nodes = cnt->last_shadow_prims = 0;
+        const float rec[7] = {st.origin.x, st.origin.y, st.origin.z, st.dir.x, st.dir.y, st.dir.z, kMaxFloat};
+        for (int k = 0; k < 7; ++k)
+            cnt->last_closest_ray[k] = rec[k];
+        cnt->last_shadow_count = 0;
     }
     Surface surf;
     if (hit_valid)

@@ -24,6 +24,8 @@ class Emulator:
         lib.mcpt_emu_nodes.argtypes = [ctypes.c_char_p, _u32p, _f32p, ctypes.c_uint32]
         lib.mcpt_emu_wave_model.restype = ctypes.c_int
         lib.mcpt_emu_wave_model.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
+        lib.mcpt_emu_pool_model.restype = ctypes.c_int
+        lib.mcpt_emu_pool_model.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double)]
         lib.mcpt_emu_walk.restype = ctypes.c_int
         lib.mcpt_emu_walk.argtypes = [ctypes.c_char_p, _f32p, _f32p, ctypes.c_uint32, ctypes.c_uint32, _u32p]
         self.lib = lib
@@ -53,6 +55,15 @@ class Emulator:
             raise RuntimeError(self.lib.mcpt_emu_last_error().decode())
         keys = ("lane_node_steps", "wave_node_steps_separate", "wave_node_steps_paired",
                 "lane_prim_tests", "wave_prim_phases_separate", "wave_prim_phases_paired")
+        return dict(zip(keys, out))
+
+    def pool_model(self, mcsd_path):
+        """Per-lane walk vs a wavefront-shared pool of (ray, node) items (see emulator.cpp)."""
+        out = (ctypes.c_double * 8)()
+        if self.lib.mcpt_emu_pool_model(str(mcsd_path).encode(), out) != 0:
+            raise RuntimeError(self.lib.mcpt_emu_last_error().decode())
+        keys = ("lane_wave_node_steps", "lane_node_visits", "lane_wave_prim_phases", "lane_prim_tests",
+                "pool_node_steps", "pool_node_visits", "pool_prim_steps", "pool_prim_tests")
         return dict(zip(keys, out))
 
     def walk(self, mcsd_path, capacity=1 << 21):

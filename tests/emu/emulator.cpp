@@ -8,6 +8,7 @@
 // container without a GPU.  It is NOT part of libmcpt_hip.so, is never used by
 // the product path, bench.py or smoke(), and is not a fallback: the product has
 // no CPU rendering path.
+#include <array>
 #include <atomic>
 #include <cstring>
 #include <mutex>
@@ -244,6 +245,182 @@ int mcpt_emu_wave_model(const char *mcsd_path, double *out)
         for (std::thread &t : pool)
             t.join();
         for (int i = 0; i < 6; ++i)
+            out[i] = acc[i];
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+// Pooled-traversal model: the rays of one wavefront phase (<= 64) share one LIFO pool of
+// (ray, node) items; every step the top 64 items are processed, one per lane.  Returns
+// steps and visits so that it can be compared with the per-lane walk.
+struct PoolModel
+{
+    double node_steps = 0, node_visits = 0, prim_steps = 0, prim_tests = 0;
+};
+
+void RunPool(const DeviceScene &sc, const std::vector<std::array<float, 7>> &rays, bool any, PoolModel &m)
+{
+    struct Item
+    {
+        uint32_t ray, ref;
+    };
+    const size_t n = rays.size();
+    if (n == 0 || sc.integrator.n_walk_nodes == 0)
+        return;
+    std::vector<Ray> r(n);
+    std::vector<uint64_t> best(n, ~0ull);
+    std::vector<char> done(n, 0);
+    for (size_t i = 0; i < n; ++i)
+    {
+        r[i] = make_ray(V3{rays[i][0], rays[i][1], rays[i][2]}, V3{rays[i][3], rays[i][4], rays[i][5]});
+        r[i].t_max = rays[i][6];
+    }
+    std::vector<Item> nodes, leaves;
+    for (size_t i = 0; i < n; ++i)
+        nodes.push_back(Item{static_cast<uint32_t>(i), 0u});
+    while (!nodes.empty() || !leaves.empty())
+    {
+        // policy: run the primitive phase when a full wavefront of leaves waits or no nodes are left
+        if (leaves.size() >= 64 || nodes.empty())
+        {
+            const size_t take = std::min<size_t>(64, leaves.size());
+            std::vector<Item> batch(leaves.end() - take, leaves.end());
+            leaves.resize(leaves.size() - take);
+            m.prim_steps += 1;
+            for (const Item &it : batch)
+            {
+                if (done[it.ray])
+                    continue;
+                m.prim_tests += 1;
+                const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(it.ref & ~kWalkLeaf);
+                HitRaw cand;
+                Ray &ray = r[it.ray];
+                if (triangle_hit_slot(p, ray, cand) && any)
+                    done[it.ray] = 1;
+            }
+            continue;
+        }
+        const size_t take = std::min<size_t>(64, nodes.size());
+        std::vector<Item> batch(nodes.end() - take, nodes.end());
+        nodes.resize(nodes.size() - take);
+        m.node_steps += 1;
+        // lanes take items from the top downwards; their pushes land in lane order
+        for (size_t l = 0; l < take; ++l)
+        {
+            const Item it = batch[take - 1 - l];
+            if (done[it.ray])
+                continue;
+            m.node_visits += 1;
+            const float4 *q = sc.walk_nodes + 4 * static_cast<size_t>(it.ref);
+            float e0, e1;
+            const bool h0 = box_enter(q[0], q[1], r[it.ray], e0), h1 = box_enter(q[2], q[3], r[it.ray], e1);
+            const uint32_t r0 = as_uint(q[0].w), r1 = as_uint(q[1].w);
+            const bool first0 = e0 <= e1;
+            // far child first, so that the near one is on top
+            const uint32_t order[2] = {first0 ? r1 : r0, first0 ? r0 : r1};
+            const bool hit[2] = {first0 ? h1 : h0, first0 ? h0 : h1};
+            for (int k = 0; k < 2; ++k)
+                if (hit[k])
+                    ((order[k] & kWalkLeaf) ? leaves : nodes).push_back(Item{it.ray, order[k]});
+        }
+    }
+}
+
+// out: per-lane model {node steps (wave), node visits (lane), prim phases, prim tests} followed by the
+// pooled model's {node steps, node visits, prim steps, prim tests}; triangle-only scenes.
+int mcpt_emu_pool_model(const char *mcsd_path, double *out)
+{
+    try
+    {
+        const FlatScene flat = CommitScene(mcsd::Load(mcsd_path));
+        const DeviceScene sc = flat.HostView();
+        if (flat.integrator.has_masks || (flat.features & kFeatAnalytic))
+            throw std::runtime_error("triangle-only scenes without masks");
+        using C = Config<kFeatVolPath | kFeatEmitters | kFeatTextures | kFeatMicrofacet | kFeatOrderedWalk>;
+        const uint32_t w = sc.camera.width, h = sc.camera.height;
+        const uint32_t tx = (w + 7) / 8, ty = (h + 7) / 8;
+        std::vector<double> acc(8, 0.0);
+        std::mutex mu;
+        std::atomic<uint32_t> next{0};
+        auto work = [&]()
+        {
+            std::vector<double> a(8, 0.0);
+            PoolModel pm;
+            for (;;)
+            {
+                const uint32_t tile = next.fetch_add(1);
+                if (tile >= tx * ty)
+                    break;
+                PathState st[64];
+                std::vector<LaneCounters> cnt(64);
+                std::vector<uint32_t> stacks(64 * kWalkStackMax);
+                bool has[64];
+                for (uint32_t l = 0; l < 64; ++l)
+                {
+                    const uint32_t x = (tile % tx) * 8 + (l & 7), y = (tile / tx) * 8 + (l >> 3);
+                    has[l] = x < w && y < h;
+                    cnt[l] = LaneCounters{};
+                    st[l].stack = &stacks[l * kWalkStackMax];
+                    if (has[l])
+                        start_pixel(st[l], y * w + x);
+                }
+                for (;;)
+                {
+                    bool any = false;
+                    std::vector<std::array<float, 7>> closest, shadow;
+                    uint32_t mcn = 0, mcp = 0, msn = 0, msp = 0;
+                    for (uint32_t l = 0; l < 64; ++l)
+                    {
+                        if (!has[l])
+                            continue;
+                        if (!st[l].alive)
+                        {
+                            if (st[l].sample >= sc.camera.spp)
+                            {
+                                has[l] = false;
+                                continue;
+                            }
+                            start_sample(sc, st[l]);
+                        }
+                        any = true;
+                        path_step<C>(sc, st[l], &cnt[l]);
+                        std::array<float, 7> rec;
+                        std::copy(cnt[l].last_closest_ray, cnt[l].last_closest_ray + 7, rec.begin());
+                        closest.push_back(rec);
+                        if (cnt[l].last_shadow_count)
+                        {
+                            std::copy(cnt[l].last_shadow_ray, cnt[l].last_shadow_ray + 7, rec.begin());
+                            shadow.push_back(rec);
+                        }
+                        const uint32_t cn = cnt[l].last_closest_nodes / 2, cp = cnt[l].last_closest_prims;
+                        const uint32_t sn = cnt[l].last_shadow_nodes / 2, sp = cnt[l].last_shadow_prims;
+                        a[1] += cn + sn, a[3] += cp + sp;
+                        mcn = std::max(mcn, cn), mcp = std::max(mcp, cp), msn = std::max(msn, sn), msp = std::max(msp, sp);
+                    }
+                    if (!any)
+                        break;
+                    a[0] += mcn + msn, a[2] += mcp + msp;
+                    RunPool(sc, closest, false, pm);
+                    RunPool(sc, shadow, true, pm);
+                }
+            }
+            a[4] = pm.node_steps, a[5] = pm.node_visits, a[6] = pm.prim_steps, a[7] = pm.prim_tests;
+            std::lock_guard<std::mutex> lock(mu);
+            for (int i = 0; i < 8; ++i)
+                acc[i] += a[i];
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < std::max(1u, std::thread::hardware_concurrency()); ++t)
+            pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool)
+            t.join();
+        for (int i = 0; i < 8; ++i)
             out[i] = acc[i];
         return 0;
     }
