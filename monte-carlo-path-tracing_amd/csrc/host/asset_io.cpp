@@ -541,14 +541,58 @@ ImageData LoadExr(const std::string &path)
 
 } // namespace
 
-ImageData LoadFloatImage(const std::string &path)
+ImageData LoadFloatImage(const std::string &path, float gamma)
 {
     const std::string suffix = SuffixOf(path);
-    if (suffix == "pfm")
-        return LoadPfm(path);
+    auto srgb_to_linear = [](float v) // image_io.cpp:113-118, 137-142
+    { return v <= 0.04045f ? v / 12.92f : static_cast<float>(std::pow((v + 0.055f) / 1.055f, 2.4f)); };
+    ImageData img;
     if (suffix == "exr")
-        return LoadExr(path);
-    throw std::runtime_error("unsupport input image format for image '" + path + "' (supported: .exr, .pfm).");
+    {
+        img = LoadExr(path);
+        if (gamma != 0.0f)
+        {
+            // image_io.cpp:91-96: applied while the channel count still reads 1, i.e. to the
+            // first width*height floats of the RGBA data
+            const size_t n = static_cast<size_t>(img.width) * img.height;
+            for (size_t i = 0; i < n; ++i)
+                img.data[i] = std::pow(img.data[i], gamma);
+        }
+    }
+    else if (suffix == "pfm")
+    {
+        img = LoadPfm(path);
+        if (gamma != 0.0f)
+            for (float &v : img.data)
+                v = std::pow(v, gamma);
+    }
+    else if (suffix == "hdr" || suffix == "pic")
+    {
+        img = LoadRadianceHdr(path);
+        if (gamma == -1.0f)
+            for (float &v : img.data)
+                v = srgb_to_linear(v);
+        else if (gamma != 0.0f)
+            for (float &v : img.data)
+                v = std::pow(v, gamma);
+    }
+    else if (suffix == "png")
+    {
+        std::vector<uint8_t> px;
+        LoadPng8(path, img.width, img.height, img.channel, px);
+        img.data.resize(px.size());
+        for (size_t i = 0; i < px.size(); ++i)
+        {
+            const float v = static_cast<int>(px[i]) / 255.0f;
+            img.data[i] = (gamma == 0.0f || gamma == -1.0f) ? srgb_to_linear(v) : std::pow(v, gamma);
+        }
+    }
+    else
+    {
+        throw std::runtime_error("unsupport input image format for image '" + path +
+                                 "' (supported: .exr, .pfm, .hdr, .png).");
+    }
+    return img;
 }
 
 } // namespace mcpt

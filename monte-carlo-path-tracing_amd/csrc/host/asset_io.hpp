@@ -23,9 +23,23 @@ struct ImageData
     std::vector<float> data; // row 0 = top
 };
 
+// How the reference treats the `gamma` of a bitmap depends on the file type
+// (src/utils/image_io.cpp:75-147).
+enum class ImageKind
+{
+    kExr,  // exponent applied to the first width*height floats only (reference quirk), none when 0
+    kHdr,  // -1: sRGB decode, otherwise exponent, none when 0
+    kLdr,  // 8-bit: 0 or -1: sRGB decode, otherwise exponent
+    kPfm,  // (not read by the reference) exponent, none when 0
+};
+
 MeshData LoadObj(const std::string &path, bool flip_texcoords, bool face_normals);
 MeshData LoadSerialized(const std::string &path, int shape_index);
-ImageData LoadFloatImage(const std::string &path);
+// `gamma` is applied per the file type's rule; the result is what the reference's
+// image_io::Read returns (before its optional down-scaling).
+ImageData LoadFloatImage(const std::string &path, float gamma = 0.0f);
+void LoadPng8(const std::string &path, int &width, int &height, int &channel, std::vector<uint8_t> &pixels);
+ImageData LoadRadianceHdr(const std::string &path);
 
 // One PIZ-compressed EXR block -> raw scanline bytes (exr_piz.cpp).  `words_per_sample`: per
 // channel in file order, 1 for HALF and 2 for FLOAT / UINT.

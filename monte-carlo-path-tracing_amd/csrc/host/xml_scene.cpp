@@ -385,17 +385,7 @@ private:
     }
     uint32_t AddBitmap(const std::string &path, const std::string &id, float gamma, float scale, const int *width_max)
     {
-        ImageData img = LoadFloatImage(path);
-        const size_t dot = path.find_last_of('.');
-        const bool is_exr = dot != std::string::npos && (path.substr(dot + 1) == "exr" || path.substr(dot + 1) == "EXR");
-        if (gamma != 0.0f)
-        {
-            // image_io.cpp:91-96: the reference applies the exponent while its channel
-            // count still reads 1, i.e. to the first width*height floats of the RGBA data
-            const size_t n = is_exr ? static_cast<size_t>(img.width) * img.height : img.data.size();
-            for (size_t i = 0; i < n; ++i)
-                img.data[i] = std::pow(img.data[i], gamma);
-        }
+        ImageData img = LoadFloatImage(path, gamma);
         if (width_max && img.width > *width_max)
             std::fprintf(stderr,
                          "[warning] '%s' is wider than the reference's resize target (%d); it is used at full size.\n",

@@ -872,3 +872,116 @@ def test_piz_reader_on_the_reference_renders(pkg, tmp_path, scene):
     for c in range(3):
         rho = spearmanr(img[..., c].ravel()[::97], png[..., c].ravel()[::97]).statistic
         assert rho > 0.98, (scene, c, rho)
+
+
+# ---------------------------------------------------------------------------
+# 8-bit and Radiance images (reference: stb_image, image_io.cpp:99-147)
+# ---------------------------------------------------------------------------
+def _srgb_to_linear(v):
+    v = v.astype(np.float32)
+    return np.where(v <= np.float32(0.04045), v / np.float32(12.92),
+                    np.power((v + np.float32(0.055)) / np.float32(1.055), np.float32(2.4))).astype(np.float32)
+
+
+@pytest.mark.parametrize("mode", ["L", "RGB", "RGBA", "P", "I;16", "1"])
+def test_png_reader(pkg, tmp_path, mode):
+    """PNG files written by PIL in every colour type the reader handles: the texels are
+    value/255 through the sRGB curve (gamma 0), or value/255 to the given exponent."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    w, h = 23, 17
+    if mode == "L":
+        arr = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        img, want8 = Image.fromarray(arr, "L"), arr[..., None]
+    elif mode == "RGB":
+        arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        img, want8 = Image.fromarray(arr, "RGB"), arr
+    elif mode == "RGBA":
+        arr = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        img, want8 = Image.fromarray(arr, "RGBA"), arr
+    elif mode == "P":
+        arr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        img = Image.fromarray(arr, "RGB").quantize(16)
+        want8 = np.asarray(img.convert("RGB"))
+    elif mode == "I;16":
+        arr = rng.integers(0, 65536, (h, w), dtype=np.uint16)
+        img, want8 = Image.fromarray(arr), (arr >> 8).astype(np.uint8)[..., None]
+    else:
+        arr = rng.integers(0, 2, (h, w), dtype=np.uint8) * 255
+        img, want8 = Image.fromarray(arr, "L").convert("1"), arr[..., None]
+    (tmp_path / "tex").mkdir()
+    img.save(tmp_path / "tex" / "a.png")
+    body = """<texture type="bitmap" id="a"><string name="filename" value="tex/a.png"/></texture>
+              <texture type="bitmap" id="b"><string name="filename" value="tex/a.png"/><float name="gamma" value="2.2"/></texture>"""
+    s = translate(pkg, tmp_path, scene_xml(body))
+    a, b = s.textures
+    assert (a.width, a.height, a.channel) == (w, h, want8.shape[2])
+    unit = want8.astype(np.int32) / np.float32(255.0)
+    np.testing.assert_allclose(np.asarray(a.data).reshape(want8.shape), _srgb_to_linear(unit), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(np.asarray(b.data).reshape(want8.shape), np.power(unit.astype(np.float32), np.float32(2.2)),
+                               rtol=2e-6, atol=1e-7)
+
+
+def _rgbe(img):
+    m = img.max(axis=2)
+    e = np.where(m > 1e-32, np.floor(np.log2(np.maximum(m, 1e-38))) + 1, 0)
+    scale = np.where(m > 1e-32, 256.0 / np.exp2(e), 0)
+    rgb = np.clip(img * scale[..., None], 0, 255).astype(np.uint8)
+    return np.concatenate([rgb, np.where(m > 1e-32, e + 128, 0).astype(np.uint8)[..., None]], axis=2)
+
+
+def _hdr_bytes(rgbe, rle):
+    h, w, _ = rgbe.shape
+    out = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n" + f"-Y {h} +X {w}\n".encode()
+    for y in range(h):
+        if not rle:
+            out += rgbe[y].tobytes()
+            continue
+        out += bytes([2, 2, w >> 8, w & 255])
+        for c in range(4):
+            row, x = rgbe[y, :, c], 0
+            while x < w:
+                run = 1
+                while x + run < w and run < 127 and row[x + run] == row[x]:
+                    run += 1
+                if run >= 3:
+                    out += bytes([128 + run, row[x]])
+                    x += run
+                else:
+                    n = min(w - x, 100)
+                    out += bytes([n]) + row[x:x + n].tobytes()
+                    x += n
+    return out
+
+
+@pytest.mark.parametrize("rle", [False, True])
+def test_radiance_hdr_reader(pkg, tmp_path, rle):
+    rng = np.random.default_rng(8)
+    img = (rng.random((13, 40, 3)) ** 3 * 50).astype(np.float32)
+    img[2, 3:30] = 0.25                               # a long run for the run-length coder
+    img[5, 5] = 0
+    rgbe = _rgbe(img)
+    files = {"sky.hdr": _hdr_bytes(rgbe, rle)}
+    body = """<emitter type="envmap"><string name="filename" value="sky.hdr"/></emitter>"""
+    s = translate(pkg, tmp_path, scene_xml(body), files=files)
+    t = s.textures[0]
+    assert (t.width, t.height, t.channel) == (40, 13, 3)
+    want = rgbe[..., :3].astype(np.float32) * np.exp2(rgbe[..., 3:].astype(np.float32) - 136)
+    want[rgbe[..., 3] == 0] = 0
+    np.testing.assert_array_equal(np.asarray(t.data).reshape(13, 40, 3), want.astype(np.float32))
+    # (and the test's own encoder is sane: RGBE keeps 8 bits relative to the largest channel)
+    assert (np.abs(want - img) <= img.max(axis=2, keepdims=True) / 128 + 1e-6).all()
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_SCENES + "/lte-orb/textures/Checker.png"), reason="reference files not present")
+def test_png_reader_on_a_reference_texture(pkg, tmp_path):
+    """The lte-orb scenes' Checker.png (their OBJ meshes are not shipped, so the scenes
+    themselves cannot be loaded): same texels as PIL decodes."""
+    from PIL import Image
+    os.symlink(f"{REF_SCENES}/lte-orb/textures/Checker.png", tmp_path / "c.png")
+    body = '<texture type="bitmap" id="t"><string name="filename" value="c.png"/><float name="gamma" value="1"/></texture>'
+    t = translate(pkg, tmp_path, scene_xml(body)).textures[0]
+    ref = np.asarray(Image.open(f"{REF_SCENES}/lte-orb/textures/Checker.png"))
+    ref = ref[..., None] if ref.ndim == 2 else ref
+    assert (t.height, t.width, t.channel) == ref.shape
+    np.testing.assert_array_equal(np.asarray(t.data).reshape(ref.shape), ref.astype(np.int32) / np.float32(255.0))
