@@ -984,4 +984,4 @@ def test_png_reader_on_a_reference_texture(pkg, tmp_path):
     ref = np.asarray(Image.open(f"{REF_SCENES}/lte-orb/textures/Checker.png"))
     ref = ref[..., None] if ref.ndim == 2 else ref
     assert (t.height, t.width, t.channel) == ref.shape
-    np.testing.assert_array_equal(np.asarray(t.data).reshape(ref.shape), ref.astype(np.int32) / np.float32(255.0))
+    np.testing.assert_array_equal(np.asarray(t.data).reshape(ref.shape), ref.astype(np.float32) / np.float32(255.0))
