@@ -223,10 +223,16 @@ public:
         slot_prim_.clear();
         if (order_.empty())
             return 0;
-        nodes_.resize(4); // top node
+        // A subtree over k primitives has k - 1 interior nodes and k leaf slots, so node
+        // ids (pre-order) and slots are known before a subtree is built: the arrays are
+        // sized up front and large subtrees are built by separate threads in place.
+        const uint32_t n = static_cast<uint32_t>(order_.size());
+        nodes_.resize(4 * static_cast<size_t>(n)); // top node + n - 1 interior nodes
+        slot_prim_.resize(n);
+        threads_left_ = static_cast<int>(std::max(1u, std::thread::hardware_concurrency())) - 1;
         Bounds all;
         uint32_t depth = 0;
-        const uint32_t root = Emit(0, static_cast<uint32_t>(order_.size()), kWalkDepthMax - 1, all, depth);
+        const uint32_t root = Emit(0, n, kWalkDepthMax - 1, 1, all, depth);
         Bounds none; // lo = +max, hi = -max: never entered
         nodes_[0] = Pack(all.lo, Bits(root)), nodes_[1] = Pack(all.hi, Bits(root));
         nodes_[2] = Pack(none.lo, 0.0f), nodes_[3] = Pack(none.hi, 0.0f);
@@ -338,23 +344,43 @@ private:
         return mid;
     }
 
-    uint32_t Emit(uint32_t begin, uint32_t end, uint32_t budget, Bounds &box, uint32_t &depth)
+    // Builds the subtree over order_[begin, end); its interior nodes get the ids
+    // [id, id + (end - begin) - 1), its leaves the slots [begin, end).
+    uint32_t Emit(uint32_t begin, uint32_t end, uint32_t budget, uint32_t id, Bounds &box, uint32_t &depth)
     {
         if (begin + 1 == end)
         {
-            const uint32_t slot = static_cast<uint32_t>(slot_prim_.size());
-            slot_prim_.push_back(order_[begin]);
+            slot_prim_[begin] = order_[begin];
             box = boxes_[order_[begin]];
             depth = 0;
-            return kWalkLeaf | slot;
+            return kWalkLeaf | begin;
         }
-        const uint32_t id = static_cast<uint32_t>(nodes_.size() / 4);
-        nodes_.resize(nodes_.size() + 4);
         const uint32_t mid = Split(begin, end, budget);
+        // left subtree: (mid - begin) - 1 interior nodes right after this one
+        const uint32_t id_left = id + 1, id_right = id + 1 + (mid - begin - 1);
         Bounds b0, b1;
-        uint32_t d0 = 0, d1 = 0;
-        const uint32_t r0 = Emit(begin, mid, budget - 1, b0, d0);
-        const uint32_t r1 = Emit(mid, end, budget - 1, b1, d1);
+        uint32_t d0 = 0, d1 = 0, r0 = 0, r1 = 0;
+        bool spawned = false;
+        std::thread helper;
+        if (end - begin >= kParallelGrain)
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            if (threads_left_ > 0)
+                --threads_left_, spawned = true;
+        }
+        if (spawned)
+        {
+            helper = std::thread([&]() { r0 = Emit(begin, mid, budget - 1, id_left, b0, d0); });
+            r1 = Emit(mid, end, budget - 1, id_right, b1, d1);
+            helper.join();
+            std::lock_guard<std::mutex> lock(mutex_);
+            ++threads_left_;
+        }
+        else
+        {
+            r0 = Emit(begin, mid, budget - 1, id_left, b0, d0);
+            r1 = Emit(mid, end, budget - 1, id_right, b1, d1);
+        }
         nodes_[4 * size_t(id)] = Pack(b0.lo, Bits(r0)), nodes_[4 * size_t(id) + 1] = Pack(b0.hi, Bits(r1));
         nodes_[4 * size_t(id) + 2] = Pack(b1.lo, 0.0f), nodes_[4 * size_t(id) + 3] = Pack(b1.hi, 0.0f);
         box.lo = vmin(b0.lo, b1.lo), box.hi = vmax(b0.hi, b1.hi);
@@ -362,6 +388,9 @@ private:
         return id;
     }
 
+    static constexpr uint32_t kParallelGrain = 1u << 14;
+    std::mutex mutex_;
+    int threads_left_ = 0;
     const std::vector<Bounds> &boxes_;
     std::vector<float4> &nodes_;
     std::vector<uint32_t> &slot_prim_;
