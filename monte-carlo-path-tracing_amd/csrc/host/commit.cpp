@@ -486,6 +486,24 @@ struct TriangleRecord
 // the reference's tangent-frame rules (scene.cpp:15-111).  The "area" is
 // |e1 x e2|, i.e. twice the triangle area, exactly as the reference stores it
 // (scene.cpp:49) — light sampling and MIS use it consistently.
+// fn(begin, end) over [0, count) on several threads when the range is large.
+template <class Fn>
+void ParallelFor(size_t count, Fn fn)
+{
+    constexpr size_t kGrain = 1u << 15;
+    const size_t workers = std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), count / kGrain);
+    if (workers <= 1)
+    {
+        fn(size_t(0), count);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (size_t w = 0; w < workers; ++w)
+        pool.emplace_back(fn, count * w / workers, count * (w + 1) / workers);
+    for (std::thread &t : pool)
+        t.join();
+}
+
 void BakeTriangles(MeshSource m, const Mat4f &to_world, std::vector<TriangleRecord> &tris,
                    std::vector<float> &areas)
 {
@@ -510,13 +528,19 @@ void BakeTriangles(MeshSource m, const Mat4f &to_world, std::vector<TriangleReco
     tris.resize(count);
     areas.resize(count);
     const size_t n_vert = m.pos.size();
-    for (size_t i = 0; i < count; ++i)
+    for (const uint32_t id : m.idx)
+        if (id >= n_vert)
+            throw std::runtime_error("mesh index out of range.");
+    for (const std::vector<V3> *attr : {&m.nrm, &m.tan, &m.bit})
+        if (!attr->empty() && attr->size() < n_vert)
+            throw std::runtime_error("mesh attribute array shorter than the vertex array.");
+    if (!m.uv.empty() && m.uv.size() < n_vert)
+        throw std::runtime_error("mesh attribute array shorter than the vertex array.");
+    ParallelFor(count, [&](size_t first, size_t last) {
+    for (size_t i = first; i < last; ++i)
     {
         TriangleRecord &tri = tris[i];
         const uint32_t *id = &m.idx[3 * i];
-        for (int j = 0; j < 3; ++j)
-            if (id[j] >= n_vert)
-                throw std::runtime_error("mesh index out of range.");
         if (m.uv.empty())
             tri.uv[0] = {0, 0}, tri.uv[1] = {1, 0}, tri.uv[2] = {1, 1};
         else
@@ -567,6 +591,7 @@ void BakeTriangles(MeshSource m, const Mat4f &to_world, std::vector<TriangleReco
             }
         }
     }
+    });
 }
 
 // ---- Kulla-Conty ------------------------------------------------------------
