@@ -384,25 +384,25 @@ MCPT_HD bool triangle_hit_slot(const float4 *p, Ray &ray, HitRaw &out)
     const float Bx = comp(B, ray.kx) - ray.shear.x * Bkz, By = comp(B, ray.ky) - ray.shear.y * Bkz;
     const float Cx = comp(C, ray.kx) - ray.shear.x * Ckz, Cy = comp(C, ray.ky) - ray.shear.y * Ckz;
     float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
-    if (U == 0.0f || V == 0.0f || W == 0.0f)
+    if (U == 0.0f || V == 0.0f || W == 0.0f) // rare: the only branch kept
     {
         U = static_cast<float>(D(Cx) * D(By) - D(Cy) * D(Bx));
         V = static_cast<float>(D(Ax) * D(Cy) - D(Ay) * D(Cx));
         W = static_cast<float>(D(Bx) * D(Ay) - D(By) * D(Ax));
     }
-    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f))
-        return false;
+    // the reference's early-outs (triangle.cpp:52-87) as one predicate: everything is
+    // computed, rejected lanes keep their state (a zero determinant only yields values
+    // that are thrown away)
+    const bool mixed_signs = (U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f);
     const float det = U + V + W;
-    if (det == 0.0f)
-        return false;
     const float T = U * (ray.shear.z * Akz) + V * (ray.shear.z * Bkz) + W * (ray.shear.z * Ckz);
     const float det_inv = 1.0f / det;
     const float t = T * det_inv;
-    if (t > ray.t_max || t < kEpsDistance)
-        return false;
-    ray.t_max = t;
-    out.a = U * det_inv, out.b = V * det_inv, out.c = W * det_inv, out.inside = det_inv < 0;
-    return true;
+    const bool accepted = !mixed_signs && det != 0.0f && !(t > ray.t_max || t < kEpsDistance);
+    ray.t_max = accepted ? t : ray.t_max;
+    out.a = accepted ? U * det_inv : out.a, out.b = accepted ? V * det_inv : out.b, out.c = accepted ? W * det_inv : out.c;
+    out.inside = accepted ? det_inv < 0 : out.inside;
+    return accepted;
 }
 
 // True for exactly one of the currently active lanes of the wavefront.
