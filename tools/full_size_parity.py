@@ -1,4 +1,6 @@
-"""GPU box: BASELINE configs at their full film sizes, HIP frame vs the oracle's frame."""
+"""GPU box: BASELINE configs at their full film sizes, HIP frame vs the oracle's frame
+(about 11 minutes of box time, most of it the CPU oracle).  The matpreview / volumetric
+configurations come from scratch/real/*.mcsd (tools/convert_reference_scenes.py)."""
 import sys, os, time, json, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
