@@ -27,6 +27,8 @@
 #include <fstream>
 #include <map>
 #include <sstream>
+#include <vector>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "../vecmath.h"
@@ -77,25 +79,84 @@ float Radians(float deg) { return deg * 0.01745329251994329576923690768489f; }
 // ---- named material data (reference src/parser/ior_lut.cpp, medium_lut.cpp) -----
 #include "material_tables.inc"
 
+// "name | n n n | n n n ..." lines -> (name, numbers) records.  Numbers are read as
+// float literals (strtof), like the constants of the reference's tables.
+struct MaterialRecord
+{
+    std::string name;
+    std::vector<float> values;
+};
+std::vector<MaterialRecord> ParseMaterialTable(const char *text)
+{
+    std::vector<MaterialRecord> records;
+    std::istringstream lines(text);
+    std::string line;
+    while (std::getline(lines, line))
+    {
+        const size_t bar = line.find('|');
+        if (bar == std::string::npos)
+            continue;
+        MaterialRecord r;
+        r.name = line.substr(0, bar);
+        while (!r.name.empty() && r.name.back() == ' ')
+            r.name.pop_back();
+        const char *p = line.c_str() + bar + 1;
+        for (;;)
+        {
+            while (*p == ' ' || *p == '|')
+                ++p;
+            if (!*p)
+                break;
+            char *end = nullptr;
+            r.values.push_back(std::strtof(p, &end));
+            if (end == p)
+                break;
+            p = end;
+        }
+        records.push_back(std::move(r));
+    }
+    return records;
+}
+const MaterialRecord *FindMaterial(const std::vector<MaterialRecord> &table, const std::string &name)
+{
+    for (const MaterialRecord &r : table)
+        if (r.name == name)
+            return &r;
+    return nullptr;
+}
+
 bool LookupDielectricIor(const std::string &name, float *ior) // ior_lut.cpp:252-264
 {
-    for (const auto &e : kDielectricIor)
-        if (name == e.name)
-        {
-            *ior = e.ior;
-            return true;
-        }
-    return false;
+    static const std::vector<MaterialRecord> table = ParseMaterialTable(kDielectricIorText);
+    const MaterialRecord *r = FindMaterial(table, name);
+    if (r)
+        *ior = r->values.at(0);
+    return r != nullptr;
 }
 bool LookupConductorIor(const std::string &name, V3 *eta, V3 *k) // ior_lut.cpp:266-278
 {
-    for (const auto &e : kConductorIor)
-        if (name == e.name)
-        {
-            *eta = V3{e.eta[0], e.eta[1], e.eta[2]}, *k = V3{e.k[0], e.k[1], e.k[2]};
-            return true;
-        }
-    return false;
+    static const std::vector<MaterialRecord> table = ParseMaterialTable(kConductorIorText);
+    const MaterialRecord *r = FindMaterial(table, name);
+    if (r)
+        *eta = V3{r->values.at(0), r->values.at(1), r->values.at(2)}, *k = V3{r->values.at(3), r->values.at(4), r->values.at(5)};
+    return r != nullptr;
+}
+// medium_lut.cpp:191-219: measured media (with g) first, then the isotropic fits
+bool LookupMedium(const std::string &name, V3 *sigma_a, V3 *sigma_s, V3 *g, bool *has_g)
+{
+    static const std::vector<MaterialRecord> measured = ParseMaterialTable(kMeasuredMediaText),
+                                             isotropic = ParseMaterialTable(kIsotropicMediaText);
+    const MaterialRecord *r = FindMaterial(measured, name);
+    *has_g = r != nullptr;
+    if (!r)
+        r = FindMaterial(isotropic, name);
+    if (!r)
+        return false;
+    *sigma_s = V3{r->values.at(0), r->values.at(1), r->values.at(2)};
+    *sigma_a = V3{r->values.at(3), r->values.at(4), r->values.at(5)};
+    if (*has_g)
+        *g = V3{r->values.at(6), r->values.at(7), r->values.at(8)};
+    return true;
 }
 
 class SceneBuilder
@@ -519,21 +580,18 @@ private:
             // named medium (parser.cpp:731-757); the default name "skin1" is in neither table
             const Node *name_node = n.Child("string");
             const std::string name = name_node ? name_node->Str("value", "skin1") : "skin1";
-            bool found = false;
-            for (const auto &e : kMeasuredMedia)
-                if (!found && name == e.name)
+            V3 table_a, table_s, table_g;
+            bool has_g = false;
+            const bool found = LookupMedium(name, &table_a, &table_s, &table_g, &has_g);
+            if (found)
+            {
+                store(table_a, table_s);
+                if (has_g)
                 {
-                    store(V3{e.sigma_a[0], e.sigma_a[1], e.sigma_a[2]}, V3{e.sigma_s[0], e.sigma_s[1], e.sigma_s[2]});
                     m.phase_type = MCSD_PHASE_HG;
-                    m.g[0] = e.g[0], m.g[1] = e.g[1], m.g[2] = e.g[2];
-                    found = true;
+                    m.g[0] = table_g.x, m.g[1] = table_g.y, m.g[2] = table_g.z;
                 }
-            for (const auto &e : kIsotropicMedia)
-                if (!found && name == e.name)
-                {
-                    store(V3{e.sigma_a[0], e.sigma_a[1], e.sigma_a[2]}, V3{e.sigma_s[0], e.sigma_s[1], e.sigma_s[2]});
-                    found = true;
-                }
+            }
             if (!found)
                 throw std::runtime_error("unsupport medium type '" + name + "'.");
         }
