@@ -186,30 +186,35 @@ def main():
                        "film": (f"{W}x{H}: side scaled with sqrt(N) so that every GPU renders 512x512 pixels' worth "
                                 "of tiles (weak scaling)") if weak else f"{W}x{H}"},
         }
-        # ---- roofline of the render kernel (counting mode, outside the timed region)
+        # ---- roofline of the render kernel (counting mode, outside the timed region).  N > 1: rank 0's
+        # GPU and its share of the tiles, kernel time from one more (blocking) draw of that share.
+        count_spp = min(SPP, 16)
+        rc = pkg.capi.Renderer(pkg.capi.Config.builtin("cornell-box").set_film(W, H, count_spp), device=local_rank)
+        _, counts = rc.draw(counted=True)
+        scene_info = rc.info()
+        rc.close()
+        if world > 1:
+            st = renderer.draw_device(fg.packed.data_ptr(), rng, packed=True, stream=stream, blocking=True)
+            kernel_ms = st["kernel_milliseconds"]
+        rank_samples = samples if world == 1 else len(pkg.tiling.rank_tiles(0, world, W, H)) * 64 * SPP
+        b_per_sample = algorithmic_bytes_per_sample(counts, SPP)
+        achieved = b_per_sample * rank_samples / (kernel_ms * 1e-3) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(),
+            "kernel": "mcpt::render_kernel", "kernel_ms": kernel_ms,
+            "bytes_per_sample": b_per_sample,
+            "per_sample": {k: counts[k] / counts["samples"] for k in
+                           ("closest_rays", "shadow_rays", "node_tests", "prim_tests", "shaded_hits")},
+            "note": "%salgorithmic bytes (32 B/box test, 36 B/triangle test, 132 B/shaded hit, "
+                    "12 B/pixel) over the kernel time; the scene (%d two-box nodes, %d triangles) is "
+                    "staged in LDS, so HBM traffic (`traffic`: bytes per launch from the rocprofv3 "
+                    "PMC passes in profiles/, FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE) is "
+                    "far below this figure and the kernel is VALU-issue bound, not HBM bound"
+                    % ("per GPU (rank 0's share of the tiles): " if world > 1 else "",
+                       scene_info["walk_nodes"], scene_info["primitives"]),
+        }
         if world == 1:
-            count_spp = min(SPP, 16)
-            rc = pkg.capi.Renderer(pkg.capi.Config.builtin("cornell-box").set_film(W, H, count_spp),
-                                   device=local_rank)
-            _, counts = rc.draw(counted=True)
-            scene_info = rc.info()
-            rc.close()
-            b_per_sample = algorithmic_bytes_per_sample(counts, SPP)
-            achieved = b_per_sample * samples / (kernel_ms * 1e-3) / 1e9
-            out["roofline"] = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(),
-                "kernel": "mcpt::render_kernel", "kernel_ms": kernel_ms,
-                "bytes_per_sample": b_per_sample,
-                "per_sample": {k: counts[k] / counts["samples"] for k in
-                               ("closest_rays", "shadow_rays", "node_tests", "prim_tests", "shaded_hits")},
-                "note": "algorithmic bytes (32 B/box test, 36 B/triangle test, 132 B/shaded hit, "
-                        "12 B/pixel) over the kernel time; the scene (%d two-box nodes, %d triangles) is "
-                        "staged in LDS, so HBM traffic (`traffic`: bytes per launch from the rocprofv3 "
-                        "PMC passes in profiles/, FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE) is "
-                        "far below this figure and the kernel is VALU-issue bound, not HBM bound"
-                        % (scene_info["walk_nodes"], scene_info["primitives"]),
-            }
             if not args.no_cpu_baseline:
                 rec, scene, cpu_frame = cpu_baseline(pkg, W, H)
                 out["cpu_baseline"] = rec
@@ -222,8 +227,6 @@ def main():
                                  "rmse": float(np.sqrt((d ** 2).mean())), "mean_l2": float(l2.mean()),
                                  "max_l2": float(l2.max()), "frac_gt_1e-3": float((l2 > 1e-3).mean()),
                                  "frac_exact": float((l2 == 0).mean())}
-        else:
-            out["roofline"] = None
         print(json.dumps(out))
     if rank == 0 and args.force_gather:
         # the gathered frame must be the plain full-frame draw, bit for bit
