@@ -28,11 +28,16 @@ namespace mcpt
 // Register budget: the lean instantiations (no microfacet / volume code) are
 // held to 128 VGPRs = 4 wavefronts per SIMD = 4 workgroups of 256 per CU, so
 // that a 512x512 frame (262 144 pixels = 256 CUs x 1024 lanes) is resident in
-// one round; the full instantiation needs ~230 VGPRs and runs 2 per SIMD.
+// one round; the material instantiations run 3 per SIMD.
 template <uint32_t kFeatures>
 struct Budget
 {
-    static constexpr int kWavesPerSimd = (kFeatures & (kFeatMicrofacet | kFeatVolPath | kFeatAnalytic)) ? 2 : 4;
+    // measured: the full instantiation at 3 per SIMD (<= 168 VGPRs) is 17 % faster on the
+    // volumetric scenes than at 2 (208 VGPRs); the surface-materials instantiation needs 168
+    // either way and is 3 % slower when the compiler is held to it
+    static constexpr int kWavesPerSimd = (kFeatures & (kFeatVolPath | kFeatAnalytic)) ? 3
+                                         : (kFeatures & kFeatMicrofacet)              ? 2
+                                                                                      : 4;
 };
 
 // kLdsGeometry: the arrays the ray queries and the light sampler read (both
