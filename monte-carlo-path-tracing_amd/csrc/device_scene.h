@@ -212,6 +212,7 @@ struct IntegratorRec // reference integrator.hpp:31-69 (the scalar part)
     uint32_t n_walk_nodes; // ordered-walk hierarchy (0 = empty scene)
     uint32_t walk_depth;   // stack entries a lane needs: the tree's depth + 1 (sentinel)
     uint32_t has_masks;    // some BSDF carries an opacity map: the walk must keep the reference's order
+    uint32_t walk_hold;    // ... or when at least this many lanes hold a primitive (0 = never for that reason)
     uint32_t walk_break;   // wavefront scheduling of the ordered walk (traversal.h, walk_ordered_vote): leave
                            // the node phase when fewer lanes than this are searching; 0 = wait for all
 };

@@ -971,7 +971,9 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
         ig.n_walk_nodes = static_cast<uint32_t>(fs.walk_nodes.size() / 4);
         // measured: on meshes a wavefront should stop waiting for its last
         // few searching lanes (matpreview +30 % at 8..16), in box-like scenes it should not
-        ig.walk_break = n_prims >= 2048 ? 12u : 0u;
+        // (sweep on the matpreview scene and a 0.8 M-triangle scene: flat optimum around 6..8 / 10..12)
+        ig.walk_break = n_prims >= 2048 ? 8u : 0u;
+        ig.walk_hold = n_prims >= 2048 ? 12u : 0u;
         fs.walk_prims.reserve(3 * slot_prim.size());
         for (const uint32_t prim : slot_prim)
         {

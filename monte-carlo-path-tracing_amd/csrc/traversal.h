@@ -528,11 +528,13 @@ MCPT_HD uint32_t lanes_where(bool p)
 // average number of node steps; waiting for them before every primitive phase
 // (walk_ordered) leaves most lanes idle (node-phase lane utilisation 12 % on the
 // matpreview scene).  Here the wavefront switches to the primitive phase as soon as
-// fewer than sc.integrator.walk_break lanes are still searching: the stragglers are
+// fewer than sc.integrator.walk_break lanes are still searching (and somebody holds a
+// primitive), or as soon as sc.integrator.walk_hold lanes hold one: the stragglers are
 // parked with their cursor, the other lanes test their primitive, pop, and rejoin the
 // node phase, so the stragglers' long walks overlap with the others' next steps
-// (matpreview 266 -> 347 Msamples/s at 8..16).  With walk_break == 0 it is
-// walk_ordered plus two ballots per step.  One lane's visiting order never changes.
+// (matpreview 266 -> 347 Msamples/s with walk_break 8..16, another 6 % with
+// walk_hold 10..12).  With both 0 it is walk_ordered plus one ballot per step.  One
+// lane's visiting order never changes.
 template <bool kAny, bool kAnalytic, bool kCount>
 MCPT_HD bool walk_ordered_vote(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitRaw &hit, TraceStats &stats)
 {
@@ -545,7 +547,7 @@ MCPT_HD bool walk_ordered_vote(const DeviceScene &sc, uint32_t *stack, Ray &ray,
     stack[0] = kWalkDone;
     uint32_t depth = 1; // entries on the stack
     uint32_t cur = 0;   // the top node
-    const uint32_t break_below = sc.integrator.walk_break;
+    const uint32_t break_below = sc.integrator.walk_break, hold_enough = sc.integrator.walk_hold;
     for (;;)
     {
         // ---- node phase: runs while enough lanes of the wavefront are searching ----
@@ -553,8 +555,14 @@ MCPT_HD bool walk_ordered_vote(const DeviceScene &sc, uint32_t *stack, Ray &ray,
         {
             const bool searching = !(cur & kWalkLeaf);
             const uint32_t n_searching = lanes_where(searching);
-            if (n_searching == 0 || (n_searching < break_below && lanes_where(cur != kWalkDone && !searching) != 0))
+            if (n_searching == 0)
                 break;
+            if (break_below | hold_enough)
+            {
+                const uint32_t n_holding = lanes_where(cur != kWalkDone && !searching);
+                if ((n_searching < break_below && n_holding != 0) || (hold_enough && n_holding >= hold_enough))
+                    break;
+            }
             if (!searching)
                 continue;
             const float4 *n = sc.walk_nodes + 4 * static_cast<size_t>(cur);
