@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build box only (needs /root/reference): translates the reference's scene files with
 the XML front end and stores the configurations as scratch/real/*.mcsd (git-ignored;
-they travel to the GPU box with gpurun), for tools/full_size_parity.py and
+they travel to the GPU box with gpurun), for tests/full_size_parity.py and
 tools/render_scene.py.  No GPU needed."""
 import os
 import sys
