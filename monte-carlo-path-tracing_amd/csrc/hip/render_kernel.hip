@@ -10,13 +10,13 @@
 // between lanes: the per-pixel sequential RNG chain of the reference makes
 // the pixel the unit of parallelism.
 //
-// Memory.  All scene tables are read-only arrays in HBM (device_scene.h).  The
-// walk reads one 32-byte node (two float4 loads) per step and one 48-byte
-// triangle record per leaf; hit attributes (144 B) are read once per shaded
-// hit.  Path state lives in registers; the only writes are 12 B per finished
-// pixel.  There is no matrix-shaped work here: no MFMA, no LDS staging of
-// operands — the node/triangle arrays of small scenes sit in the per-CU L1 /
-// per-XCD L2, large ones stream from HBM through L2.
+// Memory.  All scene tables are read-only arrays in HBM (device_scene.h).  A ray
+// query reads one 64-byte two-box node (four float4 loads) per step and one 48-byte
+// primitive slot per leaf; hit attributes (144 B) are read once per shaded hit.
+// Path state lives in registers, the traversal stacks in LDS (lane-interleaved);
+// the only global writes are 12 B per finished pixel.  Scenes whose traversal data
+// fits 24 KiB are staged into LDS per workgroup, larger ones are read through
+// L1 / L2.  There is no matrix-shaped work here: no MFMA.
 #include <hip/hip_runtime.h>
 
 #include "../path_core.h"

@@ -1,6 +1,12 @@
 // Ray / scene intersection on the flat scene of device_scene.h.
 //
-// * STACKLESS two-level traversal: nodes are stored in the reference
+// Two ray queries with the same answers:
+//   walk_ordered / walk_ordered_vote   the production query: near-child-first walk of
+//                                      the SAH hierarchy (further down in this file);
+//   walk_scene                         the reference's trees in the reference's order
+//                                      (scenes with opacity masks; validation mode).
+//
+// * walk_scene — STACKLESS two-level traversal: nodes are stored in the reference
 //   builder's pre-order, so "descend" is `index + 1` and every other move is
 //   the node's precomputed `skip` link.  This visits nodes in exactly the
 //   reference's order (left child first, then right; tlas.cpp:22-41,
