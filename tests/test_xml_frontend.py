@@ -835,6 +835,58 @@ def test_cli_film_overrides_reach_the_configuration(pkg, tmp_path):
         assert r.returncode == 1 and "no HIP device" in r.stderr
 
 
+def _read_uncompressed_exr(raw):
+    """Scanline EXR with compression NONE and FLOAT channels -> {name: array (h, w)}."""
+    assert struct.unpack("<I", raw[:4])[0] == 20000630
+    at, attrs = 8, {}
+    while raw[at] != 0:
+        e = raw.index(b"\0", at)
+        name = raw[at:e].decode()
+        e2 = raw.index(b"\0", e + 1)
+        size = struct.unpack("<i", raw[e2 + 1:e2 + 5])[0]
+        attrs[name] = raw[e2 + 5:e2 + 5 + size]
+        at = e2 + 5 + size
+    at += 1
+    assert attrs["compression"][0] == 0
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    names, p = [], 0
+    ch = attrs["channels"]
+    while ch[p] != 0:
+        e = ch.index(b"\0", p)
+        names.append(ch[p:e].decode())
+        assert struct.unpack("<i", ch[e + 1:e + 5])[0] == 2      # FLOAT
+        p = e + 17
+    offsets = struct.unpack(f"<{h}Q", raw[at:at + 8 * h])
+    out = {n: np.zeros((h, w), np.float32) for n in names}
+    for off in offsets:
+        y, size = struct.unpack("<ii", raw[off:off + 8])
+        row = np.frombuffer(raw[off + 8:off + 8 + size], "<f4").reshape(len(names), w)
+        for k, n in enumerate(names):
+            out[n][y - y0] = row[k]
+    return out
+
+
+@pytest.mark.gpu
+def test_cli_xml_to_exr(pkg, tmp_path):
+    """The north-star command line: `--gpu -i scene.xml -o out.exr`."""
+    body = """<bsdf type="diffuse" id="grey"><rgb name="reflectance" value="0.6"/></bsdf>
+    <shape type="sphere"><float name="radius" value="0.7"/><point name="center" x="0" y="0" z="3"/><ref id="grey"/></shape>
+    <shape type="rectangle"><transform name="toWorld"><scale value="4"/><rotate x="1" angle="90"/><translate y="-0.7"/></transform>
+        <ref id="grey"/></shape>
+    <emitter type="constant"><rgb name="radiance" value="0.8"/></emitter>"""
+    xml = tmp_path / "scene.xml"
+    xml.write_text(scene_xml(body))
+    out = tmp_path / "out.exr"
+    r = run_cli(pkg, "--gpu", "-i", xml, "-o", out, "-w", 40, "-h", 24, "-s", 8)
+    assert r.returncode == 0, r.stderr
+    planes = _read_uncompressed_exr(out.read_bytes())
+    got = np.stack([planes["R"], planes["G"], planes["B"]], axis=-1)
+    frame, _ = pkg.capi.Renderer(pkg.capi.Config.load_xml(xml).set_film(40, 24, 8)).draw()
+    np.testing.assert_array_equal(got, frame)
+    assert frame.mean() > 0.2
+
+
 @pytest.mark.gpu
 def test_cli_renders_like_the_library(pkg, tmp_path):
     scene = pkg.scenes.cornell_box(48, 48, 4)
