@@ -207,7 +207,11 @@ def test_rccl_gather_path_on_one_gpu():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import socket
+    with socket.socket() as sock:          # a free port for the rendezvous
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-gather", "--width", "200", "--height",
                         "120", "--spp", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
                        env=env, capture_output=True, text=True, timeout=600)
