@@ -127,7 +127,14 @@ def main():
     # line therefore keeps the per-GPU work fixed — the film side grows with sqrt(N) (same scene, same
     # camera, same cost per sample): weak scaling.  --strong keeps 512x512.
     weak = world > 1 and not args.strong and not args.width and not args.height
-    side = int(round(512.0 * (world ** 0.5) / 8.0)) * 8 if weak else 512
+    side = 512
+    if weak:
+        # the largest square film (side a multiple of the 8-pixel tile) whose per-rank share still
+        # fits the 262 144 lanes of one GPU in ONE round: a few pixels more would start a second
+        # round that costs a whole extra pixel chain (N = 2: 720, N = 4: 1024, N = 8: 1448)
+        side = int(512.0 * (world ** 0.5) / 8.0) * 8
+        while -(-((side // 8) ** 2) // world) * 64 > 512 * 512:
+            side -= 8
     W, H, SPP = args.width or side, args.height or side, args.spp
     cfg = pkg.capi.Config.builtin("cornell-box").set_film(W, H, SPP)
     renderer = pkg.capi.Renderer(cfg, device=local_rank)
