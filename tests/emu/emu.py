@@ -59,11 +59,13 @@ class Emulator:
 
     def pool_model(self, mcsd_path):
         """Per-lane walk vs a wavefront-shared pool of (ray, node) items (see emulator.cpp)."""
-        out = (ctypes.c_double * 8)()
+        out = (ctypes.c_double * 24)()
         if self.lib.mcpt_emu_pool_model(str(mcsd_path).encode(), out) != 0:
             raise RuntimeError(self.lib.mcpt_emu_last_error().decode())
-        keys = ("lane_wave_node_steps", "lane_node_visits", "lane_wave_prim_phases", "lane_prim_tests",
-                "pool_node_steps", "pool_node_visits", "pool_prim_steps", "pool_prim_tests")
+        keys = ["lane_wave_node_steps", "lane_node_visits", "lane_wave_prim_phases", "lane_prim_tests",
+                "pool_node_steps", "pool_node_visits", "pool_prim_steps", "pool_prim_tests"]
+        for spec in range(4):   # lock-step while-while with `spec` speculatively collected primitives
+            keys += [f"spec{spec}_node_steps", f"spec{spec}_node_visits", f"spec{spec}_prim_steps", f"spec{spec}_prim_tests"]
         return dict(zip(keys, out))
 
     def walk(self, mcsd_path, capacity=1 << 21):

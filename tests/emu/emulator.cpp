@@ -331,6 +331,125 @@ void RunPool(const DeviceScene &sc, const std::vector<std::array<float, 7>> &ray
     }
 }
 
+// Per-lane ordered walk of one wavefront phase, simulated in lock step, with
+// SPECULATION: a lane that holds a primitive may keep searching (with its stale t_max)
+// and collect up to `spec` more primitives while some lane that holds none is still
+// searching; the primitive phase then tests every lane's collected primitives in the order
+// found.  spec = 0 is the production while-while loop.  Returns wave-level node steps and
+// primitive-phase iterations, and the lane-level visits / tests.
+void RunSpeculative(const DeviceScene &sc, const std::vector<std::array<float, 7>> &rays, bool any, uint32_t spec,
+                    PoolModel &m)
+{
+    const size_t n = rays.size();
+    if (n == 0 || sc.integrator.n_walk_nodes == 0)
+        return;
+    struct Lane
+    {
+        Ray ray;
+        std::vector<uint32_t> stack, pending;
+        uint32_t cur = 0;
+        bool done = false, found = false;
+        uint32_t best_rank = 0;
+    };
+    std::vector<Lane> lanes(n);
+    for (size_t i = 0; i < n; ++i)
+    {
+        lanes[i].ray = make_ray(V3{rays[i][0], rays[i][1], rays[i][2]}, V3{rays[i][3], rays[i][4], rays[i][5]});
+        lanes[i].ray.t_max = rays[i][6];
+    }
+    auto pop = [](Lane &l)
+    {
+        if (l.stack.empty())
+        {
+            l.cur = kWalkDone;
+            return;
+        }
+        l.cur = l.stack.back();
+        l.stack.pop_back();
+    };
+    for (;;)
+    {
+        // ---- node phase ----
+        for (;;)
+        {
+            bool needed = false; // a lane with nothing collected is still searching
+            for (Lane &l : lanes)
+                if (!l.done && l.pending.empty() && l.cur != kWalkDone && !(l.cur & kWalkLeaf))
+                    needed = true;
+            // lanes standing on a leaf collect it (free bookkeeping) and move on if allowed
+            bool moved = true;
+            while (moved)
+            {
+                moved = false;
+                for (Lane &l : lanes)
+                    if (!l.done && l.cur != kWalkDone && (l.cur & kWalkLeaf) && l.pending.size() < 1 + spec)
+                    {
+                        l.pending.push_back(l.cur);
+                        pop(l);
+                        moved = true;
+                    }
+            }
+            needed = false;
+            for (Lane &l : lanes)
+                if (!l.done && l.pending.empty() && l.cur != kWalkDone)
+                    needed = true;
+            if (!needed)
+                break;
+            m.node_steps += 1;
+            for (Lane &l : lanes)
+            {
+                if (l.done || l.cur == kWalkDone || (l.cur & kWalkLeaf))
+                    continue; // finished, or holding a full set of primitives
+                m.node_visits += 1;
+                const float4 *q = sc.walk_nodes + 4 * static_cast<size_t>(l.cur);
+                float e0, e1;
+                const bool h0 = box_enter(q[0], q[1], l.ray, e0), h1 = box_enter(q[2], q[3], l.ray, e1);
+                const uint32_t r0 = as_uint(q[0].w), r1 = as_uint(q[1].w);
+                if (h0 && h1)
+                {
+                    const bool first0 = e0 <= e1;
+                    l.stack.push_back(first0 ? r1 : r0);
+                    l.cur = first0 ? r0 : r1;
+                }
+                else if (h0 || h1)
+                    l.cur = h0 ? r0 : r1;
+                else
+                    pop(l);
+            }
+        }
+        // ---- primitive phase: as many iterations as the fullest lane has collected ----
+        size_t most = 0;
+        bool anything = false;
+        for (Lane &l : lanes)
+        {
+            most = std::max(most, l.done ? size_t(0) : l.pending.size());
+            anything = anything || (!l.done && (!l.pending.empty() || l.cur != kWalkDone));
+        }
+        if (!anything)
+            break;
+        m.prim_steps += static_cast<double>(most);
+        for (Lane &l : lanes)
+        {
+            if (l.done)
+                continue;
+            for (const uint32_t ref : l.pending)
+            {
+                m.prim_tests += 1;
+                const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(ref & ~kWalkLeaf);
+                HitRaw cand;
+                if (triangle_hit_slot(p, l.ray, cand) && any)
+                {
+                    l.done = true;
+                    break;
+                }
+            }
+            l.pending.clear();
+            if (!l.done && l.cur == kWalkDone)
+                l.done = true;
+        }
+    }
+}
+
 // out: per-lane model {node steps (wave), node visits (lane), prim phases, prim tests} followed by the
 // pooled model's {node steps, node visits, prim steps, prim tests}; triangle-only scenes.
 int mcpt_emu_pool_model(const char *mcsd_path, double *out)
@@ -344,13 +463,13 @@ int mcpt_emu_pool_model(const char *mcsd_path, double *out)
         using C = Config<kFeatVolPath | kFeatEmitters | kFeatTextures | kFeatMicrofacet | kFeatOrderedWalk>;
         const uint32_t w = sc.camera.width, h = sc.camera.height;
         const uint32_t tx = (w + 7) / 8, ty = (h + 7) / 8;
-        std::vector<double> acc(8, 0.0);
+        std::vector<double> acc(24, 0.0);
         std::mutex mu;
         std::atomic<uint32_t> next{0};
         auto work = [&]()
         {
-            std::vector<double> a(8, 0.0);
-            PoolModel pm;
+            std::vector<double> a(8 + 16, 0.0);
+            PoolModel pm, sm[4];
             for (;;)
             {
                 const uint32_t tile = next.fetch_add(1);
@@ -407,11 +526,19 @@ int mcpt_emu_pool_model(const char *mcsd_path, double *out)
                     a[0] += mcn + msn, a[2] += mcp + msp;
                     RunPool(sc, closest, false, pm);
                     RunPool(sc, shadow, true, pm);
+                    for (uint32_t spec = 0; spec < 4; ++spec)
+                    {
+                        RunSpeculative(sc, closest, false, spec, sm[spec]);
+                        RunSpeculative(sc, shadow, true, spec, sm[spec]);
+                    }
                 }
             }
             a[4] = pm.node_steps, a[5] = pm.node_visits, a[6] = pm.prim_steps, a[7] = pm.prim_tests;
+            for (int k = 0; k < 4; ++k)
+                a[8 + 4 * k] = sm[k].node_steps, a[9 + 4 * k] = sm[k].node_visits, a[10 + 4 * k] = sm[k].prim_steps,
+                          a[11 + 4 * k] = sm[k].prim_tests;
             std::lock_guard<std::mutex> lock(mu);
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 24; ++i)
                 acc[i] += a[i];
         };
         std::vector<std::thread> pool;
@@ -420,7 +547,7 @@ int mcpt_emu_pool_model(const char *mcsd_path, double *out)
         work();
         for (std::thread &t : pool)
             t.join();
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 24; ++i)
             out[i] = acc[i];
         return 0;
     }
