@@ -236,6 +236,8 @@ class Reference:
         lib.mcpt_ref_vdc3.restype = ctypes.c_float
         lib.mcpt_ref_vdc3.argtypes = [ctypes.c_uint32]
         lib.mcpt_ref_kulla_conty.argtypes = [_f32p, _f32p]
+        lib.mcpt_ref_binding_round_trip.restype = ctypes.c_int
+        lib.mcpt_ref_binding_round_trip.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
         lib.mcpt_ref_bvh_build.restype = ctypes.c_int
         lib.mcpt_ref_bvh_build.argtypes = [ctypes.c_uint32, _f32p, _f32p] + \
             [_u32p] * 4 + [_f32p] * 2
@@ -259,6 +261,11 @@ class Reference:
         if rc != 0:
             raise RuntimeError(self.lib.mcpt_ref_last_error().decode())
         return frame, {"seconds": sec.value}
+
+    def binding_round_trip(self, mcsd_path, out_path):
+        """MCSD -> csrt::RendererConfig -> MCSD through integration/mcpt_backend.hpp."""
+        if self.lib.mcpt_ref_binding_round_trip(str(mcsd_path).encode(), str(out_path).encode()) != 0:
+            raise RuntimeError(self.lib.mcpt_ref_last_error().decode())
 
     def open(self, mcsd_path):
         h = self.lib.mcpt_ref_open(str(mcsd_path).encode())

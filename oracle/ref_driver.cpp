@@ -39,6 +39,11 @@
 
 #include "mcsd_scene.hpp"
 
+// the reference-side binding shipped in integration/ (header only; the library calls
+// are left out here: this driver only checks its RendererConfig -> MCSD direction)
+#define MCPT_BACKEND_NO_LIBRARY
+#include "../integration/mcpt_backend.hpp"
+
 namespace
 {
 
@@ -289,6 +294,24 @@ int mcpt_ref_render(const char *mcsd_path, float *frame, double *render_seconds)
         const auto t1 = std::chrono::steady_clock::now();
         if (render_seconds)
             *render_seconds = std::chrono::duration<double>(t1 - t0).count();
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return 1;
+    }
+}
+
+// MCSD file -> csrt::RendererConfig (ToConfig above) -> MCSD bytes through the binding
+// a reference maintainer would use (integration/mcpt_backend.hpp, csrt::ToMcsd).
+// Returns 0 and writes the bytes to out_path.
+int mcpt_ref_binding_round_trip(const char *mcsd_path, const char *out_path)
+{
+    try
+    {
+        const csrt::RendererConfig cfg = ToConfig(mcsd::Load(mcsd_path));
+        mcsd::Save(csrt::ToMcsd(cfg), out_path);
         return 0;
     }
     catch (const std::exception &e)

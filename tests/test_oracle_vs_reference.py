@@ -103,3 +103,15 @@ def test_lbvh_random(oracle, reference):
 def test_kulla_conty(oracle, reference):
     a, b = oracle.kulla_conty(), reference.kulla_conty()
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_reference_binding_round_trip(pkg, reference, mcsd_file, tmp_path):
+    """The binding a reference maintainer would add (integration/mcpt_backend.hpp,
+    csrt::ToMcsd): every field of csrt::RendererConfig must reach the C ABI's
+    configuration — MCSD -> RendererConfig -> MCSD returns the same bytes."""
+    from golden_cases import cases
+    for name, scene in cases(pkg.scenes).items():
+        path = mcsd_file(scene, name + ".mcsd")
+        out = tmp_path / (name + ".round_trip.mcsd")
+        reference.binding_round_trip(path, out)
+        assert out.read_bytes() == open(path, "rb").read(), name
