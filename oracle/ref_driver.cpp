@@ -41,7 +41,9 @@
 
 // the reference-side binding shipped in integration/ (header only; the library calls
 // are left out here: this driver only checks its RendererConfig -> MCSD direction)
+#ifndef MCPT_BACKEND_DEMO
 #define MCPT_BACKEND_NO_LIBRARY
+#endif
 #include "../integration/mcpt_backend.hpp"
 
 namespace
@@ -502,5 +504,35 @@ int main(int argc, char **argv)
     std::fclose(f);
     std::printf("{\"render_seconds\": %.6f}\n", seconds);
     return 0;
+}
+#endif
+
+#ifdef MCPT_BACKEND_DEMO
+// backend_demo <scene.mcsd> <out.f32>: what the reference's RayTracer would do with the
+// binding of integration/mcpt_backend.hpp — RendererConfig in, frame out, on the GPU
+// through libmcpt_hip.so.  Built by `make ref` next to the library; the GPU tests run it.
+int main(int argc, char **argv)
+{
+    if (argc != 3)
+    {
+        std::fprintf(stderr, "usage: %s scene.mcsd out.f32\n", argv[0]);
+        return 2;
+    }
+    try
+    {
+        const csrt::RendererConfig config = ToConfig(mcsd::Load(argv[1]));
+        std::vector<float> frame(static_cast<size_t>(config.camera.width) * config.camera.height * 3);
+        csrt::HipBackend backend(config, 0);
+        backend.Draw(frame.data());
+        FILE *f = std::fopen(argv[2], "wb");
+        std::fwrite(frame.data(), sizeof(float), frame.size(), f);
+        std::fclose(f);
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        std::fprintf(stderr, "%s\n", e.what());
+        return 1;
+    }
 }
 #endif

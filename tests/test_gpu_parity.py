@@ -221,3 +221,22 @@ def test_rccl_gather_path_on_one_gpu():
     assert lines, r.stdout[-2000:]
     line = json.loads(lines[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0
+
+
+def test_reference_side_binding_renders_the_same_frame(pkg, mcsd_file, tmp_path):
+    """integration/mcpt_backend.hpp compiled against the reference's headers
+    (oracle/_ref/backend_demo, built where /root/reference exists): RendererConfig ->
+    csrt::HipBackend -> frame must be the frame the C ABI gives directly."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    demo = os.path.join(root, "oracle", "_ref", "backend_demo")
+    if not os.path.exists(demo):
+        pytest.skip("oracle/_ref/backend_demo not built (needs the reference sources)")
+    scene = pkg.scenes.material_preview("rough_conductor", "mixed", "mesh", 40, 24, 4)
+    path = mcsd_file(scene)
+    out = tmp_path / "frame.f32"
+    r = subprocess.run([demo, path, str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.fromfile(out, dtype=np.float32).reshape(24, 40, 3)
+    frame, _ = gpu_render(pkg, scene)
+    assert np.array_equal(got, frame)
