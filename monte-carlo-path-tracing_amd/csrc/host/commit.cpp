@@ -200,6 +200,8 @@ private:
 // the same primitives, only the visiting order and the number of visited nodes
 // differ.  The depth is bounded (kWalkDepthMax) because it sizes the per-lane
 // traversal stack.
+int g_walk_tree_strategy = 0; // SetWalkTreeStrategyForTesting
+
 class WalkTreeBuilder
 {
 public:
@@ -280,8 +282,45 @@ private:
                              });
             return mid;
         };
-        if (count <= 2 || budget <= Log2Ceil(count))
+        if (count <= 2 || budget <= Log2Ceil(count) || g_walk_tree_strategy == 2)
             return count == 2 ? begin + 1 : median();
+        if (g_walk_tree_strategy == 1 && count <= 4096)
+        {
+            // exact sweep over every split position of every axis (test strategy)
+            double best = 1e300;
+            uint32_t best_left = 0;
+            std::vector<uint32_t> sorted(order_.begin() + begin, order_.begin() + end), best_order;
+            std::vector<double> right_area(count);
+            for (int axis = 0; axis < 3; ++axis)
+            {
+                std::sort(sorted.begin(), sorted.end(),
+                          [&](uint32_t a, uint32_t b)
+                          {
+                              const float ca = comp(centre_[a], axis), cb2 = comp(centre_[b], axis);
+                              return ca < cb2 || (ca == cb2 && a < b);
+                          });
+                Bounds acc;
+                for (uint32_t k = count; k-- > 1;)
+                {
+                    acc.Add(boxes_[sorted[k]]);
+                    right_area[k] = HalfArea(acc);
+                }
+                acc = Bounds();
+                for (uint32_t k = 1; k < count; ++k)
+                {
+                    acc.Add(boxes_[sorted[k - 1]]);
+                    if (Log2Ceil(std::max(k, count - k)) > budget - 1)
+                        continue;
+                    const double cost = HalfArea(acc) * k + right_area[k] * (count - k);
+                    if (cost < best)
+                        best = cost, best_left = k, best_order = sorted;
+                }
+            }
+            if (best_order.empty())
+                return median();
+            std::copy(best_order.begin(), best_order.end(), order_.begin() + begin);
+            return begin + best_left;
+        }
         constexpr int kBins = 16;
         double best_cost = 1e300;
         int best_axis = -1, best_bin = 0;
@@ -381,6 +420,8 @@ private:
             r0 = Emit(begin, mid, budget - 1, id_left, b0, d0);
             r1 = Emit(mid, end, budget - 1, id_right, b1, d1);
         }
+        if (g_walk_tree_strategy == 3)
+            std::swap(b0, b1), std::swap(r0, r1);
         nodes_[4 * size_t(id)] = Pack(b0.lo, Bits(r0)), nodes_[4 * size_t(id) + 1] = Pack(b0.hi, Bits(r1));
         nodes_[4 * size_t(id) + 2] = Pack(b1.lo, 0.0f), nodes_[4 * size_t(id) + 3] = Pack(b1.hi, 0.0f);
         box.lo = vmin(b0.lo, b1.lo), box.hi = vmax(b0.hi, b1.hi);
@@ -703,6 +744,8 @@ size_t FlatScene::GeometryBytes() const
     return nodes.size() * sizeof(float4) + walk_nodes.size() * sizeof(float4) + walk_prims.size() * sizeof(float4) +
            tri_pos.size() * sizeof(float4) + tri_attr.size() * sizeof(float4);
 }
+
+void SetWalkTreeStrategyForTesting(int strategy) { g_walk_tree_strategy = strategy; }
 
 void BuildReferenceLbvh(uint32_t n, const float *boxes, const float *areas, std::vector<float4> &nodes,
                         std::vector<float> &node_area)

@@ -59,6 +59,11 @@ struct LbvhAccelerator
                        std::vector<float> &node_area) = 0;
 };
 
+// TESTS ONLY: how the ordered-walk hierarchy is split.  0 = binned SAH (production),
+// 1 = exact SAH sweep, 2 = object median, 3 = binned SAH with the children swapped.  The
+// image must not depend on it (tests/test_host.py::test_image_does_not_depend_on_the_walk_tree).
+void SetWalkTreeStrategyForTesting(int strategy);
+
 // Throws std::runtime_error with the reference's wording on invalid input.
 FlatScene CommitScene(const mcsd::Scene &scene, LbvhAccelerator *lbvh = nullptr);
 

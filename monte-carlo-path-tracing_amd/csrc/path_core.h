@@ -51,6 +51,9 @@ struct LaneCounters
     // ... and the rays themselves (origin, direction, t_max); last_shadow_count of them
     float last_closest_ray[7], last_shadow_ray[7];
     uint32_t last_shadow_count;
+    uint32_t last_hit_prim;  // primitive of the last closest hit (kNone: miss) and its distance
+    float last_hit_t;
+    uint32_t last_shadow_hit; // result of the last shadow walk
 };
 
 // Per-lane path state that survives from one step to the next.
@@ -162,6 +165,7 @@ MCPT_HD bool shadow_walk(const DeviceScene &sc, uint32_t *stack, V3 origin, V3 d
         ++cnt->shadow_rays, cnt->node_tests += ts.node_tests, cnt->prim_tests += ts.prim_tests;
         cnt->wave_node_steps += ts.wave_node_steps, cnt->wave_prim_steps += ts.wave_prim_steps;
         cnt->last_shadow_nodes += ts.node_tests, cnt->last_shadow_prims += ts.prim_tests;
+        cnt->last_shadow_hit = hit ? 1u : 0u;
     }
     return hit;
 }
@@ -358,6 +362,7 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
         for (int k = 0; k < 7; ++k)
             cnt->last_closest_ray[k] = rec[k];
         cnt->last_shadow_count = 0;
+        cnt->last_hit_prim = hit_valid ? raw.prim : kNone, cnt->last_hit_t = ray.t_max;
     }
     Surface surf;
     if (hit_valid)

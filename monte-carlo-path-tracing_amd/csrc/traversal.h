@@ -381,8 +381,18 @@ MCPT_HD bool box_enter(const float4 &lo, const float4 &hi, const Ray &r, float &
     return t_enter <= t_exit;
 }
 
-// Watertight triangle test of triangle_hit on a walk_prims record (no mask).
-MCPT_HD bool triangle_hit_slot(const float4 *p, Ray &ray, HitRaw &out)
+// Watertight triangle test of triangle_hit on a walk_prims record, WITHOUT the
+// distance bound (and without a mask): does the ray's line hit the triangle at
+// t >= kEpsDistance, and where.  Predicated: one rare branch (the double-precision
+// edge fallback), no early-outs.
+struct SlotHit
+{
+    bool hit;
+    float t, a, b, c;
+    bool inside;
+};
+
+MCPT_HD SlotHit triangle_probe(const float4 *p, const Ray &ray)
 {
     const V3 A = xyz(p[0]) - ray.origin, B = xyz(p[1]) - ray.origin, C = xyz(p[2]) - ray.origin;
     const float Akz = comp(A, ray.kz), Bkz = comp(B, ray.kz), Ckz = comp(C, ray.kz);
@@ -390,25 +400,115 @@ MCPT_HD bool triangle_hit_slot(const float4 *p, Ray &ray, HitRaw &out)
     const float Bx = comp(B, ray.kx) - ray.shear.x * Bkz, By = comp(B, ray.ky) - ray.shear.y * Bkz;
     const float Cx = comp(C, ray.kx) - ray.shear.x * Ckz, Cy = comp(C, ray.ky) - ray.shear.y * Ckz;
     float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
-    if (U == 0.0f || V == 0.0f || W == 0.0f) // rare: the only branch kept
+    if (U == 0.0f || V == 0.0f || W == 0.0f)
     {
         U = static_cast<float>(D(Cx) * D(By) - D(Cy) * D(Bx));
         V = static_cast<float>(D(Ax) * D(Cy) - D(Ay) * D(Cx));
         W = static_cast<float>(D(Bx) * D(Ay) - D(By) * D(Ax));
     }
-    // the reference's early-outs (triangle.cpp:52-87) as one predicate: everything is
-    // computed, rejected lanes keep their state (a zero determinant only yields values
-    // that are thrown away)
     const bool mixed_signs = (U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f);
     const float det = U + V + W;
     const float T = U * (ray.shear.z * Akz) + V * (ray.shear.z * Bkz) + W * (ray.shear.z * Ckz);
     const float det_inv = 1.0f / det;
-    const float t = T * det_inv;
-    const bool accepted = !mixed_signs && det != 0.0f && !(t > ray.t_max || t < kEpsDistance);
-    ray.t_max = accepted ? t : ray.t_max;
-    out.a = accepted ? U * det_inv : out.a, out.b = accepted ? V * det_inv : out.b, out.c = accepted ? W * det_inv : out.c;
-    out.inside = accepted ? det_inv < 0 : out.inside;
-    return accepted;
+    SlotHit h;
+    h.t = T * det_inv;
+    h.hit = !mixed_signs && det != 0.0f && !(h.t < kEpsDistance);
+    h.a = U * det_inv, h.b = V * det_inv, h.c = W * det_inv, h.inside = det_inv < 0;
+    return h;
+}
+
+// Would the reference's walk reach primitive `prim` of `inst` with the bound `t_max`?
+// Its TLAS / BLAS boxes on the way are supersets of the primitive's own leaf box and the
+// slab test is monotone, so it comes down to that leaf box (see commit.cpp, WalkTreeBuilder).
+template <bool kAnalytic>
+MCPT_HD bool reference_leaf_box_passes(const DeviceScene &sc, uint32_t inst, uint32_t prim, Ray ray, float t_max)
+{
+    ray.t_max = t_max;
+    if (kAnalytic && sc.instances[inst].kind != kInstTriangles)
+    {
+        const size_t root = sc.instances[inst].blas_root; // a quadric is the single leaf of its BLAS
+        return box_hit(sc.nodes[2 * root], sc.nodes[2 * root + 1], ray);
+    }
+    const float4 *p = sc.tri_pos + 3 * static_cast<size_t>(prim);
+    const V3 lo = vmin(vmin(xyz(p[0]), xyz(p[1])), xyz(p[2])), hi = vmax(vmax(xyz(p[0]), xyz(p[1])), xyz(p[2]));
+    return box_hit(float4{lo.x, lo.y, lo.z, 0.0f}, float4{hi.x, hi.y, hi.z, 0.0f}, ray); // triangle.cpp:9-15
+}
+
+// State of a closest query of the ordered walk.  ray.t_max is the CULLING bound of the
+// box tests: slightly beyond the best distance, so that every primitive whose hit lies
+// within rounding distance of the best one is still visited and compared.
+struct ClosestState
+{
+    bool found;
+    float best_t;
+    uint32_t best_rank;
+};
+constexpr float kCullSlack = 1.000001f; // culling bound = best distance * this
+constexpr float kNearTie = 1e-5f;       // two hits closer than this (relative) are decided as the reference would
+
+// One primitive of the ordered walk.  Shadow queries: accepted iff hit within the fixed
+// bound.  Closest queries: the nearer hit wins; two hits within rounding distance of each
+// other are decided by replaying what the reference does with that pair: it visits them
+// in rank order, the first is accepted, the second only if its leaf box still passes with
+// the first one's distance as the bound and its own distance is not larger
+// (triangle.cpp:82) — and the later accepted one is kept.  This covers exact ties (shared
+// edges, two surfaces in one plane) and the case where a flat box's entry distance and
+// the triangle's own distance differ in the last bit.  Returns whether `hit` changed.
+template <bool kAny, bool kAnalytic>
+MCPT_HD bool test_slot(const DeviceScene &sc, uint32_t slot, Ray &ray, HitRaw &hit, ClosestState &best)
+{
+    const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(slot);
+    const uint32_t prim = as_uint(p[0].w), inst = as_uint(p[1].w), rank = as_uint(p[2].w);
+    SlotHit h;
+    if (!kAnalytic || sc.instances[inst].kind == kInstTriangles)
+    {
+        h = triangle_probe(p, ray);
+    }
+    else
+    {
+        const InstanceRec &rec = sc.instances[inst];
+        Ray probe = ray;
+        if (!kAny)
+            probe.t_max = kMaxFloat;
+        HitRaw cand;
+        cand.a = cand.b = cand.c = 0.0f, cand.inside = false;
+        uint32_t unused_rng = 0;
+        if (rec.kind == kInstSphere)
+            h.hit = sphere_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, probe, unused_rng, cand);
+        else if (rec.kind == kInstDisk)
+            h.hit = disk_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, probe, unused_rng, cand);
+        else
+            h.hit = cylinder_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, probe, unused_rng, cand);
+        h.t = probe.t_max, h.a = cand.a, h.b = cand.b, h.c = cand.c, h.inside = cand.inside;
+    }
+    bool take;
+    if (kAny)
+    {
+        take = h.hit && !(h.t > ray.t_max);
+    }
+    else
+    {
+        take = h.hit && (best.found ? h.t < best.best_t : !(h.t > ray.t_max));
+        if (h.hit && best.found && fabsf(h.t - best.best_t) <= kNearTie * best.best_t)
+        {
+            // rare: replay the reference on the pair (current best, this primitive)
+            if (rank > best.best_rank) // the reference comes here second
+                take = !(h.t > best.best_t) && reference_leaf_box_passes<kAnalytic>(sc, inst, prim, ray, best.best_t);
+            else // the reference came here first; the current best is its second
+                take = !(!(best.best_t > h.t) && reference_leaf_box_passes<kAnalytic>(sc, hit.inst, hit.prim, ray, h.t));
+        }
+    }
+    if (take)
+    {
+        hit.inst = inst, hit.prim = prim, hit.a = h.a, hit.b = h.b, hit.c = h.c, hit.inside = h.inside;
+        best.found = true;
+        if (!kAny)
+        {
+            best.best_t = h.t, best.best_rank = rank;
+            ray.t_max = h.t * kCullSlack;
+        }
+    }
+    return take;
 }
 
 // True for exactly one of the currently active lanes of the wavefront.
@@ -432,8 +532,7 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
 {
     if (sc.integrator.n_walk_nodes == 0)
         return false;
-    bool found = false;
-    uint32_t best_rank = 0;
+    ClosestState best{false, ray.t_max, 0};
     // entry 0 of the stack is a sentinel that reads as "no more work": popping never
     // has to test for an empty stack
     stack[0] = kWalkDone;
@@ -478,45 +577,14 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
             if (is_leading_lane())
                 ++stats.wave_prim_steps;
         }
-        const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(cur & ~kWalkLeaf);
-        const uint32_t prim = as_uint(p[0].w), inst = as_uint(p[1].w), rank = as_uint(p[2].w);
-        const float t_before = ray.t_max;
-        HitRaw cand;
-        cand.inst = inst, cand.prim = prim, cand.a = cand.b = cand.c = 0.0f, cand.inside = false;
-        bool accepted;
-        uint32_t unused_rng = 0;
-        if (!kAnalytic)
-        {
-            accepted = triangle_hit_slot(p, ray, cand);
-        }
-        else
-        {
-            const InstanceRec &rec = sc.instances[inst];
-            if (rec.kind == kInstTriangles)
-                accepted = triangle_hit_slot(p, ray, cand);
-            else if (rec.kind == kInstSphere)
-                accepted = sphere_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, ray, unused_rng, cand);
-            else if (rec.kind == kInstDisk)
-                accepted = disk_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, ray, unused_rng, cand);
-            else
-                accepted = cylinder_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, ray, unused_rng, cand);
-        }
-        // equal distance: the reference keeps whichever it visits later
-        if (accepted && !kAny && found && ray.t_max == t_before && rank < best_rank)
-            accepted = false;
-        if (accepted)
-        {
-            found = true;
-            hit = cand;
-            hit.inst = inst, hit.prim = prim;
-            best_rank = rank;
-            if (kAny)
-                return true;
-        }
+        if (test_slot<kAny, kAnalytic>(sc, cur & ~kWalkLeaf, ray, hit, best) && kAny)
+            return true;
         --depth;
         cur = stack[depth * kWalkStackStride];
     }
-    return found;
+    if (!kAny)
+        ray.t_max = best.found ? best.best_t : ray.t_max; // the exact distance, not the culling bound
+    return best.found;
 }
 
 // Number of lanes of the wavefront for which `p` holds (1 or 0 on the host).
@@ -546,8 +614,7 @@ MCPT_HD bool walk_ordered_vote(const DeviceScene &sc, uint32_t *stack, Ray &ray,
 {
     if (sc.integrator.n_walk_nodes == 0)
         return false;
-    bool found = false;
-    uint32_t best_rank = 0;
+    ClosestState best{false, ray.t_max, 0};
     // entry 0 of the stack is a sentinel that reads as "no more work": popping never
     // has to test for an empty stack
     stack[0] = kWalkDone;
@@ -607,48 +674,17 @@ MCPT_HD bool walk_ordered_vote(const DeviceScene &sc, uint32_t *stack, Ray &ray,
             if (is_leading_lane())
                 ++stats.wave_prim_steps;
         }
-        const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(cur & ~kWalkLeaf);
-        const uint32_t prim = as_uint(p[0].w), inst = as_uint(p[1].w), rank = as_uint(p[2].w);
-        const float t_before = ray.t_max;
-        HitRaw cand;
-        cand.inst = inst, cand.prim = prim, cand.a = cand.b = cand.c = 0.0f, cand.inside = false;
-        bool accepted;
-        uint32_t unused_rng = 0;
-        if (!kAnalytic)
+        if (test_slot<kAny, kAnalytic>(sc, cur & ~kWalkLeaf, ray, hit, best) && kAny)
         {
-            accepted = triangle_hit_slot(p, ray, cand);
-        }
-        else
-        {
-            const InstanceRec &rec = sc.instances[inst];
-            if (rec.kind == kInstTriangles)
-                accepted = triangle_hit_slot(p, ray, cand);
-            else if (rec.kind == kInstSphere)
-                accepted = sphere_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, ray, unused_rng, cand);
-            else if (rec.kind == kInstDisk)
-                accepted = disk_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, ray, unused_rng, cand);
-            else
-                accepted = cylinder_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, ray, unused_rng, cand);
-        }
-        // equal distance: the reference keeps whichever it visits later
-        if (accepted && !kAny && found && ray.t_max == t_before && rank < best_rank)
-            accepted = false;
-        if (accepted)
-        {
-            found = true;
-            hit = cand;
-            hit.inst = inst, hit.prim = prim;
-            best_rank = rank;
-            if (kAny)
-            {
-                cur = kWalkDone;
-                continue;
-            }
+            cur = kWalkDone;
+            continue;
         }
         --depth;
         cur = stack[depth * kWalkStackStride];
     }
-    return found;
+    if (!kAny)
+        ray.t_max = best.found ? best.best_t : ray.t_max; // the exact distance, not the culling bound
+    return best.found;
 }
 
 // Shading frame of the closest hit (second half of the reference's primitive

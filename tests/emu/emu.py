@@ -47,6 +47,11 @@ class Emulator:
     ORDERED = 32      # feature bit of the ordered walk in a forced `variant`
     REFERENCE = -2    # `variant`: the launcher's pick, but with the reference-order walk
 
+    def set_walk_tree(self, strategy: int):
+        """Split rule of the ordered-walk hierarchy for later renders: 0 production,
+        1 exact sweep, 2 median, 3 children swapped."""
+        self.lib.mcpt_emu_set_walk_tree(int(strategy))
+
     def wave_model(self, mcsd_path):
         """Lock-step 64-lane model of the walks (see emulator.cpp): what a wavefront pays
         when the shadow walk runs on its own vs paired with the next closest walk."""

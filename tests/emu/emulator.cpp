@@ -74,6 +74,10 @@ extern "C"
 
 const char *mcpt_emu_last_error(void) { return g_error.c_str(); }
 
+// 0 = production split rule of the ordered-walk hierarchy, 1 = exact sweep, 2 = median,
+// 3 = children swapped (commit.hpp).  Process-wide.
+void mcpt_emu_set_walk_tree(int strategy) { SetWalkTreeStrategyForTesting(strategy); }
+
 // variant: -1 = pick like the GPU launcher does, otherwise a feature mask to
 // force (must be a superset of the scene's features).  Bit kFeatOrderedWalk of a
 // forced mask selects the ordered walk; -1 uses it whenever the launcher would
@@ -298,10 +302,14 @@ void RunPool(const DeviceScene &sc, const std::vector<std::array<float, 7>> &ray
                     continue;
                 m.prim_tests += 1;
                 const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(it.ref & ~kWalkLeaf);
-                HitRaw cand;
                 Ray &ray = r[it.ray];
-                if (triangle_hit_slot(p, ray, cand) && any)
-                    done[it.ray] = 1;
+                const SlotHit sh = triangle_probe(p, ray);
+                if (sh.hit && !(sh.t > ray.t_max))
+                {
+                    ray.t_max = sh.t;
+                    if (any)
+                        done[it.ray] = 1;
+                }
             }
             continue;
         }
@@ -436,11 +444,15 @@ void RunSpeculative(const DeviceScene &sc, const std::vector<std::array<float, 7
             {
                 m.prim_tests += 1;
                 const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(ref & ~kWalkLeaf);
-                HitRaw cand;
-                if (triangle_hit_slot(p, l.ray, cand) && any)
+                const SlotHit sh = triangle_probe(p, l.ray);
+                if (sh.hit && !(sh.t > l.ray.t_max))
                 {
-                    l.done = true;
-                    break;
+                    l.ray.t_max = sh.t;
+                    if (any)
+                    {
+                        l.done = true;
+                        break;
+                    }
                 }
             }
             l.pending.clear();
@@ -555,6 +567,46 @@ int mcpt_emu_pool_model(const char *mcsd_path, double *out)
     {
         g_error = e.what();
         return 1;
+    }
+}
+
+// Debug: the steps of one pixel with either walk.  out: per step 12 floats
+// {closest ray (7), hit primitive, hit distance, shadow count, shadow result, rng}.
+int mcpt_emu_debug_pixel(const char *mcsd_path, uint32_t pixel, int ordered, float *out, uint32_t capacity)
+{
+    try
+    {
+        const FlatScene flat = CommitScene(mcsd::Load(mcsd_path));
+        const DeviceScene sc = flat.HostView();
+        constexpr uint32_t kAllF = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
+        PathState st;
+        uint32_t stack[kWalkStackMax];
+        st.stack = stack;
+        LaneCounters cnt{};
+        start_pixel(st, pixel);
+        uint32_t n = 0;
+        while (!pixel_done(sc, st) && n < capacity)
+        {
+            if (!st.alive)
+                start_sample(sc, st);
+            if (ordered)
+                path_step<Config<kAllF | kFeatOrderedWalk>>(sc, st, &cnt);
+            else
+                path_step<Config<kAllF>>(sc, st, &cnt);
+            float *o = out + 12 * n++;
+            for (int k = 0; k < 7; ++k)
+                o[k] = cnt.last_closest_ray[k];
+            o[7] = static_cast<float>(cnt.last_hit_prim == kNone ? -1.0 : double(cnt.last_hit_prim));
+            o[8] = cnt.last_hit_t, o[9] = static_cast<float>(cnt.last_shadow_count);
+            o[10] = static_cast<float>(cnt.last_shadow_hit);
+            std::memcpy(&o[11], &st.rng, 4);
+        }
+        return static_cast<int>(n);
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return -1;
     }
 }
 
