@@ -29,15 +29,19 @@ namespace mcpt
 // held to 128 VGPRs = 4 wavefronts per SIMD = 4 workgroups of 256 per CU, so
 // that a 512x512 frame (262 144 pixels = 256 CUs x 1024 lanes) is resident in
 // one round; the material instantiations run 3 per SIMD.
-template <uint32_t kFeatures>
+template <uint32_t kFeatures, bool kLdsGeometry = true>
 struct Budget
 {
+    // The lean instantiations for scenes too large for LDS are memory-latency bound (0.8 M
+    // triangles: 63 % of wave cycles waiting, VALU pipe 41 % busy): held to 6 per SIMD (80 VGPRs,
+    // some spilling) they are 11 % (blob field) and 19 % (terrain) faster than at 4.
     // measured: the full instantiation at 3 per SIMD (<= 168 VGPRs) is 17 % faster on the
     // volumetric scenes than at 2 (208 VGPRs); the surface-materials instantiation needs 168
     // either way and is 3 % slower when the compiler is held to it
     static constexpr int kWavesPerSimd = (kFeatures & (kFeatVolPath | kFeatAnalytic)) ? 3
                                          : (kFeatures & kFeatMicrofacet)              ? 2
-                                                                                      : 4;
+                                         : kLdsGeometry                                ? 4
+                                                                                      : 6;
 };
 
 // kLdsGeometry: the arrays the ray queries and the light sampler read (both
@@ -49,7 +53,7 @@ struct Budget
 // The ordered walk's stacks always live in LDS: lane t of the workgroup owns the
 // words t, t + 256, t + 512, ... of the stack area.
 template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
-__global__ void __launch_bounds__(kBlockSize, Budget<kFeatures>::kWavesPerSimd)
+__global__ void __launch_bounds__(kBlockSize, (Budget<kFeatures, kLdsGeometry>::kWavesPerSimd))
 render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ out, TraceCounters *__restrict__ counters)
 {
     using C = Config<kFeatures>;
