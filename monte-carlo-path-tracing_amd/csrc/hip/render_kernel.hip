@@ -36,10 +36,11 @@ struct Budget
     // triangles: 63 % of wave cycles waiting, VALU pipe 41 % busy): held to 6 per SIMD (80 VGPRs,
     // some spilling) they are 11 % (blob field) and 19 % (terrain) faster than at 4.
     // measured: the full instantiation at 3 per SIMD (<= 168 VGPRs) is 17 % faster on the
-    // volumetric scenes than at 2 (208 VGPRs); the surface-materials instantiation needs 168
-    // either way and is 3 % slower when the compiler is held to it
+    // volumetric scenes than at 2 (208 VGPRs), slower again at 4 (-3 %) and 6 (-24 %); the
+    // surface-materials instantiation (matpreview) is fastest at 6 (rough dielectric +25 %,
+    // rough conductor +3 % over its natural 168 VGPRs)
     static constexpr int kWavesPerSimd = (kFeatures & (kFeatVolPath | kFeatAnalytic)) ? 3
-                                         : (kFeatures & kFeatMicrofacet)              ? 2
+                                         : (kFeatures & kFeatMicrofacet)              ? 6
                                          : kLdsGeometry                                ? 4
                                                                                       : 6;
 };
