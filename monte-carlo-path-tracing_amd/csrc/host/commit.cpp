@@ -234,7 +234,13 @@ public:
         threads_left_ = static_cast<int>(std::max(1u, std::thread::hardware_concurrency())) - 1;
         Bounds all;
         uint32_t depth = 0;
-        const uint32_t root = Emit(0, n, kWalkDepthMax - 1, 1, all, depth);
+        // Depth budget.  The traversal stacks live in LDS at 1 KiB per level and workgroup, and
+        // six workgroups per CU (the occupancy the latency-bound mesh kernels want) fit 26 levels
+        // including the sentinel: aim for at most 24 interior levels below the top node whenever
+        // that leaves a few levels of slack over a balanced tree, otherwise the hard bound.
+        const uint32_t balanced = Log2Ceil(n);
+        const uint32_t budget = balanced + 4 <= 24 ? 24u : kWalkDepthMax - 1;
+        const uint32_t root = Emit(0, n, budget, 1, all, depth);
         Bounds none; // lo = +max, hi = -max: never entered
         nodes_[0] = Pack(all.lo, Bits(root)), nodes_[1] = Pack(all.hi, Bits(root));
         nodes_[2] = Pack(none.lo, 0.0f), nodes_[3] = Pack(none.hi, 0.0f);
