@@ -46,6 +46,228 @@ std::string SuffixOf(const std::string &path)
 } // namespace
 
 // ---------------------------------------------------------------------------
+// PLY (ascii and binary_little_endian): x y z [nx ny nz] [s t | u v] per vertex,
+// faces as index lists (fans).  The reference imports PLY through assimp with
+// aiProcess_GenSmoothNormals (model_loader.cpp:506-529); without stored normals the
+// vertex normals here are the normalised sums of the (area-weighted) face normals of the
+// faces sharing the vertex — assimp's rule for vertices that share an index; assimp also
+// merges vertices at equal positions and limits the smoothing angle, which is not
+// reproduced (same caveat as for OBJ tangents).
+// ---------------------------------------------------------------------------
+MeshData LoadPly(const std::string &path, bool face_normals)
+{
+    const std::vector<uint8_t> f = ReadAll(path);
+    size_t at = 0;
+    auto line = [&]()
+    {
+        std::string s;
+        while (at < f.size() && f[at] != '\n')
+            s += static_cast<char>(f[at++]);
+        ++at;
+        if (!s.empty() && s.back() == '\r')
+            s.pop_back();
+        return s;
+    };
+    if (line() != "ply")
+        throw std::runtime_error("not a PLY file: '" + path + "'.");
+    struct Property
+    {
+        std::string name, type, count_type; // count_type non-empty: list
+    };
+    struct Element
+    {
+        std::string name;
+        size_t count = 0;
+        std::vector<Property> props;
+    };
+    std::vector<Element> elements;
+    bool binary = false;
+    for (;;)
+    {
+        if (at >= f.size())
+            throw std::runtime_error("truncated PLY header in '" + path + "'.");
+        std::istringstream ss(line());
+        std::string word;
+        ss >> word;
+        if (word == "end_header")
+            break;
+        if (word == "format")
+        {
+            ss >> word;
+            if (word == "binary_little_endian")
+                binary = true;
+            else if (word != "ascii")
+                throw std::runtime_error("unsupported PLY format '" + word + "' in '" + path + "'.");
+        }
+        else if (word == "element")
+        {
+            Element e;
+            ss >> e.name >> e.count;
+            elements.push_back(e);
+        }
+        else if (word == "property" && !elements.empty())
+        {
+            Property p;
+            ss >> p.type;
+            if (p.type == "list")
+                ss >> p.count_type >> p.type;
+            ss >> p.name;
+            elements.back().props.push_back(p);
+        }
+    }
+    auto type_size = [&](const std::string &t) -> size_t
+    {
+        if (t == "char" || t == "uchar" || t == "int8" || t == "uint8")
+            return 1;
+        if (t == "short" || t == "ushort" || t == "int16" || t == "uint16")
+            return 2;
+        if (t == "int" || t == "uint" || t == "float" || t == "int32" || t == "uint32" || t == "float32")
+            return 4;
+        if (t == "double" || t == "float64")
+            return 8;
+        throw std::runtime_error("unknown PLY type '" + t + "' in '" + path + "'.");
+    };
+    std::istringstream text;
+    if (!binary)
+        text.str(std::string(reinterpret_cast<const char *>(f.data()) + at, f.size() - at));
+    auto read_number = [&](const std::string &t) -> double
+    {
+        if (!binary)
+        {
+            double v = 0;
+            if (!(text >> v))
+                throw std::runtime_error("truncated PLY body in '" + path + "'.");
+            return v;
+        }
+        const size_t n = type_size(t);
+        if (at + n > f.size())
+            throw std::runtime_error("truncated PLY body in '" + path + "'.");
+        double v = 0;
+        const uint8_t *p = &f[at];
+        at += n;
+        if (t == "float" || t == "float32")
+        {
+            float x;
+            std::memcpy(&x, p, 4);
+            v = x;
+        }
+        else if (t == "double" || t == "float64")
+            std::memcpy(&v, p, 8);
+        else if (t == "char" || t == "int8")
+            v = static_cast<int8_t>(p[0]);
+        else if (t == "uchar" || t == "uint8")
+            v = p[0];
+        else if (t == "short" || t == "int16")
+        {
+            int16_t x;
+            std::memcpy(&x, p, 2);
+            v = x;
+        }
+        else if (t == "ushort" || t == "uint16")
+        {
+            uint16_t x;
+            std::memcpy(&x, p, 2);
+            v = x;
+        }
+        else if (t == "int" || t == "int32")
+        {
+            int32_t x;
+            std::memcpy(&x, p, 4);
+            v = x;
+        }
+        else
+        {
+            uint32_t x;
+            std::memcpy(&x, p, 4);
+            v = x;
+        }
+        return v;
+    };
+    MeshData m;
+    bool has_normals = false, has_uv = false;
+    for (const Element &e : elements)
+    {
+        int ix = -1, iy = -1, iz = -1, inx = -1, iny = -1, inz = -1, iu = -1, iv = -1;
+        for (size_t k = 0; k < e.props.size(); ++k)
+        {
+            const std::string &n = e.props[k].name;
+            const int i = static_cast<int>(k);
+            if (n == "x") ix = i; else if (n == "y") iy = i; else if (n == "z") iz = i;
+            else if (n == "nx") inx = i; else if (n == "ny") iny = i; else if (n == "nz") inz = i;
+            else if (n == "s" || n == "u" || n == "texture_u") iu = i;
+            else if (n == "t" || n == "v" || n == "texture_v") iv = i;
+        }
+        if (e.name == "vertex")
+        {
+            if (ix < 0 || iy < 0 || iz < 0)
+                throw std::runtime_error("PLY vertices without x y z in '" + path + "'.");
+            has_normals = inx >= 0 && iny >= 0 && inz >= 0, has_uv = iu >= 0 && iv >= 0;
+        }
+        std::vector<double> row;
+        for (size_t r = 0; r < e.count; ++r)
+        {
+            row.assign(e.props.size(), 0.0);
+            std::vector<uint32_t> list;
+            for (size_t k = 0; k < e.props.size(); ++k)
+            {
+                const Property &p = e.props[k];
+                if (p.count_type.empty())
+                    row[k] = read_number(p.type);
+                else
+                {
+                    const size_t n = static_cast<size_t>(read_number(p.count_type));
+                    std::vector<uint32_t> values(n);
+                    for (size_t j = 0; j < n; ++j)
+                        values[j] = static_cast<uint32_t>(read_number(p.type));
+                    if (e.name == "face" && (p.name == "vertex_indices" || p.name == "vertex_index"))
+                        list = values;
+                }
+            }
+            if (e.name == "vertex")
+            {
+                m.positions.insert(m.positions.end(), {float(row[ix]), float(row[iy]), float(row[iz])});
+                if (has_normals)
+                    m.normals.insert(m.normals.end(), {float(row[inx]), float(row[iny]), float(row[inz])});
+                if (has_uv)
+                    m.texcoords.insert(m.texcoords.end(), {float(row[iu]), float(row[iv])});
+            }
+            else if (e.name == "face")
+                for (size_t j = 1; j + 1 < list.size(); ++j)
+                    m.indices.insert(m.indices.end(), {list[0], list[j], list[j + 1]});
+        }
+    }
+    const size_t n_vert = m.positions.size() / 3;
+    for (const uint32_t i : m.indices)
+        if (i >= n_vert)
+            throw std::runtime_error("vertex index out of range in '" + path + "'.");
+    if (face_normals)
+        m.normals.clear();
+    else if (!has_normals)
+    {
+        std::vector<double> sum(3 * n_vert, 0.0);
+        for (size_t t = 0; t + 2 < m.indices.size(); t += 3)
+        {
+            const float *a = &m.positions[3 * m.indices[t]], *b = &m.positions[3 * m.indices[t + 1]],
+                        *c = &m.positions[3 * m.indices[t + 2]];
+            const double e1[3] = {double(b[0]) - a[0], double(b[1]) - a[1], double(b[2]) - a[2]},
+                         e2[3] = {double(c[0]) - a[0], double(c[1]) - a[1], double(c[2]) - a[2]};
+            const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            for (int k = 0; k < 3; ++k)
+                for (int j = 0; j < 3; ++j)
+                    sum[3 * m.indices[t + k] + j] += n[j];
+        }
+        m.normals.resize(3 * n_vert);
+        for (size_t v = 0; v < n_vert; ++v)
+        {
+            const double len = std::sqrt(sum[3 * v] * sum[3 * v] + sum[3 * v + 1] * sum[3 * v + 1] + sum[3 * v + 2] * sum[3 * v + 2]);
+            for (int j = 0; j < 3; ++j)
+                m.normals[3 * v + j] = len > 0 ? static_cast<float>(sum[3 * v + j] / len) : (j == 1 ? 1.0f : 0.0f);
+        }
+    }
+    return m;
+}
+
+// ---------------------------------------------------------------------------
 // OBJ.  Like the reference's assimp import without aiProcess_JoinIdenticalVertices
 // (model_loader.cpp:512-517): one vertex per face corner, faces triangulated as
 // fans, v texture coordinate flipped when asked (aiProcess_FlipUVs).

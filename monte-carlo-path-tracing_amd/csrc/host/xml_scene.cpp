@@ -20,7 +20,7 @@
 //     (parser.cpp:1545-1549);
 //   * integer values go through stoi, so max_depth = -1 becomes 0xFFFFFFFF.
 // Not supported (reported as errors): sun / sky emitters (Hosek-Wilkie model),
-// bitmap formats other than EXR (NONE/ZIP) and PFM, glTF / PLY meshes.
+// JPEG and other stb-only bitmap formats, glTF meshes.
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -807,7 +807,7 @@ private:
             const Node *radius = n.Child("float");
             in.cyl_radius = radius ? radius->Float("value", 1.0f) : 1.0f;
         }
-        else if (type == "obj" || type == "serialized")
+        else if (type == "obj" || type == "serialized" || type == "ply")
         {
             in.type = MCSD_INST_MESHES;
             const Node *file = n.Child("string");
@@ -816,6 +816,8 @@ private:
             MeshData mesh;
             if (type == "obj")
                 mesh = LoadObj(path, ReadBool(n, {"flip_tex_coords", "flipTexCoords"}, true), face_normals);
+            else if (type == "ply")
+                mesh = LoadPly(path, face_normals);
             else
             {
                 const Node *index = n.Child("integer");

@@ -1037,3 +1037,47 @@ def test_png_reader_on_a_reference_texture(pkg, tmp_path):
     ref = ref[..., None] if ref.ndim == 2 else ref
     assert (t.height, t.width, t.channel) == ref.shape
     np.testing.assert_array_equal(np.asarray(t.data).reshape(ref.shape), ref.astype(np.float32) / np.float32(255.0))
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_ply_shapes(pkg, tmp_path, binary):
+    """PLY meshes (the reference's box scene uses one): ascii and binary_little_endian,
+    extra vertex properties skipped, polygons fan-triangulated, smooth vertex normals
+    generated when the file has none, dropped when faceNormals is set."""
+    verts = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0.5, 0.5, 1]], np.float32)
+    faces = [[0, 1, 2, 3], [0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4]]
+    header = ("ply\nformat %s 1.0\ncomment test\nelement vertex 5\nproperty float x\nproperty float y\n"
+              "property float z\nproperty float confidence\nelement face 5\nproperty list uchar int vertex_indices\n"
+              "end_header\n" % ("binary_little_endian" if binary else "ascii")).encode()
+    if binary:
+        body = b"".join(struct.pack("<4f", *v, 0.5) for v in verts)
+        body += b"".join(struct.pack("<B%di" % len(f), len(f), *f) for f in faces)
+    else:
+        body = "".join("%g %g %g 0.5\n" % tuple(v) for v in verts).encode()
+        body += "".join("%d %s\n" % (len(f), " ".join(map(str, f))) for f in faces).encode()
+    files = {"models/p.ply": header + body}
+    body_xml = """<shape type="ply"><string name="filename" value="models/p.ply"/></shape>
+                  <shape type="ply"><string name="filename" value="models/p.ply"/><boolean name="faceNormals" value="true"/></shape>"""
+    s = translate(pkg, tmp_path, scene_xml(body_xml), files=files)
+    smooth, flat = s.instances
+    np.testing.assert_array_equal(smooth.positions, verts)
+    want = [[0, 1, 2], [0, 2, 3], [0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4]]
+    np.testing.assert_array_equal(smooth.indices, want)
+    assert flat.normals.size == 0
+    tri = verts[np.array(want)]
+    fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).astype(np.float64)
+    acc = np.zeros((5, 3))
+    for t, n in zip(want, fn):
+        acc[t] += n
+    np.testing.assert_allclose(smooth.normals, acc / np.linalg.norm(acc, axis=1, keepdims=True), atol=1e-6)
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_SCENES + "/box/scene_v0.6.xml"), reason="reference scene files not present")
+def test_box_scene_file(pkg, tmp_path):
+    cfg = pkg.capi.Config.load_xml(REF_SCENES + "/box/scene_v0.6.xml")
+    out = tmp_path / "box.mcsd"
+    cfg.save_mcsd(out)
+    s = pkg.mcsd.load(out)
+    bunny = max(s.instances, key=lambda i: len(i.indices))
+    assert len(bunny.indices) == 16301 and len(bunny.positions) == 8171 and len(bunny.normals) == 8171
+    assert np.allclose(np.linalg.norm(bunny.normals, axis=1), 1, atol=1e-5)
