@@ -798,10 +798,13 @@ ImageData LoadFloatImage(const std::string &path, float gamma)
             for (float &v : img.data)
                 v = std::pow(v, gamma);
     }
-    else if (suffix == "png")
+    else if (suffix == "png" || suffix == "jpg" || suffix == "jpeg")
     {
         std::vector<uint8_t> px;
-        LoadPng8(path, img.width, img.height, img.channel, px);
+        if (suffix == "png")
+            LoadPng8(path, img.width, img.height, img.channel, px);
+        else
+            LoadJpeg8(path, img.width, img.height, img.channel, px);
         img.data.resize(px.size());
         for (size_t i = 0; i < px.size(); ++i)
         {
@@ -812,7 +815,7 @@ ImageData LoadFloatImage(const std::string &path, float gamma)
     else
     {
         throw std::runtime_error("unsupport input image format for image '" + path +
-                                 "' (supported: .exr, .pfm, .hdr, .png).");
+                                 "' (supported: .exr, .pfm, .hdr, .png, .jpg).");
     }
     return img;
 }

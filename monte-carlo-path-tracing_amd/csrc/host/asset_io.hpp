@@ -39,6 +39,7 @@ MeshData LoadPly(const std::string &path, bool face_normals);
 // `gamma` is applied per the file type's rule; the result is what the reference's
 // image_io::Read returns (before its optional down-scaling).
 ImageData LoadFloatImage(const std::string &path, float gamma = 0.0f);
+void LoadJpeg8(const std::string &path, int &width, int &height, int &channel, std::vector<uint8_t> &pixels);
 void LoadPng8(const std::string &path, int &width, int &height, int &channel, std::vector<uint8_t> &pixels);
 ImageData LoadRadianceHdr(const std::string &path);
 

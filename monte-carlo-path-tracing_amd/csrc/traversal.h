@@ -317,6 +317,7 @@ MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &
         // host-vs-device differential test, tests/test_gpu_units.py).
         HitRaw cand;
         cand.inst = inst, cand.prim = object, cand.a = cand.b = cand.c = 0.0f, cand.inside = false;
+        const float t_before = ray.t_max;
         bool accepted;
         if (!kAnalytic || inst_kind == kInstTriangles)
             accepted = triangle_hit<kTextures>(sc, object, inst_bsdf, ray, rng, cand);
@@ -326,6 +327,14 @@ MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &
             accepted = disk_hit<kTextures>(sc, sc.analytic[inst_analytic], object, inst_bsdf, ray, rng, cand);
         else
             accepted = cylinder_hit<kTextures>(sc, sc.analytic[inst_analytic], object, inst_bsdf, ray, rng, cand);
+        if (accepted && !kAny && !(ray.t_max <= t_before))
+        {
+            // NaN distance (a ray with NaN components passes every test of the reference too):
+            // the reference walks the instance with a copy of the ray and merges the result only
+            // if `local.t_max <= ray.t_max` (tlas.cpp:27-33), which drops it
+            ray.t_max = t_before;
+            accepted = false;
+        }
         if (accepted)
         {
             found = true;
@@ -488,7 +497,9 @@ MCPT_HD bool test_slot(const DeviceScene &sc, uint32_t slot, Ray &ray, HitRaw &h
     }
     else
     {
-        take = h.hit && (best.found ? h.t < best.best_t : !(h.t > ray.t_max));
+        // (a NaN distance — a ray with NaN components "hits" everything — is never kept: the
+        //  reference drops such an instance hit when it merges it, tlas.cpp:27-33)
+        take = h.hit && (best.found ? h.t < best.best_t : h.t <= ray.t_max);
         if (h.hit && best.found && fabsf(h.t - best.best_t) <= kNearTie * best.best_t)
         {
             // rare: replay the reference on the pair (current best, this primitive)

@@ -36,11 +36,22 @@ def edge_scenes(pkg):
                                   positions=np.array([[0, 1, 0], [0, 1, 0], [0.2, 1.2, 0]], np.float32),
                                   indices=np.array([[0, 1, 2]], np.uint32)))
     out["degenerate_triangle"] = s
+    # a mesh whose texture coordinates are all equal and that has no normals: the tangent rule divides by a
+    # zero uv determinant, the shading frame is NaN, the scattered ray is NaN — which "passes" every
+    # comparison of the reference's box and triangle tests and is only dropped when an instance's hit is
+    # merged (tlas.cpp:27-33).  (Found with the reference's classroom scene, where one such triangle made
+    # 88 % of the pixels differ before closest queries dropped NaN distances.)
+    s = S.cornell_box(24, 24, 4)
+    s.instances.append(M.Instance(type=M.INST_MESHES, id_bsdf=2,
+                                  positions=np.array([[-0.6, 0.9, -0.5], [0.6, 0.9, -0.5], [0, 0.9, 0.7]], np.float32),
+                                  texcoords=np.array([[0, 1], [0, 1], [0, 1]], np.float32),
+                                  indices=np.array([[0, 1, 2]], np.uint32)))
+    out["nan_shading_frame"] = s
     return out
 
 
 NAMES = ["empty_scene_constant_emitter", "empty_scene_dark", "light_only", "no_lights", "film_1x1", "film_3x5",
-         "film_65x9", "spp_1", "depth_max_0", "depth_max_1", "roulette_from_start", "degenerate_triangle"]
+         "film_65x9", "spp_1", "depth_max_0", "depth_max_1", "roulette_from_start", "degenerate_triangle", "nan_shading_frame"]
 
 
 @pytest.fixture(scope="module")
@@ -65,7 +76,7 @@ def test_edge_case_on_cpu(name, pkg, oracle, emulator, mcsd_file, request):
     import checkers
     # (the compiled reference rebuilds its Kulla-Conty table on every render: ~5 s, so a subset)
     if checkers.reference_available() and name in ("empty_scene_constant_emitter", "film_3x5", "depth_max_0",
-                                                   "degenerate_triangle"):
+                                                   "degenerate_triangle", "nan_shading_frame"):
         ref, _ = checkers.Reference().render(path, w, h)
         np.testing.assert_array_equal(ref, want)
 

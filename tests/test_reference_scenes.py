@@ -34,3 +34,30 @@ def test_scene_file_renders_identically_everywhere(pkg, oracle, reference, emula
     assert np.isfinite(want).all() and want.max() > 0
     np.testing.assert_array_equal(got_oracle, want)
     np.testing.assert_array_equal(got_kernel_body, want)
+
+
+@pytest.mark.parametrize("scene", ["classroom", "dining-room"])
+def test_textured_scene_renders_identically_everywhere(pkg, oracle, reference, emulator, tmp_path, scene):
+    """classroom and dining-room (dozens of OBJ meshes, JPEG / PNG textures, rough plastic /
+    conductor / dielectric materials) with their out-of-scope `sunsky` emitter replaced by a
+    constant one.  Besides being the largest instance counts tested, classroom contains a
+    triangle with identical texture coordinates at all corners: NaN shading frame, NaN
+    rays (see tests/test_edge_cases.py, nan_shading_frame)."""
+    import re
+    src = f"{REF_SCENES}/{scene}"
+    text = re.sub(r'<emitter type="sunsky".*?</emitter>',
+                  '<emitter type="constant"><rgb name="radiance" value="1"/></emitter>',
+                  open(f"{src}/scene_v0.6.xml").read(), flags=re.S)
+    for sub in ("models", "textures"):
+        os.symlink(f"{src}/{sub}", tmp_path / sub)
+    (tmp_path / "scene.xml").write_text(text)
+    w, h, spp = 48, 27, 2
+    cfg = pkg.capi.Config.load_xml(tmp_path / "scene.xml").set_film(w, h, spp)
+    path = tmp_path / "scene.mcsd"
+    cfg.save_mcsd(path)
+    want, _ = reference.render(path, w, h)
+    got_oracle, _ = oracle.render(path)
+    np.testing.assert_array_equal(got_oracle, want)
+    for variant in (-1, emulator.REFERENCE):
+        got, _ = emulator.render(path, w, h, variant=variant)
+        np.testing.assert_array_equal(got, want)

@@ -1081,3 +1081,68 @@ def test_box_scene_file(pkg, tmp_path):
     bunny = max(s.instances, key=lambda i: len(i.indices))
     assert len(bunny.indices) == 16301 and len(bunny.positions) == 8171 and len(bunny.normals) == 8171
     assert np.allclose(np.linalg.norm(bunny.normals, axis=1), 1, atol=1e-5)
+
+
+@pytest.mark.parametrize("subsampling, size, grey", [(0, (40, 24), False), (2, (40, 24), False), (2, (37, 21), False),
+                                                     (1, (33, 18), False), (0, (19, 30), True), (2, (130, 70), False)])
+def test_jpeg_reader(pkg, tmp_path, subsampling, size, grey):
+    """Baseline JPEG files written by PIL (4:4:4, 4:2:2, 4:2:0, greyscale, sizes that are
+    not MCU multiples) against PIL's own decoder.  The reader follows stb_image's
+    numerical choices (the reference's decoder); libjpeg-turbo differs from those in the
+    precision of its inverse DCT (13-bit constants against 12), in the rounding of the
+    chroma filter and in the colour conversion: agreement within 1 level of 255 for
+    greyscale, 2 for full-resolution chroma, 3 for subsampled chroma, and most samples
+    exactly equal."""
+    from PIL import Image
+    rng = np.random.default_rng(size[0] * 31 + subsampling)
+    w, h = size
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([128 + 100 * np.sin(xx * 0.21), 128 + 90 * np.cos(yy * 0.17), 128 + 80 * np.sin((xx + yy) * 0.11)], -1)
+    arr = np.clip(base + rng.normal(0, 6, (h, w, 3)), 0, 255).astype(np.uint8)
+    img = Image.fromarray(arr[..., 0], "L") if grey else Image.fromarray(arr, "RGB")
+    (tmp_path / "tex").mkdir()
+    path = tmp_path / "tex" / "a.jpg"
+    img.save(path, quality=90, **({} if grey else {"subsampling": subsampling}))
+    want = np.asarray(Image.open(path)).astype(np.int32)
+    want = want[..., None] if grey else want
+    body = '<texture type="bitmap" id="a"><string name="filename" value="tex/a.jpg"/><float name="gamma" value="1"/></texture>'
+    t = translate(pkg, tmp_path, scene_xml(body)).textures[0]
+    assert (t.width, t.height, t.channel) == (w, h, 1 if grey else 3)
+    got = np.rint(np.asarray(t.data).reshape(want.shape) * 255).astype(np.int32)
+    tol = 1 if grey else (2 if subsampling == 0 else 3)
+    diff = np.abs(got - want)
+    if subsampling == 1:
+        # stb_image's 2:1 horizontal filter weights the LAST BUT ONE chroma sample 3:1 over the last one
+        # in the second-to-last output column (stb_image.h:3492) where libjpeg does the opposite; followed
+        # on purpose, so that column is not compared
+        diff = diff[:, :-2]
+    assert diff.max() <= tol and diff.mean() < 0.4 and (diff == 0).mean() > 0.6, (diff.max(), diff.mean(), (diff == 0).mean())
+
+
+@pytest.mark.skipif(not os.path.isfile(REF_SCENES + "/dining-room/scene_v0.6.xml"), reason="reference scene files not present")
+@pytest.mark.parametrize("scene, n_bitmaps", [("classroom", 3), ("dining-room", 3)])
+def test_textured_reference_scenes(pkg, tmp_path, scene, n_bitmaps):
+    """classroom (79 OBJ meshes, three JPEG textures) and dining-room (53 meshes, JPEG and
+    PNG textures): everything loads up to their `sunsky` emitter (Hosek-Wilkie model, out
+    of scope), which stops the translation with a clear message; with that element taken
+    out the scenes translate and commit."""
+    import re
+    src = f"{REF_SCENES}/{scene}"
+    with pytest.raises(RuntimeError, match="sun / sky"):
+        pkg.capi.Config.load_xml(f"{src}/scene_v0.6.xml")
+    text = open(f"{src}/scene_v0.6.xml").read()
+    text, n = re.subn(r'<emitter type="sunsky".*?</emitter>', '<emitter type="constant"><rgb name="radiance" value="1"/></emitter>',
+                      text, flags=re.S)
+    assert n == 1
+    for sub in ("models", "textures"):
+        os.symlink(f"{src}/{sub}", tmp_path / sub)
+    (tmp_path / "scene.xml").write_text(text)
+    cfg = pkg.capi.Config.load_xml(tmp_path / "scene.xml")
+    out = tmp_path / "s.mcsd"
+    cfg.save_mcsd(out)
+    s = pkg.mcsd.load(out)
+    assert len(s.instances) > 40 and sum(len(i.indices) for i in s.instances) > 10000
+    bitmaps = [t for t in s.textures if t.type == pkg.mcsd.TEX_BITMAP]
+    assert len(bitmaps) >= n_bitmaps
+    for t in bitmaps:
+        assert t.channel in (1, 3, 4) and 0 <= min(t.data) and max(t.data) <= 1
