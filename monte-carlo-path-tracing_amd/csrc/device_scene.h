@@ -215,6 +215,8 @@ struct IntegratorRec // reference integrator.hpp:31-69 (the scalar part)
     uint32_t walk_hold;    // ... or when at least this many lanes hold a primitive (0 = never for that reason)
     uint32_t walk_break;   // wavefront scheduling of the ordered walk (traversal.h, walk_ordered_vote): leave
                            // the node phase when fewer lanes than this are searching; 0 = wait for all
+    float walk_tie;        // distance below which two hits of the ordered walk count as tied (traversal.h,
+                           // test_slot): ~16 float roundings at the scene's largest coordinate
 };
 
 // Feature bits: which parts of the hot path a scene actually exercises.  The

@@ -6,10 +6,9 @@
 // :426-504 for .serialized) and src/utils/image_io.cpp:55-158 (tinyexr, stb).
 // Neither assimp nor tinyexr exists here, so these are written from the file
 // format definitions.  Mesh records come out the way the reference hands them
-// to the renderer: positions / normals / texcoords per vertex + index triples,
-// tangents left empty (that selects the renderer's own UV-derived tangent frame,
-// reference scene.cpp:63-80; assimp's CalcTangentSpace output is not
-// reproducible without assimp — SURVEY.md §8c).
+// to the renderer: positions / normals / texcoords / tangents / bitangents per vertex +
+// index triples; generated normals and the tangent frames restate assimp's
+// post-processing steps (mesh_postprocess.cpp; unpinned — SURVEY.md §8c).
 #include "asset_io.hpp"
 
 #include <cmath>
@@ -264,6 +263,8 @@ MeshData LoadPly(const std::string &path, bool face_normals)
                 m.normals[3 * v + j] = len > 0 ? static_cast<float>(sum[3 * v + j] / len) : (j == 1 ? 1.0f : 0.0f);
         }
     }
+    if (!face_normals)
+        CalcTangentSpace(m); // (with face_normals a PLY without stored normals has none to build the frame on)
     return m;
 }
 
@@ -367,8 +368,14 @@ MeshData LoadObj(const std::string &path, bool flip_texcoords, bool face_normals
         throw std::runtime_error("no faces in '" + path + "'.");
     if (!all_have_uv)
         m.texcoords.clear();
-    if (!all_have_normal || face_normals)
-        m.normals.clear(); // flat normals are derived by the commit (scene.cpp:51-56)
+    if (!all_have_normal)
+        m.normals.clear();
+    // the importer steps the reference asks for (model_loader.cpp:512-517), in assimp's order
+    if (m.normals.empty() && !face_normals)
+        GenerateSmoothNormals(m);
+    CalcTangentSpace(m); // from the file's or the generated normals; nothing without normals or texcoords
+    if (face_normals)
+        m.normals.clear(); // not handed over (model_loader.cpp:362); flat normals come from the commit (scene.cpp:51-56)
     return m;
 }
 

@@ -14,8 +14,13 @@ struct MeshData
     std::vector<float> positions; // 3 per vertex
     std::vector<float> normals;   // 3 per vertex or empty
     std::vector<float> texcoords; // 2 per vertex or empty
+    std::vector<float> tangents, bitangents; // 3 per vertex or empty (mesh_postprocess.cpp)
     std::vector<uint32_t> indices; // 3 per triangle
 };
+
+// The importer post-processing the reference requests for OBJ / PLY (mesh_postprocess.cpp).
+void GenerateSmoothNormals(MeshData &m);
+void CalcTangentSpace(MeshData &m);
 
 struct ImageData
 {

@@ -1023,6 +1023,16 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
         // (sweep on the matpreview scene and a 0.8 M-triangle scene: flat optimum around 6..8 / 10..12)
         ig.walk_break = n_prims >= 2048 ? 8u : 0u;
         ig.walk_hold = n_prims >= 2048 ? 12u : 0u;
+        // The triangle test's distance carries an ABSOLUTE error of a few roundings at the magnitude
+        // of the vertices' offsets from the ray origin (it is a weighted mean of those), whatever the
+        // distance itself is; a leaf box's entry distance does not.  Hits closer together than that
+        // are "tied": the walk must visit both and decide like the reference (traversal.h, test_slot).
+        // Offsets are at most (largest |coordinate| of the geometry or the eye) * 2.
+        float coordinate = std::max({fabsf(fs.camera.eye.x), fabsf(fs.camera.eye.y), fabsf(fs.camera.eye.z)});
+        for (const Bounds &b : prim_box)
+            coordinate = std::max({coordinate, fabsf(b.lo.x), fabsf(b.lo.y), fabsf(b.lo.z), fabsf(b.hi.x), fabsf(b.hi.y),
+                                   fabsf(b.hi.z)});
+        ig.walk_tie = 2.0f * coordinate * 1e-6f;
         fs.walk_prims.reserve(3 * slot_prim.size());
         for (const uint32_t prim : slot_prim)
         {

@@ -826,6 +826,8 @@ private:
             in.positions = std::move(mesh.positions);
             in.normals = std::move(mesh.normals);
             in.texcoords = std::move(mesh.texcoords);
+            in.tangents = std::move(mesh.tangents);
+            in.bitangents = std::move(mesh.bitangents);
             in.indices = std::move(mesh.indices);
         }
         else

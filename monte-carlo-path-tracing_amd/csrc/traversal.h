@@ -264,6 +264,7 @@ template <bool kAny, bool kAnalytic, bool kTextures, bool kCount>
 MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &hit, TraceStats &stats)
 {
     bool found = false;
+    const float t_start = ray.t_max;
     uint32_t node = sc.integrator.n_tlas_nodes ? 0u : kEndOfTree;
     uint32_t resume = kEndOfTree; // TLAS link to continue from once the current BLAS is exhausted
     bool in_blas = false;
@@ -317,7 +318,6 @@ MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &
         // host-vs-device differential test, tests/test_gpu_units.py).
         HitRaw cand;
         cand.inst = inst, cand.prim = object, cand.a = cand.b = cand.c = 0.0f, cand.inside = false;
-        const float t_before = ray.t_max;
         bool accepted;
         if (!kAnalytic || inst_kind == kInstTriangles)
             accepted = triangle_hit<kTextures>(sc, object, inst_bsdf, ray, rng, cand);
@@ -327,14 +327,6 @@ MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &
             accepted = disk_hit<kTextures>(sc, sc.analytic[inst_analytic], object, inst_bsdf, ray, rng, cand);
         else
             accepted = cylinder_hit<kTextures>(sc, sc.analytic[inst_analytic], object, inst_bsdf, ray, rng, cand);
-        if (accepted && !kAny && !(ray.t_max <= t_before))
-        {
-            // NaN distance (a ray with NaN components passes every test of the reference too):
-            // the reference walks the instance with a copy of the ray and merges the result only
-            // if `local.t_max <= ray.t_max` (tlas.cpp:27-33), which drops it
-            ray.t_max = t_before;
-            accepted = false;
-        }
         if (accepted)
         {
             found = true;
@@ -344,6 +336,17 @@ MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &
                 return true;
         }
         node = after;
+    }
+    if (!kAny && found && ray.t_max != ray.t_max)
+    {
+        // NaN distance: a ray with NaN components passes every test (of the reference too), each
+        // "hit" is accepted because `t > t_max` is false, and the result stays NaN.  The reference
+        // walks an instance with a copy of the ray and merges the result only if
+        // `local.t_max <= ray.t_max` (tlas.cpp:27-33), which drops it: the query misses.
+        // (Decided once, here: a second writer of ray.t_max inside the loop made hipcc drop real
+        //  sphere hits on gfx950 — tests/test_gpu_parity.py::test_ordered_walk_equals_reference_walk.)
+        ray.t_max = t_start;
+        found = false;
     }
     return found;
 }
@@ -452,8 +455,6 @@ struct ClosestState
     float best_t;
     uint32_t best_rank;
 };
-constexpr float kCullSlack = 1.000001f; // culling bound = best distance * this
-constexpr float kNearTie = 1e-5f;       // two hits closer than this (relative) are decided as the reference would
 
 // One primitive of the ordered walk.  Shadow queries: accepted iff hit within the fixed
 // bound.  Closest queries: the nearer hit wins; two hits within rounding distance of each
@@ -500,7 +501,7 @@ MCPT_HD bool test_slot(const DeviceScene &sc, uint32_t slot, Ray &ray, HitRaw &h
         // (a NaN distance — a ray with NaN components "hits" everything — is never kept: the
         //  reference drops such an instance hit when it merges it, tlas.cpp:27-33)
         take = h.hit && (best.found ? h.t < best.best_t : h.t <= ray.t_max);
-        if (h.hit && best.found && fabsf(h.t - best.best_t) <= kNearTie * best.best_t)
+        if (h.hit && best.found && fabsf(h.t - best.best_t) <= sc.integrator.walk_tie)
         {
             // rare: replay the reference on the pair (current best, this primitive)
             if (rank > best.best_rank) // the reference comes here second
@@ -516,7 +517,7 @@ MCPT_HD bool test_slot(const DeviceScene &sc, uint32_t slot, Ray &ray, HitRaw &h
         if (!kAny)
         {
             best.best_t = h.t, best.best_rank = rank;
-            ray.t_max = h.t * kCullSlack;
+            ray.t_max = h.t + sc.integrator.walk_tie;
         }
     }
     return take;

@@ -610,6 +610,40 @@ int mcpt_emu_debug_pixel(const char *mcsd_path, uint32_t pixel, int ordered, flo
     }
 }
 
+// Debug: every triangle slot the ray (origin, direction) hits, brute force: 6 floats per
+// hit {primitive, instance, rank, distance, leaf box passes with `t_bound`, reference-walk
+// distance of a query restricted to nothing — 0}.
+int mcpt_emu_probe_ray(const char *mcsd_path, const float *ray7, float t_bound, float *out, uint32_t capacity)
+{
+    try
+    {
+        const FlatScene flat = CommitScene(mcsd::Load(mcsd_path));
+        const DeviceScene sc = flat.HostView();
+        const Ray ray = make_ray(V3{ray7[0], ray7[1], ray7[2]}, V3{ray7[3], ray7[4], ray7[5]});
+        uint32_t n = 0;
+        for (uint32_t slot = 0; slot < flat.integrator.n_prims && n < capacity; ++slot)
+        {
+            const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(slot);
+            const uint32_t prim = as_uint(p[0].w), inst = as_uint(p[1].w), rank = as_uint(p[2].w);
+            if (sc.instances[inst].kind != kInstTriangles)
+                continue;
+            const SlotHit h = triangle_probe(p, ray);
+            if (!h.hit)
+                continue;
+            float *o = out + 6 * n++;
+            o[0] = float(prim), o[1] = float(inst), o[2] = float(rank), o[3] = h.t;
+            o[4] = reference_leaf_box_passes<true>(sc, inst, prim, ray, t_bound) ? 1.0f : 0.0f;
+            o[5] = 0;
+        }
+        return static_cast<int>(n);
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return -1;
+    }
+}
+
 // The ordered-walk hierarchy of the product's host commit: 16 floats per node,
 // 12 per primitive slot (bit patterns preserved), and (n_nodes, n_slots, depth,
 // has_masks) in `counts`.  Returns 0, or the required capacities in counts on -2.

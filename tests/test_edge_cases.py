@@ -47,11 +47,28 @@ def edge_scenes(pkg):
                                   texcoords=np.array([[0, 1], [0, 1], [0, 1]], np.float32),
                                   indices=np.array([[0, 1, 2]], np.uint32)))
     out["nan_shading_frame"] = s
+    # per-vertex tangents and / or bitangents handed over with the mesh (what the reference gets from
+    # assimp's CalcTangentSpace; scene.cpp:81-100, transformed by to_world at :271-280): an anisotropic
+    # conductor makes the frame's orientation visible
+    for name, use_t, use_b in (("supplied_tangents", True, True), ("supplied_tangents_only", True, False),
+                               ("supplied_bitangents_only", False, True)):
+        s = S.material_preview("rough_conductor_aniso", "mixed", "mesh", 24, 24, 4)
+        inst = next(i for i in s.instances if i.type == M.INST_MESHES)
+        n = inst.normals.astype(np.float64)
+        t = np.cross(n, [0.3, 1.0, 0.2])
+        t /= np.linalg.norm(t, axis=1, keepdims=True) + 1e-30
+        if use_t:
+            inst.tangents = (0.7 * t).astype(np.float32)            # not unit length on purpose
+        if use_b:
+            inst.bitangents = np.cross(n, t).astype(np.float32)
+        inst.to_world = (S.translate_scale(t=(0.1, 0.0, -0.2), s=(1.0, 1.2, 0.9)) @ S.rot_x(20)).astype(np.float32)
+        out[name] = s
     return out
 
 
 NAMES = ["empty_scene_constant_emitter", "empty_scene_dark", "light_only", "no_lights", "film_1x1", "film_3x5",
-         "film_65x9", "spp_1", "depth_max_0", "depth_max_1", "roulette_from_start", "degenerate_triangle", "nan_shading_frame"]
+         "film_65x9", "spp_1", "depth_max_0", "depth_max_1", "roulette_from_start", "degenerate_triangle", "nan_shading_frame",
+         "supplied_tangents", "supplied_tangents_only", "supplied_bitangents_only"]
 
 
 @pytest.fixture(scope="module")
@@ -76,7 +93,8 @@ def test_edge_case_on_cpu(name, pkg, oracle, emulator, mcsd_file, request):
     import checkers
     # (the compiled reference rebuilds its Kulla-Conty table on every render: ~5 s, so a subset)
     if checkers.reference_available() and name in ("empty_scene_constant_emitter", "film_3x5", "depth_max_0",
-                                                   "degenerate_triangle", "nan_shading_frame"):
+                                                   "degenerate_triangle", "nan_shading_frame", "supplied_tangents",
+                                                   "supplied_tangents_only", "supplied_bitangents_only"):
         ref, _ = checkers.Reference().render(path, w, h)
         np.testing.assert_array_equal(ref, want)
 
