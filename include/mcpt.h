@@ -152,6 +152,13 @@ int mcpt_debug_intersect(mcpt_renderer *r, uint32_t n, const float *rays, const 
 int mcpt_debug_bsdf(mcpt_renderer *r, uint32_t id_bsdf, int mode, uint32_t n, const float *records,
                     const uint32_t *seeds, float *out, uint32_t *seeds_out);
 
+/* Diagnostics: the steps of one pixel (index y * width + x) on the device, one lane, all of the
+ * pixel's samples: 16 floats per step = ray origin[3], direction[3], largest throughput
+ * component after the step, primitive hit (-1: none), distance, shadow queries, last shadow
+ * result, LCG state after the step (bit pattern), radiance accumulated so far [3], depth.
+ * n_steps[0] = steps written (<= capacity).  No reference counterpart. */
+int mcpt_debug_trace_pixel(mcpt_renderer *r, uint32_t pixel, uint32_t capacity, float *out, uint32_t *n_steps);
+
 /* Replaces Renderer::~Renderer / ReleaseData (renderer.cpp:350-369). */
 void mcpt_renderer_destroy(mcpt_renderer *r);
 

@@ -92,6 +92,7 @@ def lib():
     L.mcpt_debug_lbvh_build.argtypes = [u32, vp, vp, i32, vp, vp, ctypes.POINTER(ctypes.c_double)]
     L.mcpt_debug_intersect.argtypes = [vp, u32, vp, vp, vp, vp]
     L.mcpt_debug_bsdf.argtypes = [vp, u32, i32, u32, vp, vp, vp, vp]
+    L.mcpt_debug_trace_pixel.argtypes = [vp, u32, u32, vp, vp]
     L.mcpt_renderer_destroy.argtypes = [vp]
     L.mcpt_renderer_destroy.restype = None
     L.mcpt_write_image.argtypes = [cp, vp, i32, i32]
@@ -111,7 +112,7 @@ EXPORTED_SYMBOLS = [
     "mcpt_renderer_draw", "mcpt_renderer_draw_device", "mcpt_renderer_draw_counted",
     "mcpt_renderer_tile_count", "mcpt_tile_range_size", "mcpt_unpack_tiles",
     "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_set_walk", "mcpt_renderer_destroy",
-    "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build",
+    "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_trace_pixel",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
 ]
 
@@ -237,6 +238,15 @@ class Renderer:
         _check(lib().mcpt_debug_bsdf(self._h, id_bsdf, mode, n, records.ctypes.data, seeds.ctypes.data,
                                      out.ctypes.data, after.ctypes.data))
         return out, after
+
+    def trace_pixel(self, x, y, capacity=4096):
+        """Per-step records of one pixel on the device (see mcpt.h): (steps[n, 16] float32,
+        lcg[n] uint32 = column 11 reinterpreted)."""
+        out = np.zeros((capacity, 16), dtype=np.float32)
+        n = np.zeros(1, dtype=np.uint32)
+        _check(lib().mcpt_debug_trace_pixel(self._h, y * self.width + x, capacity, out.ctypes.data, n.ctypes.data))
+        steps = out[:int(n[0])]
+        return steps, steps[:, 11].copy().view(np.uint32)
 
     def table(self, what: str) -> np.ndarray:
         data, count = ctypes.c_void_p(), ctypes.c_size_t()

@@ -603,6 +603,31 @@ int mcpt_debug_bsdf(mcpt_renderer *r, uint32_t id_bsdf, int mode, uint32_t n, co
                    { return mcpt::LaunchBsdf(r->dev, n, id_bsdf, mode, a, b, c, d, nullptr); });
 }
 
+int mcpt_debug_trace_pixel(mcpt_renderer *r, uint32_t pixel, uint32_t capacity, float *out, uint32_t *n_steps)
+{
+    if (!r || !out || !n_steps)
+        return Fail("null argument");
+    float *d_out = nullptr;
+    uint32_t *d_n = nullptr;
+    int rc = 0;
+    try
+    {
+        Check(hipSetDevice(r->device), "select device");
+        Check(hipMalloc(reinterpret_cast<void **>(&d_out), std::max<size_t>(1, capacity) * 64), "allocate");
+        Check(hipMalloc(reinterpret_cast<void **>(&d_n), 4), "allocate");
+        Check(mcpt::LaunchTracePixel(r->dev, pixel, capacity, d_out, d_n, nullptr), "launch trace kernel");
+        Check(hipDeviceSynchronize(), "trace kernel");
+        Check(hipMemcpy(out, d_out, size_t(capacity) * 64, hipMemcpyDeviceToHost), "download");
+        Check(hipMemcpy(n_steps, d_n, 4, hipMemcpyDeviceToHost), "download");
+    }
+    catch (const std::exception &e)
+    {
+        rc = Fail(e.what());
+    }
+    (void)hipFree(d_out), (void)hipFree(d_n);
+    return rc;
+}
+
 void mcpt_renderer_destroy(mcpt_renderer *r)
 {
     if (r)

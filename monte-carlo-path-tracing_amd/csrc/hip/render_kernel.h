@@ -34,6 +34,8 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
 // Unit kernels for diagnostics and parity tests (one query per lane).
 hipError_t LaunchIntersect(const DeviceScene &sc, uint32_t n, const float *rays, const uint32_t *seeds, float *out,
                            uint32_t *seeds_out, bool reference_walk, hipStream_t stream);
+hipError_t LaunchTracePixel(const DeviceScene &sc, uint32_t pixel, uint32_t capacity, float *out, uint32_t *n_steps,
+                            hipStream_t stream);
 hipError_t LaunchBsdf(const DeviceScene &sc, uint32_t n, uint32_t id_bsdf, int mode, const float *recs,
                       const uint32_t *seeds, float *out, uint32_t *seeds_out, hipStream_t stream);
 

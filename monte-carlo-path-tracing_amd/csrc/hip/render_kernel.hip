@@ -183,6 +183,46 @@ __global__ void intersect_kernel(const DeviceScene sc, uint32_t n, const float *
         o[7 + 3 * k] = v[k].x, o[8 + 3 * k] = v[k].y, o[9 + 3 * k] = v[k].z;
 }
 
+// The steps of one pixel, one lane, reference-order walk (both walks give the same frame):
+// per step 16 floats {ray origin[3], ray direction[3], throughput max, hit primitive (-1 = none),
+// distance, shadow queries, last shadow result, LCG state after the step (bits), L[3] so far,
+// depth}.  n_steps[0] = steps written.  The CPU build of the same code is tests/emu's
+// mcpt_emu_debug_pixel: comparing the two shows where a device frame leaves the host's.
+__global__ void trace_pixel_kernel(const DeviceScene sc, uint32_t pixel, uint32_t capacity, float *__restrict__ out,
+                                   uint32_t *__restrict__ n_steps)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0)
+        return;
+    PathState st;
+    st.stack = nullptr;
+    LaneCounters cnt{};
+    start_pixel(st, pixel);
+    uint32_t n = 0;
+    while (!pixel_done(sc, st) && n < capacity)
+    {
+        if (!st.alive)
+            start_sample(sc, st);
+        path_step<Config<kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet>>(sc, st, &cnt);
+        float *o = out + 16 * static_cast<size_t>(n++);
+        for (int k = 0; k < 6; ++k)
+            o[k] = cnt.last_closest_ray[k];
+        o[6] = max_component(st.throughput);
+        o[7] = cnt.last_hit_prim == kNone ? -1.0f : static_cast<float>(cnt.last_hit_prim);
+        o[8] = cnt.last_hit_t, o[9] = static_cast<float>(cnt.last_shadow_count);
+        o[10] = static_cast<float>(cnt.last_shadow_hit);
+        o[11] = __uint_as_float(st.rng);
+        o[12] = st.L.x, o[13] = st.L.y, o[14] = st.L.z, o[15] = static_cast<float>(st.depth);
+    }
+    n_steps[0] = n;
+}
+
+hipError_t LaunchTracePixel(const DeviceScene &sc, uint32_t pixel, uint32_t capacity, float *out, uint32_t *n_steps,
+                            hipStream_t stream)
+{
+    hipLaunchKernelGGL(trace_pixel_kernel, dim3(1), dim3(64), 0, stream, sc, pixel, capacity, out, n_steps);
+    return hipGetLastError();
+}
+
 // in (18 floats per query): wo, wi, normal, tangent, bitangent, uv, inside.
 // out (8 floats): valid, pdf, attenuation[3], wi[3].  mode 0 = evaluate, 1 = sample.
 __global__ void bsdf_kernel(const DeviceScene sc, uint32_t n, uint32_t id_bsdf, int mode,

@@ -47,6 +47,20 @@ class Emulator:
     ORDERED = 32      # feature bit of the ordered walk in a forced `variant`
     REFERENCE = -2    # `variant`: the launcher's pick, but with the reference-order walk
 
+    def trace_pixel(self, mcsd_path, x, y, width, ordered=True, capacity=4096):
+        """Per-step records of one pixel (steps[n, 16], lcg[n]): the CPU twin of
+        capi.Renderer.trace_pixel / mcpt_debug_trace_pixel."""
+        self.lib.mcpt_emu_debug_pixel.restype = ctypes.c_int
+        self.lib.mcpt_emu_debug_pixel.argtypes = [ctypes.c_char_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p,
+                                                   ctypes.c_uint32]
+        out = np.zeros((capacity, 16), np.float32)
+        n = self.lib.mcpt_emu_debug_pixel(str(mcsd_path).encode(), y * width + x, 1 if ordered else 0, out.ctypes.data,
+                                          capacity)
+        if n < 0:
+            raise RuntimeError(self.lib.mcpt_emu_last_error().decode())
+        steps = out[:n]
+        return steps, steps[:, 11].copy().view(np.uint32)
+
     def set_walk_tree(self, strategy: int):
         """Split rule of the ordered-walk hierarchy for later renders: 0 production,
         1 exact sweep, 2 median, 3 children swapped."""

@@ -570,8 +570,8 @@ int mcpt_emu_pool_model(const char *mcsd_path, double *out)
     }
 }
 
-// Debug: the steps of one pixel with either walk.  out: per step 12 floats
-// {closest ray (7), hit primitive, hit distance, shadow count, shadow result, rng}.
+// Debug: the steps of one pixel with either walk: the CPU build of hip/render_kernel.hip's
+// trace_pixel_kernel, same 16-float record per step (mcpt.h, mcpt_debug_trace_pixel).
 int mcpt_emu_debug_pixel(const char *mcsd_path, uint32_t pixel, int ordered, float *out, uint32_t capacity)
 {
     try
@@ -593,13 +593,15 @@ int mcpt_emu_debug_pixel(const char *mcsd_path, uint32_t pixel, int ordered, flo
                 path_step<Config<kAllF | kFeatOrderedWalk>>(sc, st, &cnt);
             else
                 path_step<Config<kAllF>>(sc, st, &cnt);
-            float *o = out + 12 * n++;
-            for (int k = 0; k < 7; ++k)
+            float *o = out + 16 * n++;
+            for (int k = 0; k < 6; ++k)
                 o[k] = cnt.last_closest_ray[k];
+            o[6] = max_component(st.throughput);
             o[7] = static_cast<float>(cnt.last_hit_prim == kNone ? -1.0 : double(cnt.last_hit_prim));
             o[8] = cnt.last_hit_t, o[9] = static_cast<float>(cnt.last_shadow_count);
             o[10] = static_cast<float>(cnt.last_shadow_hit);
             std::memcpy(&o[11], &st.rng, 4);
+            o[12] = st.L.x, o[13] = st.L.y, o[14] = st.L.z, o[15] = static_cast<float>(st.depth);
         }
         return static_cast<int>(n);
     }

@@ -240,3 +240,32 @@ def test_reference_side_binding_renders_the_same_frame(pkg, mcsd_file, tmp_path)
     got = np.fromfile(out, dtype=np.float32).reshape(24, 40, 3)
     frame, _ = gpu_render(pkg, scene)
     assert np.array_equal(got, frame)
+
+
+def test_device_pixel_trace_matches_the_host_build(pkg, mcsd_file):
+    """mcpt_debug_trace_pixel: the per-step record of a pixel on the device against the CPU build
+    of the same kernel body (tests/emu): same primitives, same LCG states, same depths, rays
+    and throughput within a few roundings (device libm).  This is the tool that showed why the
+    reference's classroom scene cannot match per pixel between ANY two float implementations:
+    a last-bit difference in a scattered direction grows ~30-100x per bounce among its thin
+    curved furniture parts."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
+    import emu
+    scene = pkg.scenes.cornell_box(16, 16, 2)
+    path = mcsd_file(scene)
+    renderer = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene))
+    frame, _ = renderer.draw()
+    host = emu.Emulator()
+    for x, y in ((0, 0), (7, 9), (15, 15)):
+        dev, dev_lcg = renderer.trace_pixel(x, y)
+        cpu, cpu_lcg = host.trace_pixel(path, x, y, 16, ordered=False)
+        assert len(dev) == len(cpu) > 0
+        np.testing.assert_array_equal(dev_lcg, cpu_lcg)
+        np.testing.assert_array_equal(dev[:, [7, 9, 10, 15]], cpu[:, [7, 9, 10, 15]])   # primitive, shadow rays, depth
+        np.testing.assert_allclose(dev[:, :7], cpu[:, :7], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(dev[:, 12:15], cpu[:, 12:15], rtol=1e-3, atol=1e-5)
+        # the last record of each sample carries that sample's radiance: their mean is the pixel
+        ends = [k for k in range(len(dev)) if k + 1 == len(dev) or np.array_equal(dev[k + 1, :3], dev[0, :3])]
+        np.testing.assert_allclose(dev[ends, 12:15].sum(0) / 2, frame[y, x], rtol=1e-5, atol=1e-6)
+    renderer.close()

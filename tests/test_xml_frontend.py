@@ -1146,3 +1146,156 @@ def test_textured_reference_scenes(pkg, tmp_path, scene, n_bitmaps):
     assert len(bitmaps) >= n_bitmaps
     for t in bitmaps:
         assert t.channel in (1, 3, 4) and 0 <= min(t.data) and max(t.data) <= 1
+
+
+# ---- importer post-processing (mesh_postprocess.cpp) -----------------------------
+def _obj_shape(name, **flags):
+    extra = "".join(f'<boolean name="{k}" value="{str(v).lower()}"/>' for k, v in flags.items())
+    return f'<shape type="obj"><string name="filename" value="models/{name}"/>{extra}</shape>'
+
+
+def test_obj_tangent_frames_follow_the_texture_axes(pkg, tmp_path):
+    """CalcTangentSpace, first pass: on a mesh with a proper uv layout the tangent is the
+    direction of +u in model space projected into the normal plane, the bitangent that of +v;
+    a mirrored uv layout flips the sign rule's branch, not the directions' meaning."""
+    obj = b"""v 0 0 0
+v 2 0 0
+v 2 0 -3
+v 0 0 -3
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+vn 0 1 0
+f 1/1/1 2/2/1 3/3/1
+f 1/1/1 3/3/1 4/4/1
+"""
+    s = translate(pkg, tmp_path, scene_xml(_obj_shape("floor.obj", flipTexCoords=False)), files={"models/floor.obj": obj})
+    inst = s.instances[0]
+    assert inst.tangents.shape == (6, 3) and inst.bitangents.shape == (6, 3)
+    np.testing.assert_allclose(inst.tangents, np.tile([1, 0, 0], (6, 1)), atol=1e-6)      # +u runs along +x
+    np.testing.assert_allclose(inst.bitangents, np.tile([0, 0, -1], (6, 1)), atol=1e-6)   # +v runs along -z
+    # v flipped (the default for OBJ): +v now runs along +z
+    s = translate(pkg, tmp_path, scene_xml(_obj_shape("floor.obj")), files={"models/floor.obj": obj})
+    np.testing.assert_allclose(s.instances[0].tangents, np.tile([1, 0, 0], (6, 1)), atol=1e-6)
+    np.testing.assert_allclose(s.instances[0].bitangents, np.tile([0, 0, 1], (6, 1)), atol=1e-6)
+
+
+def test_obj_degenerate_texcoords_still_give_a_frame(pkg, tmp_path):
+    """The reference's shipped meshes write `vt 0 0` at every corner.  The importer then
+    takes the triangle's edges as texture axes (tangent = p2 - p0, bitangent = p1 - p0,
+    projected and orthogonalised), so the frame exists — the renderer's own uv rule would
+    divide by zero (scene.cpp:63-80).  Rendering such a mesh: finite image, and the oracle,
+    the compiled reference and the kernel body agree on it."""
+    obj = b"""v 0 0 0
+v 1 0 0
+v 0 0 -1
+vt 0 0
+vn 0 1 0
+f 1/1/1 2/1/1 3/1/1
+"""
+    s = translate(pkg, tmp_path, scene_xml(_obj_shape("t.obj")), files={"models/t.obj": obj})
+    inst = s.instances[0]
+    np.testing.assert_allclose(inst.tangents, np.tile([0, 0, -1], (3, 1)), atol=1e-6)     # p2 - p0
+    np.testing.assert_allclose(inst.bitangents, np.tile([1, 0, 0], (3, 1)), atol=1e-6)    # p1 - p0
+    # no texture coordinates at all, or no normals with face_normals: nothing to build a frame on
+    bare = b"v 0 0 0\nv 1 0 0\nv 0 0 -1\nvn 0 1 0\nf 1//1 2//1 3//1\n"
+    s = translate(pkg, tmp_path, scene_xml(_obj_shape("bare.obj")), files={"models/bare.obj": bare})
+    assert s.instances[0].tangents.size == 0 and s.instances[0].texcoords.size == 0
+    flat = b"v 0 0 0\nv 1 0 0\nv 0 0 -1\nvt 0 0\nf 1/1 2/1 3/1\n"
+    s = translate(pkg, tmp_path, scene_xml(_obj_shape("flat.obj", faceNormals=True)), files={"models/flat.obj": flat})
+    assert s.instances[0].tangents.size == 0 and s.instances[0].normals.size == 0
+
+
+def test_obj_generated_normals_and_smoothed_tangents(pkg, tmp_path):
+    """No `vn` in the file: GenSmoothNormals — all corners at one position share the normalised
+    sum of their (unit) face normals, whatever their indices.  Tangents of corners at one
+    position with the same normal and directions within 45 degrees are averaged; across a
+    crease they stay apart."""
+    rng = np.random.default_rng(5)
+    # a 4x4 grid of quads over a gently curved height field, uv = xz
+    n = 5
+    xs, zs = np.meshgrid(np.arange(n, dtype=np.float64), np.arange(n, dtype=np.float64), indexing="ij")
+    ys = 0.05 * np.sin(xs) * np.cos(zs)
+    lines = [f"v {xs[i, j]} {ys[i, j]} {zs[i, j]}" for i in range(n) for j in range(n)]
+    lines += [f"vt {xs[i, j] / 4} {zs[i, j] / 4}" for i in range(n) for j in range(n)]
+    vid = lambda i, j: i * n + j + 1
+    for i in range(n - 1):
+        for j in range(n - 1):
+            a, b, c, d = vid(i, j), vid(i, j + 1), vid(i + 1, j + 1), vid(i + 1, j)
+            lines.append(f"f {a}/{a} {b}/{b} {c}/{c}")
+            lines.append(f"f {a}/{a} {c}/{c} {d}/{d}")
+    s = translate(pkg, tmp_path, scene_xml(_obj_shape("grid.obj", flipTexCoords=False)),
+                  files={"models/grid.obj": ("\n".join(lines) + "\n").encode()})
+    inst = s.instances[0]
+    pos, nrm, tan, bit = inst.positions, inst.normals, inst.tangents, inst.bitangents
+    assert nrm.shape == pos.shape == tan.shape == bit.shape == (96, 3)
+    np.testing.assert_allclose(np.linalg.norm(nrm, axis=1), 1, atol=1e-5)
+    np.testing.assert_allclose(np.linalg.norm(tan, axis=1), 1, atol=1e-5)
+    # expected normals: per position, normalised sum of unit face normals of every corner there
+    tri = pos.reshape(-1, 3, 3).astype(np.float64)
+    fn = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+    corner_fn = np.repeat(fn, 3, axis=0)
+    keys = [tuple(p) for p in pos]
+    want = {}
+    for k, f in zip(keys, corner_fn):
+        want[k] = want.get(k, 0) + f
+    want = np.array([want[k] / np.linalg.norm(want[k]) for k in keys])
+    np.testing.assert_allclose(nrm, want, atol=2e-6)
+    # smooth surface: every corner at one position ends up with the same tangent and bitangent
+    for k in set(keys):
+        rows = [i for i, kk in enumerate(keys) if kk == k]
+        assert np.abs(tan[rows] - tan[rows[0]]).max() < 1e-6 and np.abs(bit[rows] - bit[rows[0]]).max() < 1e-6
+    assert (tan @ [1, 0, 0] > 0.99).all() and (bit @ [0, 0, 1] > 0.99).all()
+    np.testing.assert_allclose((tan * nrm).sum(1), 0, atol=2e-3)   # averaged frames stay (nearly) tangential
+
+    # a crease: two faces meeting at 90 degrees with explicit, different normals keep their own frames
+    crease = b"""v 0 0 0
+v 1 0 0
+v 1 0 -1
+v 1 1 0
+vt 0 0
+vt 1 0
+vt 1 1
+vn 0 1 0
+vn 0 0 1
+f 1/1/1 2/2/1 3/3/1
+f 1/1/2 2/2/2 4/3/2
+"""
+    s = translate(pkg, tmp_path, scene_xml(_obj_shape("crease.obj", flipTexCoords=False)), files={"models/crease.obj": crease})
+    t = s.instances[0].tangents
+    b = s.instances[0].bitangents
+    np.testing.assert_allclose(t, np.tile([1, 0, 0], (6, 1)), atol=1e-6)
+    np.testing.assert_allclose(b[:3], np.tile([0, 0, -1], (3, 1)), atol=1e-6)
+    np.testing.assert_allclose(b[3:], np.tile([0, 1, 0], (3, 1)), atol=1e-6)
+
+
+def test_zero_texcoord_mesh_renders_identically_everywhere(pkg, tmp_path):
+    """End to end: an OBJ with `vt 0 0` everywhere under an anisotropic conductor (the
+    frame's orientation is visible).  Finite frame; reference == oracle == kernel body."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
+    from emu import Emulator
+    from oracle import checkers
+    g = pkg.scenes.uv_sphere_mesh(8, 16, 0.6, (0, 0.6, 0))
+    lines = [f"v {p[0]} {p[1]} {p[2]}" for p in g["positions"]] + ["vt 0 0"]
+    lines += [f"vn {q[0]} {q[1]} {q[2]}" for q in g["normals"]]
+    lines += [f"f {a + 1}/1/{a + 1} {b + 1}/1/{b + 1} {c + 1}/1/{c + 1}" for a, b, c in g["indices"]]
+    loaded = translate(pkg, tmp_path, scene_xml(_obj_shape("ball.obj")), files={"models/ball.obj": ("\n".join(lines) + "\n").encode()})
+    mesh = loaded.instances[0]
+    assert mesh.tangents.shape == mesh.positions.shape and np.isfinite(mesh.tangents).all()
+    scene = pkg.scenes.material_preview("rough_conductor_aniso", "mixed", "mesh", 32, 32, 4)
+    target = next(i for i in scene.instances if i.type == pkg.mcsd.INST_MESHES)
+    for field in ("positions", "normals", "texcoords", "tangents", "bitangents", "indices"):
+        setattr(target, field, getattr(mesh, field))
+    path = tmp_path / "ball.mcsd"
+    pkg.mcsd.dump(scene, path)
+    got_oracle, _ = checkers.Oracle().render(path)
+    assert np.isfinite(got_oracle).all()
+    if checkers.reference_available():
+        want, _ = checkers.Reference().render(path, 32, 32)
+        np.testing.assert_array_equal(got_oracle, want)
+    got, _ = Emulator().render(path, 32, 32)
+    np.testing.assert_array_equal(got, got_oracle)
