@@ -44,6 +44,10 @@ MeshData LoadPly(const std::string &path, bool face_normals);
 // `gamma` is applied per the file type's rule; the result is what the reference's
 // image_io::Read returns (before its optional down-scaling).
 ImageData LoadFloatImage(const std::string &path, float gamma = 0.0f);
+
+// stb_image_resize2's default float down-scaling (image_resize.cpp): what the reference applies
+// to an environment map wider than the film can resolve.
+ImageData ResizeLikeReference(const ImageData &in, int out_width, int out_height);
 void LoadJpeg8(const std::string &path, int &width, int &height, int &channel, std::vector<uint8_t> &pixels);
 void LoadPng8(const std::string &path, int &width, int &height, int &channel, std::vector<uint8_t> &pixels);
 ImageData LoadRadianceHdr(const std::string &path);

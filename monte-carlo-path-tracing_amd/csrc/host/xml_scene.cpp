@@ -447,10 +447,8 @@ private:
     uint32_t AddBitmap(const std::string &path, const std::string &id, float gamma, float scale, const int *width_max)
     {
         ImageData img = LoadFloatImage(path, gamma);
-        if (width_max && img.width > *width_max)
-            std::fprintf(stderr,
-                         "[warning] '%s' is wider than the reference's resize target (%d); it is used at full size.\n",
-                         path.c_str(), *width_max);
+        if (width_max && img.width > *width_max && *width_max > 0) // image_io.cpp:160-169
+            img = ResizeLikeReference(img, *width_max, *width_max * img.height / img.width);
         for (float &v : img.data)
             v *= scale;
         const uint32_t index = static_cast<uint32_t>(out_.textures.size());

@@ -206,6 +206,50 @@ def reference_available() -> bool:
     return os.path.exists(REF_SO)
 
 
+STB_SO = os.path.join(HERE, "_ref", "libstb_ref.so")
+
+
+def stb_available() -> bool:
+    return os.path.exists(STB_SO)
+
+
+class Stb:
+    """The reference's vendored image decoder / resizer (extern/stb), compiled by
+    oracle/Makefile from the headers where they lie (oracle/stb_driver.c)."""
+
+    def __init__(self):
+        if not os.path.exists(STB_SO):
+            raise RuntimeError("oracle/_ref/libstb_ref.so is not built")
+        self.lib = ctypes.CDLL(STB_SO)
+        ip = ctypes.POINTER(ctypes.c_int)
+        self.lib.mcpt_stb_load8.argtypes = [ctypes.c_char_p, ip, ip, ip, ctypes.c_void_p, ctypes.c_size_t]
+        self.lib.mcpt_stb_loadf.argtypes = [ctypes.c_char_p, ip, ip, ip, ctypes.c_void_p, ctypes.c_size_t]
+        self.lib.mcpt_stb_resize.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int]
+
+    def _load(self, fn, dtype, path, capacity=1 << 26):
+        w, h, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        buf = np.zeros(capacity, dtype=dtype)
+        rc = fn(str(path).encode(), ctypes.byref(w), ctypes.byref(h), ctypes.byref(c), buf.ctypes.data, capacity)
+        if rc != 0:
+            raise RuntimeError(f"stb_image could not read {path} (rc {rc})")
+        return buf[:w.value * h.value * c.value].reshape(h.value, w.value, c.value).copy()
+
+    def load8(self, path):
+        return self._load(self.lib.mcpt_stb_load8, np.uint8, path)
+
+    def loadf(self, path):
+        return self._load(self.lib.mcpt_stb_loadf, np.float32, path)
+
+    def resize(self, image, out_w, out_h):
+        image = np.ascontiguousarray(image, dtype=np.float32)
+        h, w, c = image.shape
+        out = np.zeros((out_h, out_w, c), dtype=np.float32)
+        if self.lib.mcpt_stb_resize(image.ctypes.data, w, h, out.ctypes.data, out_w, out_h, c) != 0:
+            raise RuntimeError("stbir_resize_float_linear failed")
+        return out
+
+
 class Reference:
     """The compiled reference (oracle/_ref).  Not reentrant (file-scope globals
     in renderer.cpp:17-22): one render at a time per process."""

@@ -1299,3 +1299,96 @@ def test_zero_texcoord_mesh_renders_identically_everywhere(pkg, tmp_path):
         np.testing.assert_array_equal(got_oracle, want)
     got, _ = Emulator().render(path, 32, 32)
     np.testing.assert_array_equal(got, got_oracle)
+
+
+# ---- the reference's image library (extern/stb) as the yardstick ------------------
+def _bitmap_through_front_end(pkg, tmp_path, name, raw):
+    (tmp_path / name).write_bytes(bytes(raw))
+    body = f'<texture type="bitmap" id="a"><string name="filename" value="{name}"/><float name="gamma" value="1"/></texture>'
+    return translate(pkg, tmp_path, scene_xml(body)).textures[0]
+
+
+def _envmap_through_front_end(pkg, tmp_path, name, raw, film_width, fov):
+    (tmp_path / name).write_bytes(bytes(raw))
+    xml = f"""<scene version="0.6.0"><integrator type="path"/>
+    <sensor type="perspective"><float name="fov" value="{fov}"/>
+      <film type="hdrfilm"><integer name="width" value="{film_width}"/><integer name="height" value="{film_width}"/></film>
+      <sampler type="independent"><integer name="sampleCount" value="1"/></sampler></sensor>
+    <emitter type="envmap"><string name="filename" value="{name}"/></emitter></scene>"""
+    (tmp_path / "env.xml").write_text(xml)
+    cfg = pkg.capi.Config.load_xml(tmp_path / "env.xml")
+    cfg.save_mcsd(tmp_path / "env.mcsd")
+    return pkg.mcsd.load(tmp_path / "env.mcsd").textures[-1]
+
+
+def test_image_vectors_of_the_reference_library(pkg, tmp_path):
+    """Golden vectors made with stb_image / stb_image_resize2 as the reference vendors them
+    (tests/golden/make_stb_golden.py): the JPEG, PNG and Radiance readers decode every file
+    to exactly the library's samples; the environment-map down-scaling agrees with
+    stbir_resize_float_linear to 2e-5 of the value range (same filter, same edge rule, same
+    normalisation; the library's summation order and its handling of taps at the very edge of
+    the filter's support are not reproduced — typically 2e-7)."""
+    vec = np.load(os.path.join(os.path.dirname(__file__), "golden", "stb_vectors.npz"))
+    kinds = sorted({k.split("_")[0] for k in vec.files})
+    assert sum(k.startswith("jpeg") for k in kinds) == 5 and sum(k.startswith("png") for k in kinds) == 4
+    for kind in kinds:
+        if kind.startswith(("jpeg", "png")):
+            want = vec[kind + "_pixels"]
+            t = _bitmap_through_front_end(pkg, tmp_path, kind + (".jpg" if kind.startswith("jpeg") else ".png"), vec[kind + "_file"])
+            assert (t.height, t.width, t.channel) == want.shape, kind
+            got = np.rint(np.asarray(t.data).reshape(want.shape) * 255).astype(np.int32)
+            np.testing.assert_array_equal(got, want.astype(np.int32), err_msg=kind)
+        elif kind.startswith("hdr"):
+            want = vec[kind + "_pixels"]
+            t = _envmap_through_front_end(pkg, tmp_path, kind + ".hdr", vec[kind + "_file"], 64, 45)
+            np.testing.assert_array_equal(np.asarray(t.data).reshape(want.shape), want, err_msg=kind)
+        else:
+            src, want = vec[kind + "_in"], vec[kind + "_out"]
+            h, w, c = src.shape
+            oh, ow, _ = want.shape
+            if c == 4:
+                continue        # PFM carries 1 or 3 channels; the 4-channel vector is used below
+            # film width and fov chosen so that width * 360 / fov == ow exactly
+            raw = f"{'PF' if c == 3 else 'Pf'}\n{w} {h}\n-1.0\n".encode() + src[::-1].astype("<f4").tobytes()
+            t = _envmap_through_front_end(pkg, tmp_path, kind + ".pfm", raw, ow, 360)
+            assert (t.height, t.width, t.channel) == (oh, ow, c), kind
+            got = np.asarray(t.data).reshape(want.shape)
+            assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), (kind, np.abs(got - want).max())
+    # RGBA with alpha 1 (what the EXR reader hands over): the library's alpha weighting is the identity there
+    src, want = vec["resize3_in"], vec["resize3_out"]
+    files = {"e.exr": exr_bytes({n: src[..., i] for i, n in enumerate("RGBA")}, 0)}
+    for name, raw in files.items():
+        t = _envmap_through_front_end(pkg, tmp_path, name, raw, want.shape[1], 360)
+    assert (t.height, t.width, t.channel) == want.shape
+    assert np.abs(np.asarray(t.data).reshape(want.shape) - want).max() <= 2e-5 * np.abs(want).max()
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "libstb_ref.so")),
+                    reason="oracle/_ref/libstb_ref.so is not built (needs /root/reference)")
+def test_readers_equal_the_reference_library_on_its_own_textures(pkg, tmp_path):
+    """Live against the compiled library: every JPEG / PNG texture the reference ships decodes to
+    exactly what stb_image returns (blackboard.jpg 1600x1600 ... Teacup.png), and a 600x300
+    environment map shrinks like stbir_resize_float_linear."""
+    from oracle import checkers
+    stb = checkers.Stb()
+    n = 0
+    for scene in ("classroom", "dining-room", "lte-orb"):
+        folder = f"{REF_SCENES}/{scene}/textures"
+        if not os.path.isdir(folder):
+            continue
+        for name in sorted(os.listdir(folder)):
+            if not name.lower().endswith((".jpg", ".jpeg", ".png")):
+                continue
+            want = stb.load8(os.path.join(folder, name)).astype(np.int32)
+            t = _bitmap_through_front_end(pkg, tmp_path, name, open(os.path.join(folder, name), "rb").read())
+            got = np.rint(np.asarray(t.data).reshape(want.shape) * 255).astype(np.int32)
+            np.testing.assert_array_equal(got, want, err_msg=name)
+            n += 1
+    assert n >= 6
+    rng = np.random.default_rng(77)
+    src = (rng.random((300, 600, 3)) ** 2 * 5).astype(np.float32)
+    raw = f"PF\n600 300\n-1.0\n".encode() + src[::-1].astype("<f4").tobytes()
+    t = _envmap_through_front_end(pkg, tmp_path, "big.pfm", raw, 64, 90)       # 64 * 360 / 90 = 256 texels
+    assert (t.width, t.height) == (256, 128)
+    want = stb.resize(src, 256, 128)
+    assert np.abs(np.asarray(t.data).reshape(want.shape) - want).max() <= 2e-5 * want.max()
