@@ -40,7 +40,11 @@ struct Budget
     // surface-materials instantiation (matpreview) is fastest at 6 (rough dielectric +25 %,
     // rough conductor +3 % over its natural 168 VGPRs)
     static constexpr int kWavesPerSimd = (kFeatures & (kFeatVolPath | kFeatAnalytic)) ? 3
+#ifdef MCPT_EXPERIMENT_MICROFACET_WAVES
+                                         : (kFeatures & kFeatMicrofacet)              ? MCPT_EXPERIMENT_MICROFACET_WAVES
+#else
                                          : (kFeatures & kFeatMicrofacet)              ? 6
+#endif
                                          : kLdsGeometry                                ? 4
                                                                                       : 6;
 };
