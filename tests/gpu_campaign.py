@@ -1,0 +1,44 @@
+"""Differential campaign on the GPU (not collected by pytest; run by hand: python tests/gpu_campaign.py <seed> ...).
+Rrandom scenes (test_random_combinations' generator with more
+seeds, plus mesh resolutions on both sides of the 2048-primitive switch to the vote walk, supplied
+tangents, object transforms), both walks, plain and counting kernels, against the oracle.  Round-1 result: profiles/r01_gpu_campaign.json."""
+import sys, time, importlib, tempfile, os, json, numpy as np
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+pkg = importlib.import_module('monte-carlo-path-tracing_amd')
+from oracle import checkers
+from test_random_combinations import combos
+orc = checkers.Oracle()
+S, M = pkg.scenes, pkg.mcsd
+tmp = tempfile.mkdtemp()
+seeds = [int(s) for s in sys.argv[1:]] or list(range(100, 112))
+bad, n, worst = [], 0, 0.0
+t0 = time.time()
+for seed in seeds:
+    rng = np.random.default_rng(seed * 7 + 1)
+    for name, scene in combos(pkg, 40, seed=seed):
+        for inst in scene.instances:
+            if inst.type == M.INST_MESHES and inst.normals is not None and len(inst.normals) and rng.random() < 0.5:
+                res = int(rng.choice([6, 24, 40]))
+                g = S.uv_sphere_mesh(res, 2 * res, 0.6, (0, 0.6, 0))
+                inst.positions, inst.normals, inst.texcoords, inst.indices = g["positions"], g["normals"], g["texcoords"], g["indices"]
+                if rng.random() < 0.5:
+                    nrm = inst.normals.astype(np.float64)
+                    t = np.cross(nrm, rng.normal(size=3)); t /= np.linalg.norm(t, axis=1, keepdims=True) + 1e-30
+                    inst.tangents = t.astype(np.float32); inst.bitangents = np.cross(nrm, t).astype(np.float32)
+                if rng.random() < 0.5:
+                    inst.to_world = (S.translate_scale(t=tuple(rng.normal(size=3) * 0.1), s=tuple(1 + rng.random(3) * 0.3)) @ S.rot_x(float(rng.random() * 40))).astype(np.float32)
+        path = os.path.join(tmp, 's.mcsd'); M.dump(scene, path)
+        want, _ = orc.render(path)
+        r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
+        a, _ = r.draw(); c, _ = r.draw(counted=True); r.set_walk(True); b, _ = r.draw(); r.close()
+        n += 1
+        d = np.abs(a.astype(np.float64) - want)
+        ok = np.array_equal(a, b) and np.array_equal(a, c) and np.isfinite(a).all() and d.mean() <= 4e-3 and np.median(d) <= 1e-6
+        worst = max(worst, float(d.mean()))
+        if not ok:
+            bad.append({'seed': seed, 'name': name, 'walks_equal': bool(np.array_equal(a, b)), 'counted_equal': bool(np.array_equal(a, c)),
+                        'finite': bool(np.isfinite(a).all()), 'mean': float(d.mean()), 'median': float(np.median(d)), 'max': float(d.max())})
+            print('BAD', bad[-1], flush=True)
+    print('seed', seed, 'done; scenes', n, 'bad', len(bad), 'elapsed', round(time.time() - t0), flush=True)
+json.dump({'scenes': n, 'bad': bad, 'worst_mean': worst}, open('/root/repo/gpurun_out/campaign.json', 'w'), indent=1)
+print('scenes', n, 'bad', len(bad), 'worst mean', worst)
