@@ -1,9 +1,10 @@
 """Differential campaign on the GPU (not collected by pytest; run by hand: python tests/gpu_campaign.py <seed> ...).
-Rrandom scenes (test_random_combinations' generator with more
+Random scenes (test_random_combinations' generator with more
 seeds, plus mesh resolutions on both sides of the 2048-primitive switch to the vote walk, supplied
 tangents, object transforms), both walks, plain and counting kernels, against the oracle.  Round-1 result: profiles/r01_gpu_campaign.json."""
 import sys, time, importlib, tempfile, os, json, numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 pkg = importlib.import_module('monte-carlo-path-tracing_amd')
 from oracle import checkers
 from test_random_combinations import combos
@@ -40,5 +41,5 @@ for seed in seeds:
                         'finite': bool(np.isfinite(a).all()), 'mean': float(d.mean()), 'median': float(np.median(d)), 'max': float(d.max())})
             print('BAD', bad[-1], flush=True)
     print('seed', seed, 'done; scenes', n, 'bad', len(bad), 'elapsed', round(time.time() - t0), flush=True)
-json.dump({'scenes': n, 'bad': bad, 'worst_mean': worst}, open('/root/repo/gpurun_out/campaign.json', 'w'), indent=1)
+json.dump({'scenes': n, 'bad': bad, 'worst_mean': worst}, open(os.path.join(ROOT, 'gpurun_out', 'campaign.json'), 'w'), indent=1)
 print('scenes', n, 'bad', len(bad), 'worst mean', worst)
