@@ -63,6 +63,8 @@ constexpr uint32_t kEndOfTree = 0xFFFFFFFFu;
 constexpr uint32_t kNone = 0xFFFFFFFFu; // reference kInvalidId (defs.hpp:22)
 constexpr uint32_t kWalkLeaf = 0x80000000u; // walk_nodes child reference: primitive slot, not a node
 constexpr uint32_t kWalkDone = 0xFFFFFFFFu; // bottom-of-stack sentinel of the ordered walk
+constexpr uint32_t kWalkSliver = 0x80000000u; // walk_prims rank word: the triangle's computed distance is unreliable
+                                              // (commit.cpp); the low 31 bits are the rank
 constexpr uint32_t kWalkDepthMax = 56;      // bound on the ordered-walk tree depth
 constexpr uint32_t kWalkStackMax = kWalkDepthMax + 1; // stack entries: one per level + the sentinel
 constexpr int kLutRes = 128;            // kulla_conty.hpp:9
@@ -216,7 +218,9 @@ struct IntegratorRec // reference integrator.hpp:31-69 (the scalar part)
     uint32_t walk_break;   // wavefront scheduling of the ordered walk (traversal.h, walk_ordered_vote): leave
                            // the node phase when fewer lanes than this are searching; 0 = wait for all
     float walk_tie;        // distance below which two hits of the ordered walk count as tied (traversal.h,
-                           // test_slot): ~16 float roundings at the scene's largest coordinate
+                           // test_slot): ~40 float roundings at the scene's largest coordinate
+    float walk_sliver_reach; // culling slack while the best hit is a sliver (kWalkSliver): the largest amount a
+                             // sliver's leaf box was grown by (commit.cpp), never below walk_tie; 0 = the scene has none
 };
 
 // Feature bits: which parts of the hot path a scene actually exercises.  The
@@ -233,6 +237,8 @@ enum SceneFeature : uint32_t
     kFeatOrderedWalk = 1u << 5,
     // the ordered walk schedules its phases by wavefront vote (large scenes)
     kFeatVoteWalk = 1u << 6,
+    // the scene has sliver triangles (IntegratorRec::walk_sliver_reach > 0): test_slot handles them
+    kFeatSlivers = 1u << 7,
 };
 
 // Device view: raw pointers into HBM + the scalar records.

@@ -337,16 +337,30 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
         return hipErrorNotSupported;
     return Launch<kO, false, true>(sc, job, out, nullptr, stream, n_cus);
 #endif
+    constexpr uint32_t kS = kFeatSlivers;
+    const bool slivers = sc.integrator.walk_sliver_reach > 0.0f;
     if (counters != nullptr)
     {
         *variant = ordered ? "all+count" : "all+count, reference walk";
-        return ordered ? Launch<kAll | kV, true>(sc, job, out, counters, stream, n_cus)
+        return ordered ? Launch<kAll | kV | kS, true>(sc, job, out, counters, stream, n_cus)
                        : Launch<kAll, true>(sc, job, out, counters, stream, n_cus);
     }
     if (!ordered)
     {
         *variant = "all, reference walk";
         return Launch<kAll, false>(sc, job, out, nullptr, stream, n_cus);
+    }
+    constexpr uint32_t kSurface = kFeatEmitters | kFeatTextures | kFeatMicrofacet;
+    if (slivers)
+    {
+        // sliver triangles: the instantiations whose primitive test replays the reference on them
+        if ((f & ~kSurface) == 0)
+        {
+            *variant = "surface-materials+slivers";
+            return Launch<kSurface | kV | kS, false>(sc, job, out, nullptr, stream, n_cus);
+        }
+        *variant = "all+slivers";
+        return Launch<kAll | kV | kS, false>(sc, job, out, nullptr, stream, n_cus);
     }
     const bool lds = StagedBytes(sc, true) <= kLdsGeometryBytes;
     if (f == 0)
@@ -361,10 +375,10 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
         return lds ? Launch<kFeatEmitters | kO, false, true>(sc, job, out, nullptr, stream, n_cus)
                    : Launch<kFeatEmitters | kV, false>(sc, job, out, nullptr, stream, n_cus);
     }
-    if ((f & ~(kFeatEmitters | kFeatTextures | kFeatMicrofacet)) == 0)
+    if ((f & ~kSurface) == 0)
     {
         *variant = "surface-materials";
-        return Launch<kFeatEmitters | kFeatTextures | kFeatMicrofacet | kV, false>(sc, job, out, nullptr, stream, n_cus);
+        return Launch<kSurface | kV, false>(sc, job, out, nullptr, stream, n_cus);
     }
     *variant = "all";
     return Launch<kAll | kV, false>(sc, job, out, nullptr, stream, n_cus);

@@ -1015,8 +1015,42 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
                 for (const TreeNode &b : blas[t.object])
                     if (b.object != kNoObject)
                         rank[prim_base[t.object] + b.object] = counter++;
+        float coordinate = std::max({fabsf(fs.camera.eye.x), fabsf(fs.camera.eye.y), fabsf(fs.camera.eye.z)});
+        for (const Bounds &b : prim_box)
+            coordinate = std::max({coordinate, fabsf(b.lo.x), fabsf(b.lo.y), fabsf(b.lo.z), fabsf(b.hi.x), fabsf(b.hi.y),
+                                   fabsf(b.hi.z)});
+        // Leaf boxes of the hierarchy = the reference's leaf boxes, except for SLIVERS.  The
+        // reference's triangle distance is a mean of the vertices' depths weighted by the edge
+        // functions; in a sliver those are differences of nearly equal products and the computed
+        // distance can sit far in front of the triangle's plane — classroom has a 40 x 0.04 one whose
+        // distance comes out 7e-4 short at coordinates of 20 (600 roundings), and the reference
+        // then prefers it to a surface that is really nearer.  To give the same answer the walk has
+        // to reach such a triangle although its box starts behind the current best hit: its leaf box
+        // is grown by the error it can make, roundings at the scene's scale times the aspect ratio
+        // (longest edge / height).  Supersets only ever add visits.
+        std::vector<Bounds> leaf_box = prim_box;
+        std::vector<uint8_t> sliver(n_prims, 0);
+        float largest_grow = 0.0f;
+        for (uint32_t p = 0; p < n_prims; ++p)
+        {
+            if (fs.instances[prim_inst[p]].kind != kInstTriangles)
+                continue;
+            const float4 *v = &fs.tri_pos[3 * static_cast<size_t>(p)];
+            const V3 a{v[0].x, v[0].y, v[0].z}, b{v[1].x, v[1].y, v[1].z}, c{v[2].x, v[2].y, v[2].z};
+            const V3 ab = b - a, ac = c - a, bc = c - b;
+            const float longest2 = std::max({dot(ab, ab), dot(ac, ac), dot(bc, bc)}), area2 = length(cross(ab, ac));
+            if (!(area2 > 0.0f))
+                continue; // degenerate: never hit (triangle.cpp:66-68)
+            const float aspect = longest2 / area2; // longest edge / the height over it
+            if (aspect <= 128.0f)
+                continue; // (measured roundings-per-aspect below: 0.3; up to here the tie radius covers it)
+            const float grow = std::min(kEpsFloat * coordinate * aspect, 0.01f * coordinate);
+            leaf_box[p].lo = leaf_box[p].lo - V3{grow, grow, grow}, leaf_box[p].hi = leaf_box[p].hi + V3{grow, grow, grow};
+            largest_grow = std::max(largest_grow, grow);
+            sliver[p] = 1; // ... and every comparison it takes part in is decided like the reference would (kWalkSliver)
+        }
         std::vector<uint32_t> slot_prim;
-        ig.walk_depth = WalkTreeBuilder(prim_box, fs.walk_nodes, slot_prim).Build() + 1; // + sentinel entry
+        ig.walk_depth = WalkTreeBuilder(leaf_box, fs.walk_nodes, slot_prim).Build() + 1; // + sentinel entry
         ig.n_walk_nodes = static_cast<uint32_t>(fs.walk_nodes.size() / 4);
         // measured: on meshes a wavefront should stop waiting for its last
         // few searching lanes (matpreview +30 % at 8..16), in box-like scenes it should not
@@ -1028,18 +1062,15 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
         // distance itself is; a leaf box's entry distance does not.  Hits closer together than that
         // are "tied": the walk must visit both and decide like the reference (traversal.h, test_slot).
         // Offsets are at most (largest |coordinate| of the geometry or the eye) * 2.
-        float coordinate = std::max({fabsf(fs.camera.eye.x), fabsf(fs.camera.eye.y), fabsf(fs.camera.eye.z)});
-        for (const Bounds &b : prim_box)
-            coordinate = std::max({coordinate, fabsf(b.lo.x), fabsf(b.lo.y), fabsf(b.lo.z), fabsf(b.hi.x), fabsf(b.hi.y),
-                                   fabsf(b.hi.z)});
-        ig.walk_tie = 2.0f * coordinate * 1e-6f;
+        ig.walk_tie = 5e-6f * coordinate;
+        ig.walk_sliver_reach = largest_grow > 0.0f ? std::max(ig.walk_tie, largest_grow) : 0.0f; // 0: no slivers
         fs.walk_prims.reserve(3 * slot_prim.size());
         for (const uint32_t prim : slot_prim)
         {
             const float4 *p = &fs.tri_pos[3 * static_cast<size_t>(prim)];
             fs.walk_prims.push_back(float4{p[0].x, p[0].y, p[0].z, Bits(prim)});
             fs.walk_prims.push_back(float4{p[1].x, p[1].y, p[1].z, Bits(prim_inst[prim])});
-            fs.walk_prims.push_back(float4{p[2].x, p[2].y, p[2].z, Bits(rank[prim])});
+            fs.walk_prims.push_back(float4{p[2].x, p[2].y, p[2].z, Bits(rank[prim] | (sliver[prim] ? kWalkSliver : 0u))});
         }
         fs.seconds_walk = seconds_since(t_walk);
     }

@@ -40,6 +40,7 @@ struct Config
     static constexpr bool kMicrofacet = (kFeatures & kFeatMicrofacet) != 0;
     static constexpr bool kOrdered = (kFeatures & kFeatOrderedWalk) != 0; // which ray query runs (traversal.h)
     static constexpr bool kVote = (kFeatures & kFeatVoteWalk) != 0;       // ... scheduled by wavefront vote
+    static constexpr bool kSlivers = (kFeatures & kFeatSlivers) != 0;     // ... with the sliver handling of test_slot
 };
 
 struct LaneCounters
@@ -135,10 +136,10 @@ MCPT_HD bool trace(const DeviceScene &sc, uint32_t *stack, Ray &r, uint32_t &rng
     if (C::kOrdered)
     {
         if (C::kVote)
-            return count ? walk_ordered_vote<kAny, C::kAnalytic, true>(sc, stack, r, hit, ts)
-                         : walk_ordered_vote<kAny, C::kAnalytic, false>(sc, stack, r, hit, ts);
-        return count ? walk_ordered<kAny, C::kAnalytic, true>(sc, stack, r, hit, ts)
-                     : walk_ordered<kAny, C::kAnalytic, false>(sc, stack, r, hit, ts);
+            return count ? walk_ordered_vote<kAny, C::kAnalytic, true, C::kSlivers>(sc, stack, r, hit, ts)
+                         : walk_ordered_vote<kAny, C::kAnalytic, false, C::kSlivers>(sc, stack, r, hit, ts);
+        return count ? walk_ordered<kAny, C::kAnalytic, true, C::kSlivers>(sc, stack, r, hit, ts)
+                     : walk_ordered<kAny, C::kAnalytic, false, C::kSlivers>(sc, stack, r, hit, ts);
     }
     return count ? walk_scene<kAny, C::kAnalytic, C::kTextures, true>(sc, r, rng, hit, ts)
                  : walk_scene<kAny, C::kAnalytic, C::kTextures, false>(sc, r, rng, hit, ts);

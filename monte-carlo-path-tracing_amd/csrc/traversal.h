@@ -464,11 +464,11 @@ struct ClosestState
 // (triangle.cpp:82) — and the later accepted one is kept.  This covers exact ties (shared
 // edges, two surfaces in one plane) and the case where a flat box's entry distance and
 // the triangle's own distance differ in the last bit.  Returns whether `hit` changed.
-template <bool kAny, bool kAnalytic>
+template <bool kAny, bool kAnalytic, bool kSlivers = true>
 MCPT_HD bool test_slot(const DeviceScene &sc, uint32_t slot, Ray &ray, HitRaw &hit, ClosestState &best)
 {
     const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(slot);
-    const uint32_t prim = as_uint(p[0].w), inst = as_uint(p[1].w), rank = as_uint(p[2].w);
+    const uint32_t prim = as_uint(p[0].w), inst = as_uint(p[1].w), rank = as_uint(p[2].w); // rank | kWalkSliver
     SlotHit h;
     if (!kAnalytic || sc.instances[inst].kind == kInstTriangles)
     {
@@ -492,19 +492,40 @@ MCPT_HD bool test_slot(const DeviceScene &sc, uint32_t slot, Ray &ray, HitRaw &h
         h.t = probe.t_max, h.a = cand.a, h.b = cand.b, h.c = cand.c, h.inside = cand.inside;
     }
     bool take;
+    // A sliver's leaf box in the hierarchy is larger than the reference's (commit.cpp), so the walk
+    // gets here in cases where the reference does not — e.g. when the ray STARTS on the sliver and its
+    // flat box ends before t_min while the computed distance lands just above it, or passes along an
+    // edge that neither neighbour's box admits.  Kernels for scenes without slivers are compiled
+    // without all of it (kSlivers; it costs the VALU-bound cornell kernel 2 %).
+    const bool slivers = kSlivers && sc.integrator.walk_sliver_reach > 0.0f;
+    const bool sliver = slivers && (rank & kWalkSliver) != 0;
     if (kAny)
     {
         take = h.hit && !(h.t > ray.t_max);
+        if (slivers && take && sliver) // reached through its grown box: would the reference's own leaf box let the ray in?
+            take = reference_leaf_box_passes<kAnalytic>(sc, inst, prim, ray, ray.t_max);
     }
     else
     {
         // (a NaN distance — a ray with NaN components "hits" everything — is never kept: the
         //  reference drops such an instance hit when it merges it, tlas.cpp:27-33)
         take = h.hit && (best.found ? h.t < best.best_t : h.t <= ray.t_max);
-        if (h.hit && best.found && fabsf(h.t - best.best_t) <= sc.integrator.walk_tie)
+        float tie = sc.integrator.walk_tie;
+        bool reachable = true;
+        if (slivers)
         {
-            // rare: replay the reference on the pair (current best, this primitive)
-            if (rank > best.best_rank) // the reference comes here second
+            if ((rank | best.best_rank) & kWalkSliver)
+                tie = sc.integrator.walk_sliver_reach; // what a sliver's distance can be off by
+            if (h.hit && sliver)
+                reachable = reference_leaf_box_passes<kAnalytic>(sc, inst, prim, ray, kMaxFloat);
+        }
+        if (!reachable)
+            take = false; // the reference never tests it for this ray, whatever it has found so far
+        else if (h.hit && best.found && fabsf(h.t - best.best_t) <= tie)
+        {
+            // rare: replay the reference on the pair (current best, this primitive) — hits within the
+            // tie radius of each other
+            if ((kSlivers ? (rank & ~kWalkSliver) > (best.best_rank & ~kWalkSliver) : rank > best.best_rank)) // the reference comes here second
                 take = !(h.t > best.best_t) && reference_leaf_box_passes<kAnalytic>(sc, inst, prim, ray, best.best_t);
             else // the reference came here first; the current best is its second
                 take = !(!(best.best_t > h.t) && reference_leaf_box_passes<kAnalytic>(sc, hit.inst, hit.prim, ray, h.t));
@@ -517,7 +538,7 @@ MCPT_HD bool test_slot(const DeviceScene &sc, uint32_t slot, Ray &ray, HitRaw &h
         if (!kAny)
         {
             best.best_t = h.t, best.best_rank = rank;
-            ray.t_max = h.t + sc.integrator.walk_tie;
+            ray.t_max = h.t + ((kSlivers && (rank & kWalkSliver)) ? sc.integrator.walk_sliver_reach : sc.integrator.walk_tie);
         }
     }
     return take;
@@ -539,7 +560,7 @@ MCPT_HD bool is_leading_lane()
 // primitive (or is done) before paying for one primitive phase; leaving the node
 // phase earlier (when only a few lanes are still searching) was measured and is
 // slower at every threshold (cornell: -2 % at 8 lanes ... -26 % at 64).
-template <bool kAny, bool kAnalytic, bool kCount>
+template <bool kAny, bool kAnalytic, bool kCount, bool kSlivers = true>
 MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitRaw &hit, TraceStats &stats)
 {
     if (sc.integrator.n_walk_nodes == 0)
@@ -589,7 +610,7 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
             if (is_leading_lane())
                 ++stats.wave_prim_steps;
         }
-        if (test_slot<kAny, kAnalytic>(sc, cur & ~kWalkLeaf, ray, hit, best) && kAny)
+        if (test_slot<kAny, kAnalytic, kSlivers>(sc, cur & ~kWalkLeaf, ray, hit, best) && kAny)
             return true;
         --depth;
         cur = stack[depth * kWalkStackStride];
@@ -621,7 +642,7 @@ MCPT_HD uint32_t lanes_where(bool p)
 // (matpreview 266 -> 347 Msamples/s with walk_break 8..16, another 6 % with
 // walk_hold 10..12).  With both 0 it is walk_ordered plus one ballot per step.  One
 // lane's visiting order never changes.
-template <bool kAny, bool kAnalytic, bool kCount>
+template <bool kAny, bool kAnalytic, bool kCount, bool kSlivers = true>
 MCPT_HD bool walk_ordered_vote(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitRaw &hit, TraceStats &stats)
 {
     if (sc.integrator.n_walk_nodes == 0)
@@ -686,7 +707,7 @@ MCPT_HD bool walk_ordered_vote(const DeviceScene &sc, uint32_t *stack, Ray &ray,
             if (is_leading_lane())
                 ++stats.wave_prim_steps;
         }
-        if (test_slot<kAny, kAnalytic>(sc, cur & ~kWalkLeaf, ray, hit, best) && kAny)
+        if (test_slot<kAny, kAnalytic, kSlivers>(sc, cur & ~kWalkLeaf, ray, hit, best) && kAny)
         {
             cur = kWalkDone;
             continue;

@@ -61,6 +61,17 @@ class Emulator:
         steps = out[:n]
         return steps, steps[:, 11].copy().view(np.uint32)
 
+    def closest(self, mcsd_path, rays, ordered=True):
+        """Closest-hit queries (rays[n, 6]) with the ordered or the reference-order walk:
+        (primitive[n] int64 with -1 = miss, distance[n] float32)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        out = np.zeros((len(rays), 2), np.float32)
+        self.lib.mcpt_emu_closest.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+        if self.lib.mcpt_emu_closest(str(mcsd_path).encode(), rays.ctypes.data, len(rays), 1 if ordered else 0,
+                                     out.ctypes.data) != 0:
+            raise RuntimeError(self.lib.mcpt_emu_last_error().decode())
+        return out[:, 0].astype(np.int64), out[:, 1].copy()
+
     def set_walk_tree(self, strategy: int):
         """Split rule of the ordered-walk hierarchy for later renders: 0 production,
         1 exact sweep, 2 median, 3 children swapped."""

@@ -117,6 +117,16 @@ int mcpt_emu_render(const char *mcsd_path, float *frame, int variant, uint32_t *
         // like the launcher: plain ordered walk in the two lean instantiations, vote-scheduled
         // (a no-op on the one-lane "wavefronts" of the host build) in the others
         constexpr uint32_t kO = kFeatOrderedWalk, kV = kFeatOrderedWalk | kFeatVoteWalk;
+        constexpr uint32_t kSurfaceF = kFeatEmitters | kFeatTextures | kFeatMicrofacet;
+        if (ordered && flat.integrator.walk_sliver_reach > 0.0f)
+        {
+            // like the launcher: scenes with sliver triangles run the sliver-aware instantiations
+            if ((pick & ~kSurfaceF) == 0)
+                RenderAll<kSurfaceF | kV | kFeatSlivers>(sc, frame, cnt);
+            else
+                RenderAll<kAll | kV | kFeatSlivers>(sc, frame, cnt);
+        }
+        else
         switch (pick | (ordered ? kO : 0u))
         {
         case 0:
@@ -590,7 +600,7 @@ int mcpt_emu_debug_pixel(const char *mcsd_path, uint32_t pixel, int ordered, flo
             if (!st.alive)
                 start_sample(sc, st);
             if (ordered)
-                path_step<Config<kAllF | kFeatOrderedWalk>>(sc, st, &cnt);
+                path_step<Config<kAllF | kFeatOrderedWalk | kFeatSlivers>>(sc, st, &cnt);
             else
                 path_step<Config<kAllF>>(sc, st, &cnt);
             float *o = out + 16 * n++;
@@ -604,6 +614,45 @@ int mcpt_emu_debug_pixel(const char *mcsd_path, uint32_t pixel, int ordered, flo
             o[12] = st.L.x, o[13] = st.L.y, o[14] = st.L.z, o[15] = static_cast<float>(st.depth);
         }
         return static_cast<int>(n);
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return -1;
+    }
+}
+
+// Closest-hit queries with either walk, one per ray (6 floats each): out = 2 floats per ray
+// {global primitive or -1, distance}.  Multi-threaded over the rays.
+int mcpt_emu_closest(const char *mcsd_path, const float *rays, uint32_t n, int ordered, float *out)
+{
+    try
+    {
+        const FlatScene flat = CommitScene(mcsd::Load(mcsd_path));
+        const DeviceScene sc = flat.HostView();
+        const unsigned n_threads = std::max(1u, std::thread::hardware_concurrency());
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_threads; ++t)
+            pool.emplace_back(
+                [&, t]()
+                {
+                    std::vector<uint32_t> stack(kWalkStackMax * kWalkStackStride);
+                    for (uint32_t i = t; i < n; i += n_threads)
+                    {
+                        Ray ray = make_ray(V3{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]},
+                                           V3{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]});
+                        HitRaw raw;
+                        TraceStats ts{0, 0, 0, 0};
+                        uint32_t rng = 1;
+                        const bool hit = ordered ? walk_ordered<false, true, false>(sc, stack.data(), ray, raw, ts)
+                                                 : walk_scene<false, true, true, false>(sc, ray, rng, raw, ts);
+                        out[2 * i] = hit ? static_cast<float>(raw.prim) : -1.0f;
+                        out[2 * i + 1] = ray.t_max;
+                    }
+                });
+        for (std::thread &th : pool)
+            th.join();
+        return 0;
     }
     catch (const std::exception &e)
     {

@@ -47,6 +47,32 @@ def edge_scenes(pkg):
                                   texcoords=np.array([[0, 1], [0, 1], [0, 1]], np.float32),
                                   indices=np.array([[0, 1, 2]], np.uint32)))
     out["nan_shading_frame"] = s
+    # slivers: triangles ~1000 times longer than wide, lying in and just above the floor and across the box.
+    # Their computed hit distance is unreliable (cancellation in the edge functions) and so is whether a ray
+    # that starts on one "hits" it again just beyond t_min; the reference's answers then depend on its
+    # visiting order and on its flat leaf boxes.  The ordered walk marks them (kWalkSliver), reaches them
+    # through grown boxes and replays the reference's decision (commit.cpp, traversal.h::test_slot).
+    s = S.cornell_box(40, 40, 4)
+    rng = np.random.default_rng(12)
+    pos, idx = [], []
+    for k in range(60):
+        a = rng.uniform(-0.9, 0.9, 3)
+        d = rng.normal(size=3)
+        if k % 3 == 0:
+            a[1], d[1] = 0.0, 0.0                      # in the floor plane (y = 0 in this scene)
+        elif k % 3 == 1:
+            a[1], d[1] = 1e-4, 0.0                     # a hair above it
+        d /= np.linalg.norm(d)
+        side = np.cross(d, [0.3, 1.0, 0.2])
+        side /= np.linalg.norm(side)
+        if k % 3 != 2:
+            side[1] = 0.0
+        b, c = a + 1.9 * d, a + 0.5 * 1.9 * d + 0.002 * side
+        idx.append([len(pos), len(pos) + 1, len(pos) + 2])
+        pos += [a, b, c]
+    s.instances.append(M.Instance(type=M.INST_MESHES, id_bsdf=1, positions=np.asarray(pos, np.float32),
+                                  indices=np.asarray(idx, np.uint32)))
+    out["slivers"] = s
     # per-vertex tangents and / or bitangents handed over with the mesh (what the reference gets from
     # assimp's CalcTangentSpace; scene.cpp:81-100, transformed by to_world at :271-280): an anisotropic
     # conductor makes the frame's orientation visible
@@ -67,7 +93,7 @@ def edge_scenes(pkg):
 
 
 NAMES = ["empty_scene_constant_emitter", "empty_scene_dark", "light_only", "no_lights", "film_1x1", "film_3x5",
-         "film_65x9", "spp_1", "depth_max_0", "depth_max_1", "roulette_from_start", "degenerate_triangle", "nan_shading_frame",
+         "film_65x9", "spp_1", "depth_max_0", "depth_max_1", "roulette_from_start", "degenerate_triangle", "nan_shading_frame", "slivers",
          "supplied_tangents", "supplied_tangents_only", "supplied_bitangents_only"]
 
 
@@ -93,7 +119,7 @@ def test_edge_case_on_cpu(name, pkg, oracle, emulator, mcsd_file, request):
     import checkers
     # (the compiled reference rebuilds its Kulla-Conty table on every render: ~5 s, so a subset)
     if checkers.reference_available() and name in ("empty_scene_constant_emitter", "film_3x5", "depth_max_0",
-                                                   "degenerate_triangle", "nan_shading_frame", "supplied_tangents",
+                                                   "degenerate_triangle", "nan_shading_frame", "slivers", "supplied_tangents",
                                                    "supplied_tangents_only", "supplied_bitangents_only"):
         ref, _ = checkers.Reference().render(path, w, h)
         np.testing.assert_array_equal(ref, want)

@@ -342,3 +342,48 @@ def test_emulated_counters_match_oracle(pkg, oracle, emulator, mcsd_file):
     for key in ("closest_rays", "shadow_rays", "shaded_hits", "samples"):
         assert ordered[key] == got[key], key
     assert 0 < ordered["prim_tests"] and ordered["node_tests"] % 2 == 0
+
+
+def test_slivers_are_decided_like_the_reference(pkg, emulator, tmp_path):
+    """A window-frame strip as in the reference's classroom scene: two 40-unit-long, 0.04-wide triangles
+    meeting a vertical face along an edge, at coordinates of 7 .. 20.  The reference's triangle distance
+    for such a sliver is off by up to ~1e-3 (weighted mean of vertex depths with ill-conditioned
+    weights), so which of two surfaces it reports near the edge depends on its visiting order and on
+    whether the sliver's flat leaf box still passes — and a ray that starts on a sliver may or may not
+    "hit" it again just beyond t_min.  500 000 closest queries, ordered walk == reference-order walk in
+    primitive and distance.  (Without the sliver handling of commit.cpp / traversal.h::test_slot:
+    10 mismatches.)"""
+    S, M = pkg.scenes, pkg.mcsd
+    s = S.cornell_box(8, 8, 1)
+    s.instances = s.instances[-1:]
+    P = np.array([[6.87156, 1.0016, 20.268], [6.87156, 1.0016, -20.294], [6.9114, 1.0016, -20.294], [6.9114, 1.0016, 20.268],
+                  [6.87156, 1.13605, 20.268], [6.87156, 1.13605, -20.294]], np.float32)
+    s.instances.append(M.Instance(type=M.INST_MESHES, id_bsdf=0, positions=P,
+                                  indices=np.array([[0, 1, 2], [0, 2, 3], [4, 1, 0], [4, 5, 1]], np.uint32)))
+    Q = np.array([[-30, 0, -30], [30, 0, -30], [30, 0, 30], [-30, 0, 30], [6.95, -5, -30], [6.95, 5, -30], [6.95, 5, 30],
+                  [6.95, -5, 30]], np.float32)
+    s.instances.append(M.Instance(type=M.INST_MESHES, id_bsdf=1, positions=Q,
+                                  indices=np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7]], np.uint32)))
+    path = tmp_path / "sliver.mcsd"
+    M.dump(s, path)
+    _, prims, _ = emulator.walk(path)
+    flags = prims[:, 2, 3].copy().view(np.uint32) >> 31
+    slot_prim = prims[:, 0, 3].copy().view(np.uint32)
+    # primitives 0, 1 = the light; 2..5 = the strip (40 x 0.04) and its face (40 x 0.13): aspect ratios 1000 and 300
+    assert sorted(slot_prim[flags == 1]) == [2, 3, 4, 5]
+    rng = np.random.default_rng(1)
+    n = 400000
+    target = np.stack([6.87156 + rng.normal(0, 0.01, n), 1.0016 + rng.normal(0, 0.01, n), rng.uniform(-20, 20, n)], 1)
+    origin = target + np.stack([-rng.uniform(1, 6, n), rng.uniform(0.2, 4, n), rng.normal(0, 4, n)], 1)
+    d = target - origin
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    m = 100000                                                     # rays that start ON the slivers
+    o2 = np.stack([rng.uniform(6.87156, 6.9114, m), np.full(m, 1.0016), rng.uniform(-20, 20, m)], 1)
+    d2 = rng.normal(size=(m, 3))
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    rays = np.concatenate([np.concatenate([origin, d], 1), np.concatenate([o2, d2], 1)]).astype(np.float32)
+    a_prim, a_t = emulator.closest(path, rays, ordered=True)
+    b_prim, b_t = emulator.closest(path, rays, ordered=False)
+    assert (b_prim >= 0).mean() > 0.9
+    bad = (a_prim != b_prim) | (a_t != b_t)
+    assert not bad.any(), (int(bad.sum()), rays[bad][:3], a_prim[bad][:3], b_prim[bad][:3])
