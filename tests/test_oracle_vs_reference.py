@@ -59,7 +59,7 @@ def test_bsdf_units(pkg, oracle, reference, mcsd_file):
                      "dielectric", "rough_dielectric", "thin_dielectric", "plastic", "rough_plastic"):
         path = mcsd_file(pkg.scenes.material_preview(material, "constant", "sphere", 8, 8, 1))
         with oracle.open(path) as so, reference.open(path) as sr:
-            for _ in range(600):
+            for _ in range(300):
                 n = unit(rng.normal(size=3))
                 t = unit(np.cross(n, rng.normal(size=3)) + 0.2 * rng.normal(size=3))
                 b = unit(np.cross(n, t))
@@ -77,7 +77,7 @@ def test_intersection_units(pkg, oracle, reference, mcsd_file):
     for shape in ("mesh", "sphere", "disk", "cylinder", "cube"):
         path = mcsd_file(pkg.scenes.material_preview("bumpy_diffuse", "area", shape, 8, 8, 1))
         with oracle.open(path) as so, reference.open(path) as sr:
-            for _ in range(1200):
+            for _ in range(600):
                 org = rng.normal(size=3) * 1.5 + [0, 0.8, 0]
                 d = np.array([0, 0.6, 0]) + rng.normal(size=3) * 0.5 - org
                 d /= np.linalg.norm(d)
