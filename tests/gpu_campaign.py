@@ -28,6 +28,17 @@ for seed in seeds:
                     inst.tangents = t.astype(np.float32); inst.bitangents = np.cross(nrm, t).astype(np.float32)
                 if rng.random() < 0.5:
                     inst.to_world = (S.translate_scale(t=tuple(rng.normal(size=3) * 0.1), s=tuple(1 + rng.random(3) * 0.3)) @ S.rot_x(float(rng.random() * 40))).astype(np.float32)
+        if rng.random() < 0.3:
+            # a fan of sliver triangles (aspect ~1000) through the scene: the sliver-aware kernel variants
+            pos, idx = [], []
+            for k in range(int(rng.integers(5, 40))):
+                a = rng.uniform(-1.5, 1.5, 3); a[1] = abs(a[1]) * (0 if k % 4 == 0 else 1)
+                d = rng.normal(size=3); d[1] *= 0.2 * (k % 4 != 0); d /= np.linalg.norm(d)
+                side = np.cross(d, rng.normal(size=3)); side /= np.linalg.norm(side)
+                b, c = a + 3.0 * d, a + 1.5 * d + 0.003 * side
+                idx.append([len(pos), len(pos) + 1, len(pos) + 2]); pos += [a, b, c]
+            scene.instances.append(M.Instance(type=M.INST_MESHES, id_bsdf=0, positions=np.asarray(pos, np.float32),
+                                              indices=np.asarray(idx, np.uint32)))
         path = os.path.join(tmp, 's.mcsd'); M.dump(scene, path)
         want, _ = orc.render(path)
         r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
