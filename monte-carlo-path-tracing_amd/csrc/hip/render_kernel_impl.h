@@ -1,0 +1,218 @@
+// HIP render kernel for gfx950 (MI355X): persistent lanes running the streaming
+// path-tracing state machine of path_core.h.
+//
+// Launch shape.  A workgroup is 256 lanes = 4 wavefronts of 64.  Work items are
+// pixels enumerated tile by tile (8x8 pixels per tile, so one wavefront starts
+// on one coherent tile); a lane processes item q, q + stride, ... where stride
+// is the total number of launched lanes, so the grid is sized to the machine
+// (CUs x resident workgroups) rather than to the image, and every lane keeps
+// regenerating paths until its pixels are exhausted.  No data is exchanged
+// between lanes: the per-pixel sequential RNG chain of the reference makes
+// the pixel the unit of parallelism.
+//
+// Memory.  All scene tables are read-only arrays in HBM (device_scene.h).  A ray
+// query reads one 64-byte two-box node (four float4 loads) per step and one 48-byte
+// primitive slot per leaf; hit attributes (144 B) are read once per shaded hit.
+// Path state lives in registers, the traversal stacks in LDS (lane-interleaved);
+// the only global writes are 12 B per finished pixel.  Scenes whose traversal data
+// fits 24 KiB are staged into LDS per workgroup, larger ones are read through
+// L1 / L2.  There is no matrix-shaped work here: no MFMA.
+//
+// This file is the shared part of the kernel translation units: the kernel template and its
+// launcher.  The instantiations are spread over render_kernel.hip (lean variants, unit kernels,
+// the dispatcher), render_variants_all.hip, render_variants_counted.hip and
+// render_variants_surface.hip so that `make -j` compiles them side by side (one unit took 3.7
+// minutes); the `extern template` lines below keep a unit from instantiating another unit's kernels.
+#ifndef MCPT_RENDER_KERNEL_IMPL_H
+#define MCPT_RENDER_KERNEL_IMPL_H
+
+#include <hip/hip_runtime.h>
+
+#include "../path_core.h"
+#include "render_kernel.h"
+
+namespace mcpt
+{
+
+// Register budget: the lean instantiations (no microfacet / volume code) are
+// held to 128 VGPRs = 4 wavefronts per SIMD = 4 workgroups of 256 per CU, so
+// that a 512x512 frame (262 144 pixels = 256 CUs x 1024 lanes) is resident in
+// one round; the material instantiations run 3 per SIMD.
+template <uint32_t kFeatures, bool kLdsGeometry = true>
+struct Budget
+{
+    // The lean instantiations for scenes too large for LDS are memory-latency bound (0.8 M
+    // triangles: 63 % of wave cycles waiting, VALU pipe 41 % busy): held to 6 per SIMD (80 VGPRs,
+    // some spilling) they are 11 % (blob field) and 19 % (terrain) faster than at 4.
+    // measured: the full instantiation at 3 per SIMD (<= 168 VGPRs) is 17 % faster on the
+    // volumetric scenes than at 2 (208 VGPRs), slower again at 4 (-3 %) and 6 (-24 %); the
+    // surface-materials instantiation (matpreview) is fastest at 6 (rough dielectric +25 %,
+    // rough conductor +3 % over its natural 168 VGPRs)
+    static constexpr int kWavesPerSimd = (kFeatures & (kFeatVolPath | kFeatAnalytic)) ? 3
+#ifdef MCPT_EXPERIMENT_MICROFACET_WAVES
+                                         : (kFeatures & kFeatMicrofacet)              ? MCPT_EXPERIMENT_MICROFACET_WAVES
+#else
+                                         : (kFeatures & kFeatMicrofacet)              ? 6
+#endif
+                                         : kLdsGeometry                                ? 4
+                                                                                      : 6;
+};
+
+// kLdsGeometry: the arrays the ray queries and the light sampler read (both
+// hierarchies, walk primitives, triangle positions) are copied into LDS by each
+// workgroup before it starts and read from there (ds_read_b128) instead of
+// through L1.  Used for scenes whose traversal data fits kLdsGeometryBytes
+// (cornell: 8 KB); a walk is a chain of dependent loads, so the shorter LDS
+// latency shortens every step.  Large scenes stream from HBM / L2.
+// The ordered walk's stacks always live in LDS: lane t of the workgroup owns the
+// words t, t + 256, t + 512, ... of the stack area.
+template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
+__global__ void __launch_bounds__(kBlockSize, (Budget<kFeatures, kLdsGeometry>::kWavesPerSimd))
+render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ out, TraceCounters *__restrict__ counters)
+{
+    using C = Config<kFeatures>;
+    extern __shared__ float4 lds_geometry[];
+    DeviceScene sc = sc_in;
+    uint32_t n_staged = 0;
+    if (kLdsGeometry)
+    {
+        const uint32_t n_node_vec = 2u * sc_in.integrator.n_nodes, n_tri_vec = 3u * sc_in.integrator.n_prims;
+        const uint32_t n_walk_vec = C::kOrdered ? 4u * sc_in.integrator.n_walk_nodes : 0u;
+        const uint32_t n_slot_vec = C::kOrdered ? n_tri_vec : 0u;
+        for (uint32_t i = threadIdx.x; i < n_node_vec; i += blockDim.x)
+            lds_geometry[i] = sc_in.nodes[i];
+        for (uint32_t i = threadIdx.x; i < n_tri_vec; i += blockDim.x)
+            lds_geometry[n_node_vec + i] = sc_in.tri_pos[i];
+        for (uint32_t i = threadIdx.x; i < n_walk_vec; i += blockDim.x)
+            lds_geometry[n_node_vec + n_tri_vec + i] = sc_in.walk_nodes[i];
+        for (uint32_t i = threadIdx.x; i < n_slot_vec; i += blockDim.x)
+            lds_geometry[n_node_vec + n_tri_vec + n_walk_vec + i] = sc_in.walk_prims[i];
+        __syncthreads();
+        sc.nodes = lds_geometry;
+        sc.tri_pos = lds_geometry + n_node_vec;
+        if (C::kOrdered)
+        {
+            sc.walk_nodes = lds_geometry + n_node_vec + n_tri_vec;
+            sc.walk_prims = lds_geometry + n_node_vec + n_tri_vec + n_walk_vec;
+        }
+        n_staged = n_node_vec + n_tri_vec + n_walk_vec + n_slot_vec;
+    }
+    const uint32_t stride = gridDim.x * blockDim.x;
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t width = static_cast<uint32_t>(sc.camera.width), height = static_cast<uint32_t>(sc.camera.height);
+
+    LaneCounters local{};
+    LaneCounters *cnt = kCount ? &local : nullptr;
+
+    PathState st;
+    st.alive = false;
+    st.stack = reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + threadIdx.x;
+    bool has_pixel = false;
+    uint32_t slot = 0; // where this pixel's result goes
+    for (;;)
+    {
+        if (!has_pixel)
+        {
+            if (q >= job.n_items)
+                break;
+            // item -> tile -> pixel
+            const uint32_t local_tile = q >> 6, r = q & 63u;
+            const uint32_t tile = job.tile_first + local_tile * job.tile_stride;
+            const uint32_t x = (tile % job.tiles_x) * 8u + (r & 7u), y = (tile / job.tiles_x) * 8u + (r >> 3);
+            const uint32_t item = q;
+            q += stride;
+            if (x >= width || y >= height)
+                continue; // padding of an edge tile
+            const uint32_t pixel = y * width + x;
+            start_pixel(st, pixel);
+            slot = job.packed ? item : pixel;
+            has_pixel = true;
+        }
+        if (!st.alive)
+        {
+            if (st.sample >= sc.camera.spp)
+            {
+                const V3 c = pixel_value(sc, st);
+                float *dst = out + 3 * static_cast<size_t>(slot);
+                dst[0] = c.x, dst[1] = c.y, dst[2] = c.z;
+                has_pixel = false;
+                continue;
+            }
+            start_sample(sc, st);
+            if (kCount)
+                ++local.samples;
+        }
+        path_step<C>(sc, st, cnt);
+    }
+
+    if (kCount)
+    {
+        atomicAdd(&counters->closest_rays, static_cast<unsigned long long>(local.closest_rays));
+        atomicAdd(&counters->shadow_rays, static_cast<unsigned long long>(local.shadow_rays));
+        atomicAdd(&counters->node_tests, static_cast<unsigned long long>(local.node_tests));
+        atomicAdd(&counters->prim_tests, static_cast<unsigned long long>(local.prim_tests));
+        atomicAdd(&counters->shaded_hits, static_cast<unsigned long long>(local.shaded_hits));
+        atomicAdd(&counters->samples, static_cast<unsigned long long>(local.samples));
+        if (local.wave_node_steps)
+            atomicAdd(&counters->wave_node_steps, static_cast<unsigned long long>(local.wave_node_steps));
+        if (local.wave_prim_steps)
+            atomicAdd(&counters->wave_prim_steps, static_cast<unsigned long long>(local.wave_prim_steps));
+    }
+}
+
+constexpr uint32_t kAll = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
+constexpr uint32_t kSurface = kFeatEmitters | kFeatTextures | kFeatMicrofacet;
+constexpr uint32_t kO = kFeatOrderedWalk, kV = kFeatOrderedWalk | kFeatVoteWalk, kS = kFeatSlivers;
+
+inline size_t StagedBytes(const DeviceScene &sc, bool ordered)
+{
+    size_t vecs = 2ull * sc.integrator.n_nodes + 3ull * sc.integrator.n_prims;
+    if (ordered)
+        vecs += 4ull * sc.integrator.n_walk_nodes + 3ull * sc.integrator.n_prims;
+    return vecs * sizeof(float4);
+}
+
+template <uint32_t kFeatures, bool kCount, bool kLdsGeometry = false>
+hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters, hipStream_t stream,
+                  uint32_t max_blocks)
+{
+    constexpr bool kOrdered = (kFeatures & kFeatOrderedWalk) != 0;
+    const size_t lds_bytes = (kLdsGeometry ? StagedBytes(sc, kOrdered) : 0) +
+                             (kOrdered ? size_t(sc.integrator.walk_depth) * kBlockSize * sizeof(uint32_t) : 0);
+    int per_cu = 0;
+    hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &per_cu, render_kernel<kFeatures, kCount, kLdsGeometry>, kBlockSize, lds_bytes);
+    if (err != hipSuccess)
+        return err;
+    if (per_cu < 1)
+        per_cu = 1;
+    uint32_t blocks = (job.n_items + kBlockSize - 1) / kBlockSize;
+    const uint32_t resident = max_blocks * static_cast<uint32_t>(per_cu);
+    if (blocks > resident)
+        blocks = resident;
+    if (blocks == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL((render_kernel<kFeatures, kCount, kLdsGeometry>), dim3(blocks), dim3(kBlockSize), lds_bytes,
+                       stream, sc, job, out, counters);
+    return hipGetLastError();
+}
+
+// who instantiates what
+#define MCPT_LAUNCH_ARGS const DeviceScene &, const RenderJob &, float *, TraceCounters *, hipStream_t, uint32_t
+#if !defined(MCPT_UNIT_ALL)
+extern template hipError_t Launch<kAll, false, false>(MCPT_LAUNCH_ARGS);
+extern template hipError_t Launch<kAll | kV, false, false>(MCPT_LAUNCH_ARGS);
+extern template hipError_t Launch<kAll | kV | kS, false, false>(MCPT_LAUNCH_ARGS);
+#endif
+#if !defined(MCPT_UNIT_COUNTED)
+extern template hipError_t Launch<kAll, true, false>(MCPT_LAUNCH_ARGS);
+extern template hipError_t Launch<kAll | kV | kS, true, false>(MCPT_LAUNCH_ARGS);
+#endif
+#if !defined(MCPT_UNIT_SURFACE)
+extern template hipError_t Launch<kSurface | kV, false, false>(MCPT_LAUNCH_ARGS);
+extern template hipError_t Launch<kSurface | kV | kS, false, false>(MCPT_LAUNCH_ARGS);
+#endif
+
+} // namespace mcpt
+
+#endif // MCPT_RENDER_KERNEL_IMPL_H

@@ -1,0 +1,12 @@
+// Render-kernel instantiations compiled in this unit (see render_kernel_impl.h).
+#define MCPT_UNIT_ALL
+#include "render_kernel_impl.h"
+
+namespace mcpt
+{
+
+template hipError_t Launch<kAll, false, false>(MCPT_LAUNCH_ARGS);
+template hipError_t Launch<kAll | kV, false, false>(MCPT_LAUNCH_ARGS);
+template hipError_t Launch<kAll | kV | kS, false, false>(MCPT_LAUNCH_ARGS);
+
+} // namespace mcpt

@@ -1,0 +1,11 @@
+// Render-kernel instantiations compiled in this unit (see render_kernel_impl.h).
+#define MCPT_UNIT_COUNTED
+#include "render_kernel_impl.h"
+
+namespace mcpt
+{
+
+template hipError_t Launch<kAll, true, false>(MCPT_LAUNCH_ARGS);
+template hipError_t Launch<kAll | kV | kS, true, false>(MCPT_LAUNCH_ARGS);
+
+} // namespace mcpt
