@@ -183,7 +183,9 @@ def main():
             "metric": "Msamples/sec (W*H*spp/s)", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # the default series over N keeps the per-GPU work fixed (see above): every line of it,
+            # N = 1 included, is labelled "weak"; --strong or an explicit film fix the total work
+            "scaling": "strong" if (args.strong or args.width or args.height) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cornell-box {W}x{H} spp={SPP} (builtin scene = "
                                    "resources/scene/cornell-box/scene_v0.6.xml, path integrator, "
                                    "diffuse + MIS area light)",
