@@ -1,13 +1,16 @@
 // Image writers.  PNG follows the reference's output conversion
 // (src/utils/image_io.cpp:25-53: linear -> sRGB curve, scale by 255, truncate);
-// EXR / PFM / raw keep the linear float32 frame.  No external libraries: PNG
-// uses stored (uncompressed) deflate blocks, EXR uses uncompressed scanlines.
+// EXR / PFM / raw keep the linear float32 frame.  zlib (already needed for the
+// .serialized meshes) does the deflate of the PNG stream and of the EXR ZIP blocks.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <vector>
+
+#include <zlib.h>
 
 #include "frontend.hpp"
 
@@ -109,25 +112,11 @@ void WritePng(const std::string &path, const float *frame, int w, int h)
         for (int x = 0; x < 3 * w; ++x)
             scan.push_back(ToSrgb8(frame[static_cast<size_t>(y) * 3 * w + x]));
     }
-    // zlib stream of stored blocks
-    std::vector<uint8_t> z = {0x78, 0x01};
-    uint32_t a = 1, b = 0;
-    for (uint8_t c : scan)
-        a = (a + c) % 65521u, b = (b + a) % 65521u;
-    size_t pos = 0;
-    while (pos < scan.size() || scan.empty())
-    {
-        const size_t n = std::min<size_t>(65535, scan.size() - pos);
-        z.push_back(pos + n == scan.size() ? 1 : 0);
-        z.push_back(n & 0xff), z.push_back(n >> 8), z.push_back(~n & 0xff), z.push_back((~n >> 8) & 0xff);
-        z.insert(z.end(), scan.begin() + pos, scan.begin() + pos + n);
-        pos += n;
-        if (scan.empty())
-            break;
-    }
-    const uint32_t adler = (b << 16) | a;
-    for (int s = 24; s >= 0; s -= 8)
-        z.push_back(static_cast<uint8_t>(adler >> s));
+    uLongf z_size = compressBound(static_cast<uLong>(scan.size()));
+    std::vector<uint8_t> z(z_size);
+    if (compress2(z.data(), &z_size, scan.data(), static_cast<uLong>(scan.size()), 6) != Z_OK)
+        throw std::runtime_error("deflate failed for '" + path + "'.");
+    z.resize(z_size);
 
     Bytes out;
     const uint8_t magic[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
@@ -141,8 +130,10 @@ void WritePng(const std::string &path, const float *frame, int w, int h)
     WriteAll(path, out.v);
 }
 
-// OpenEXR 2.0 single-part scanline file, channels B, G, R as FLOAT, no
-// compression, increasing-y line order.
+// OpenEXR 2.0 single-part scanline file, channels B, G, R as FLOAT, ZIP compression
+// (blocks of 16 scanlines: bytes split into even / odd halves, delta-predicted,
+// deflated; a block that does not shrink is stored raw, as the format prescribes),
+// increasing-y line order.
 void WriteExr(const std::string &path, const float *frame, int w, int h)
 {
     Bytes out;
@@ -165,7 +156,7 @@ void WriteExr(const std::string &path, const float *frame, int w, int h)
     channels.u8(0);
     attr("channels", "chlist", channels);
     Bytes comp;
-    comp.u8(0);
+    comp.u8(3); // ZIP_COMPRESSION
     attr("compression", "compression", comp);
     Bytes window;
     window.le32(0), window.le32(0), window.le32(w - 1), window.le32(h - 1);
@@ -184,22 +175,46 @@ void WriteExr(const std::string &path, const float *frame, int w, int h)
     attr("screenWindowWidth", "float", one);
     out.u8(0); // end of header
 
-    const size_t line_bytes = static_cast<size_t>(w) * 3 * 4;
-    const uint64_t table_start = out.v.size();
-    const uint64_t data_start = table_start + 8ull * h;
-    for (int y = 0; y < h; ++y)
-        out.le64(data_start + static_cast<uint64_t>(y) * (8 + line_bytes));
+    constexpr int kLinesPerBlock = 16;
+    const int n_blocks = (h + kLinesPerBlock - 1) / kLinesPerBlock;
+    std::vector<std::vector<uint8_t>> blocks(n_blocks);
     std::vector<float> plane(w);
-    for (int y = 0; y < h; ++y)
+    for (int k = 0; k < n_blocks; ++k)
     {
-        out.le32(y);
-        out.le32(static_cast<uint32_t>(line_bytes));
-        for (int c = 2; c >= 0; --c) // B, G, R planes
-        {
-            for (int x = 0; x < w; ++x)
-                plane[x] = frame[(static_cast<size_t>(y) * w + x) * 3 + c];
-            out.raw(plane.data(), static_cast<size_t>(w) * 4);
-        }
+        const int y0 = k * kLinesPerBlock, y1 = std::min(h, y0 + kLinesPerBlock);
+        Bytes raw;
+        for (int y = y0; y < y1; ++y)
+            for (int c = 2; c >= 0; --c) // B, G, R planes
+            {
+                for (int x = 0; x < w; ++x)
+                    plane[x] = frame[(static_cast<size_t>(y) * w + x) * 3 + c];
+                raw.raw(plane.data(), static_cast<size_t>(w) * 4);
+            }
+        const size_t n = raw.v.size();
+        std::vector<uint8_t> shuffled(n);
+        const size_t half = (n + 1) / 2;
+        for (size_t i = 0; i < n; ++i)
+            shuffled[(i & 1) ? half + i / 2 : i / 2] = raw.v[i];
+        for (size_t i = n; i-- > 1;)
+            shuffled[i] = static_cast<uint8_t>(shuffled[i] - shuffled[i - 1] + 128);
+        uLongf z_size = compressBound(static_cast<uLong>(n));
+        std::vector<uint8_t> z(z_size);
+        if (compress2(z.data(), &z_size, shuffled.data(), static_cast<uLong>(n), 6) != Z_OK)
+            throw std::runtime_error("deflate failed for '" + path + "'.");
+        z.resize(z_size);
+        blocks[k] = z.size() < n ? std::move(z) : std::move(raw.v);
+    }
+    uint64_t offset = out.v.size() + 8ull * n_blocks;
+    for (int k = 0; k < n_blocks; ++k)
+    {
+        out.le64(offset);
+        offset += 8 + blocks[k].size();
+    }
+    for (int k = 0; k < n_blocks; ++k)
+    {
+        out.le32(k * kLinesPerBlock);
+        out.le32(static_cast<uint32_t>(blocks[k].size()));
+        out.raw(blocks[k].data(), blocks[k].size());
     }
     WriteAll(path, out.v);
 }

@@ -70,6 +70,7 @@ def test_bad_input_is_rejected(pkg, lib, tmp_path):
 
 
 def test_image_writers(pkg, lib, tmp_path):
+    from exr_util import read_exr_zip
     from PIL import Image
     rng = np.random.default_rng(0)
     frame = rng.random((20, 30, 3)).astype(np.float32)
@@ -86,12 +87,16 @@ def test_image_writers(pkg, lib, tmp_path):
     assert raw.startswith(b"PF\n30 20\n-1.0\n")
     body = np.frombuffer(raw[len(b"PF\n30 20\n-1.0\n"):], dtype="<f4").reshape(20, 30, 3)
     assert np.array_equal(body[::-1], frame)
-    pkg.capi.write_image(tmp_path / "a.exr", frame)
-    exr = (tmp_path / "a.exr").read_bytes()
-    assert exr[:4] == b"\x76\x2f\x31\x01"
-    # uncompressed scanlines: last line's R plane is the tail of the file
-    tail = np.frombuffer(exr[-30 * 4:], dtype="<f4")
-    assert np.array_equal(tail, frame[-1, :, 0])
+    # EXR: ZIP-compressed scanline file (blocks of 16 lines), channels B, G, R as FLOAT
+    yy, xx = np.mgrid[0:37, 0:50]
+    smooth = np.stack([np.sin(xx * 0.1), np.cos(yy * 0.1), (xx + yy) * 0.01], -1).astype(np.float32)
+    for name, img in (("a", frame), ("smooth", smooth), ("one", frame[:1, :1].copy())):
+        pkg.capi.write_image(tmp_path / f"{name}.exr", img)
+        got = read_exr_zip(tmp_path / f"{name}.exr")
+        assert np.array_equal(got, img), name
+    assert (tmp_path / "smooth.exr").stat().st_size < 0.8 * smooth.nbytes       # it does compress
+    pkg.capi.write_image(tmp_path / "smooth.png", np.clip(smooth, 0, 1))
+    assert (tmp_path / "smooth.png").stat().st_size < 0.75 * 37 * 50 * 3   # deflated, not stored
     with pytest.raises(pkg.capi.McptError):
         pkg.capi.write_image(tmp_path / "a.bmp", frame)
 

@@ -835,38 +835,6 @@ def test_cli_film_overrides_reach_the_configuration(pkg, tmp_path):
         assert r.returncode == 1 and "no HIP device" in r.stderr
 
 
-def _read_uncompressed_exr(raw):
-    """Scanline EXR with compression NONE and FLOAT channels -> {name: array (h, w)}."""
-    assert struct.unpack("<I", raw[:4])[0] == 20000630
-    at, attrs = 8, {}
-    while raw[at] != 0:
-        e = raw.index(b"\0", at)
-        name = raw[at:e].decode()
-        e2 = raw.index(b"\0", e + 1)
-        size = struct.unpack("<i", raw[e2 + 1:e2 + 5])[0]
-        attrs[name] = raw[e2 + 5:e2 + 5 + size]
-        at = e2 + 5 + size
-    at += 1
-    assert attrs["compression"][0] == 0
-    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"])
-    w, h = x1 - x0 + 1, y1 - y0 + 1
-    names, p = [], 0
-    ch = attrs["channels"]
-    while ch[p] != 0:
-        e = ch.index(b"\0", p)
-        names.append(ch[p:e].decode())
-        assert struct.unpack("<i", ch[e + 1:e + 5])[0] == 2      # FLOAT
-        p = e + 17
-    offsets = struct.unpack(f"<{h}Q", raw[at:at + 8 * h])
-    out = {n: np.zeros((h, w), np.float32) for n in names}
-    for off in offsets:
-        y, size = struct.unpack("<ii", raw[off:off + 8])
-        row = np.frombuffer(raw[off + 8:off + 8 + size], "<f4").reshape(len(names), w)
-        for k, n in enumerate(names):
-            out[n][y - y0] = row[k]
-    return out
-
-
 @pytest.mark.gpu
 def test_cli_xml_to_exr(pkg, tmp_path):
     """The north-star command line: `--gpu -i scene.xml -o out.exr`."""
@@ -880,8 +848,8 @@ def test_cli_xml_to_exr(pkg, tmp_path):
     out = tmp_path / "out.exr"
     r = run_cli(pkg, "--gpu", "-i", xml, "-o", out, "-w", 40, "-h", 24, "-s", 8)
     assert r.returncode == 0, r.stderr
-    planes = _read_uncompressed_exr(out.read_bytes())
-    got = np.stack([planes["R"], planes["G"], planes["B"]], axis=-1)
+    from exr_util import read_exr_zip
+    got = read_exr_zip(out)
     frame, _ = pkg.capi.Renderer(pkg.capi.Config.load_xml(xml).set_film(40, 24, 8)).draw()
     np.testing.assert_array_equal(got, frame)
     assert frame.mean() > 0.2
@@ -1392,3 +1360,16 @@ def test_readers_equal_the_reference_library_on_its_own_textures(pkg, tmp_path):
     assert (t.width, t.height) == (256, 128)
     want = stb.resize(src, 256, 128)
     assert np.abs(np.asarray(t.data).reshape(want.shape) - want).max() <= 2e-5 * want.max()
+
+
+def test_written_exr_is_read_back(pkg, tmp_path):
+    """Writer (ZIP scanline EXR, image_io.cpp) -> reader (asset_io.cpp, LoadExr): the frame a render
+    writes can be used as an environment map, value for value (alpha 1 added by the reader)."""
+    rng = np.random.default_rng(3)
+    img = (rng.random((37, 64, 3)) * 4).astype(np.float32)
+    pkg.capi.write_image(tmp_path / "env.exr", img)
+    t = _envmap_through_front_end(pkg, tmp_path, "env.exr", (tmp_path / "env.exr").read_bytes(), 64, 45)
+    got = np.asarray(t.data).reshape(t.height, t.width, t.channel)
+    assert (t.width, t.height, t.channel) == (64, 37, 4)
+    np.testing.assert_array_equal(got[..., :3], img)
+    assert (got[..., 3] == 1).all()
