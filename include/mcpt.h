@@ -129,6 +129,13 @@ int mcpt_renderer_info(const mcpt_renderer *r, uint64_t info[9]);
  * during the walk). */
 int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order);
 
+/* Tuning knob of the vote-scheduled ordered walk (scenes of >= 2048 primitives; the image does not
+ * depend on it): a wavefront leaves its box-test phase for the primitive tests as soon as fewer than
+ * `leave_below` lanes are still searching, or as soon as `leave_at` lanes hold a primitive (0 = never
+ * for that reason).  The commit's defaults are 8 / 12 (0 / 0 for small scenes).  No reference
+ * counterpart. */
+int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint32_t leave_at);
+
 /* The reference-topology LBVH (reference src/rtcore/accel/bvh_builder.cpp:74-207) of n
  * boxes (6 floats each: lo.xyz, hi.xyz) with areas, built by the host builder
  * (on_device == 0, no GPU needed) or by the HIP builder.

@@ -89,6 +89,7 @@ def lib():
     L.mcpt_renderer_table.argtypes = [vp, cp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
     L.mcpt_renderer_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.mcpt_renderer_set_walk.argtypes = [vp, ctypes.c_int]
+    L.mcpt_renderer_set_walk_schedule.argtypes = [vp, u32, u32]
     L.mcpt_debug_lbvh_build.argtypes = [u32, vp, vp, i32, vp, vp, ctypes.POINTER(ctypes.c_double)]
     L.mcpt_debug_intersect.argtypes = [vp, u32, vp, vp, vp, vp]
     L.mcpt_debug_bsdf.argtypes = [vp, u32, i32, u32, vp, vp, vp, vp]
@@ -111,7 +112,8 @@ EXPORTED_SYMBOLS = [
     "mcpt_config_save_mcsd", "mcpt_config_destroy", "mcpt_renderer_create",
     "mcpt_renderer_draw", "mcpt_renderer_draw_device", "mcpt_renderer_draw_counted",
     "mcpt_renderer_tile_count", "mcpt_tile_range_size", "mcpt_unpack_tiles",
-    "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_set_walk", "mcpt_renderer_destroy",
+    "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_set_walk", "mcpt_renderer_set_walk_schedule",
+    "mcpt_renderer_destroy",
     "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_trace_pixel",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
 ]
@@ -265,6 +267,11 @@ class Renderer:
         """False (default): ordered walk of the SAH hierarchy; True: the reference's
         trees in the reference's order (validation mode)."""
         _check(lib().mcpt_renderer_set_walk(self._h, 1 if reference_order else 0))
+        return self
+
+    def set_walk_schedule(self, leave_below: int, leave_at: int):
+        """Vote thresholds of the ordered walk on large scenes (see mcpt.h); the image does not change."""
+        _check(lib().mcpt_renderer_set_walk_schedule(self._h, leave_below, leave_at))
         return self
 
     def close(self):

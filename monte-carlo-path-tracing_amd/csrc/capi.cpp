@@ -542,6 +542,18 @@ int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order)
     return 0;
 }
 
+int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint32_t leave_at)
+{
+    if (!r)
+        return Fail("null argument");
+    if (leave_below > 64 || leave_at > 64)
+        return Fail("a wavefront has 64 lanes");
+    // the scene record travels by value with every launch: no upload needed
+    r->dev.integrator.walk_break = r->flat.integrator.walk_break = leave_below;
+    r->dev.integrator.walk_hold = r->flat.integrator.walk_hold = leave_at;
+    return 0;
+}
+
 int mcpt_renderer_info(const mcpt_renderer *r, uint64_t info[9])
 {
     if (!r || !info)

@@ -269,3 +269,22 @@ def test_device_pixel_trace_matches_the_host_build(pkg, mcsd_file):
         ends = [k for k in range(len(dev)) if k + 1 == len(dev) or np.array_equal(dev[k + 1, :3], dev[0, :3])]
         np.testing.assert_allclose(dev[ends, 12:15].sum(0) / 2, frame[y, x], rtol=1e-5, atol=1e-6)
     renderer.close()
+
+
+def test_walk_schedule_does_not_change_the_image(pkg, scenes):
+    """mcpt_renderer_set_walk_schedule: the vote thresholds of the ordered walk on large scenes are a pure
+    scheduling decision — the frame stays the same bit for bit (a 6 400-triangle mesh, so that the vote
+    walk runs)."""
+    scene = pkg.scenes.material_preview("rough_conductor", "mixed", "mesh", 64, 48, 4)
+    inst = next(i for i in scene.instances if i.type == pkg.mcsd.INST_MESHES)
+    g = pkg.scenes.uv_sphere_mesh(40, 80, 0.6, (0, 0.6, 0))
+    inst.positions, inst.normals, inst.texcoords, inst.indices = g["positions"], g["normals"], g["texcoords"], g["indices"]
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene))
+    base, _ = r.draw()
+    for below, at in ((0, 0), (4, 8), (16, 12), (64, 64), (1, 1)):
+        r.set_walk_schedule(below, at)
+        frame, _ = r.draw()
+        assert np.array_equal(frame, base), (below, at)
+    with pytest.raises(pkg.capi.McptError, match="64 lanes"):
+        r.set_walk_schedule(65, 0)
+    r.close()
