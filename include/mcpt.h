@@ -38,6 +38,18 @@ int mcpt_config_from_mcsd_bytes(const void *bytes, size_t size, mcpt_config **ou
  * (parser.cpp:94-1617 + model_loader.cpp).  Supported subset: see DESIGN.md. */
 int mcpt_config_load_xml(const char *path, mcpt_config **out);
 
+/* The same, for a scene whose file names mesh files that are not on disk (the reference repository ships
+ * resources/scene/dragon/scene.xml without four of its OBJ files, /root/reference/.MISSING_LARGE_BLOBS).
+ * `standins` is a text table, one line per missing file: the file name as written in the XML followed by a
+ * procedural mesh description ("blob ..." / "sheet ...", see csrc/host/standin_mesh.cpp).  A file that IS on
+ * disk is always read; a missing file without a line is the reference's error (model_loader.cpp:440-447). */
+int mcpt_config_load_xml_with_standins(const char *path, const char *standins, mcpt_config **out);
+/* Replaces the mesh of triangle-mesh instance `instance` (scene order) by the stand-in one table line
+ * describes; BSDF, media and to_world stay.  For configurations stored as MCSD with small placeholders where
+ * the large stand-ins go (tests/golden/dragon_real_meshes.mcsd): the result equals loading the XML with the
+ * same table. */
+int mcpt_config_set_instance_standin(mcpt_config *cfg, uint32_t instance, const char *standin_line);
+
 /* Built-in scenes ("cornell-box"): the same records the XML front end produces
  * for the reference's example scenes, available without any scene file. */
 int mcpt_config_builtin(const char *name, mcpt_config **out);

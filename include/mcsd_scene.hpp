@@ -120,7 +120,7 @@ struct Reader
     size_t size, off = 0;
     void need(size_t n)
     {
-        if (off + n > size)
+        if (n > size - off) // off <= size always; written so that a huge n cannot wrap around
             throw std::runtime_error("MCSD: truncated file");
     }
     uint32_t u32()
@@ -140,14 +140,20 @@ struct Reader
         off += 4;
         return v;
     }
+    void need_words(size_t n) // n 4-byte elements, n taken from the file
+    {
+        if (n > (size - off) / 4)
+            throw std::runtime_error("MCSD: truncated file");
+    }
     void floats(float *dst, size_t n)
     {
-        need(4 * n);
+        need_words(n);
         std::memcpy(dst, p + off, 4 * n);
         off += 4 * n;
     }
     void fvec(std::vector<float> *dst, size_t n)
     {
+        need_words(n); // before the allocation: a 100-byte file must not reserve gigabytes
         dst->resize(n);
         if (n)
             floats(dst->data(), n);
@@ -315,8 +321,8 @@ inline Scene Parse(const uint8_t *bytes, size_t size)
         r.fvec(&in.normals, 3 * static_cast<size_t>(n[2]));
         r.fvec(&in.tangents, 3 * static_cast<size_t>(n[3]));
         r.fvec(&in.bitangents, 3 * static_cast<size_t>(n[4]));
+        r.need_words(3 * static_cast<size_t>(n[5]));
         in.indices.resize(3 * static_cast<size_t>(n[5]));
-        r.need(4 * in.indices.size());
         if (!in.indices.empty())
             std::memcpy(in.indices.data(), r.p + r.off, 4 * in.indices.size());
         r.off += 4 * in.indices.size();

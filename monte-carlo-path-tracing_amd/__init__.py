@@ -9,5 +9,6 @@ Sub-modules:
   scenes   programmatic test scenes (cornell box, volumetric caustic, ...)
   capi     ctypes binding of the C-ABI in include/mcpt.h (the HIP renderer)
   tiling   multi-GPU image partition + the single gather of finished tiles
+  workloads  the BASELINE.json configurations by name (baseline_scenes/ fixtures)
 """
-from . import capi, mcsd, scenes, tiling  # noqa: F401
+from . import capi, mcsd, scenes, tiling, workloads  # noqa: F401

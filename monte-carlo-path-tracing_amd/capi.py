@@ -71,6 +71,8 @@ def lib():
     L.mcpt_version.restype = cp
     for name in ("mcpt_config_load_mcsd", "mcpt_config_load_xml", "mcpt_config_builtin"):
         getattr(L, name).argtypes = [cp, ctypes.POINTER(vp)]
+    L.mcpt_config_load_xml_with_standins.argtypes = [cp, cp, ctypes.POINTER(vp)]
+    L.mcpt_config_set_instance_standin.argtypes = [vp, u32, cp]
     L.mcpt_config_from_mcsd_bytes.argtypes = [cp, ctypes.c_size_t, ctypes.POINTER(vp)]
     L.mcpt_config_set_film.argtypes = [vp, i32, i32, i32]
     L.mcpt_config_get_film.argtypes = [vp] + [ctypes.POINTER(i32)] * 3
@@ -108,7 +110,7 @@ def _check(rc):
 
 EXPORTED_SYMBOLS = [
     "mcpt_config_load_mcsd", "mcpt_config_from_mcsd_bytes", "mcpt_config_load_xml",
-    "mcpt_config_builtin", "mcpt_config_set_film", "mcpt_config_get_film",
+    "mcpt_config_load_xml_with_standins", "mcpt_config_set_instance_standin", "mcpt_config_builtin", "mcpt_config_set_film", "mcpt_config_get_film",
     "mcpt_config_save_mcsd", "mcpt_config_destroy", "mcpt_renderer_create",
     "mcpt_renderer_draw", "mcpt_renderer_draw_device", "mcpt_renderer_draw_counted",
     "mcpt_renderer_tile_count", "mcpt_tile_range_size", "mcpt_unpack_tiles",
@@ -161,12 +163,20 @@ class Config:
         return cls.from_mcsd_bytes(mcsd.dumps(scene))
 
     @classmethod
-    def load_xml(cls, path):
-        return cls._make(lib().mcpt_config_load_xml, str(path).encode())
+    def load_xml(cls, path, standins=None):
+        """`standins`: text table of procedural stand-ins for mesh files that are not on disk
+        (include/mcpt.h, mcpt_config_load_xml_with_standins)."""
+        if standins is None:
+            return cls._make(lib().mcpt_config_load_xml, str(path).encode())
+        return cls._make(lib().mcpt_config_load_xml_with_standins, str(path).encode(), standins.encode())
 
     @classmethod
     def builtin(cls, name):
         return cls._make(lib().mcpt_config_builtin, name.encode())
+
+    def set_instance_standin(self, instance, line):
+        _check(lib().mcpt_config_set_instance_standin(self._h, instance, line.encode()))
+        return self
 
     def set_film(self, width=0, height=0, spp=0):
         _check(lib().mcpt_config_set_film(self._h, width, height, spp))

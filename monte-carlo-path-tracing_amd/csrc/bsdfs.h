@@ -50,8 +50,8 @@ MCPT_HD V3 tex(const ShadeTables &T, uint32_t id, V2 uv)
 // ---- GGX --------------------------------------------------------------------
 MCPT_HD void ggx_sample_aniso(float xi0, float xi1, float au, float av, V3 &h, float &pdf) // microfacet.cpp:21-35
 {
-    const float phi = (atanf(av / au * tanf(kPi + k2Pi * xi1)) + kPi * floorf(2.0f * xi1 + 0.5f));
-    const float cos_p = cosf(phi), sin_p = sinf(phi), a2 = 1.0f / (sqr(cos_p / au) + sqr(sin_p / av));
+    const float phi = (gl::atanf(av / au * gl::tanf(kPi + k2Pi * xi1)) + kPi * floorf(2.0f * xi1 + 0.5f));
+    const float cos_p = gl::cosf(phi), sin_p = gl::sinf(phi), a2 = 1.0f / (sqr(cos_p / au) + sqr(sin_p / av));
     const float tan2 = static_cast<float>(D(a2 * xi0) / (1.0 - D(xi0)));
     const float cos_t = 1.0f / sqrtf(1.0f + tan2), sin_t = sqrtf(1.0f - sqr(cos_t));
     h = V3{sin_t * cos_p, sin_t * sin_p, cos_t};
@@ -151,7 +151,7 @@ MCPT_HD void oren_nayar(float rough, V3 albedo, BsdfQuery &q)
     float phi_i, theta_i, phi_o, theta_o;
     to_spherical(li, theta_i, phi_i);
     to_spherical(lo, theta_o, phi_o);
-    const float cos_dphi = cosf(phi_i) * cosf(phi_o) + sinf(phi_i) * sinf(phi_o);
+    const float cos_dphi = gl::cosf(phi_i) * gl::cosf(phi_o) + gl::sinf(phi_i) * gl::sinf(phi_o);
     const float alpha = fmaxf(theta_i, theta_o), beta = fminf(theta_i, theta_o);
     float sin_a, sin_b, tan_b;
     if (n_i > n_o)

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -19,6 +20,7 @@
 #include "hip/render_kernel.h"
 #include "host/commit.hpp"
 #include "host/frontend.hpp"
+#include "host/standin_mesh.hpp"
 #include "mcsd_scene.hpp"
 
 struct mcpt_config
@@ -278,6 +280,50 @@ int mcpt_config_load_xml(const char *path, mcpt_config **out)
         std::unique_ptr<mcpt_config> cfg(new mcpt_config);
         cfg->scene = mcpt::LoadXmlScene(path);
         *out = cfg.release();
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(e.what());
+    }
+}
+
+int mcpt_config_load_xml_with_standins(const char *path, const char *standins, mcpt_config **out)
+{
+    if (!path || !out)
+        return Fail("null argument");
+    try
+    {
+        std::unique_ptr<mcpt_config> cfg(new mcpt_config);
+        cfg->scene = mcpt::LoadXmlScene(path, standins ? standins : "");
+        *out = cfg.release();
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(e.what());
+    }
+}
+
+int mcpt_config_set_instance_standin(mcpt_config *cfg, uint32_t instance, const char *standin_line)
+{
+    if (!cfg || !standin_line)
+        return Fail("null argument");
+    try
+    {
+        if (instance >= cfg->scene.instances.size() || cfg->scene.instances[instance].type != MCSD_INST_MESHES)
+            return Fail("mcpt_config_set_instance_standin: not a triangle-mesh instance");
+        std::istringstream first(standin_line);
+        std::string name;
+        first >> name;
+        const mcpt::StandinTable table(standin_line);
+        if (!table.Has(name))
+            return Fail("mcpt_config_set_instance_standin: empty stand-in line");
+        mcpt::MeshData mesh = table.Build(name);
+        mcsd::Instance &in = cfg->scene.instances[instance];
+        in.positions = std::move(mesh.positions), in.normals = std::move(mesh.normals);
+        in.texcoords = std::move(mesh.texcoords), in.tangents = std::move(mesh.tangents);
+        in.bitangents = std::move(mesh.bitangents), in.indices = std::move(mesh.indices);
         return 0;
     }
     catch (const std::exception &e)

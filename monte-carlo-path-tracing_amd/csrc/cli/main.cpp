@@ -27,7 +27,8 @@ void Usage()
                  "mcpt_cli (%s)\n\n"
                  "  mcpt_cli [-g|--gpu] -i|--input <scene.xml | scene.mcsd | builtin:cornell-box>\n"
                  "           [-o|--output <result.png|.exr|.pfm|.f32>] [-w|--width N] [-h|--height N]\n"
-                 "           [-s|--spp N] [-d|--device N] [--save-config <file.mcsd>]\n\n"
+                 "           [-s|--spp N] [-d|--device N] [--save-config <file.mcsd>] [--standins <table.txt>]\n\n"
+                 "  --standins   procedural stand-ins for mesh files the scene names but that are not on disk\n"
                  "  --gpu        render with HIP on the selected device (the default and only backend)\n"
                  "  --cpu        refused: this build has no CPU renderer\n",
                  mcpt_version());
@@ -49,7 +50,7 @@ int Fail(const char *what)
 
 int main(int argc, char **argv)
 {
-    std::string input, output = "result.png", save_config;
+    std::string input, output = "result.png", save_config, standins_file;
     int width = 0, height = 0, spp = 0, device = 0;
     for (int i = 1; i < argc; ++i)
     {
@@ -81,6 +82,8 @@ int main(int argc, char **argv)
             output = argv[++i];
         else if (a == "--save-config" && has_value)
             save_config = argv[++i];
+        else if (a == "--standins" && has_value)
+            standins_file = argv[++i];
         else if (a == "--help")
         {
             Usage();
@@ -105,6 +108,24 @@ int main(int argc, char **argv)
         rc = mcpt_config_builtin(input.c_str() + 8, &config);
     else if (EndsWith(input, ".mcsd"))
         rc = mcpt_config_load_mcsd(input.c_str(), &config);
+    else if (!standins_file.empty())
+    {
+        std::string table;
+        if (FILE *f = std::fopen(standins_file.c_str(), "rb"))
+        {
+            char buf[4096];
+            size_t n;
+            while ((n = std::fread(buf, 1, sizeof buf, f)) > 0)
+                table.append(buf, n);
+            std::fclose(f);
+        }
+        else
+        {
+            std::fprintf(stderr, "[error] cannot read '%s'.\n", standins_file.c_str());
+            return 2;
+        }
+        rc = mcpt_config_load_xml_with_standins(input.c_str(), table.c_str(), &config);
+    }
     else
         rc = mcpt_config_load_xml(input.c_str(), &config);
     if (rc != 0)

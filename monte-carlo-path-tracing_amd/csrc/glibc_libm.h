@@ -1,0 +1,410 @@
+// Float elementary functions that return, bit for bit, what GNU libc 2.35 (x86-64, the
+// image's /lib/x86_64-linux-gnu/libm.so.6, FMA-capable host) returns.
+//
+// Why this exists.  The reference CPU integrator calls sinf / cosf / acosf / atan2f / atanf /
+// tanf from the host's libm (reference src/utils/math.cpp:24-38,102-128,
+// src/renderer/bsdfs/microfacet.cpp:21-38, src/renderer/emitters/spot_light.cpp,
+// src/rtcore/primitives/{sphere,disk,cylinder}.cpp).  None of these is correctly rounded in
+// glibc 2.35, so "a good sinf" on the device differs from the host's in the last bit on a few
+// percent of the arguments, and one such bit at a bounce flips a later path decision: the GPU
+// frame then matches the CPU frame only statistically.  With the host library's own algorithms
+// restated here, device == host on every argument and the GPU frame is the CPU frame.
+//
+// Third-party dependency restated: GNU C Library 2.35 (Ubuntu GLIBC 2.35-0ubuntu3.11), not part of
+// /root/reference.  Algorithms (published sources, restated, not copied):
+//   sinf, cosf   sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h, sincosf_data.c (the
+//                "optimized routines" design: argument and polynomial in double, one multiply-
+//                subtract range reduction below 120, a 192-bit 4/pi table above), in the
+//                multiarch variant the dynamic loader selects on FMA hosts (products feeding a
+//                sum are fused: sysdeps/x86_64/fpu/multiarch/s_sinf.c built with -mfma -mavx2);
+//   acosf        sysdeps/ieee754/flt-32/e_acosf.c      (fdlibm, float arithmetic)
+//   atanf        sysdeps/ieee754/flt-32/s_atanf.c      (fdlibm, float arithmetic)
+//   atan2f       sysdeps/ieee754/flt-32/e_atan2f.c     (fdlibm, float arithmetic)
+//   tanf         sysdeps/ieee754/flt-32/s_tanf.c (reduction shared with sinf, unfused), k_tanf.c (fdlibm)
+// Pinned by tests/test_glibc_libm.py: every one of the 2^32 float arguments of the unary
+// functions (2^31 + edge sweeps for atan2f) against the host's libm.
+//
+// errno, exception flags and signalling NaNs are not reproduced (the renderer never looks).
+// Build with -ffp-contract=off: every operation below is the one written.
+#ifndef MCPT_GLIBC_LIBM_H
+#define MCPT_GLIBC_LIBM_H
+
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MCPT_GL_HD __host__ __device__ __forceinline__
+#else
+#define MCPT_GL_HD inline
+#endif
+
+namespace mcpt
+{
+namespace gl
+{
+
+MCPT_GL_HD uint32_t bits(float x)
+{
+    uint32_t u;
+    __builtin_memcpy(&u, &x, 4);
+    return u;
+}
+MCPT_GL_HD float from_bits(uint32_t u)
+{
+    float x;
+    __builtin_memcpy(&x, &u, 4);
+    return x;
+}
+MCPT_GL_HD double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// ---- sinf / cosf ----------------------------------------------------------------------------
+// Polynomials on [-pi/4, pi/4] in double: cos r = c0 + c1 r^2 + ... + c4 r^8,
+// sin r = r + s1 r^3 + s2 r^5 + s3 r^7.
+constexpr double kC0 = 0x1p0, kC1 = -0x1.ffffffd0c621cp-2, kC2 = 0x1.55553e1068f19p-5, kC3 = -0x1.6c087e89a359dp-10,
+                 kC4 = 0x1.99343027bf8c3p-16;
+constexpr double kS1 = -0x1.555545995a603p-3, kS2 = 0x1.1107605230bc4p-7, kS3 = -0x1.994eb3774cf24p-13;
+constexpr double kHalfPiInvScaled = 0x1.45F306DC9C883p+23; // 2/pi * 2^24
+constexpr double kHalfPi = 0x1.921FB54442D18p0;
+constexpr double kPi63 = 0x1.921FB54442D18p-62; // 2 pi * 2^-64
+
+MCPT_GL_HD uint32_t abstop12(float x) { return (bits(x) >> 20) & 0x7ffu; }
+
+// `negate_cos`: quadrants 2 and 3 use the negated cosine polynomial.
+MCPT_GL_HD float sincos_poly(double x, double x2, bool negate_cos, int n)
+{
+    if ((n & 1) == 0)
+    {
+        const double x3 = x * x2;
+        const double s1 = fmad(x2, kS3, kS2);
+        const double x7 = x3 * x2;
+        const double s = fmad(x3, kS1, x);
+        return static_cast<float>(fmad(x7, s1, s));
+    }
+    const double sg = negate_cos ? -1.0 : 1.0;
+    const double x4 = x2 * x2;
+    const double c2 = fmad(x2, sg * kC4, sg * kC3);
+    const double c1 = fmad(x2, sg * kC1, sg * kC0);
+    const double x6 = x4 * x2;
+    const double c = fmad(x4, sg * kC2, c1);
+    return static_cast<float>(fmad(x6, c2, c));
+}
+
+// |x| < 120: one multiply-subtract.  The quadrant lands in bits 24..31 of the scaled product.
+MCPT_GL_HD double reduce_fast(double x, int &n)
+{
+    const double r = x * kHalfPiInvScaled;
+    n = (static_cast<int32_t>(r) + 0x800000) >> 24;
+    return fmad(-static_cast<double>(n), kHalfPi, x);
+}
+
+// 4/pi, 192 bits, as overlapping 32-bit windows 8 bits apart: window k = bits [8k-24, 8k+8) of
+// 0xa2f9836e4e441529fc2757d1f534ddc0db6295993c439041.
+MCPT_GL_HD uint32_t inv_pio4_window(uint32_t k)
+{
+    const uint64_t w0 = 0xa2f9836e4e441529ull, w1 = 0xfc2757d1f534ddc0ull, w2 = 0xdb6295993c439041ull;
+    // bit string B = w0 w1 w2 (192 bits, big endian); window k holds bits [8k - 24, 8k + 8) counted from
+    // the top, with zeros above the string
+    const int first = 8 * static_cast<int>(k) - 24; // index of the window's top bit
+    uint64_t hi, lo;                                // the 128 bits starting at 64-bit word `word`
+    const int word = first < 0 ? -1 : first / 64;
+    if (word < 0)
+        hi = 0, lo = w0;
+    else if (word == 0)
+        hi = w0, lo = w1;
+    else if (word == 1)
+        hi = w1, lo = w2;
+    else
+        hi = w2, lo = 0;
+    const int off = first - 64 * word; // 0..63 within hi
+    const uint64_t v = off == 0 ? hi : ((hi << off) | (lo >> (64 - off)));
+    return static_cast<uint32_t>(v >> 32);
+}
+
+// |x| >= 120: exact fixed-point product with 4/pi.
+MCPT_GL_HD double reduce_large(uint32_t xi, int &np)
+{
+    const uint32_t k = (xi >> 26) & 15u;
+    const int shift = (xi >> 23) & 7;
+    xi = (xi & 0xffffffu) | 0x800000u;
+    xi <<= shift;
+    uint64_t res0 = static_cast<uint32_t>(xi * inv_pio4_window(k));
+    const uint64_t res1 = static_cast<uint64_t>(xi) * inv_pio4_window(k + 4);
+    const uint64_t res2 = static_cast<uint64_t>(xi) * inv_pio4_window(k + 8);
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    const uint64_t n = (res0 + (1ull << 61)) >> 62;
+    res0 -= n << 62;
+    const double x = static_cast<double>(static_cast<int64_t>(res0));
+    np = static_cast<int>(n);
+    return x * kPi63;
+}
+
+template <bool kCosine>
+MCPT_GL_HD float sin_or_cos(float y)
+{
+    double x = y;
+    int n;
+    const int flip = kCosine ? 1 : 0;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f))
+    {
+        if (abstop12(y) < abstop12(0x1p-12f))
+            return kCosine ? 1.0f : y;
+        return sincos_poly(x, x * x, false, flip);
+    }
+    if (abstop12(y) < abstop12(120.0f))
+    {
+        x = reduce_fast(x, n);
+        const double s = ((n + 1) & 2) ? -1.0 : 1.0; // {1, -1, -1, 1}[n & 3]
+        return sincos_poly(x * s, x * x, (n & 2) != 0, n ^ flip);
+    }
+    if (abstop12(y) < abstop12(__builtin_inff()))
+    {
+        const uint32_t xi = bits(y);
+        const int sign = static_cast<int>(xi >> 31);
+        x = reduce_large(xi, n);
+        const int q = n + sign;
+        const double s = ((q + 1) & 2) ? -1.0 : 1.0;
+        return sincos_poly(x * s, x * x, (q & 2) != 0, n ^ flip);
+    }
+    return __builtin_nanf("");
+}
+
+MCPT_GL_HD float sinf(float y) { return sin_or_cos<false>(y); }
+MCPT_GL_HD float cosf(float y) { return sin_or_cos<true>(y); }
+
+// ---- acosf ----------------------------------------------------------------------------------
+MCPT_GL_HD float acos_ratio(float z)
+{
+    constexpr float pS0 = 1.6666667163e-01f, pS1 = -3.2556581497e-01f, pS2 = 2.0121252537e-01f, pS3 = -4.0055535734e-02f,
+                    pS4 = 7.9153501429e-04f, pS5 = 3.4793309169e-05f, qS1 = -2.4033949375e+00f, qS2 = 2.0209457874e+00f,
+                    qS3 = -6.8828397989e-01f, qS4 = 7.7038154006e-02f;
+    const float p = z * (pS0 + z * (pS1 + z * (pS2 + z * (pS3 + z * (pS4 + z * pS5)))));
+    const float q = 1.0f + z * (qS1 + z * (qS2 + z * (qS3 + z * qS4)));
+    return p / q;
+}
+
+MCPT_GL_HD float acosf(float x)
+{
+    constexpr float pi = 3.1415925026e+00f, pio2_hi = 1.5707962513e+00f, pio2_lo = 7.5497894159e-08f;
+    const int32_t hx = static_cast<int32_t>(bits(x)), ix = hx & 0x7fffffff;
+    if (ix == 0x3f800000)
+        return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
+    if (ix > 0x3f800000)
+        return __builtin_nanf("");
+    if (ix < 0x3f000000) // |x| < 0.5
+    {
+        if (ix <= 0x32800000)
+            return pio2_hi + pio2_lo;
+        const float r = acos_ratio(x * x);
+        return pio2_hi - (x - (pio2_lo - x * r));
+    }
+    if (hx < 0) // x < -0.5
+    {
+        const float z = (1.0f + x) * 0.5f;
+        const float r = acos_ratio(z), s = ::sqrtf(z);
+        const float w = r * s - pio2_lo;
+        return pi - 2.0f * (s + w);
+    }
+    const float z = (1.0f - x) * 0.5f, s = ::sqrtf(z);
+    const float df = from_bits(bits(s) & 0xfffff000u);
+    const float c = (z - df * df) / (s + df);
+    const float r = acos_ratio(z);
+    const float w = r * s + c;
+    return 2.0f * (df + w);
+}
+
+// ---- atanf ----------------------------------------------------------------------------------
+MCPT_GL_HD float atanf(float x)
+{
+    constexpr float hi0 = 4.6364760399e-01f, hi1 = 7.8539812565e-01f, hi2 = 9.8279368877e-01f, hi3 = 1.5707962513e+00f;
+    constexpr float lo0 = 5.0121582440e-09f, lo1 = 3.7748947079e-08f, lo2 = 3.4473217170e-08f, lo3 = 7.5497894159e-08f;
+    constexpr float a0 = 3.3333334327e-01f, a1 = -2.0000000298e-01f, a2 = 1.4285714924e-01f, a3 = -1.1111110449e-01f,
+                    a4 = 9.0908870101e-02f, a5 = -7.6918758452e-02f, a6 = 6.6610731184e-02f, a7 = -5.8335702866e-02f,
+                    a8 = 4.9768779427e-02f, a9 = -3.6531571299e-02f, a10 = 1.6285819933e-02f;
+    const int32_t hx = static_cast<int32_t>(bits(x)), ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) // |x| >= 2^25
+    {
+        if (ix > 0x7f800000)
+            return x + x;
+        return hx > 0 ? hi3 + lo3 : -hi3 - lo3;
+    }
+    if (ix < 0x3ee00000) // |x| < 0.4375
+    {
+        if (ix < 0x31000000)
+            return x;
+        id = -1;
+    }
+    else
+    {
+        x = ::fabsf(x);
+        if (ix < 0x3f980000)
+        {
+            if (ix < 0x3f300000)
+                id = 0, x = (2.0f * x - 1.0f) / (2.0f + x);
+            else
+                id = 1, x = (x - 1.0f) / (x + 1.0f);
+        }
+        else
+        {
+            if (ix < 0x401c0000)
+                id = 2, x = (x - 1.5f) / (1.0f + 1.5f * x);
+            else
+                id = 3, x = -1.0f / x;
+        }
+    }
+    const float z = x * x, w = z * z;
+    const float s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));
+    const float s2 = w * (a1 + w * (a3 + w * (a5 + w * (a7 + w * a9))));
+    if (id < 0)
+        return x - x * (s1 + s2);
+    const float hi = id == 0 ? hi0 : (id == 1 ? hi1 : (id == 2 ? hi2 : hi3));
+    const float lo = id == 0 ? lo0 : (id == 1 ? lo1 : (id == 2 ? lo2 : lo3));
+    const float r = hi - ((x * (s1 + s2) - lo) - x);
+    return hx < 0 ? -r : r;
+}
+
+// ---- atan2f ---------------------------------------------------------------------------------
+MCPT_GL_HD float atan2f(float y, float x)
+{
+    constexpr float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f,
+                    pi_lo = -8.7422776573e-08f;
+    const int32_t hx = static_cast<int32_t>(bits(x)), ix = hx & 0x7fffffff;
+    const int32_t hy = static_cast<int32_t>(bits(y)), iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000)
+        return x + y;
+    if (hx == 0x3f800000)
+        return gl::atanf(y);
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0)
+    {
+        if (m < 2)
+            return y;
+        return m == 2 ? pi + tiny : -pi - tiny;
+    }
+    if (ix == 0)
+        return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000)
+    {
+        if (iy == 0x7f800000)
+        {
+            switch (m)
+            {
+            case 0: return pi_o_4 + tiny;
+            case 1: return -pi_o_4 - tiny;
+            case 2: return 3.0f * pi_o_4 + tiny;
+            default: return -3.0f * pi_o_4 - tiny;
+            }
+        }
+        switch (m)
+        {
+        case 0: return 0.0f;
+        case 1: return -0.0f;
+        case 2: return pi + tiny;
+        default: return -pi - tiny;
+        }
+    }
+    if (iy == 0x7f800000)
+        return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int32_t k = (iy - ix) >> 23;
+    float z;
+    if (k > 60)
+        z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60)
+        z = 0.0f;
+    else
+        z = gl::atanf(::fabsf(y / x));
+    switch (m)
+    {
+    case 0: return z;
+    case 1: return from_bits(bits(z) ^ 0x80000000u);
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}
+
+// ---- tanf -------------------------------------------------------------------------------------
+MCPT_GL_HD float kernel_tanf(float x, float y, int iy)
+{
+    constexpr float pio4 = 7.8539812565e-01f, pio4lo = 3.7748947079e-08f;
+    constexpr float T0 = 3.3333334327e-01f, T1 = 1.3333334029e-01f, T2 = 5.3968254477e-02f, T3 = 2.1869488060e-02f,
+                    T4 = 8.8632395491e-03f, T5 = 3.5920790397e-03f, T6 = 1.4562094584e-03f, T7 = 5.8804126456e-04f,
+                    T8 = 2.4646313977e-04f, T9 = 7.8179444245e-05f, T10 = 7.1407252108e-05f, T11 = -1.8558637748e-05f,
+                    T12 = 2.5907305826e-05f;
+    const int32_t hx = static_cast<int32_t>(bits(x)), ix = hx & 0x7fffffff;
+    if (ix < 0x39000000) // |x| < 2^-13
+    {
+        if (static_cast<int>(x) == 0)
+        {
+            if ((ix | (iy + 1)) == 0)
+                return 1.0f / ::fabsf(x);
+            if (iy == 1)
+                return x;
+            return -1.0f / x;
+        }
+    }
+    if (ix >= 0x3f2ca140) // |x| >= 0.6744
+    {
+        if (hx < 0)
+            x = -x, y = -y;
+        const float z = pio4 - x, w = pio4lo - y;
+        x = z + w, y = 0.0f;
+        if (::fabsf(x) < 0x1p-13f)
+            return (1 - ((hx >> 30) & 2)) * iy * (1.0f - 2 * iy * x);
+    }
+    float z = x * x, w = z * z;
+    float r = T1 + w * (T3 + w * (T5 + w * (T7 + w * (T9 + w * T11))));
+    float v = z * (T2 + w * (T4 + w * (T6 + w * (T8 + w * (T10 + w * T12)))));
+    float s = z * x;
+    r = y + z * (s * (r + v) + y);
+    r += T0 * s;
+    w = x + r;
+    if (ix >= 0x3f2ca140)
+    {
+        v = static_cast<float>(iy);
+        return static_cast<float>(1 - ((hx >> 30) & 2)) * (v - 2.0f * (x - (w * w / (w + v) - r)));
+    }
+    if (iy == 1)
+        return w;
+    // -1 / (x + r), accurately
+    z = from_bits(bits(w) & 0xfffff000u);
+    v = r - (z - x);
+    const float a = -1.0f / w;
+    const float t = from_bits(bits(a) & 0xfffff000u);
+    s = 1.0f + t * z;
+    return t + a * (s + t * v);
+}
+
+// s_tanf.c: the argument reduction of sinf / cosf (in double; this translation unit of the library is
+// not built with FMA, so the multiply-subtract is two operations), the remainder split into a float
+// head and tail for the fdlibm kernel.
+MCPT_GL_HD float tanf(float x)
+{
+    const int32_t ix = static_cast<int32_t>(bits(x)) & 0x7fffffff;
+    if (ix <= 0x3f490fda)
+        return kernel_tanf(x, 0.0f, 1);
+    if (ix >= 0x7f800000)
+        return __builtin_nanf("");
+    double dx = x;
+    int n;
+    if (abstop12(x) < abstop12(120.0f))
+    {
+        const double r = dx * kHalfPiInvScaled;
+        n = (static_cast<int32_t>(r) + 0x800000) >> 24;
+        dx = dx - static_cast<double>(n) * kHalfPi;
+    }
+    else
+    {
+        const uint32_t xi = bits(x);
+        dx = reduce_large(xi, n);
+        dx = (xi >> 31) ? -dx : dx;
+    }
+    const float y0 = static_cast<float>(dx), y1 = static_cast<float>(dx - static_cast<double>(y0));
+    return kernel_tanf(y0, y1, 1 - ((n & 1) << 1));
+}
+
+} // namespace gl
+} // namespace mcpt
+
+#endif // MCPT_GLIBC_LIBM_H

@@ -13,7 +13,9 @@ namespace mcpt
 {
 
 // Mitsuba-style XML scene -> configuration (xml_scene.cpp).
-mcsd::Scene LoadXmlScene(const std::string &path);
+// `standins`: table of procedural stand-ins for mesh files the scene names but that are not on disk
+// (standin_mesh.cpp); empty = a missing file is an error, as in the reference.
+mcsd::Scene LoadXmlScene(const std::string &path, const std::string &standins = "");
 
 // Scenes available without files: "cornell-box".
 mcsd::Scene BuiltinScene(const std::string &name);

@@ -99,6 +99,12 @@ public:
 
 private:
     [[noreturn]] void Fail(const char *what) const { throw std::runtime_error(std::string(what) + ": '" + path_ + "'."); }
+    int U8() // one payload byte; a truncated or crafted segment fails instead of reading past the file
+    {
+        if (at_ >= f_.size())
+            Fail("truncated JPEG");
+        return f_[at_++];
+    }
     size_t Be16()
     {
         if (at_ + 2 > f_.size())
@@ -126,13 +132,13 @@ private:
     {
         while (at_ < end)
         {
-            const int pq_tq = f_[at_++];
+            const int pq_tq = U8();
             const int precision = pq_tq >> 4, id = pq_tq & 15;
-            if (id > 3)
+            if (id > 3 || precision > 1 || at_ + (precision ? 128u : 64u) > end || end > f_.size())
                 Fail("bad quantisation table");
             for (int k = 0; k < 64; ++k)
             {
-                const int q = precision ? static_cast<int>(Be16()) : f_[at_++];
+                const int q = precision ? static_cast<int>(Be16()) : U8();
                 quant_[id][kZigZag[k]] = static_cast<uint16_t>(q); // stored in natural order
             }
         }
@@ -141,9 +147,9 @@ private:
     {
         while (at_ < end)
         {
-            const int tc_th = f_[at_++];
+            const int tc_th = U8();
             const int cls = tc_th >> 4, id = tc_th & 15;
-            if (cls > 1 || id > 3 || at_ + 16 > end)
+            if (cls > 1 || id > 3 || at_ + 16 > end || end > f_.size())
                 Fail("bad Huffman table");
             HuffmanTable &t = tables_[cls][id];
             int total = 0, code = 0;
@@ -164,19 +170,19 @@ private:
     }
     void ReadFrame()
     {
-        if (f_[at_++] != 8)
+        if (U8() != 8)
             Fail("only 8-bit JPEG is supported");
         height_ = static_cast<int>(Be16()), width_ = static_cast<int>(Be16());
-        const int n = f_[at_++];
+        const int n = U8();
         if (width_ <= 0 || height_ <= 0 || (n != 1 && n != 3))
             Fail("unsupported JPEG frame");
         comps_.assign(n, Component());
         for (Component &c : comps_)
         {
-            c.id = f_[at_++];
-            c.h = f_[at_] >> 4, c.v = f_[at_] & 15;
-            ++at_;
-            c.tq = f_[at_++];
+            c.id = U8();
+            const int hv = U8();
+            c.h = hv >> 4, c.v = hv & 15;
+            c.tq = U8();
             if (c.h < 1 || c.h > 4 || c.v < 1 || c.v > 4 || c.tq > 3)
                 Fail("bad JPEG component");
             h_max_ = std::max(h_max_, c.h), v_max_ = std::max(v_max_, c.v);
@@ -191,12 +197,12 @@ private:
     }
     void ReadScanHeader()
     {
-        const int n = f_[at_++];
+        const int n = U8();
         if (comps_.empty() || n != static_cast<int>(comps_.size()))
             Fail("unsupported JPEG scan (non-interleaved scans are not handled)");
         for (int i = 0; i < n; ++i)
         {
-            const int id = f_[at_++], tables = f_[at_++];
+            const int id = U8(), tables = U8();
             Component *c = nullptr;
             for (Component &k : comps_)
                 if (k.id == id)

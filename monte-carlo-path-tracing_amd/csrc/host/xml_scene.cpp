@@ -34,6 +34,7 @@
 #include "../vecmath.h"
 #include "matrix.hpp"
 #include "asset_io.hpp"
+#include "standin_mesh.hpp"
 #include "frontend.hpp"
 #include "xml_dom.hpp"
 
@@ -162,7 +163,7 @@ bool LookupMedium(const std::string &name, V3 *sigma_a, V3 *sigma_s, V3 *g, bool
 class SceneBuilder
 {
 public:
-    explicit SceneBuilder(const std::string &path) : directory_(DirectoryOf(path)) {}
+    SceneBuilder(const std::string &path, StandinTable standins) : directory_(DirectoryOf(path)), standins_(std::move(standins)) {}
 
     mcsd::Scene Run(const Node &scene)
     {
@@ -809,10 +810,15 @@ private:
         {
             in.type = MCSD_INST_MESHES;
             const Node *file = n.Child("string");
-            const std::string path = directory_ + (file ? file->Str("value") : "");
+            const std::string name = file ? file->Str("value") : "";
+            const std::string path = directory_ + name;
             const bool face_normals = ReadBool(n, {"face_normals", "faceNormals"}, false);
             MeshData mesh;
-            if (type == "obj")
+            // a file that is not there: the reference fails (model_loader.cpp:440-447) — and so does this
+            // loader unless the caller supplied a stand-in for exactly this file (standin_mesh.cpp)
+            if (standins_.Has(name) && !std::ifstream(path, std::ios::binary))
+                mesh = standins_.Build(name);
+            else if (type == "obj")
                 mesh = LoadObj(path, ReadBool(n, {"flip_tex_coords", "flipTexCoords"}, true), face_normals);
             else if (type == "ply")
                 mesh = LoadPly(path, face_normals);
@@ -898,6 +904,7 @@ private:
     }
 
     std::string directory_;
+    StandinTable standins_;
     mcsd::Scene out_;
     std::map<std::string, std::string> defaults_;
     std::map<std::string, uint32_t> texture_ids_, bsdf_ids_, medium_ids_;
@@ -905,7 +912,7 @@ private:
 
 } // namespace
 
-mcsd::Scene LoadXmlScene(const std::string &path)
+mcsd::Scene LoadXmlScene(const std::string &path, const std::string &standins)
 {
     std::ifstream f(path, std::ios::binary);
     if (!f)
@@ -918,7 +925,7 @@ mcsd::Scene LoadXmlScene(const std::string &path)
     const std::unique_ptr<xml::Node> root = xml::Parse(buffer.str());
     if (root->name != "scene")
         throw std::runtime_error("[error] read config file failed.");
-    return SceneBuilder(path).Run(*root);
+    return SceneBuilder(path, StandinTable(standins)).Run(*root);
 }
 
 } // namespace mcpt

@@ -99,7 +99,7 @@ MCPT_HD V3 emitter_eval_sample(const LightTables &T, const EmitterRec &e, const 
             fall *= texture_color(T.textures, T.texels, e.texture, uv, T.all_constant);
         }
         if (d.z < e.cos_beam)
-            fall *= (e.cutoff - acosf(d.z)) * e.transition_rcp;
+            fall *= (e.cutoff - gl::acosf(d.z)) * e.transition_rcp;
         return from(e.intensity) * fall * sqr(1.0f / s.distance);
     }
     case kEmitDirectional:
@@ -149,7 +149,7 @@ MCPT_HD float emitter_pdf(const LightTables &T, const EmitterRec &e, V3 look) //
     const float row = fminf(fmaxf(uv.u * e.height, 0), e.height - 1);
     const int ri = static_cast<int>(row);
     const float t = row - ri;
-    const float denom = fmaxf(fabsf(sinf(theta)), 1e-4f);
+    const float denom = fmaxf(fabsf(gl::sinf(theta)), 1e-4f);
     if (t == 0)
         return luminance(c) * wr[ri] * e.normalization / denom;
     return luminance(c) * lerp(wr[ri], wr[ri + 1], t) * e.normalization / denom;
@@ -289,7 +289,7 @@ MCPT_HD void phase_sample(const MediumRec &m, uint32_t &rng, PhaseQuery &r)
     r.valid = true;
     const float sin_t = sqrtf(fmaxf(0.0f, 1.0f - sqr(cos_t)));
     const float phi = k2Pi * lcg_next(rng);
-    r.wi = -frame_to_world(V3{sin_t * cosf(phi), sin_t * sinf(phi), cos_t}, r.wo);
+    r.wi = -frame_to_world(V3{sin_t * gl::cosf(phi), sin_t * gl::sinf(phi), cos_t}, r.wo);
 }
 
 MCPT_HD void phase_eval(const MediumRec &m, PhaseQuery &r)

@@ -21,6 +21,13 @@ MCPT_HD BitmapTap bitmap_tap(const TextureRec &t, V2 uv)
 {
     const V3 p = transform_point(t.to_uv, V3{uv.u, uv.v, 0.0f});
     float x = p.x * t.width, y = p.y * t.height;
+    // Beyond 2^24 texture widths a subtraction of the width no longer changes x and the reference's loop
+    // never ends (a NaN leaves the loops and is then cast to an index): such coordinates read texel 0
+    // here instead of hanging a persistent kernel.  Below that the repeated arithmetic is the reference's.
+    if (!(fabsf(x) < 16777216.0f * t.width))
+        x = 0.0f;
+    if (!(fabsf(y) < 16777216.0f * t.height))
+        y = 0.0f;
     while (x < 0)
         x += t.width;
     while (x > t.width - 1)
@@ -59,6 +66,10 @@ MCPT_HD V3 bitmap_color(const TextureRec &t, const float *texels, V2 uv) // bitm
 MCPT_HD V3 checker_color(const TextureRec &t, V2 uv) // checkboard.cpp:6-21
 {
     V3 p = transform_point(t.to_uv, V3{uv.u, uv.v, 0.0f});
+    if (!(fabsf(p.x) < 16777216.0f)) // see bitmap_tap
+        p.x = 0.0f;
+    if (!(fabsf(p.y) < 16777216.0f))
+        p.y = 0.0f;
     while (p.x > 1)
         p.x -= 1;
     while (p.x < 0)

@@ -240,7 +240,7 @@ MCPT_HD bool cylinder_hit(const DeviceScene &sc, const AnalyticRec &q, uint32_t 
         return false;
     const V3 p_local = o + t * d;
     if (kTextures &&
-        masked_out<kTextures>(sc, bsdf, V2{atan2f(p_local.y, p_local.x) * k1Div2Pi, p_local.z / q.length}, rng))
+        masked_out<kTextures>(sc, bsdf, V2{gl::atan2f(p_local.y, p_local.x) * k1Div2Pi, p_local.z / q.length}, rng))
         return false;
     t = length(transform_point(q.to_world, p_local) - ray.origin);
     if (t > ray.t_max || t < kEpsDistance)
@@ -813,7 +813,7 @@ MCPT_HD Surface make_surface(const DeviceScene &sc, const Ray &ray, const HitRaw
         }
         else
         {
-            s.uv = V2{atan2f(p_local.y, p_local.x) * k1Div2Pi, p_local.z / q.length};
+            s.uv = V2{gl::atan2f(p_local.y, p_local.x) * k1Div2Pi, p_local.z / q.length};
             s.position = transform_point(q.to_world, p_local);
             s.normal = transform_dir(q.normal_to_world, normalize(V3{p_local.x, p_local.y, 0.0f}));
             s.tangent = transform_dir(q.normal_to_world, V3{0, 0, 1});
@@ -876,9 +876,9 @@ MCPT_HD LightPoint sample_instance(const DeviceScene &sc, uint32_t inst, float x
     if (rec.kind == kInstSphere)
     {
         const float cos_t = 1.0f - 2.0f * xi1;
-        lp.uv = V2{xi2, acosf(cos_t) * k1DivPi};
+        lp.uv = V2{xi2, gl::acosf(cos_t) * k1DivPi};
         const float sin_t = sqrtf(1.0f - sqr(cos_t)), phi = k2Pi * xi2;
-        const V3 n_local = V3{sin_t * cosf(phi), sin_t * sinf(phi), cos_t};
+        const V3 n_local = V3{sin_t * gl::cosf(phi), sin_t * gl::sinf(phi), cos_t};
         lp.position = transform_point(q.to_world, from(q.center) + q.radius * n_local);
         lp.normal = transform_dir(q.normal_to_world, n_local);
     }
@@ -893,15 +893,15 @@ MCPT_HD LightPoint sample_instance(const DeviceScene &sc, uint32_t inst, float x
         else
             r = r2, phi = kPiDiv2 - (r1 / r2) * kPiDiv4;
         lp.uv = V2{r, phi * k1Div2Pi};
-        lp.position = transform_point(q.to_world, V3{(r * cosf(phi)) * 0.5f, (r * sinf(phi)) * 0.5f, 0});
+        lp.position = transform_point(q.to_world, V3{(r * gl::cosf(phi)) * 0.5f, (r * gl::sinf(phi)) * 0.5f, 0});
         lp.normal = transform_dir(q.normal_to_world, V3{0, 0, 1});
     }
     else
     {
         const float phi = k2Pi * xi1, z = xi2 * q.length;
         lp.uv = V2{xi1, xi2};
-        lp.position = transform_point(q.to_world, V3{cosf(phi) * q.radius, sinf(phi) * q.radius, z});
-        lp.normal = transform_dir(q.normal_to_world, V3{cosf(phi), sinf(phi), 0});
+        lp.position = transform_point(q.to_world, V3{gl::cosf(phi) * q.radius, gl::sinf(phi) * q.radius, z});
+        lp.normal = transform_dir(q.normal_to_world, V3{gl::cosf(phi), gl::sinf(phi), 0});
     }
     return lp;
 }

@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "device_scene.h"
+#include "glibc_libm.h"
 
 #if defined(__HIPCC__)
 #define MCPT_HD __host__ __device__ __forceinline__
@@ -185,7 +186,7 @@ MCPT_HD void sample_hemisphere_cosine(float xi0, float xi1, V3 &dir, float &pdf)
 {
     const float cos_t = sqrtf(xi0), phi = k2Pi * xi1;
     const float sin_t = sqrtf(1.0f - sqr(cos_t)); // double sqrt -> float == sqrtf
-    dir = V3{sin_t * cosf(phi), sin_t * sinf(phi), cos_t};
+    dir = V3{sin_t * gl::cosf(phi), sin_t * gl::sinf(phi), cos_t};
     pdf = k1DivPi * cos_t;
 }
 
@@ -193,14 +194,14 @@ MCPT_HD V3 sample_sphere_uniform(float xi0, float xi1) // math.cpp:24-29
 {
     const float cos_t = 1.0f - 2.0f * xi0, phi = k2Pi * xi1;
     const float sin_t = sqrtf(1.0f - sqr(cos_t));
-    return V3{sin_t * cosf(phi), sin_t * sinf(phi), cos_t};
+    return V3{sin_t * gl::cosf(phi), sin_t * gl::sinf(phi), cos_t};
 }
 
 MCPT_HD V3 sample_cone_uniform(float cos_cutoff, float xi0, float xi1) // math.cpp:15-22
 {
     const float cos_t = 1.0f - (1.0f - cos_cutoff) * xi0, phi = 2.0f * kPi * xi1;
     const float sin_t = sqrtf(fmaxf(0.0f, 1.0f - cos_t * cos_t));
-    return V3{sin_t * cosf(phi), sin_t * sinf(phi), cos_t};
+    return V3{sin_t * gl::cosf(phi), sin_t * gl::sinf(phi), cos_t};
 }
 
 MCPT_HD uint32_t cdf_search(uint32_t num, const float *cdf, float target) // math.cpp:40-55
@@ -251,14 +252,14 @@ MCPT_HD bool solve_quadratic(float a, float b, float c, float &x0, float &x1) //
 MCPT_HD void to_spherical(V3 v, float &theta, float &phi)
 {
     v = normalize(v);
-    theta = acosf(fminf(1.0f, fmaxf(-1.0f, v.y)));
+    theta = gl::acosf(fminf(1.0f, fmaxf(-1.0f, v.y)));
     if (v.z == 0 && v.x == 0)
     {
         phi = 0;
     }
     else
     {
-        phi = atan2f(v.z, v.x);
+        phi = gl::atan2f(v.z, v.x);
         if (phi < 0.0f)
             phi += 2.0f * kPi;
     }
@@ -266,8 +267,8 @@ MCPT_HD void to_spherical(V3 v, float &theta, float &phi)
 
 MCPT_HD V3 from_spherical(float theta, float phi, float r)
 {
-    const float sin_t = sinf(theta);
-    return V3{r * sinf(phi) * sin_t, r * cosf(theta), r * cosf(phi) * sin_t};
+    const float sin_t = gl::sinf(theta);
+    return V3{r * gl::sinf(phi) * sin_t, r * gl::cosf(theta), r * gl::cosf(phi) * sin_t};
 }
 
 // math.cpp:130-145; the reciprocal square roots are float / double-sqrt.
@@ -310,7 +311,7 @@ MCPT_HD void ggx_sample_iso(float xi0, float xi1, float alpha, V3 &h, float &pdf
     const float tan2 = a2 * xi0 / (1.0f - xi0), phi = k2Pi * xi1;
     const float cos_t = static_cast<float>(1.0 / sqrt(D(1.0f + tan2)));
     const float sin_t = sqrtf(1.0f - sqr(cos_t));
-    h = V3{sin_t * cosf(phi), sin_t * sinf(phi), cos_t};
+    h = V3{sin_t * gl::cosf(phi), sin_t * gl::sinf(phi), cos_t};
     pdf = static_cast<float>(1.0 / (D(kPi * a2) * pow3d(cos_t) * D(sqr(1.0f + tan2 / a2))));
 }
 

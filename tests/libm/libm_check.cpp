@@ -1,0 +1,108 @@
+// Test infrastructure: compares csrc/glibc_libm.h with the host's libm (GNU libc 2.35) argument by argument.
+//   libm_check <function> [stride]       sinf cosf acosf atanf tanf: all 2^32 / stride float arguments
+//   libm_check atan2f [stride]           pairs: y, x over a grid of bit patterns + structured edge cases
+// Prints the number of mismatching arguments (NaN == NaN) and the first few.
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../monte-carlo-path-tracing_amd/csrc/glibc_libm.h"
+
+using mcpt::gl::bits;
+using mcpt::gl::from_bits;
+
+static bool same(float a, float b) { return bits(a) == bits(b) || (a != a && b != b); }
+
+extern "C" long long mcpt_libm_check(const char *name, unsigned long long stride, unsigned *first_bad, int max_bad)
+{
+    float (*mine)(float) = nullptr;
+    float (*theirs)(float) = nullptr;
+    bool tan_domain = false;
+    if (!strcmp(name, "sinf")) mine = mcpt::gl::sinf, theirs = ::sinf;
+    else if (!strcmp(name, "cosf")) mine = mcpt::gl::cosf, theirs = ::cosf;
+    else if (!strcmp(name, "acosf")) mine = mcpt::gl::acosf, theirs = ::acosf;
+    else if (!strcmp(name, "atanf")) mine = mcpt::gl::atanf, theirs = ::atanf;
+    else if (!strcmp(name, "tanf")) mine = mcpt::gl::tanf, theirs = ::tanf, tan_domain = true;
+    const unsigned n_threads = std::max(1u, std::thread::hardware_concurrency());
+    std::atomic<long long> bad{0};
+    std::atomic<int> stored{0};
+    std::vector<std::thread> pool;
+    if (mine)
+    {
+        for (unsigned t = 0; t < n_threads; ++t)
+            pool.emplace_back([&, t]() {
+                long long local = 0;
+                for (unsigned long long u = t * stride; u < (1ull << 32); u += n_threads * stride)
+                {
+                    const float x = from_bits(static_cast<unsigned>(u));
+                    if (tan_domain && false)
+                        continue;
+                    if (!same(mine(x), theirs(x)))
+                    {
+                        ++local;
+                        const int k = stored.fetch_add(1);
+                        if (k < max_bad)
+                            first_bad[k] = static_cast<unsigned>(u);
+                    }
+                }
+                bad += local;
+            });
+    }
+    else if (!strcmp(name, "atan2f"))
+    {
+        // y sweeps all bit patterns with the given stride; x takes a set of bit patterns spread over the
+        // exponent range plus the special values
+        std::vector<unsigned> xs;
+        for (unsigned e = 0; e < 256; e += 1)
+            for (unsigned m : {0u, 1u, 0x400000u, 0x7fffffu, 0x2aaaabu, 0x123456u})
+                for (unsigned s : {0u, 0x80000000u})
+                    xs.push_back(s | (e << 23) | m);
+        for (unsigned t = 0; t < n_threads; ++t)
+            pool.emplace_back([&, t]() {
+                long long local = 0;
+                unsigned lcg = 12345u + t;
+                for (unsigned long long u = t * stride; u < (1ull << 32); u += n_threads * stride)
+                {
+                    const float y = from_bits(static_cast<unsigned>(u));
+                    lcg = lcg * 1664525u + 1013904223u;
+                    const unsigned picks[3] = {xs[(lcg >> 8) % xs.size()], lcg, static_cast<unsigned>(u) ^ ((lcg >> 9) & 0x3fffffu)};
+                    for (unsigned xb : picks)
+                    {
+                        const float x = from_bits(xb);
+                        if (!same(mcpt::gl::atan2f(y, x), ::atan2f(y, x)))
+                        {
+                            ++local;
+                            const int k = stored.fetch_add(2);
+                            if (k + 1 < max_bad)
+                                first_bad[k] = static_cast<unsigned>(u), first_bad[k + 1] = xb;
+                        }
+                    }
+                }
+                bad += local;
+            });
+    }
+    else
+        return -1;
+    for (auto &th : pool)
+        th.join();
+    return bad.load();
+}
+
+#ifndef MCPT_LIBM_CHECK_NO_MAIN
+int main(int argc, char **argv)
+{
+    if (argc < 2)
+        return 2;
+    const unsigned long long stride = argc > 2 ? strtoull(argv[2], nullptr, 10) : 1;
+    unsigned first[16] = {0};
+    const long long bad = mcpt_libm_check(argv[1], stride, first, 16);
+    printf("%s stride %llu: %lld mismatches\n", argv[1], stride, bad);
+    for (int k = 0; k < 16 && k < bad; ++k)
+        printf("  0x%08x\n", first[k]);
+    return bad == 0 ? 0 : 1;
+}
+#endif

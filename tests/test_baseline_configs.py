@@ -1,0 +1,115 @@
+"""Every configuration BASELINE.json names, from the committed fixtures
+(monte-carlo-path-tracing_amd/baseline_scenes/, made by tools/make_baseline_scenes.py from the reference's
+scene files with the product's XML front end).
+
+CPU part: the fixtures load, and — where /root/reference exists — are byte for byte what the XML front end
+produces today (for dragon: XML + stand-in table == fixture + mcpt_config_set_instance_standin).
+GPU part (-m gpu): each configuration against the oracle at a reduced film, and at its FULL film size
+through size-independent properties (finite, within [0, 1], sample count, deterministic, tile-composable)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+REF_SCENES = "/root/reference/resources/scene/"
+XML = {"dragon": "dragon/scene.xml", "matpreview-rc": "matpreview/rough_conductor.xml",
+       "matpreview-rd": "matpreview/rough_dielectric.xml", "volumetric": "volumetric-caustic/scene_v0.6.xml"}
+NAMES = ["cornell", "dragon", "matpreview-rc", "matpreview-rd", "volumetric"]
+
+
+def _bytes(cfg, tmp_path, name):
+    p = str(tmp_path / (name + ".mcsd"))
+    cfg.save_mcsd(p)
+    return open(p, "rb").read()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_fixture_loads_with_the_stated_film(pkg, name):
+    cfg = pkg.workloads.config(name)
+    assert cfg.film() == pkg.workloads.WORKLOADS[name][1]
+
+
+def test_dragon_has_its_real_meshes_and_the_standins(pkg, tmp_path):
+    cfg = pkg.workloads.config("dragon", 64, 36, 1)
+    scene = pkg.mcsd.loads(_bytes(cfg, tmp_path, "dragon"))
+    tris = [np.asarray(i.indices).size // 3 for i in scene.instances]
+    assert len(tris) == 16 and sum(tris) == 831580
+    assert sum(t for k, t in enumerate(tris) if k not in (4, 5, 6, 7)) == 51140  # the twelve real OBJ files
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SCENES), reason="needs the reference's scene files")
+@pytest.mark.parametrize("name", ["dragon", "matpreview-rc", "matpreview-rd", "volumetric"])
+def test_fixture_is_what_the_xml_front_end_produces(pkg, tmp_path, name):
+    film = pkg.workloads.WORKLOADS[name][1]
+    standins = open(pkg.workloads.DRAGON_STANDINS).read() if name == "dragon" else None
+    direct = pkg.capi.Config.load_xml(REF_SCENES + XML[name], standins).set_film(*film)
+    assert _bytes(direct, tmp_path, "a") == _bytes(pkg.workloads.config(name), tmp_path, "b")
+
+
+def test_missing_mesh_without_a_standin_is_the_reference_error(pkg):
+    if not os.path.isdir(REF_SCENES):
+        pytest.skip("needs the reference's scene files")
+    with pytest.raises(pkg.capi.McptError, match="Mesh012.obj"):
+        pkg.capi.Config.load_xml(REF_SCENES + XML["dragon"])
+    with pytest.raises(pkg.capi.McptError, match="stand-in"):
+        pkg.capi.Config.load_xml(REF_SCENES + XML["dragon"], "models/Mesh012.obj torus 1 2 3\n")
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------
+REDUCED = {"cornell": (128, 128, 64), "dragon": (160, 90, 32), "matpreview-rc": (128, 128, 32),
+           "matpreview-rd": (128, 128, 32), "volumetric": (160, 90, 64)}
+
+
+def _draw(pkg, cfg):
+    r = pkg.capi.Renderer(cfg, device=0)
+    try:
+        return r.draw()
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_baseline_config_against_oracle_reduced_film(pkg, oracle, tmp_path, name):
+    from test_gpu_parity import assert_parity
+    w, h, spp = REDUCED[name]
+    cfg = pkg.workloads.config(name, w, h, spp)
+    path = str(tmp_path / "scene.mcsd")
+    cfg.save_mcsd(path)
+    frame, _ = _draw(pkg, cfg)
+    want, _ = oracle.render(path)
+    assert_parity(frame, want, name, spp=spp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_baseline_config_full_size_properties(pkg, name):
+    """The full film of the configuration: every pixel finite and inside [0, 1] (per-sample clamp,
+    renderer.cpp:77-80), the kernel reports W*H*spp samples, a second renderer object gives the same
+    frame bit for bit, and the tile sets of two ranks compose to that frame."""
+    w, h, spp = pkg.workloads.WORKLOADS[name][1]
+    cfg = pkg.workloads.config(name)
+    r = pkg.capi.Renderer(cfg, device=0)
+    try:
+        frame, stats = r.draw(counted=(name == "cornell"))
+        assert frame.shape == (h, w, 3) and np.isfinite(frame).all()
+        assert frame.min() >= 0.0 and frame.max() <= 1.0
+        if name == "cornell":
+            assert stats["samples"] == w * h * spp
+        digest = hashlib.sha256(frame.tobytes()).hexdigest()
+        # two ranks' tile sets, rendered one after the other on this GPU, compose to the same frame
+        import torch
+        composed = np.zeros_like(frame)
+        for rank in range(2):
+            rng = pkg.capi.TileRange(rank, 2, 0)
+            buf = torch.zeros(r.tiles_in(rng) * 64 * 3, dtype=torch.float32, device="cuda:0")
+            r.draw_device(buf.data_ptr(), rng, packed=True)
+            pkg.capi.unpack_tiles(buf.cpu().numpy(), rng, w, h, composed)
+        assert hashlib.sha256(composed.tobytes()).hexdigest() == digest
+    finally:
+        r.close()
+    again, _ = _draw(pkg, pkg.workloads.config(name))
+    assert hashlib.sha256(again.tobytes()).hexdigest() == digest
+    print(name, "full size", (w, h, spp), "kernel ms", stats["kernel_milliseconds"],
+          "Msamples/s", w * h * spp / stats["kernel_milliseconds"] / 1e3)
