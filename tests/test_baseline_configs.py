@@ -79,7 +79,7 @@ def test_baseline_config_against_oracle_reduced_film(pkg, oracle, tmp_path, name
     cfg.save_mcsd(path)
     frame, _ = _draw(pkg, cfg)
     want, _ = oracle.render(path)
-    assert_parity(frame, want, name, spp=spp)
+    assert_parity(frame, want, name, spp=spp, has_medium=(name == "volumetric"))
 
 
 @pytest.mark.gpu

@@ -138,5 +138,10 @@ def test_edge_case_on_gpu(name, pkg, oracle, mcsd_file):
     assert np.array_equal(frame, reference_order)
     assert st["samples"] == scene.camera.width * scene.camera.height * scene.camera.spp
     d = np.abs(frame.astype(np.float64) - want)
-    # a handful of pixels, a handful of samples: one flipped decision is visible, so bound the mean
-    assert np.isfinite(frame).all() and d.mean() <= 2e-3 and np.median(d) <= 1e-6, (name, d.mean(), d.max())
+    # bit-exact (csrc/glibc_libm.h), NaN pixels cannot occur (per-sample clamp); with a medium see
+    # test_random_combinations_on_gpu
+    assert np.isfinite(frame).all()
+    if scene.media:
+        assert d.mean() <= 2e-3 and np.median(d) == 0.0, (name, d.mean(), d.max())
+    else:
+        assert np.array_equal(frame, want), (name, d.mean(), d.max())

@@ -1,13 +1,15 @@
 """HIP renderer (through the C ABI) vs the reference's golden frames and vs the
 oracle.  Needs a real MI355X: run with `-m gpu`.
 
-Tolerance (BASELINE.json north_star): per-pixel L2 <= 1e-3 against the CPU
-reference image at the same scene/spp.  Path tracing follows discrete decisions
-(hit/miss, reflect/refract, roulette), so a last-ulp difference between device
-and host libm occasionally flips one and changes an isolated pixel by up to a
-few 1e-2; the bound is therefore applied to the RMSE and to the
-mean per-pixel L2 over the frame, and the fraction of pixels off by more than
-1e-3 is bounded separately."""
+Tolerance: BASELINE.json's north_star allows per-pixel L2 <= 1e-3 against the CPU reference image at the
+same scene / spp.  The bar HERE is stricter — **bit-exact frames**: every float operation of the path is
+the reference's (csrc/vecmath.h) and the device's sinf / cosf / tanf / acosf / atanf / atan2f are the
+host libm's algorithms restated (csrc/glibc_libm.h, checked on all 2^32 arguments), so the GPU frame IS
+the CPU frame.  Round 1 (device libm) needed a statistical tolerance here; profiles/
+r02_full_size_parity_bit_exact.json has all five BASELINE configurations at full size with rmse 0.
+The only libm calls left to the device library are the double exp / log of the medium code, whose results
+are rounded to float (a differing float needs the two doubles to straddle a float rounding boundary:
+~2^-28 per call); a frame with a medium may therefore differ in isolated pixels, bounded below."""
 import json
 import os
 
@@ -22,9 +24,9 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MANIFEST = json.load(open(os.path.join(GOLDEN, "manifest.json")))
 CASE_NAMES = sorted(MANIFEST["frames"])
 
-RMSE_TOL = 1e-3      # north_star tolerance, stated for spp = 256 images
+RMSE_TOL = 1e-3      # north_star tolerance (only reachable by a frame with a medium, see above)
 MEAN_L2_TOL = 1e-3
-OUTLIER_FRACTION = 0.02  # pixels allowed to be off by more than 1e-3
+OUTLIER_FRACTION = 1e-4  # pixels allowed to be off by more than 1e-3 (frames with a medium only)
 REFERENCE_SPP = 256
 
 
@@ -36,18 +38,18 @@ def metrics(a, b):
             "exact": float((l2 == 0).mean())}
 
 
-def assert_parity(frame, want, what, spp=REFERENCE_SPP):
-    """One flipped decision changes ONE sample, i.e. a pixel by at most
-    (radiance change) / spp: the low-spp fixtures see a flip 256/spp times
-    larger than the spp-256 image the 1e-3 bound is quoted for, so the RMSE bound
-    is scaled by that factor; the mean and the outlier fraction are not."""
+def assert_parity(frame, want, what, spp=REFERENCE_SPP, has_medium=False):
+    """Bit-exact, except that a scene with a participating medium (double exp / log from the device
+    library) may have isolated pixels off: then >= 99.99 % of the pixels exact and the north_star bound."""
     assert frame.shape == want.shape
     assert np.isfinite(frame).all(), f"{what}: non-finite pixels"
     m = metrics(frame, want)
     print(what, m)
-    rmse_tol = RMSE_TOL * max(1.0, REFERENCE_SPP / spp)
-    assert m["rmse"] <= rmse_tol and m["mean_l2"] <= MEAN_L2_TOL and m["outliers"] <= OUTLIER_FRACTION, (what, m)
-    assert np.median(np.sqrt(((frame.astype(np.float64) - want) ** 2).sum(axis=2))) <= 1e-6, what
+    if not has_medium:
+        assert m["exact"] == 1.0 and m["rmse"] == 0.0, (what, m)
+        return
+    assert m["exact"] >= 0.9999 and m["rmse"] <= RMSE_TOL and m["mean_l2"] <= MEAN_L2_TOL and \
+        m["outliers"] <= OUTLIER_FRACTION, (what, m)
 
 
 @pytest.fixture(scope="module")
@@ -68,7 +70,7 @@ def gpu_render(pkg, scene, counted=False, reference_walk=False):
 def test_golden_frames(name, pkg, scenes):
     want = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
     frame, _ = gpu_render(pkg, scenes[name])
-    assert_parity(frame, want, name, spp=scenes[name].camera.spp)
+    assert_parity(frame, want, name, spp=scenes[name].camera.spp, has_medium=bool(scenes[name].media))
 
 
 def test_against_oracle_larger(pkg, oracle, mcsd_file):
@@ -80,7 +82,7 @@ def test_against_oracle_larger(pkg, oracle, mcsd_file):
                   pkg.scenes.blob_field_scene(12, 128, 256, 160, 90, 16)):   # 0.8 M triangles (config 3 stand-in)
         want, _ = oracle.render(mcsd_file(scene))
         frame, _ = gpu_render(pkg, scene)
-        assert_parity(frame, want, "oracle", spp=scene.camera.spp)
+        assert_parity(frame, want, "oracle", spp=scene.camera.spp, has_medium=bool(scene.media))
 
 
 def test_baseline_config_full_size(pkg, oracle, mcsd_file):

@@ -60,8 +60,11 @@ def test_random_combinations_on_gpu(pkg, oracle, mcsd_file):
         assert np.array_equal(frame, other), name
         d = np.abs(frame.astype(np.float64) - want)
         assert np.isfinite(frame).all(), name
-        # tiny films at spp 3: one flipped decision moves a pixel by up to 1/3, so bound the
-        # mean and the median instead of the maximum
-        assert d.mean() <= 4e-3 and np.median(d) <= 1e-6, (name, d.mean(), d.max())
+        # bit-exact (csrc/glibc_libm.h); a medium's double exp / log come from the device library and may
+        # round differently once in ~2^28 calls: there a flipped decision on a tiny film at spp 3 is bounded
+        if scene.media:
+            assert d.mean() <= 4e-3 and np.median(d) == 0.0, (name, d.mean(), d.max())
+        else:
+            assert np.array_equal(frame, want), (name, d.mean(), d.max())
         worst = max(worst, d.mean())
     print("largest mean |difference| over the combinations:", worst)
