@@ -86,6 +86,10 @@ typedef struct mcpt_stats
      * runs for all 64 lanes whether or not they have work): lane utilisation of the
      * node phase = (node_tests / 2) / (64 * wave_node_steps) */
     uint64_t wave_node_steps, wave_prim_steps;
+    /* stream kernel, counting mode: shader-clock ticks summed over wavefronts — in the shade phase, in the
+     * trace phase, waiting at the workgroup barriers between them — and the number of rounds (summed over
+     * workgroups).  0 for the lane-owns-a-path kernel. */
+    uint64_t ticks_shade, ticks_trace, ticks_wait, rounds;
 } mcpt_stats;
 
 /* Replaces Renderer::Renderer(const RendererConfig&) (reference
@@ -147,6 +151,24 @@ int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order);
  * for that reason).  The commit's defaults are 8 / 12 (0 / 0 for small scenes).  No reference
  * counterpart. */
 int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint32_t leave_at);
+
+/* Which kernel formulation later draws use; the image does not depend on it (tests assert the frames are
+ * bit-identical).  Replaces the reference's megakernel dispatch (src/renderer/renderer.cpp:88-95).
+ *   mode -1 (default): by scene class — the stream kernel for scenes whose traversal data does not fit LDS
+ *          (meshes: long, uneven walks), the lane-owns-a-path kernel for the few-KB scenes (cornell-box,
+ *          volumetric-caustic) where it is already VALU-bound and faster.
+ *   mode 1: the STREAM kernel (csrc/stream_core.h) — a workgroup owns `slots` path slots (0 = built-in
+ *          choice, otherwise a multiple of 256) whose rays go through a workgroup-local pool: emitted rays are
+ *          compacted by wavefront ballot / prefix count, a lane that finishes a ray fetches the next one
+ *          (`refill_at`: when that many lanes of a wavefront are free; 0 = built-in).  Scenes it does not cover
+ *          (opacity masks, more than two shadow rays per vertex, the reference-order validation walk) fall back
+ *          to mode 0.
+ *   mode 2: the stream kernel with `slots` (> 256) slots per workgroup whose path state lives in memory instead of
+ *          the lanes' registers (experiments; instantiated for few scene classes, otherwise falls back to mode 0).
+ *   mode 0: the lane-owns-a-path state machine (csrc/path_core.h, round 1's kernel). */
+int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_t refill_at);
+/* Name of the kernel instantiation the last draw launched ("" before the first draw); renderer-owned string. */
+const char *mcpt_renderer_last_kernel(const mcpt_renderer *r);
 
 /* The reference-topology LBVH (reference src/rtcore/accel/bvh_builder.cpp:74-207) of n
  * boxes (6 floats each: lo.xyz, hi.xyz) with areas, built by the host builder

@@ -35,7 +35,9 @@ class Stats(ctypes.Structure):
                 ("samples", ctypes.c_uint64), ("closest_rays", ctypes.c_uint64),
                 ("shadow_rays", ctypes.c_uint64), ("node_tests", ctypes.c_uint64),
                 ("prim_tests", ctypes.c_uint64), ("shaded_hits", ctypes.c_uint64),
-                ("wave_node_steps", ctypes.c_uint64), ("wave_prim_steps", ctypes.c_uint64)]
+                ("wave_node_steps", ctypes.c_uint64), ("wave_prim_steps", ctypes.c_uint64),
+                ("ticks_shade", ctypes.c_uint64), ("ticks_trace", ctypes.c_uint64),
+                ("ticks_wait", ctypes.c_uint64), ("rounds", ctypes.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -92,6 +94,9 @@ def lib():
     L.mcpt_renderer_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.mcpt_renderer_set_walk.argtypes = [vp, ctypes.c_int]
     L.mcpt_renderer_set_walk_schedule.argtypes = [vp, u32, u32]
+    L.mcpt_renderer_set_kernel.argtypes = [vp, i32, u32, u32]
+    L.mcpt_renderer_last_kernel.argtypes = [vp]
+    L.mcpt_renderer_last_kernel.restype = cp
     L.mcpt_debug_lbvh_build.argtypes = [u32, vp, vp, i32, vp, vp, ctypes.POINTER(ctypes.c_double)]
     L.mcpt_debug_intersect.argtypes = [vp, u32, vp, vp, vp, vp]
     L.mcpt_debug_bsdf.argtypes = [vp, u32, i32, u32, vp, vp, vp, vp]
@@ -115,6 +120,7 @@ EXPORTED_SYMBOLS = [
     "mcpt_renderer_draw", "mcpt_renderer_draw_device", "mcpt_renderer_draw_counted",
     "mcpt_renderer_tile_count", "mcpt_tile_range_size", "mcpt_unpack_tiles",
     "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_set_walk", "mcpt_renderer_set_walk_schedule",
+    "mcpt_renderer_set_kernel", "mcpt_renderer_last_kernel",
     "mcpt_renderer_destroy",
     "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_trace_pixel",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
@@ -278,6 +284,16 @@ class Renderer:
         trees in the reference's order (validation mode)."""
         _check(lib().mcpt_renderer_set_walk(self._h, 1 if reference_order else 0))
         return self
+
+    def set_kernel(self, stream, slots: int = 0, refill_at: int = 0):
+        """-1 (default): by scene class; True / 1: the stream kernel (workgroup-local ray pool) wherever the scene
+        allows it; False / 0: the lane-owns-a-path kernel; 2: stream with `slots` slots per workgroup in memory.
+        The image does not depend on it."""
+        _check(lib().mcpt_renderer_set_kernel(self._h, int(stream), slots, refill_at))   # 2: slots in memory
+        return self
+
+    def last_kernel(self) -> str:
+        return lib().mcpt_renderer_last_kernel(self._h).decode()
 
     def set_walk_schedule(self, leave_below: int, leave_at: int):
         """Vote thresholds of the ordered walk on large scenes (see mcpt.h); the image does not change."""

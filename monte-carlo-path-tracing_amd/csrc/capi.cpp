@@ -109,9 +109,19 @@ struct mcpt_renderer
     mcpt::TraceCounters *counters_dev = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::string variant;
+    // mcpt_renderer_set_kernel: -1 = by scene class (the default), 1 / 2 = stream kernel where the scene allows
+    // it, 0 = lane-owns-a-path kernel
+    int kernel_mode = -1;
+    uint32_t stream_slots = 0, stream_refill = 0;
+    // slot storage of the stream kernel's workgroups; one draw at a time per renderer (the reference's
+    // Renderer is not reentrant either, renderer.cpp:17-22)
+    uint32_t *scratch_dev = nullptr;
+    size_t scratch_words = 0;
 
     ~mcpt_renderer()
     {
+        if (scratch_dev)
+            (void)hipFree(scratch_dev);
         if (frame_dev)
             (void)hipFree(frame_dev);
         if (counters_dev)
@@ -161,10 +171,42 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     }
     const auto t0 = std::chrono::steady_clock::now();
     const bool timed = stats != nullptr && blocking;
+    const char *variant = "";
+    mcpt::StreamLaunch plan{};
+    plan.slots = r->stream_slots, plan.refill_at = r->stream_refill, plan.slots_in_memory = r->kernel_mode == 2 ? 1u : 0u;
+    bool streamed = false;
+    // by scene class: the stream kernel wins where walks are long and uneven (meshes: dragon stand-in 1.4x,
+    // matpreview 1.3x) and loses where the whole scene sits in LDS and the lane-owns-a-path kernel is already
+    // VALU-bound (cornell 0.77x, volumetric-caustic 0.5x): DESIGN.md section 3
+    const bool auto_stream = r->kernel_mode == -1 && !mcpt::StreamPrefersLanes(r->dev);
+    if ((r->kernel_mode > 0 || auto_stream) && job.n_items != 0 && mcpt::StreamSupports(r->dev, job))
+    {
+        const hipError_t planned = mcpt::PlanRenderStream(r->dev, job, counted, r->n_cus, &plan, &variant);
+        if (planned == hipSuccess)
+        {
+            const size_t words = static_cast<size_t>(plan.blocks) * plan.scratch_words_per_block;
+            if (words > r->scratch_words)
+            {
+                if (r->scratch_dev)
+                {
+                    Check(hipDeviceSynchronize(), "wait before growing the slot storage");
+                    Check(hipFree(r->scratch_dev), "free slot storage");
+                    r->scratch_dev = nullptr, r->scratch_words = 0;
+                }
+                Check(hipMalloc(reinterpret_cast<void **>(&r->scratch_dev), words * sizeof(uint32_t)), "allocate slot storage");
+                r->scratch_words = words;
+            }
+            streamed = true;
+        }
+        else if (planned != hipErrorNotSupported && planned != hipErrorOutOfMemory)
+            Check(planned, "plan the stream kernel");
+    }
     if (timed)
         Check(hipEventRecord(r->ev_begin, stream), "record event");
-    const char *variant = "";
-    Check(mcpt::LaunchRender(r->dev, job, out_device, counters, stream, r->n_cus, &variant), "launch render kernel");
+    if (streamed)
+        Check(mcpt::LaunchRenderStream(r->dev, job, out_device, counters, stream, r->scratch_dev, plan), "launch stream kernel");
+    else
+        Check(mcpt::LaunchRender(r->dev, job, out_device, counters, stream, r->n_cus, &variant), "launch render kernel");
     r->variant = variant;
     if (timed)
         Check(hipEventRecord(r->ev_end, stream), "record event");
@@ -198,6 +240,8 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             stats->node_tests = c.node_tests, stats->prim_tests = c.prim_tests;
             stats->wave_node_steps = c.wave_node_steps, stats->wave_prim_steps = c.wave_prim_steps;
             stats->shaded_hits = c.shaded_hits;
+            stats->ticks_shade = c.ticks_shade, stats->ticks_trace = c.ticks_trace, stats->ticks_wait = c.ticks_wait;
+            stats->rounds = c.rounds;
         }
     }
 }
@@ -587,6 +631,20 @@ int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order)
     r->reference_walk = reference_order != 0;
     return 0;
 }
+
+int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_t refill_at)
+{
+    if (!r)
+        return Fail("null argument");
+    if (mode < -1 || mode > 2)
+        return Fail("mcpt_renderer_set_kernel: mode is -1 (by scene class), 0 (lane-owns-a-path), 1 (stream) or 2 (stream, slots in memory)");
+    if (slots % 256u != 0 || slots > 4096u || refill_at > 64u)
+        return Fail("mcpt_renderer_set_kernel: slots is a multiple of 256 up to 4096, refill_at at most 64");
+    r->kernel_mode = mode, r->stream_slots = slots, r->stream_refill = refill_at;
+    return 0;
+}
+
+const char *mcpt_renderer_last_kernel(const mcpt_renderer *r) { return r ? r->variant.c_str() : ""; }
 
 int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint32_t leave_at)
 {

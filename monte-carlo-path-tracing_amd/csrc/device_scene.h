@@ -274,6 +274,7 @@ struct TraceCounters
 {
     unsigned long long closest_rays, shadow_rays, node_tests, prim_tests,
         shaded_hits, samples, wave_node_steps, wave_prim_steps;
+    unsigned long long ticks_shade, ticks_trace, ticks_wait, rounds; // stream kernel: where its wavefronts spend their time
 };
 
 } // namespace mcpt

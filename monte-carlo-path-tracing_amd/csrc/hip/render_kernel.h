@@ -28,6 +28,32 @@ struct RenderJob
     uint32_t reference_walk; // 1: force the reference-order walk (validation); masks force it anyway
 };
 
+// ---- stream kernel (stream_core.h, stream_kernel_impl.h) ------------------------------------------
+// Launch parameters of the stream kernel.  `slots` and `refill_at` are inputs of PlanRenderStream (0 = the
+// built-in choice for the scene), the rest is filled in by it.
+struct StreamLaunch
+{
+    uint32_t slots_in_memory; // input: 0 = one slot per lane, path state in registers; 1 = `slots` slots per workgroup in memory
+    uint32_t slots;      // path slots per workgroup (a multiple of 256)
+    uint32_t refill_at;  // a wavefront fetches new rays when this many of its lanes are free
+    uint32_t blocks, blocks_per_cu, lds_bytes;
+    uint32_t scratch_words_per_block; // the workgroup's region of the scratch buffer, in 32-bit words
+    uint32_t variant;    // which instantiation (index into the dispatcher's table)
+};
+
+// Can this job run on the stream kernel?  (No opacity masks — they draw random numbers during a walk, so the
+// visiting order is part of the image —, not the reference-order validation walk, at most kStreamMaxShadow shadow
+// rays per vertex, a non-empty scene.)
+bool StreamSupports(const DeviceScene &sc, const RenderJob &job);
+// Scene class for which the lane-owns-a-path kernel is the faster one: traversal data small enough for LDS.
+bool StreamPrefersLanes(const DeviceScene &sc);
+// Chooses the instantiation and the launch shape; `name` receives a description.  The caller provides a scratch
+// buffer of at least blocks * scratch_words_per_block words and then calls LaunchRenderStream with the same cfg.
+hipError_t PlanRenderStream(const DeviceScene &sc, const RenderJob &job, bool counted, uint32_t n_cus, StreamLaunch *cfg,
+                            const char **name);
+hipError_t LaunchRenderStream(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
+                              hipStream_t stream, uint32_t *scratch, const StreamLaunch &cfg);
+
 hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
                         hipStream_t stream, uint32_t n_cus, const char **variant);
 

@@ -1,0 +1,96 @@
+// Dispatcher of the stream kernel + the instantiations of unit 0 (stream_variants.inc lists them all).
+#define MCPT_STREAM_UNIT 0
+#include "stream_units.h"
+
+namespace mcpt
+{
+
+namespace
+{
+
+struct StreamVariant
+{
+    uint32_t features, shadow;
+    bool counted, small, regs;
+    const char *name;
+    hipError_t (*plan)(const DeviceScene &, const RenderJob &, uint32_t, StreamLaunch &);
+    hipError_t (*launch)(const DeviceScene &, const RenderJob &, float *, TraceCounters *, hipStream_t, uint32_t *,
+                         const StreamLaunch &);
+};
+
+#define X(index, features, S, counted, small, hot, regs, unit, name) \
+    {features, S, counted, small, regs, name, &PlanStream<(features), S, counted, small, hot, regs>, \
+     &LaunchStream<(features), S, counted, small, hot, regs>},
+const StreamVariant kVariants[] = {
+#include "stream_variants.inc"
+};
+#undef X
+constexpr uint32_t kVariantCount = sizeof(kVariants) / sizeof(kVariants[0]);
+
+} // namespace
+
+bool StreamSupports(const DeviceScene &sc, const RenderJob &job)
+{
+    const uint32_t shadows = sc.integrator.n_emitters + (sc.integrator.n_area_lights ? 1u : 0u);
+    return !job.reference_walk && !sc.integrator.has_masks && sc.integrator.n_walk_nodes != 0 && shadows <= kStreamMaxShadow;
+}
+
+bool StreamPrefersLanes(const DeviceScene &sc) { return StagedBytes(sc, true) <= kLdsGeometryBytes; }
+
+hipError_t PlanRenderStream(const DeviceScene &sc, const RenderJob &job, bool counted, uint32_t n_cus, StreamLaunch *cfg,
+                            const char **name)
+{
+    const bool regs = !cfg->slots_in_memory;
+    if (!StreamSupports(sc, job))
+        return hipErrorNotSupported;
+    const uint32_t shadows = sc.integrator.n_emitters + (sc.integrator.n_area_lights ? 1u : 0u);
+    const uint32_t need_s = shadows <= 1 ? 1u : 2u;
+    const bool slivers = sc.integrator.walk_sliver_reach > 0.0f;
+    const uint32_t f = sc.features & (kAll);
+    const bool small = StagedBytes(sc, true) <= kLdsGeometryBytes;
+    // the leanest instantiation that covers the scene: fewest feature bits, then fewest shadow records
+    int pick = -1;
+    for (uint32_t v = 0; v < kVariantCount; ++v)
+    {
+        const StreamVariant &k = kVariants[v];
+        const uint32_t kf = k.features & kAll;
+        if (k.counted != counted || k.small != small || k.regs != regs || (f & ~kf) != 0 || k.shadow < need_s)
+            continue;
+        if (slivers && !(k.features & kFeatSlivers))
+            continue;
+        if (pick < 0)
+        {
+            pick = static_cast<int>(v);
+            continue;
+        }
+        const StreamVariant &b = kVariants[pick];
+        const int cost_k = __builtin_popcount(k.features) * 4 + static_cast<int>(k.shadow);
+        const int cost_b = __builtin_popcount(b.features) * 4 + static_cast<int>(b.shadow);
+        if (cost_k < cost_b)
+            pick = static_cast<int>(v);
+    }
+    if (pick < 0)
+        return hipErrorNotSupported;
+    const StreamVariant &k = kVariants[pick];
+    cfg->variant = static_cast<uint32_t>(pick);
+    *name = k.name;
+    // Launch shape.  Small scenes: 2 slots per lane keep two workgroups on a CU (LDS: traversal data + stacks +
+    // hot fields), which measured best; meshes: 2 slots per lane, everything but the stacks and the ray list in
+    // cached global memory.  A wavefront refills when a quarter of its lanes are free.
+    if (cfg->slots == 0)
+        cfg->slots = 2 * kBlockSize;
+    cfg->slots = ((cfg->slots + kBlockSize - 1) / kBlockSize) * kBlockSize;
+    if (cfg->refill_at == 0)
+        cfg->refill_at = 16;
+    return k.plan(sc, job, n_cus, *cfg);
+}
+
+hipError_t LaunchRenderStream(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
+                              hipStream_t stream, uint32_t *scratch, const StreamLaunch &cfg)
+{
+    if (cfg.variant >= kVariantCount)
+        return hipErrorInvalidValue;
+    return kVariants[cfg.variant].launch(sc, job, out, counters, stream, scratch, cfg);
+}
+
+} // namespace mcpt

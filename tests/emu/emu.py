@@ -44,6 +44,20 @@ class Emulator:
                             (int(c) for c in counters)))
         return frame, info
 
+    def render_stream(self, mcsd_path, width, height, slots_per_block=0, counted=False):
+        """The stream formulation (csrc/stream_core.h) on the host."""
+        self.lib.mcpt_emu_render_stream.restype = ctypes.c_int
+        self.lib.mcpt_emu_render_stream.argtypes = [ctypes.c_char_p, _f32p, ctypes.c_uint32, ctypes.c_void_p]
+        frame = np.zeros((height, width, 3), dtype=np.float32)
+        counters = np.zeros(6, dtype=np.uint32)
+        rc = self.lib.mcpt_emu_render_stream(str(mcsd_path).encode(), frame, slots_per_block,
+                                             counters.ctypes.data if counted else None)
+        if rc != 0:
+            raise RuntimeError(self.lib.mcpt_emu_last_error().decode())
+        info = dict(zip(("closest_rays", "shadow_rays", "node_tests", "prim_tests", "shaded_hits", "samples"),
+                        (int(c) for c in counters))) if counted else {}
+        return frame, info
+
     ORDERED = 32      # feature bit of the ordered walk in a forced `variant`
     REFERENCE = -2    # `variant`: the launcher's pick, but with the reference-order walk
 

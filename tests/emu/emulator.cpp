@@ -18,6 +18,7 @@
 
 #include "host/commit.hpp"
 #include "path_core.h"
+#include "stream_core.h"
 
 namespace
 {
@@ -67,10 +68,140 @@ void RenderAll(const DeviceScene &sc, float *frame, LaneCounters *total)
         }
 }
 
+// The stream formulation (stream_core.h) on the host: "workgroups" of P slots run their rounds
+// (shade every slot, list the emitted rays, trace the list) one after the other.  Same functions as the
+// HIP stream kernel; only the lane loop and the ray-list bookkeeping are restated here.
+template <uint32_t kFeatures, uint32_t S>
+void RenderAllStream(const DeviceScene &sc, float *frame, LaneCounters *total, uint32_t P)
+{
+    using C = Config<kFeatures>;
+    const uint32_t n = static_cast<uint32_t>(sc.camera.width) * sc.camera.height;
+    const uint32_t n_blocks = (n + P - 1) / P;
+    const unsigned workers = std::max(1u, std::thread::hardware_concurrency());
+    std::atomic<uint32_t> next_block{0};
+    std::mutex mu;
+    auto work = [&]()
+    {
+        std::vector<uint32_t> hot(stream_hot_words(S) * P), cold(stream_cold_words(S) * P), ids((1 + S) * P);
+        std::vector<uint32_t> stack(kWalkStackMax * kWalkStackStride);
+        LaneCounters cnt{};
+        for (;;)
+        {
+            const uint32_t b = next_block.fetch_add(1);
+            if (b >= n_blocks)
+                break;
+            const StreamStore m{hot.data(), cold.data(), P};
+            std::fill(cold.begin(), cold.end(), 0u);
+            // slots: one pixel each (the frame is cut into n_blocks runs of P pixels)
+            for (uint32_t i = 0; i < P; ++i)
+            {
+                StreamSlot<S> s{};
+                const uint32_t pixel = b * P + i;
+                s.flags = pixel < n ? 0u : kSlotExhausted;
+                s.item = pixel;
+                if (pixel < n)
+                    start_pixel(s.st, pixel);
+                stream_save<C, S>(m, i, s);
+            }
+            for (;;)
+            {
+                uint32_t n_ext = 0, n_shadow = 0;
+                for (uint32_t i = 0; i < P; ++i)
+                {
+                    StreamSlot<S> s;
+                    stream_load<C, S>(m, i, s);
+                    while (stream_shade<C, S>(sc, s, &cnt) == kStreamPixelDone)
+                    {
+                        const V3 v = pixel_value(sc, s.st);
+                        frame[3 * s.st.pixel] = v.x, frame[3 * s.st.pixel + 1] = v.y, frame[3 * s.st.pixel + 2] = v.z;
+                        s.flags |= kSlotExhausted;
+                    }
+                    stream_save<C, S>(m, i, s);
+                    if (s.flags & kSlotExtRay)
+                        ids[n_ext++] = i;
+                    for (uint32_t k = 0; k < S; ++k)
+                        if (s.flags & (kSlotShadow0 << k))
+                            ids[P + n_shadow++] = (1 + k) * P + i;
+                }
+                if (n_ext + n_shadow == 0)
+                    break;
+                uint32_t cursor = 0;
+                const StreamRayList list{ids.data(), n_ext, n_shadow, &cursor};
+                stream_trace<C, true>(sc, m, list, stack.data(), 1, &cnt);
+            }
+        }
+        if (total)
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            total->closest_rays += cnt.closest_rays, total->shadow_rays += cnt.shadow_rays;
+            total->node_tests += cnt.node_tests, total->prim_tests += cnt.prim_tests;
+            total->shaded_hits += cnt.shaded_hits, total->samples += cnt.samples;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < workers; ++t)
+        pool.emplace_back(work);
+    work();
+    for (std::thread &t : pool)
+        t.join();
+}
+
 } // namespace
 
 extern "C"
 {
+
+// The stream formulation on the host (see RenderAllStream).  The scene must be one the stream kernel
+// accepts: no opacity masks, at most kStreamMaxShadow shadow rays per vertex.
+int mcpt_emu_render_stream(const char *mcsd_path, float *frame, uint32_t slots_per_block, uint32_t *counters)
+{
+    try
+    {
+        const FlatScene flat = CommitScene(mcsd::Load(mcsd_path));
+        const DeviceScene sc = flat.HostView();
+        const uint32_t n_shadow = flat.integrator.n_emitters + (flat.integrator.n_area_lights ? 1u : 0u);
+        if (flat.integrator.has_masks || n_shadow > kStreamMaxShadow || flat.integrator.n_walk_nodes == 0)
+            throw std::runtime_error("not a scene for the stream kernel (opacity masks, too many lights, or empty)");
+        LaneCounters total{};
+        constexpr uint32_t kAllF = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
+        constexpr uint32_t kSurfaceF = kFeatEmitters | kFeatTextures | kFeatMicrofacet;
+        constexpr uint32_t kO = kFeatOrderedWalk;
+        const uint32_t f = flat.features;
+        const bool slivers = flat.integrator.walk_sliver_reach > 0.0f;
+        const uint32_t P = slots_per_block ? slots_per_block : 512;
+        LaneCounters *cnt = &total;
+        if (slivers)
+        {
+            if ((f & ~kSurfaceF) == 0)
+                n_shadow <= 1 ? RenderAllStream<kSurfaceF | kO | kFeatSlivers, 1>(sc, frame, cnt, P)
+                              : RenderAllStream<kSurfaceF | kO | kFeatSlivers, 2>(sc, frame, cnt, P);
+            else
+                n_shadow <= 1 ? RenderAllStream<kAllF | kO | kFeatSlivers, 1>(sc, frame, cnt, P)
+                              : RenderAllStream<kAllF | kO | kFeatSlivers, 2>(sc, frame, cnt, P);
+        }
+        else if (f == 0)
+            RenderAllStream<kO, 1>(sc, frame, cnt, P);
+        else if ((f & ~kFeatEmitters) == 0)
+            n_shadow <= 1 ? RenderAllStream<kFeatEmitters | kO, 1>(sc, frame, cnt, P)
+                          : RenderAllStream<kFeatEmitters | kO, 2>(sc, frame, cnt, P);
+        else if ((f & ~kSurfaceF) == 0)
+            n_shadow <= 1 ? RenderAllStream<kSurfaceF | kO, 1>(sc, frame, cnt, P)
+                          : RenderAllStream<kSurfaceF | kO, 2>(sc, frame, cnt, P);
+        else
+            n_shadow <= 1 ? RenderAllStream<kAllF | kO, 1>(sc, frame, cnt, P) : RenderAllStream<kAllF | kO, 2>(sc, frame, cnt, P);
+        if (counters)
+        {
+            counters[0] = total.closest_rays, counters[1] = total.shadow_rays, counters[2] = total.node_tests;
+            counters[3] = total.prim_tests, counters[4] = total.shaded_hits, counters[5] = total.samples;
+        }
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return 1;
+    }
+}
 
 const char *mcpt_emu_last_error(void) { return g_error.c_str(); }
 

@@ -109,7 +109,19 @@ def test_baseline_config_full_size_properties(pkg, name):
         assert hashlib.sha256(composed.tobytes()).hexdigest() == digest
     finally:
         r.close()
-    again, _ = _draw(pkg, pkg.workloads.config(name))
+    # a second renderer object, with the OTHER kernel formulation: same frame
+    r2 = pkg.capi.Renderer(pkg.workloads.config(name), device=0)
+    try:
+        r2.set_kernel(0)
+        again, _ = r2.draw()
+        lanes_kernel = r2.last_kernel()
+        r2.set_kernel(1)
+        streamed, st2 = r2.draw()
+        stream_kernel = r2.last_kernel()
+    finally:
+        r2.close()
     assert hashlib.sha256(again.tobytes()).hexdigest() == digest
+    assert hashlib.sha256(streamed.tobytes()).hexdigest() == digest
+    print(name, "kernels:", lanes_kernel, "|", stream_kernel, "stream kernel ms", st2["kernel_milliseconds"])
     print(name, "full size", (w, h, spp), "kernel ms", stats["kernel_milliseconds"],
           "Msamples/s", w * h * spp / stats["kernel_milliseconds"] / 1e3)

@@ -73,6 +73,26 @@ def test_golden_frames(name, pkg, scenes):
     assert_parity(frame, want, name, spp=scenes[name].camera.spp, has_medium=bool(scenes[name].media))
 
 
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_stream_kernel_equals_lane_kernel(name, pkg, scenes):
+    """The two kernel formulations (mcpt_renderer_set_kernel) give the same frame bit for bit, and — the golden
+    test above runs the default — the reference's.  Scenes the stream kernel does not cover fall back."""
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
+    try:
+        r.set_kernel(0)
+        lanes, _ = r.draw()
+        assert not r.last_kernel().startswith("stream")
+        r.set_kernel(1)
+        stream, _ = r.draw()
+        covered = r.last_kernel().startswith("stream")
+        r.set_kernel(2, 512)
+        memory, _ = r.draw()
+    finally:
+        r.close()
+    print(name, "stream kernel used" if covered else "not covered by the stream kernel")
+    assert np.array_equal(lanes, stream) and np.array_equal(lanes, memory)
+
+
 def test_against_oracle_larger(pkg, oracle, mcsd_file):
     """Sizes beyond the committed fixtures, oracle computed on the fly."""
     for scene in (pkg.scenes.cornell_box(160, 160, 32),

@@ -292,6 +292,22 @@ def test_kernel_body_emulated_matches_golden(name, walk, pkg, emulator, mcsd_fil
     assert np.array_equal(frame, golden), f"max diff {np.abs(frame - golden).max():.3e}"
 
 
+@pytest.mark.parametrize("slots", [64, 192])
+@pytest.mark.parametrize("name", sorted(MANIFEST["frames"]))
+def test_stream_formulation_emulated_matches_golden(name, slots, pkg, emulator, mcsd_file):
+    """csrc/stream_core.h on the host — workgroups of `slots` path slots, rounds of shade (deferred shadow
+    answers, ray emission) and trace (the lane loop with retire / fetch) — reproduces the compiled reference's
+    frames bit for bit: the pooled formulation consumes each pixel's random stream in the reference's order."""
+    scene = cases(pkg.scenes)[name]
+    golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
+    try:
+        frame, _ = emulator.render_stream(mcsd_file(scene), scene.camera.width, scene.camera.height, slots)
+    except RuntimeError as e:
+        assert "not a scene for the stream kernel" in str(e)
+        pytest.skip(str(e))
+    assert np.array_equal(frame, golden), f"max diff {np.abs(frame - golden).max():.3e}"
+
+
 @pytest.mark.parametrize("strategy", [1, 2, 3])
 @pytest.mark.parametrize("name", ["cornell_64_spp8", "thin_dielectric_sun", "conductor_aniso_mixed",
                                   "volumetric_iso_64x36_spp8"])

@@ -6,7 +6,7 @@ counter group (the groups cannot share a pass), and writes one JSON summary.
 
 Runs `python bench.py --spp N --steps 1 --warmup 0 --no-cpu-baseline` under
 `rocprofv3 --kernel-trace --pmc <group>` and sums each counter over the dispatches
-whose kernel name contains "render_kernel".  Only --kernel-trace is combined with
+whose kernel name contains "render_kernel" / "stream_kernel" (not the counting instantiations).  Only --kernel-trace is combined with
 --pmc (see the MI355X guide's profiling section)."""
 import argparse
 import csv
@@ -56,7 +56,9 @@ def main():
         for row in csv.DictReader(open(files[0])):
             # the plain render kernel only: bench.py also launches the counting
             # instantiation (second template argument true) for its bookkeeping
-            if "render_kernel" not in row["Kernel_Name"] or ", true, " in row["Kernel_Name"]:
+            name = row["Kernel_Name"]
+            if ("render_kernel" not in name and "stream_kernel" not in name) or \
+                    (", true, " in name and "render_kernel" in name) or ("u, true, " in name and "stream_kernel" in name):
                 continue
             kernels.add(row["Kernel_Name"][:120])
             counters[row["Counter_Name"]] = counters.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])

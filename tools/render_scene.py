@@ -2,7 +2,7 @@
 """Renders one scene a few times on cuda:0 and prints throughput and the walk
 counters — the command tools/pmc_profile.py wraps for scenes other than the bench's.
 
-    python tools/render_scene.py builtin:cornell-box | standin:blob-field | standin:terrain | file.mcsd | scene.xml
+    python tools/render_scene.py builtin:cornell-box | workload:<cornell|dragon|matpreview-rc|matpreview-rd|volumetric> | standin:blob-field | standin:terrain | file.mcsd | scene.xml
                                  [--film W H SPP] [--draws N] [--counted]
 """
 import argparse
@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--film", type=int, nargs=3, default=None, metavar=("W", "H", "SPP"))
     ap.add_argument("--draws", type=int, default=2)
     ap.add_argument("--counted", action="store_true", help="also run the counting instantiation once")
+    ap.add_argument("--kernel", choices=["stream", "lanes"], default="stream",
+                    help="stream kernel (default) or the lane-owns-a-path kernel")
     a = ap.parse_args()
     from _pkg import load_package
     pkg = load_package()
@@ -30,6 +32,8 @@ def main():
         cfg = capi.Config.from_scene(pkg.scenes.blob_field_scene())
     elif a.scene == "standin:terrain":
         cfg = capi.Config.from_scene(pkg.scenes.terrain_scene(640, 1280, 720, 256))
+    elif a.scene.startswith("workload:"):
+        cfg = pkg.workloads.config(a.scene[9:])
     elif a.scene.endswith(".xml"):
         cfg = capi.Config.load_xml(a.scene)
     else:
@@ -38,9 +42,11 @@ def main():
         cfg.set_film(*a.film)
     w, h, spp = cfg.film()
     r = capi.Renderer(cfg)
+    r.set_kernel(a.kernel == "stream")
     out = {"scene": a.scene, "film": [w, h, spp], "info": r.info()}
     for _ in range(a.draws):
         _, st = r.draw()
+    out["kernel"] = r.last_kernel()
     out["kernel_ms"] = st["kernel_milliseconds"]
     out["msamples_per_s"] = w * h * spp / st["kernel_milliseconds"] / 1e3
     if a.counted:
