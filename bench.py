@@ -1,26 +1,35 @@
 #!/usr/bin/env python
 """Benchmark of the render hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--workload cornell|dragon|matpreview-rc|matpreview-rd|volumetric]
+                    [--gpus N] [--steps K] [--warmup W] [--weak]
 
-A "step" is one complete render of the workload frame (all pixels, all spp)
-with the scene already resident in HBM.  At N=1 the workload is BASELINE.json
-configs[1]: cornell-box 512x512 spp=256 (diffuse + MIS area light).  For N>1
-(launched by torch.distributed.run, one rank per GPU) the frame's 8x8 tiles are
-dealt round-robin to the ranks, every rank renders its tiles into a packed
-device buffer and ONE RCCL gather brings them to rank 0, which scatters them
-into the frame — all inside the timed region.  Total work is fixed as N grows
-("strong" scaling).
+A "step" is one complete render of the workload's frame (all pixels, all spp) with the scene already
+resident in HBM and the frame left in HBM.  The workloads are the configurations BASELINE.json names, at
+their stated film sizes (monte-carlo-path-tracing_amd/workloads.py); the default is configs[1], cornell-box
+512x512 spp 256.  For N > 1 (launched by torch.distributed.run, one rank per GPU) the frame's 8x8 tiles are
+dealt round-robin to the ranks, every rank renders its tiles into a packed device buffer and ONE RCCL gather
+brings them to rank 0, which scatters them into the frame — all inside the timed region.  The film is the
+workload's own for every N: the total work is fixed ("strong" scaling).  `--weak` (cornell only) grows the
+film side with sqrt(N) instead, so that every GPU renders 512x512 pixels' worth of tiles.
 
-Rank 0 prints one JSON line: metric Msamples/s (W*H*spp / t / 1e6, whole job),
-plus `roofline` (algorithmic bytes of the dominant kernel / its HIP-event
-duration against the 8 TB/s HBM peak) and, at N=1, `cpu_baseline` (the compiled
-reference, or the oracle port, timed on this host's cores on a bounded spp) and
-`parity` (GPU vs that CPU image at the same spp).
+Rank 0 prints one JSON line: metric Msamples/s (W*H*spp / t / 1e6, whole job) plus
+  roofline      the render kernel against the roof that binds it.  Counts per sample come from the kernel's
+                counting instantiation (run outside the timed region), the kernel time from HIP events on the
+                launch stream, hardware counters from rocprofv3 --pmc passes that bench.py runs on the same
+                workload right after the timed region (one pass per counter group, --kernel-trace only), the
+                HBM stream bandwidth from a device copy / reduction timed in this process.
+  cpu_baseline  at N = 1: the compiled reference (oracle/_ref, "reference") and the oracle port ("port") timed
+                on this host's cores on a bounded sample of the same workload, and `parity`: the GPU frame
+                against that CPU frame at the same film / spp.
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
 import tempfile
 import time
@@ -30,59 +39,134 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+HBM_SPEC_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E, 8 TB/s
+VALU_LANES_PER_SIMD = 16  # a 64-lane fp32 VALU instruction occupies its SIMD for 4 cycles
+N_XCD = 8
+
+PMC_GROUPS = [
+    ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+     "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"],
+    ["FETCH_SIZE"],
+    ["WRITE_SIZE"],
+]
 
 
 def algorithmic_bytes_per_sample(counts, spp):
-    """32 B per node (box) test — the ordered walk reads one
-    64-byte record per visit and tests its two boxes —, 36 B per primitive test,
-    132 B of attributes per shaded hit, 12 B/spp for the pixel store; the
-    streaming kernel keeps path state in registers, so the wavefront-state term
-    is 0."""
+    """32 B per box test (the ordered walk reads one 64-byte record per node visit and
+    tests its two boxes), 36 B per primitive test, 132 B of attributes per shaded hit, 12 B/spp for the
+    pixel store.  Path state stays in registers / LDS (and, for the stream kernel's shadow rays on meshes,
+    in a cache-resident scratch region), so the wavefront-state term is 0."""
     s = float(counts["samples"])
     return (counts["node_tests"] * 32.0 + counts["prim_tests"] * 36.0 +
             counts["shaded_hits"] * 132.0) / s + 12.0 / spp
 
 
-def measured_traffic_bytes():
-    """HBM bytes per launch of the render kernel, from the committed counter
-    summary (tools/pmc_profile.py run on the GPU box; bench.py cannot run the
-    profiler on itself).  None when no summary is present."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_cornell.json")
-    try:
-        c = json.load(open(path))["counters"]
-        return (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-    except (OSError, KeyError, ValueError):
+def stream_bandwidth(torch, device):
+    """HBM stream rates of this GPU, measured here: a 1 GiB device copy (read + write) and a 2 GiB
+    reduction (read only).  GB/s."""
+    n = 1 << 28  # floats = 1 GiB
+    a = torch.empty(n, dtype=torch.float32, device=device).fill_(1.0)
+    b = torch.empty_like(a)
+    out = {}
+
+    def timed(fn, nbytes, reps=8):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    out["copy_gbs"] = timed(lambda: b.copy_(a), 8.0 * n)
+    big = torch.cat([a, b])
+    out["read_gbs"] = timed(lambda: big.sum(), 4.0 * big.numel())
+    del a, b, big
+    torch.cuda.empty_cache()
+    return out
+
+
+def pmc_leg(workload, film, kernel_hint, timeout_s=300):
+    """Hardware counters of the render kernel for one full-size launch of the workload: rocprofv3 runs
+    tools/render_scene.py (one draw) once per counter group.  Returns None when rocprofv3 is not there."""
+    if shutil.which("rocprofv3") is None:
         return None
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    counters, kernels, failed, duration_ns = {}, set(), [], []
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for gi, group in enumerate(PMC_GROUPS):
+            d = os.path.join(tmp, f"pass{gi}")
+            target = [sys.executable, os.path.join(ROOT, "tools", "render_scene.py"), f"workload:{workload}",
+                      "--film", *map(str, film), "--draws", "1"]
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", *group, "--output-format", "csv", "-d", d, "-o", "p",
+                   "--", *target]
+            try:
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp")
+            except subprocess.TimeoutExpired:
+                failed.append({"group": group, "error": "timeout"})
+                continue
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                failed.append({"group": group, "rc": r.returncode, "stderr": r.stderr[-300:]})
+                continue
+            for row in csv.DictReader(open(files[0])):
+                name = row["Kernel_Name"]
+                if "render_kernel" not in name and "stream_kernel" not in name:
+                    continue
+                kernels.add(name.split("(")[0][-90:])
+                counters[row["Counter_Name"]] = counters.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "render_kernel" in row["Kernel_Name"] or "stream_kernel" in row["Kernel_Name"]:
+                        if gi == 0:
+                            duration_ns.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    return {"counters": counters, "kernels": sorted(kernels), "failed": failed,
+            "kernel_ns": float(np.mean(duration_ns)) if duration_ns else None}
 
 
-def cpu_baseline(pkg, width, height, budget_s=20.0):
-    """Times the CPU checker on a bounded sample of the same workload and
-    returns (record, scene_used, cpu_frame)."""
+def cpu_baseline(pkg, workload, W, H, SPP, budget_s=12.0):
+    """Times both CPU checkers on a bounded sample of the workload (its own film when the budget buys at
+    least 2 spp there, otherwise a quarter-size film) and returns (records, mcsd path dir, frame, film)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import checkers
-    use_ref = checkers.reference_available()
     cores = os.cpu_count() or 1
-    with tempfile.TemporaryDirectory() as tmp:
-        def run(spp):
-            scene = pkg.scenes.cornell_box(width, height, spp)
-            path = os.path.join(tmp, f"c{spp}.mcsd")
-            pkg.mcsd.dump(scene, path)
-            if use_ref:
-                frame, info = checkers.Reference().render(path, width, height)
-            else:
-                frame, info = checkers.Oracle().render(path)
-            return scene, frame, info["seconds"]
-        _, _, t_probe = run(1)
-        rate = width * height / max(t_probe, 1e-6)          # samples/s
-        spp = int(max(1, min(256, budget_s * rate / (width * height))))
-        scene, frame, seconds = run(spp)
-    samples = width * height * spp
-    rec = {"value": samples / seconds / 1e6, "unit": "Msamples/s", "cores": cores,
-           "kind": "reference" if use_ref else "port",
-           "sample": f"cornell-box {width}x{height} spp={spp} ({samples / 1e6:.1f} Msamples, "
-                     f"{seconds:.1f} s, all host threads)"}
-    return rec, scene, frame
+    tmp = tempfile.mkdtemp(dir="/tmp")
+    oracle = checkers.Oracle()
+
+    def scene_file(w, h, spp):
+        path = os.path.join(tmp, f"s_{w}x{h}_{spp}.mcsd")
+        pkg.workloads.config(workload, w, h, spp).save_mcsd(path)
+        return path
+
+    pw, ph = max(W // 4 // 8 * 8, 8), max(H // 4 // 8 * 8, 8)
+    _, info = oracle.render(scene_file(pw, ph, 2))
+    rate = pw * ph * 2 / max(info["seconds"], 1e-6)
+    w, h = (W, H) if budget_s * rate / (W * H) >= 2.0 else (pw, ph)
+    spp = int(max(1, min(SPP, budget_s * rate / (w * h))))
+    path = scene_file(w, h, spp)
+    recs = {}
+    frame, info = oracle.render(path)
+    samples = w * h * spp
+    sample = f"{pkg.workloads.DESCRIPTION[workload].split(' (')[0].rsplit(' ', 2)[0]} at {w}x{h} spp={spp} " \
+             f"({samples / 1e6:.1f} Msamples, all host threads)"
+    recs["port"] = {"value": samples / info["seconds"] / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+                    "seconds": info["seconds"], "sample": sample}
+    if checkers.reference_available():
+        # the compiled reference prints its progress under a mutex (renderer.cpp:700-715), which limits
+        # how far it scales over host threads: it gets a third of the port's sample count
+        rspp = max(1, spp // 3)
+        rpath = scene_file(w, h, rspp)
+        rframe, rinfo = checkers.Reference().render(rpath, w, h)
+        recs["reference"] = {"value": w * h * rspp / rinfo["seconds"] / 1e6, "unit": "Msamples/s", "cores": cores,
+                             "kind": "reference", "seconds": rinfo["seconds"],
+                             "sample": sample.replace(f"spp={spp} ", f"spp={rspp} ").replace(
+                                 f"({samples / 1e6:.1f}", f"({w * h * rspp / 1e6:.1f}")}
+        if rspp == spp:
+            recs["reference"]["equals_port_frame"] = bool(np.array_equal(rframe, frame))
+    return recs, frame, (w, h, spp)
 
 
 def main():
@@ -90,12 +174,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=0, help="film width (default: 512, scaled with the GPU count)")
+    ap.add_argument("--workload", default="cornell",
+                    choices=["cornell", "dragon", "matpreview-rc", "matpreview-rd", "volumetric"])
+    ap.add_argument("--width", type=int, default=0, help="film width (default: the workload's)")
     ap.add_argument("--height", type=int, default=0)
-    ap.add_argument("--strong", action="store_true",
-                    help="N > 1: keep the 512x512 film (strong scaling) instead of growing it with N")
-    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1, cornell: grow the film side with sqrt(N) (per-GPU work fixed) instead of "
+                         "cutting the workload's own film over the GPUs")
+    ap.add_argument("--kernel", choices=["auto", "stream", "lanes"], default="auto",
+                    help="kernel formulation (default: the library's choice by scene class)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes")
     ap.add_argument("--force-gather", action="store_true",
                     help="take the multi-GPU code path (RCCL process group, packed tiles, gather, scatter) "
                          "even with one rank: lets a 1-GPU box exercise it")
@@ -109,9 +199,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_gather = world > 1 or args.force_gather
@@ -120,24 +209,27 @@ def main():
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29511", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
 
-    # Film.  One GPU holds 262 144 pixel lanes (one pixel per lane, 4 wavefronts per SIMD) and a pixel's
-    # samples are inherently sequential (one RNG stream per pixel, data-dependent draw counts), so a
-    # 512x512 film cut over N GPUs leaves (N-1)/N of every GPU idle: measured bound on one MI355X for
-    # a 1280x720 film 1.63x / 2.84x / 3.95x at N = 2 / 4 / 8.  The multi-GPU
-    # line therefore keeps the per-GPU work fixed — the film side grows with sqrt(N) (same scene, same
-    # camera, same cost per sample): weak scaling.  --strong keeps 512x512.
-    weak = world > 1 and not args.strong and not args.width and not args.height
-    side = 512
+    name = args.workload
+    W, H, SPP = pkg.workloads.WORKLOADS[name][1]
+    weak = args.weak and world > 1
     if weak:
-        # the largest square film (side a multiple of the 8-pixel tile) whose per-rank share still
-        # fits the 262 144 lanes of one GPU in ONE round: a few pixels more would start a second
-        # round that costs a whole extra pixel chain (N = 2: 720, N = 4: 1024, N = 8: 1448)
+        if name != "cornell" or args.width or args.height:
+            raise SystemExit("--weak is defined for the cornell workload's square film only")
+        # the largest square film (side a multiple of the 8-pixel tile) whose per-rank share still fits the
+        # 262 144 lanes of one GPU in one round (N = 2: 720, N = 4: 1024, N = 8: 1448)
         side = int(512.0 * (world ** 0.5) / 8.0) * 8
         while -(-((side // 8) ** 2) // world) * 64 > 512 * 512:
             side -= 8
-    W, H, SPP = args.width or side, args.height or side, args.spp
-    cfg = pkg.capi.Config.builtin("cornell-box").set_film(W, H, SPP)
-    renderer = pkg.capi.Renderer(cfg, device=local_rank)
+        W = H = side
+    W, H, SPP = args.width or W, args.height or H, args.spp or SPP
+    kernel_mode = {"auto": -1, "stream": 1, "lanes": 0}[args.kernel]
+
+    def make_renderer(spp):
+        r = pkg.capi.Renderer(pkg.workloads.config(name, W, H, spp), device=local_rank)
+        r.set_kernel(kernel_mode)
+        return r
+
+    renderer = make_renderer(SPP)
     rng = pkg.capi.TileRange(rank, world, 0)
     assert renderer.tiles_in(rng) == len(pkg.tiling.rank_tiles(rank, world, W, H))
     stream = torch.cuda.current_stream().cuda_stream
@@ -175,6 +267,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # same stream as the launches
+    kernel_name = renderer.last_kernel()
 
     if rank == 0:
         samples = W * H * SPP
@@ -183,22 +276,21 @@ def main():
             "metric": "Msamples/sec (W*H*spp/s)", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            # the default series over N keeps the per-GPU work fixed (see above): every line of it,
-            # N = 1 included, is labelled "weak"; --strong or an explicit film fix the total work
-            "scaling": "strong" if (args.strong or args.width or args.height) else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cornell-box {W}x{H} spp={SPP} (builtin scene = "
-                                   "resources/scene/cornell-box/scene_v0.6.xml, path integrator, "
-                                   "diffuse + MIS area light)",
+            "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name}: {pkg.workloads.DESCRIPTION[name]}"
+                                   + ("" if (W, H, SPP) == pkg.workloads.WORKLOADS[name][1] else f" — film overridden: {W}x{H} spp={SPP}"),
+                       "baseline_config_index": pkg.workloads.WORKLOADS[name][2],
                        "rng": "reference stream (Tea + LCG per pixel)",
+                       "kernel": kernel_name,
                        "partition": f"8x8 tiles round-robin over {world} GPU(s)"
                                     + (", one RCCL gather to rank 0" if world > 1 else ""),
                        "film": (f"{W}x{H}: side scaled with sqrt(N) so that every GPU renders 512x512 pixels' worth "
                                 "of tiles (weak scaling)") if weak else f"{W}x{H}"},
         }
-        # ---- roofline of the render kernel (counting mode, outside the timed region).  N > 1: rank 0's
+        # ---- roofline of the render kernel (everything below is outside the timed region).  N > 1: rank 0's
         # GPU and its share of the tiles, kernel time from one more (blocking) draw of that share.
         count_spp = min(SPP, 16)
-        rc = pkg.capi.Renderer(pkg.capi.Config.builtin("cornell-box").set_film(W, H, count_spp), device=local_rank)
+        rc = make_renderer(count_spp)
         _, counts = rc.draw(counted=True)
         scene_info = rc.info()
         rc.close()
@@ -207,35 +299,91 @@ def main():
             kernel_ms = st["kernel_milliseconds"]
         rank_samples = samples if world == 1 else len(pkg.tiling.rank_tiles(0, world, W, H)) * 64 * SPP
         b_per_sample = algorithmic_bytes_per_sample(counts, SPP)
-        achieved = b_per_sample * rank_samples / (kernel_ms * 1e-3) / 1e9
-        out["roofline"] = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic_bytes(),
-            "kernel": "mcpt::render_kernel", "kernel_ms": kernel_ms,
-            "bytes_per_sample": b_per_sample,
-            "per_sample": {k: counts[k] / counts["samples"] for k in
-                           ("closest_rays", "shadow_rays", "node_tests", "prim_tests", "shaded_hits")},
-            "note": "%salgorithmic bytes (32 B/box test, 36 B/triangle test, 132 B/shaded hit, "
-                    "12 B/pixel) over the kernel time; the scene (%d two-box nodes, %d triangles) is "
-                    "staged in LDS, so HBM traffic (`traffic`: bytes per launch from the rocprofv3 "
-                    "PMC passes in profiles/, FETCH_SIZE doubled per the gfx950 note + WRITE_SIZE) is "
-                    "far below this figure and the kernel is VALU-issue bound, not HBM bound"
-                    % ("per GPU (rank 0's share of the tiles): " if world > 1 else "",
-                       scene_info["walk_nodes"], scene_info["primitives"]),
-        }
-        if world == 1:
-            if not args.no_cpu_baseline:
-                rec, scene, cpu_frame = cpu_baseline(pkg, W, H)
-                out["cpu_baseline"] = rec
-                rg = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=local_rank)
-                gpu_frame, _ = rg.draw()
-                rg.close()
-                d = gpu_frame.astype(np.float64) - cpu_frame.astype(np.float64)
-                l2 = np.sqrt((d ** 2).sum(axis=2))
-                out["parity"] = {"vs": rec["kind"], "spp": scene.camera.spp,
-                                 "rmse": float(np.sqrt((d ** 2).mean())), "mean_l2": float(l2.mean()),
-                                 "max_l2": float(l2.max()), "frac_gt_1e-3": float((l2 > 1e-3).mean()),
-                                 "frac_exact": float((l2 == 0).mean())}
+        algorithmic_bytes = b_per_sample * rank_samples
+        algorithmic_gbs = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
+        props = torch.cuda.get_device_properties(device)
+        n_simd = props.multi_processor_count * 4
+        clock_ghz = getattr(props, "clock_rate", 2.4e6) / 1e6   # (fallback only: cycles come from GRBM_GUI_ACTIVE)
+        bw = stream_bandwidth(torch, device)
+        hbm_peak = max(bw["copy_gbs"], bw["read_gbs"])
+        rays = counts["closest_rays"] + counts["shadow_rays"]
+        per_sample = {k: counts[k] / counts["samples"] for k in
+                      ("closest_rays", "shadow_rays", "node_tests", "prim_tests", "shaded_hits")}
+        walk = {"rays_per_s": rays / counts["samples"] * rank_samples / (kernel_ms * 1e-3),
+                "node_phase_lane_util": (counts["node_tests"] / 2) / (64.0 * max(counts["wave_node_steps"], 1)),
+                "prim_phase_lane_util": counts["prim_tests"] / (64.0 * max(counts["wave_prim_steps"], 1))}
+        hbm = {"algorithmic_gbs": algorithmic_gbs, "bytes_per_sample": b_per_sample,
+               "stream_peak_gbs": hbm_peak, "stream_copy_gbs": bw["copy_gbs"], "stream_read_gbs": bw["read_gbs"],
+               "spec_peak_gbs": HBM_SPEC_GBS, "frac_algorithmic_of_stream_peak": algorithmic_gbs / hbm_peak}
+        roof = {"bound": "hbm", "achieved": algorithmic_gbs, "peak": hbm_peak, "unit": "GB/s",
+                "frac": algorithmic_gbs / hbm_peak, "traffic": None,
+                "kernel": kernel_name, "kernel_ms": kernel_ms, "per_sample": per_sample, "walk": walk, "hbm": hbm,
+                "scene": {"walk_nodes": scene_info["walk_nodes"], "primitives": scene_info["primitives"],
+                          "geometry_bytes": scene_info["geometry_bytes"]}}
+        pmc = None if (args.no_pmc or world > 1) else pmc_leg(name, (W, H, SPP), kernel_name)
+        if pmc and pmc["counters"].get("SQ_INSTS_VALU") and pmc["kernel_ns"]:
+            c = pmc["counters"]
+            pmc_ms = pmc["kernel_ns"] * 1e-6
+            cycles = c["GRBM_GUI_ACTIVE"] / N_XCD if c.get("GRBM_GUI_ACTIVE") else pmc_ms * 1e-3 * clock_ghz * 1e9
+            issue = c["SQ_INSTS_VALU"] * 4.0 / (n_simd * cycles)
+            lanes = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+            valu_peak = n_simd * VALU_LANES_PER_SIMD * cycles / (pmc_ms * 1e-3) / 1e12   # T lane-ops/s at the measured clock
+            valu = {"issue_frac": issue, "lane_util": lanes, "useful_frac": issue * lanes,
+                    "valu_insts_per_sample": c["SQ_INSTS_VALU"] / samples,
+                    "wait_any_per_wave_cycle": c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0),
+                    "peak_tlaneops": valu_peak, "achieved_tlaneops": valu_peak * issue * lanes,
+                    "pmc_kernel_ms": pmc_ms, "cycles": cycles}
+            roof["valu"] = valu
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                # rocprofv3 reports KiB; FETCH_SIZE counts 64-byte requests where gfx950 moves 128 (guide's
+                # gfx950 note): doubled
+                traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+                roof["traffic"] = traffic
+                hbm.update(measured_gbs=traffic / (pmc_ms * 1e-3) / 1e9,
+                           measured_frac_of_stream_peak=traffic / (pmc_ms * 1e-3) / 1e9 / hbm_peak,
+                           traffic_over_algorithmic=traffic / algorithmic_bytes,
+                           fetch_bytes=2.0 * c["FETCH_SIZE"] * 1024.0, write_bytes=c["WRITE_SIZE"] * 1024.0)
+            # the roof the kernel is closest to: VALU issue slots or HBM bytes actually moved
+            if issue >= hbm.get("measured_frac_of_stream_peak", 0.0):
+                roof.update(bound="valu", achieved=valu["achieved_tlaneops"], peak=valu_peak, unit="Tlane-op/s",
+                            frac=issue * lanes)
+                roof["note"] = ("VALU-issue bound: %.0f %% of the issue slots of the %d SIMDs are taken, %.0f %% of the "
+                                "lanes of those instructions do work -> frac = useful fp32 lane-operations / peak (no FMA: "
+                                "the arithmetic contract forbids contraction).  HBM moves %s per launch against %s of "
+                                "algorithmic bytes: the walk's data comes from LDS / cache."
+                                % (100 * issue, n_simd, 100 * lanes,
+                                   "%.3g MB" % (roof["traffic"] / 1e6) if roof["traffic"] else "?",
+                                   "%.3g GB" % (algorithmic_bytes / 1e9)))
+            else:
+                roof.update(achieved=hbm["measured_gbs"], frac=hbm["measured_frac_of_stream_peak"])
+                roof["note"] = ("memory bound: achieved = HBM bytes moved per launch (PMC) / kernel time, peak = stream "
+                                "bandwidth measured in this process; VALU issue %.0f %% x lane utilisation %.0f %%"
+                                % (100 * issue, 100 * lanes))
+            roof["pmc"] = {"kernels": pmc["kernels"], "failed": pmc["failed"],
+                           "command": "rocprofv3 --kernel-trace --pmc <group> -- python tools/render_scene.py "
+                                      f"workload:{name} --film {W} {H} {SPP} --draws 1 (one pass per group)"}
+        else:
+            roof["note"] = ("no counter pass (rocprofv3 absent, --no-pmc or N > 1): algorithmic bytes (32 B/box test, "
+                            "36 B/primitive test, 132 B/shaded hit, 12 B/pixel) over the kernel time against the "
+                            "measured stream bandwidth")
+            if pmc:
+                roof["pmc"] = {"failed": pmc["failed"]}
+        out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            recs, cpu_frame, (cw, ch, cspp) = cpu_baseline(pkg, name, W, H, SPP)
+            out["cpu_baseline"] = recs.get("reference", recs["port"])
+            if "reference" in recs:
+                out["cpu_baseline_port"] = recs["port"]
+            rg = pkg.capi.Renderer(pkg.workloads.config(name, cw, ch, cspp), device=local_rank)
+            rg.set_kernel(kernel_mode)
+            gpu_frame, _ = rg.draw()
+            rg.close()
+            d = gpu_frame.astype(np.float64) - cpu_frame.astype(np.float64)
+            l2 = np.sqrt((d ** 2).sum(axis=2))
+            out["parity"] = {"vs": "port", "film": [cw, ch, cspp],
+                             "rmse": float(np.sqrt((d ** 2).mean())), "mean_l2": float(l2.mean()),
+                             "max_l2": float(l2.max()), "frac_gt_1e-3": float((l2 > 1e-3).mean()),
+                             "frac_exact": float((l2 == 0).mean())}
         print(json.dumps(out))
     if rank == 0 and args.force_gather:
         # the gathered frame must be the plain full-frame draw, bit for bit

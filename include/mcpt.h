@@ -60,6 +60,9 @@ int mcpt_config_set_film(mcpt_config *cfg, int width, int height, int spp);
 int mcpt_config_get_film(const mcpt_config *cfg, int *width, int *height, int *spp);
 
 int mcpt_config_save_mcsd(const mcpt_config *cfg, const char *path);
+/* The same bytes into the caller's buffer; buffer == NULL only reports the size.  (How a configuration travels to
+ * libmcpt_host.so, include/mcpt_host.h.) */
+int mcpt_config_serialize(const mcpt_config *cfg, void *buffer, size_t capacity, size_t *size);
 void mcpt_config_destroy(mcpt_config *cfg);
 
 /* ---- renderer (replaces csrt::Renderer) ---------------------------------- */
@@ -169,6 +172,31 @@ int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint
 int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_t refill_at);
 /* Name of the kernel instantiation the last draw launched ("" before the first draw); renderer-owned string. */
 const char *mcpt_renderer_last_kernel(const mcpt_renderer *r);
+
+/* ---- one frame over the GPUs of a node (replaces csrt::Renderer for N devices) ---- */
+
+/* The reference's Draw is one blocking call that returns the whole frame (renderer.cpp:678-721); this is the
+ * same call over `n_devices` HIP devices of one process (`devices` = their ordinals, NULL = 0 .. n-1): the
+ * configuration is committed ONCE and uploaded to every device (one host thread per GPU), rank k of N renders
+ * the 8x8 tiles k, k + N, ... into a packed block in its own HBM, ONE grouped ncclSend / ncclRecv gather brings
+ * the blocks to devices[0] over xGMI (librccl.so.1 is opened at first use; not needed for single-GPU renderers),
+ * devices[0] scatters them into the frame and copies it to the caller's host buffer.  The frame is bit-identical
+ * for every N (pixels are independent: one RNG stream per pixel, renderer.cpp:62-66).
+ * flags: MCPT_TILED_ALWAYS_GATHER takes the RCCL route even with one device (tests on a 1-GPU box). */
+typedef struct mcpt_tiled_renderer mcpt_tiled_renderer;
+#define MCPT_TILED_ALWAYS_GATHER 1u
+int mcpt_tiled_renderer_create(const mcpt_config *cfg, int n_devices, const int *devices, unsigned flags,
+                               mcpt_tiled_renderer **out);
+/* Blocking; `frame` is a HOST buffer of width*height*3 floats.  stats (may be NULL): wall time of the call, the
+ * slowest GPU's kernel time, samples of the whole frame. */
+int mcpt_tiled_renderer_draw(mcpt_tiled_renderer *r, float *frame, mcpt_stats *stats);
+/* mcpt_renderer_set_kernel for every rank. */
+int mcpt_tiled_renderer_set_kernel(mcpt_tiled_renderer *r, int mode, uint32_t slots, uint32_t refill_at);
+void mcpt_tiled_renderer_destroy(mcpt_tiled_renderer *r);
+/* create + draw + destroy. */
+int mcpt_render_tiled(const mcpt_config *cfg, int n_devices, const int *devices, float *frame, mcpt_stats *stats);
+/* HIP devices visible to this process (0 without a GPU; never fails for that reason). */
+int mcpt_device_count(int *n_devices);
 
 /* The reference-topology LBVH (reference src/rtcore/accel/bvh_builder.cpp:74-207) of n
  * boxes (6 floats each: lo.xyz, hi.xyz) with areas, built by the host builder

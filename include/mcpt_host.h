@@ -1,0 +1,31 @@
+/* mcpt_host — the render path's kernel body compiled for the host (libmcpt_host.so, optional).
+ *
+ * Replaces the reference's CPU back end behind `-c / --cpu` (reference apps/main.cpp:130-137,
+ * src/renderer/renderer.cpp:678-721 with BackendType::kCpu): the SAME functions the HIP kernel runs
+ * (csrc/path_core.h and below, csrc/host/commit.cpp), one pixel per task on a host thread pool.  It exists for
+ * BASELINE config 1 ("cornell-box 512x512 spp=16 on the CPU path, plumbing") and for boxes without a GPU; it is
+ * a separate shared object — libmcpt_hip.so itself has no CPU path and never loads this one — and it is not the
+ * test oracle (oracle/ is an independent restatement used only by tests).
+ */
+#ifndef MCPT_HOST_H
+#define MCPT_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Renders the configuration serialised in `mcsd_bytes` (mcpt_config_serialize, include/mcpt.h; or the contents
+ * of a .mcsd file) into `frame` (width*height*3 float32, row 0 = top) on `threads` host threads (<= 0: all).
+ * seconds (may be NULL): wall time of the pixel loop, commit excluded.  Returns 0 or non-zero with a message in
+ * mcpt_host_last_error(). */
+int mcpt_host_render(const void *mcsd_bytes, size_t size, int threads, float *frame, double *seconds);
+const char *mcpt_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MCPT_HOST_H */

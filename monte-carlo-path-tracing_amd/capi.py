@@ -104,6 +104,14 @@ def lib():
     L.mcpt_renderer_destroy.argtypes = [vp]
     L.mcpt_renderer_destroy.restype = None
     L.mcpt_write_image.argtypes = [cp, vp, i32, i32]
+    L.mcpt_config_serialize.argtypes = [vp, vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    L.mcpt_tiled_renderer_create.argtypes = [vp, i32, ctypes.POINTER(i32), ctypes.c_uint, ctypes.POINTER(vp)]
+    L.mcpt_tiled_renderer_draw.argtypes = [vp, vp, ctypes.POINTER(Stats)]
+    L.mcpt_tiled_renderer_set_kernel.argtypes = [vp, i32, u32, u32]
+    L.mcpt_tiled_renderer_destroy.argtypes = [vp]
+    L.mcpt_tiled_renderer_destroy.restype = None
+    L.mcpt_render_tiled.argtypes = [vp, i32, ctypes.POINTER(i32), vp, ctypes.POINTER(Stats)]
+    L.mcpt_device_count.argtypes = [ctypes.POINTER(i32)]
     _lib = L
     return L
 
@@ -124,6 +132,8 @@ EXPORTED_SYMBOLS = [
     "mcpt_renderer_destroy",
     "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_trace_pixel",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
+    "mcpt_config_serialize", "mcpt_tiled_renderer_create", "mcpt_tiled_renderer_draw",
+    "mcpt_tiled_renderer_set_kernel", "mcpt_tiled_renderer_destroy", "mcpt_render_tiled", "mcpt_device_count",
 ]
 
 
@@ -195,6 +205,13 @@ class Config:
 
     def save_mcsd(self, path):
         _check(lib().mcpt_config_save_mcsd(self._h, str(path).encode()))
+
+    def serialize(self) -> bytes:
+        n = ctypes.c_size_t()
+        _check(lib().mcpt_config_serialize(self._h, None, 0, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(n.value)
+        _check(lib().mcpt_config_serialize(self._h, buf, n.value, ctypes.byref(n)))
+        return buf.raw[:n.value]
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -307,6 +324,67 @@ class Renderer:
 
     def __del__(self):
         self.close()
+
+
+def device_count() -> int:
+    n = ctypes.c_int()
+    _check(lib().mcpt_device_count(ctypes.byref(n)))
+    return n.value
+
+
+TILED_ALWAYS_GATHER = 1
+
+
+class TiledRenderer:
+    """One frame over several GPUs of this process (mcpt_tiled_renderer_*): one commit, one renderer per
+    device, one RCCL gather of finished tiles to devices[0]; draw() is blocking and returns the whole frame
+    like csrt::Renderer::Draw."""
+
+    def __init__(self, config: Config, devices=(0,), flags: int = 0):
+        self.width, self.height, self.spp = config.film()
+        devs = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        _check(lib().mcpt_tiled_renderer_create(config._h, len(devices), devs, flags, ctypes.byref(h)))
+        self._h = h
+
+    def draw(self):
+        frame = np.empty((self.height, self.width, 3), dtype=np.float32)
+        st = Stats()
+        _check(lib().mcpt_tiled_renderer_draw(self._h, frame.ctypes.data, ctypes.byref(st)))
+        return frame, st.as_dict()
+
+    def set_kernel(self, mode, slots: int = 0, refill_at: int = 0):
+        _check(lib().mcpt_tiled_renderer_set_kernel(self._h, int(mode), slots, refill_at))
+        return self
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().mcpt_tiled_renderer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+HOST_LIB_PATH = os.path.join(HERE, "libmcpt_host.so")
+
+
+def host_render(config: Config, threads: int = 0):
+    """The optional host build of the kernel body (include/mcpt_host.h; what `mcpt_cli --cpu` runs):
+    (frame, seconds).  A separate shared object — libmcpt_hip.so has no CPU path."""
+    if not os.path.exists(HOST_LIB_PATH):
+        raise McptError(f"{HOST_LIB_PATH} is not built")
+    H = ctypes.CDLL(HOST_LIB_PATH)
+    H.mcpt_host_render.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
+                                   ctypes.POINTER(ctypes.c_double)]
+    H.mcpt_host_last_error.restype = ctypes.c_char_p
+    w, h, _ = config.film()
+    raw = config.serialize()
+    frame = np.empty((h, w, 3), dtype=np.float32)
+    sec = ctypes.c_double()
+    if H.mcpt_host_render(raw, len(raw), threads, frame.ctypes.data, ctypes.byref(sec)) != 0:
+        raise McptError(H.mcpt_host_last_error().decode(errors="replace"))
+    return frame, sec.value
 
 
 def unpack_tiles(packed: np.ndarray, rng: TileRange, width: int, height: int, frame: np.ndarray):

@@ -5,6 +5,9 @@
 #include "mcpt.h"
 
 #include <chrono>
+#include <dlfcn.h>
+#include <mutex>
+#include <thread>
 #include <functional>
 #include <cstdlib>
 #include <cstring>
@@ -140,6 +143,105 @@ struct mcpt_renderer
 namespace
 {
 
+void CheckDevice(int device)
+{
+    int n_devices = 0;
+    if (hipGetDeviceCount(&n_devices) != hipSuccess || n_devices == 0)
+        throw std::runtime_error("no HIP device available: this library renders on the GPU only.");
+    if (device < 0 || device >= n_devices)
+        throw std::runtime_error("invalid HIP device ordinal " + std::to_string(device) + ".");
+}
+
+// Uploads committed tables to HBM of `device` (the second half of Renderer::Renderer, renderer.cpp:259-348).
+std::unique_ptr<mcpt_renderer> MakeRenderer(mcpt::FlatScene flat, int device)
+{
+    CheckDevice(device);
+    std::unique_ptr<mcpt_renderer> r(new mcpt_renderer);
+    r->device = device;
+    Check(hipSetDevice(device), "select device");
+    hipDeviceProp_t prop;
+    Check(hipGetDeviceProperties(&prop, device), "query device");
+    r->n_cus = static_cast<uint32_t>(prop.multiProcessorCount);
+    r->flat = std::move(flat);
+    const mcpt::FlatScene &f = r->flat;
+    mcpt::DeviceScene &d = r->dev;
+    d.camera = f.camera, d.integrator = f.integrator, d.features = f.features;
+    int k = 0;
+    d.nodes = r->arrays[k++].Upload(f.nodes, "upload nodes");
+    d.node_area = r->arrays[k++].Upload(f.node_area, "upload node areas");
+    d.walk_nodes = r->arrays[k++].Upload(f.walk_nodes, "upload walk hierarchy");
+    d.walk_prims = r->arrays[k++].Upload(f.walk_prims, "upload walk primitives");
+    d.tri_pos = r->arrays[k++].Upload(f.tri_pos, "upload triangle positions");
+    d.tri_attr = r->arrays[k++].Upload(f.tri_attr, "upload triangle attributes");
+    d.instances = r->arrays[k++].Upload(f.instances, "upload instances");
+    d.analytic = r->arrays[k++].Upload(f.analytic, "upload analytic shapes");
+    d.light_inst = r->arrays[k++].Upload(f.light_inst, "upload light table");
+    d.light_cdf = r->arrays[k++].Upload(f.light_cdf, "upload light cdf");
+    d.textures = r->arrays[k++].Upload(f.textures, "upload textures");
+    d.texels = r->arrays[k++].Upload(f.texels, "upload texels");
+    d.bsdfs = r->arrays[k++].Upload(f.bsdfs, "upload BSDFs");
+    d.media = r->arrays[k++].Upload(f.media, "upload media");
+    d.emitters = r->arrays[k++].Upload(f.emitters, "upload emitters");
+    d.env_tables = r->arrays[k++].Upload(f.env_tables, "upload environment tables");
+    d.lut_brdf = r->arrays[k++].Upload(f.lut_brdf, "upload Kulla-Conty table");
+    d.lut_albedo = r->arrays[k++].Upload(f.lut_albedo, "upload Kulla-Conty table");
+    Check(hipEventCreate(&r->ev_begin), "create event");
+    Check(hipEventCreate(&r->ev_end), "create event");
+    return r;
+}
+
+// ---- RCCL, bound at first use ------------------------------------------------------------------
+// The single-GPU render path must not depend on the collective library, so librccl.so.1 is opened the
+// first time a tiled renderer needs it (a process that already holds one — PyTorch bundles its own —
+// reuses it: one HIP runtime, one RCCL per process).  Prototypes as in <rccl/rccl.h>.
+struct Rccl
+{
+    using Comm = void *;
+    int (*CommInitAll)(Comm *, int, const int *) = nullptr;
+    int (*CommDestroy)(Comm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    static constexpr int kFloat32 = 7; // ncclFloat32
+
+    static const Rccl &Get()
+    {
+        static Rccl api;
+        static std::once_flag once;
+        static std::string problem;
+        std::call_once(once, []
+                       {
+            void *h = nullptr;
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr)
+                    break;
+            if (!h)
+            {
+                problem = std::string("cannot load librccl.so.1 (") + dlerror() + ")";
+                return;
+            }
+            auto bind = [&](auto &fn, const char *symbol)
+            {
+                fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(h, symbol));
+                if (!fn && problem.empty())
+                    problem = std::string("librccl lacks ") + symbol;
+            };
+            bind(api.CommInitAll, "ncclCommInitAll"), bind(api.CommDestroy, "ncclCommDestroy");
+            bind(api.GroupStart, "ncclGroupStart"), bind(api.GroupEnd, "ncclGroupEnd");
+            bind(api.Send, "ncclSend"), bind(api.Recv, "ncclRecv"), bind(api.GetErrorString, "ncclGetErrorString"); });
+        if (!problem.empty())
+            throw std::runtime_error(problem + ".");
+        return api;
+    }
+    void Check(int rc, const char *what) const
+    {
+        if (rc != 0)
+            throw std::runtime_error(std::string("RCCL error : \"") + GetErrorString(rc) + "\" when " + what + ".");
+    }
+};
+
 uint32_t RangeSize(uint32_t tiles_total, const mcpt_tile_range &range)
 {
     if (range.tile_stride == 0 || range.tile_first >= tiles_total)
@@ -273,6 +375,43 @@ int DrawToHost(mcpt_renderer *r, float *frame, mcpt_stats *stats, bool counted)
 }
 
 } // namespace
+
+// One frame over the GPUs of a node: a renderer per device (the scene is committed once and uploaded to
+// each), rank k of N renders tiles k, k + N, ... into a packed block in its own HBM, one grouped
+// ncclSend / ncclRecv gather brings the blocks to device 0 over xGMI, device 0 scatters them into the frame.
+struct mcpt_tiled_renderer
+{
+    std::vector<std::unique_ptr<mcpt_renderer>> ranks;
+    std::vector<hipStream_t> streams;
+    std::vector<float *> packed;       // rank k's tiles, on device k
+    std::vector<void *> comms;         // ncclComm_t per rank (empty: single device without the forced gather)
+    float *gathered = nullptr;         // device 0: all ranks' blocks back to back
+    float *frame_dev = nullptr;        // device 0
+    bool through_rccl = false;
+    ~mcpt_tiled_renderer()
+    {
+        for (size_t k = 0; k < ranks.size(); ++k)
+        {
+            if (!ranks[k])
+                continue;
+            (void)hipSetDevice(ranks[k]->device);
+            if (k < comms.size() && comms[k])
+                (void)Rccl::Get().CommDestroy(comms[k]);
+            if (k < packed.size() && packed[k])
+                (void)hipFree(packed[k]);
+            if (k < streams.size() && streams[k])
+                (void)hipStreamDestroy(streams[k]);
+            if (k == 0)
+            {
+                if (gathered)
+                    (void)hipFree(gathered);
+                if (frame_dev)
+                    (void)hipFree(frame_dev);
+            }
+        }
+        ranks.clear();
+    }
+};
 
 extern "C"
 {
@@ -434,6 +573,28 @@ int mcpt_config_save_mcsd(const mcpt_config *cfg, const char *path)
     }
 }
 
+int mcpt_config_serialize(const mcpt_config *cfg, void *buffer, size_t capacity, size_t *size)
+{
+    if (!cfg || !size)
+        return Fail("null argument");
+    try
+    {
+        const std::vector<uint8_t> bytes = mcsd::Serialize(cfg->scene);
+        *size = bytes.size();
+        if (buffer)
+        {
+            if (capacity < bytes.size())
+                return Fail("mcpt_config_serialize: buffer too small");
+            std::memcpy(buffer, bytes.data(), bytes.size());
+        }
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(e.what());
+    }
+}
+
 void mcpt_config_destroy(mcpt_config *cfg) { delete cfg; }
 
 int mcpt_renderer_create(const mcpt_config *cfg, int device, mcpt_renderer **out)
@@ -442,44 +603,10 @@ int mcpt_renderer_create(const mcpt_config *cfg, int device, mcpt_renderer **out
         return Fail("null argument");
     try
     {
-        int n_devices = 0;
-        if (hipGetDeviceCount(&n_devices) != hipSuccess || n_devices == 0)
-            throw std::runtime_error("no HIP device available: this library renders on the GPU only.");
-        if (device < 0 || device >= n_devices)
-            throw std::runtime_error("invalid HIP device ordinal " + std::to_string(device) + ".");
-        std::unique_ptr<mcpt_renderer> r(new mcpt_renderer);
-        r->device = device;
+        CheckDevice(device);
         Check(hipSetDevice(device), "select device");
-        hipDeviceProp_t prop;
-        Check(hipGetDeviceProperties(&prop, device), "query device");
-        r->n_cus = static_cast<uint32_t>(prop.multiProcessorCount);
         DeviceLbvh device_lbvh; // large meshes: reference-topology LBVH on the GPU (bit-identical)
-        r->flat = mcpt::CommitScene(cfg->scene, &device_lbvh);
-        const mcpt::FlatScene &f = r->flat;
-        mcpt::DeviceScene &d = r->dev;
-        d.camera = f.camera, d.integrator = f.integrator, d.features = f.features;
-        int k = 0;
-        d.nodes = r->arrays[k++].Upload(f.nodes, "upload nodes");
-        d.node_area = r->arrays[k++].Upload(f.node_area, "upload node areas");
-        d.walk_nodes = r->arrays[k++].Upload(f.walk_nodes, "upload walk hierarchy");
-        d.walk_prims = r->arrays[k++].Upload(f.walk_prims, "upload walk primitives");
-        d.tri_pos = r->arrays[k++].Upload(f.tri_pos, "upload triangle positions");
-        d.tri_attr = r->arrays[k++].Upload(f.tri_attr, "upload triangle attributes");
-        d.instances = r->arrays[k++].Upload(f.instances, "upload instances");
-        d.analytic = r->arrays[k++].Upload(f.analytic, "upload analytic shapes");
-        d.light_inst = r->arrays[k++].Upload(f.light_inst, "upload light table");
-        d.light_cdf = r->arrays[k++].Upload(f.light_cdf, "upload light cdf");
-        d.textures = r->arrays[k++].Upload(f.textures, "upload textures");
-        d.texels = r->arrays[k++].Upload(f.texels, "upload texels");
-        d.bsdfs = r->arrays[k++].Upload(f.bsdfs, "upload BSDFs");
-        d.media = r->arrays[k++].Upload(f.media, "upload media");
-        d.emitters = r->arrays[k++].Upload(f.emitters, "upload emitters");
-        d.env_tables = r->arrays[k++].Upload(f.env_tables, "upload environment tables");
-        d.lut_brdf = r->arrays[k++].Upload(f.lut_brdf, "upload Kulla-Conty table");
-        d.lut_albedo = r->arrays[k++].Upload(f.lut_albedo, "upload Kulla-Conty table");
-        Check(hipEventCreate(&r->ev_begin), "create event");
-        Check(hipEventCreate(&r->ev_end), "create event");
-        *out = r.release();
+        *out = MakeRenderer(mcpt::CommitScene(cfg->scene, &device_lbvh), device).release();
         return 0;
     }
     catch (const std::exception &e)
@@ -764,6 +891,187 @@ int mcpt_write_image(const char *path, const float *frame, int width, int height
     {
         return Fail(e.what());
     }
+}
+
+int mcpt_tiled_renderer_create(const mcpt_config *cfg, int n_devices, const int *devices, unsigned flags,
+                               mcpt_tiled_renderer **out)
+{
+    if (!cfg || !out || n_devices < 1)
+        return Fail("invalid argument");
+    try
+    {
+        std::vector<int> devs(static_cast<size_t>(n_devices));
+        for (int k = 0; k < n_devices; ++k)
+        {
+            devs[k] = devices ? devices[k] : k;
+            CheckDevice(devs[k]);
+            for (int j = 0; j < k; ++j)
+                if (devs[j] == devs[k])
+                    throw std::runtime_error("device " + std::to_string(devs[k]) + " is listed twice.");
+        }
+        std::unique_ptr<mcpt_tiled_renderer> t(new mcpt_tiled_renderer);
+        Check(hipSetDevice(devs[0]), "select device");
+        DeviceLbvh device_lbvh;
+        const mcpt::FlatScene flat = mcpt::CommitScene(cfg->scene, &device_lbvh); // ONE commit for all devices
+        t->ranks.resize(devs.size());
+        t->streams.assign(devs.size(), nullptr), t->packed.assign(devs.size(), nullptr);
+        // uploads run side by side, one host thread per GPU
+        std::vector<std::string> problems(devs.size());
+        std::vector<std::thread> workers;
+        for (size_t k = 0; k < devs.size(); ++k)
+            workers.emplace_back([&, k]
+                                 {
+                try
+                {
+                    t->ranks[k] = MakeRenderer(flat, devs[k]);
+                    Check(hipStreamCreateWithFlags(&t->streams[k], hipStreamNonBlocking), "create stream");
+                }
+                catch (const std::exception &e)
+                {
+                    problems[k] = e.what();
+                } });
+        for (std::thread &w : workers)
+            w.join();
+        for (const std::string &p : problems)
+            if (!p.empty())
+                throw std::runtime_error(p);
+        const uint32_t tiles = t->ranks[0]->Tiles(), n = static_cast<uint32_t>(devs.size());
+        t->through_rccl = n > 1 || (flags & MCPT_TILED_ALWAYS_GATHER) != 0;
+        const size_t frame_floats = static_cast<size_t>(flat.camera.width) * flat.camera.height * 3;
+        Check(hipSetDevice(devs[0]), "select device");
+        Check(hipMalloc(reinterpret_cast<void **>(&t->frame_dev), frame_floats * sizeof(float)), "allocate frame");
+        if (t->through_rccl)
+        {
+            Check(hipMalloc(reinterpret_cast<void **>(&t->gathered), static_cast<size_t>(tiles) * 192 * sizeof(float)),
+                  "allocate gather buffer");
+            for (uint32_t k = 0; k < n; ++k)
+            {
+                const mcpt_tile_range range{k, n, 0};
+                Check(hipSetDevice(devs[k]), "select device");
+                Check(hipMalloc(reinterpret_cast<void **>(&t->packed[k]),
+                                std::max<size_t>(1, RangeSize(tiles, range)) * 192 * sizeof(float)),
+                      "allocate packed tiles");
+            }
+            const Rccl &rccl = Rccl::Get();
+            t->comms.assign(n, nullptr);
+            rccl.Check(rccl.CommInitAll(t->comms.data(), static_cast<int>(n), devs.data()), "create communicators");
+        }
+        *out = t.release();
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(std::string("error when commit renderer.\n\t") + e.what());
+    }
+}
+
+int mcpt_tiled_renderer_draw(mcpt_tiled_renderer *t, float *frame, mcpt_stats *stats)
+{
+    if (!t || !frame)
+        return Fail("null argument");
+    try
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        const uint32_t n = static_cast<uint32_t>(t->ranks.size());
+        mcpt_renderer *r0 = t->ranks[0].get();
+        const uint32_t tiles = r0->Tiles(), width = r0->flat.camera.width, height = r0->flat.camera.height;
+        const size_t frame_floats = static_cast<size_t>(width) * height * 3;
+        // every GPU starts on its tiles (asynchronous launches from this thread)
+        for (uint32_t k = 0; k < n; ++k)
+        {
+            mcpt_renderer *r = t->ranks[k].get();
+            const mcpt_tile_range range{k, n, 0};
+            Check(hipSetDevice(r->device), "select device");
+            Check(hipEventRecord(r->ev_begin, t->streams[k]), "record event");
+            if (t->through_rccl)
+                Draw(r, t->packed[k], range, true, t->streams[k], false, false, nullptr);
+            else
+                Draw(r, t->frame_dev, range, false, t->streams[k], false, false, nullptr);
+            Check(hipEventRecord(r->ev_end, t->streams[k]), "record event");
+        }
+        if (t->through_rccl)
+        {
+            // ONE gather: rank k sends its block, rank 0 receives all of them (its own included, so that every
+            // pixel of the frame takes the same route)
+            const Rccl &rccl = Rccl::Get();
+            std::vector<size_t> offset(n + 1, 0);
+            for (uint32_t k = 0; k < n; ++k)
+                offset[k + 1] = offset[k] + static_cast<size_t>(RangeSize(tiles, mcpt_tile_range{k, n, 0})) * 192;
+            rccl.Check(rccl.GroupStart(), "start the gather");
+            for (uint32_t k = 0; k < n; ++k)
+            {
+                const size_t count = offset[k + 1] - offset[k];
+                if (count == 0)
+                    continue;
+                rccl.Check(rccl.Send(t->packed[k], count, Rccl::kFloat32, 0, t->comms[k], t->streams[k]), "send tiles");
+                rccl.Check(rccl.Recv(t->gathered + offset[k], count, Rccl::kFloat32, static_cast<int>(k), t->comms[0],
+                                     t->streams[0]),
+                           "receive tiles");
+            }
+            rccl.Check(rccl.GroupEnd(), "finish the gather");
+            Check(hipSetDevice(r0->device), "select device");
+            for (uint32_t k = 0; k < n; ++k)
+                Check(mcpt::LaunchUnpackTiles(t->gathered + offset[k], t->frame_dev, k, n,
+                                              RangeSize(tiles, mcpt_tile_range{k, n, 0}), r0->TilesX(), width, height,
+                                              t->streams[0]),
+                      "scatter tiles");
+        }
+        Check(hipSetDevice(r0->device), "select device");
+        Check(hipMemcpyAsync(frame, t->frame_dev, frame_floats * sizeof(float), hipMemcpyDeviceToHost, t->streams[0]),
+              "copy frame to host");
+        double kernel_ms = 0;
+        for (uint32_t k = 0; k < n; ++k)
+        {
+            Check(hipSetDevice(t->ranks[k]->device), "select device");
+            Check(hipStreamSynchronize(t->streams[k]), "draw");
+            float ms = 0;
+            Check(hipEventElapsedTime(&ms, t->ranks[k]->ev_begin, t->ranks[k]->ev_end), "read event");
+            kernel_ms = std::max(kernel_ms, static_cast<double>(ms));
+        }
+        if (stats)
+        {
+            *stats = mcpt_stats{};
+            stats->render_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            stats->kernel_milliseconds = kernel_ms; // the slowest GPU's render kernel
+            stats->samples = static_cast<uint64_t>(width) * height * r0->flat.camera.spp;
+        }
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(std::string("error when draw.\n\t") + e.what());
+    }
+}
+
+int mcpt_tiled_renderer_set_kernel(mcpt_tiled_renderer *t, int mode, uint32_t slots, uint32_t refill_at)
+{
+    if (!t)
+        return Fail("null argument");
+    for (auto &r : t->ranks)
+        if (int rc = mcpt_renderer_set_kernel(r.get(), mode, slots, refill_at))
+            return rc;
+    return 0;
+}
+
+void mcpt_tiled_renderer_destroy(mcpt_tiled_renderer *t) { delete t; }
+
+int mcpt_render_tiled(const mcpt_config *cfg, int n_devices, const int *devices, float *frame, mcpt_stats *stats)
+{
+    mcpt_tiled_renderer *t = nullptr;
+    if (int rc = mcpt_tiled_renderer_create(cfg, n_devices, devices, 0, &t))
+        return rc;
+    const int rc = mcpt_tiled_renderer_draw(t, frame, stats);
+    mcpt_tiled_renderer_destroy(t);
+    return rc;
+}
+
+int mcpt_device_count(int *n_devices)
+{
+    if (!n_devices)
+        return Fail("null argument");
+    int n = 0;
+    *n_devices = hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+    return 0;
 }
 
 } // extern "C"

@@ -4,12 +4,16 @@
 //   [-g/--gpu] -i <scene> [-o <image>] [-w <width>] [-h <height>] [-s <spp>]
 // <scene> is a Mitsuba-style .xml file, a .mcsd configuration, or
 // "builtin:<name>".  Differences, all deliberate:
-//   * rendering always runs on the GPU; -c/--cpu is refused (the product has
-//     no CPU path) and -p/--preview (the GLUT viewer) is not part of it;
+//   * -g/--gpu is the default; --gpus N cuts the frame over N GPUs of this node (8x8 tiles round-robin, one
+//     RCCL gather, mcpt_tiled_renderer_*); -c/--cpu runs the kernel body on host threads through the optional
+//     libmcpt_host.so (include/mcpt_host.h) found next to this program — libmcpt_hip.so itself has no CPU
+//     path; -p/--preview (the GLUT viewer) is not part of this program;
 //   * the output format follows the suffix (.png .exr .pfm .f32) instead of
 //     being forced to .png; the default stays "result.png";
 //   * the exit status is non-zero on failure (the reference always returns 0).
 #include <chrono>
+#include <dlfcn.h>
+#include <unistd.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -27,10 +31,12 @@ void Usage()
                  "mcpt_cli (%s)\n\n"
                  "  mcpt_cli [-g|--gpu] -i|--input <scene.xml | scene.mcsd | builtin:cornell-box>\n"
                  "           [-o|--output <result.png|.exr|.pfm|.f32>] [-w|--width N] [-h|--height N]\n"
-                 "           [-s|--spp N] [-d|--device N] [--save-config <file.mcsd>] [--standins <table.txt>]\n\n"
+                 "           [-s|--spp N] [-d|--device N] [--gpus N] [-c|--cpu] [--threads N]\n"
+                 "           [--save-config <file.mcsd>] [--standins <table.txt>]\n\n"
                  "  --standins   procedural stand-ins for mesh files the scene names but that are not on disk\n"
-                 "  --gpu        render with HIP on the selected device (the default and only backend)\n"
-                 "  --cpu        refused: this build has no CPU renderer\n",
+                 "  --gpu        render with HIP on the selected device (the default)\n"
+                 "  --gpus N     cut the frame over HIP devices 0 .. N-1 (one RCCL gather to device 0)\n"
+                 "  --cpu        render on host threads (needs libmcpt_host.so next to this program)\n",
                  mcpt_version());
 }
 
@@ -51,16 +57,18 @@ int Fail(const char *what)
 int main(int argc, char **argv)
 {
     std::string input, output = "result.png", save_config, standins_file;
-    int width = 0, height = 0, spp = 0, device = 0;
+    int width = 0, height = 0, spp = 0, device = 0, gpus = 1, threads = 0;
+    bool on_cpu = false;
     for (int i = 1; i < argc; ++i)
     {
         const std::string a = argv[i];
         const bool has_value = i + 1 < argc;
         if (a == "--cpu" || a == "-c")
-        {
-            std::fprintf(stderr, "[error] --cpu: this program renders on the GPU only.\n");
-            return 2;
-        }
+            on_cpu = true;
+        else if (a == "--gpus" && has_value)
+            gpus = std::atoi(argv[++i]);
+        else if (a == "--threads" && has_value)
+            threads = std::atoi(argv[++i]);
         else if (a == "--preview" || a == "-p")
         {
             std::fprintf(stderr, "[error] --preview: the interactive viewer is not part of this program.\n");
@@ -136,26 +144,80 @@ int main(int argc, char **argv)
         return Fail("cannot save the configuration.");
     mcpt_config_get_film(config, &width, &height, &spp);
 
-    const auto t0 = std::chrono::steady_clock::now();
-    mcpt_renderer *renderer = nullptr;
-    rc = mcpt_renderer_create(config, device, &renderer);
-    mcpt_config_destroy(config);
-    if (rc != 0)
-        return Fail("error when create renderer.");
-    const auto t1 = std::chrono::steady_clock::now();
-
     std::vector<float> frame(static_cast<size_t>(width) * height * 3);
-    mcpt_stats stats;
-    if (mcpt_renderer_draw(renderer, frame.data(), &stats) != 0)
+    const auto t0 = std::chrono::steady_clock::now();
+    if (on_cpu)
     {
-        mcpt_renderer_destroy(renderer);
-        return Fail("error when draw.");
+        // the reference's `--cpu` (apps/main.cpp:130-137): the kernel body on host threads, from the optional
+        // host library next to this executable
+        char self[4096];
+        const ssize_t len = readlink("/proc/self/exe", self, sizeof self - 1);
+        std::string dir = len > 0 ? std::string(self, static_cast<size_t>(len)) : std::string("./mcpt_cli");
+        dir.erase(dir.find_last_of('/') == std::string::npos ? 0 : dir.find_last_of('/'));
+        void *host = dlopen((dir + "/libmcpt_host.so").c_str(), RTLD_NOW);
+        if (!host)
+        {
+            std::fprintf(stderr, "[error] --cpu: cannot load libmcpt_host.so (%s).\n", dlerror());
+            return 1;
+        }
+        auto render = reinterpret_cast<int (*)(const void *, size_t, int, float *, double *)>(dlsym(host, "mcpt_host_render"));
+        auto last_error = reinterpret_cast<const char *(*)()>(dlsym(host, "mcpt_host_last_error"));
+        size_t size = 0;
+        if (!render || !last_error || mcpt_config_serialize(config, nullptr, 0, &size) != 0)
+            return Fail("--cpu: incomplete host library.");
+        std::vector<unsigned char> bytes(size);
+        if (mcpt_config_serialize(config, bytes.data(), bytes.size(), &size) != 0)
+            return Fail("cannot serialise the configuration.");
+        mcpt_config_destroy(config);
+        double seconds = 0;
+        if (render(bytes.data(), bytes.size(), threads, frame.data(), &seconds) != 0)
+        {
+            std::fprintf(stderr, "[error] %s\n", last_error());
+            return 1;
+        }
+        std::fprintf(stderr, "[info] %d x %d, %d spp on host threads: draw %.3f s (%.2f Msamples/s)\n", width, height, spp,
+                     seconds, seconds > 0 ? double(width) * height * spp / seconds / 1e6 : 0.0);
     }
-    mcpt_renderer_destroy(renderer);
-    const double setup_s = std::chrono::duration<double>(t1 - t0).count();
-    std::fprintf(stderr, "[info] %d x %d, %d spp: scene commit %.3f s, draw %.3f s (%.1f Msamples/s)\n", width, height,
-                 spp, setup_s, stats.kernel_milliseconds * 1e-3,
-                 stats.kernel_milliseconds > 0 ? double(width) * height * spp / (stats.kernel_milliseconds * 1e3) : 0.0);
+    else if (gpus > 1)
+    {
+        mcpt_tiled_renderer *tiled = nullptr;
+        std::vector<int> devices;
+        for (int k = 0; k < gpus; ++k)
+            devices.push_back(device + k);
+        rc = mcpt_tiled_renderer_create(config, gpus, devices.data(), 0, &tiled);
+        mcpt_config_destroy(config);
+        if (rc != 0)
+            return Fail("error when create renderer.");
+        const auto t1 = std::chrono::steady_clock::now();
+        mcpt_stats stats;
+        rc = mcpt_tiled_renderer_draw(tiled, frame.data(), &stats);
+        mcpt_tiled_renderer_destroy(tiled);
+        if (rc != 0)
+            return Fail("error when draw.");
+        std::fprintf(stderr, "[info] %d x %d, %d spp on %d GPUs: scene commit %.3f s, draw %.3f s (%.1f Msamples/s)\n", width,
+                     height, spp, gpus, std::chrono::duration<double>(t1 - t0).count(), stats.render_seconds,
+                     stats.render_seconds > 0 ? double(width) * height * spp / stats.render_seconds / 1e6 : 0.0);
+    }
+    else
+    {
+        mcpt_renderer *renderer = nullptr;
+        rc = mcpt_renderer_create(config, device, &renderer);
+        mcpt_config_destroy(config);
+        if (rc != 0)
+            return Fail("error when create renderer.");
+        const auto t1 = std::chrono::steady_clock::now();
+        mcpt_stats stats;
+        if (mcpt_renderer_draw(renderer, frame.data(), &stats) != 0)
+        {
+            mcpt_renderer_destroy(renderer);
+            return Fail("error when draw.");
+        }
+        mcpt_renderer_destroy(renderer);
+        const double setup_s = std::chrono::duration<double>(t1 - t0).count();
+        std::fprintf(stderr, "[info] %d x %d, %d spp: scene commit %.3f s, draw %.3f s (%.1f Msamples/s)\n", width, height,
+                     spp, setup_s, stats.kernel_milliseconds * 1e-3,
+                     stats.kernel_milliseconds > 0 ? double(width) * height * spp / (stats.kernel_milliseconds * 1e3) : 0.0);
+    }
     if (mcpt_write_image(output.c_str(), frame.data(), width, height) != 0)
         return Fail("cannot write the image.");
     std::fprintf(stderr, "[info] save result as image \"%s\".\n", output.c_str());

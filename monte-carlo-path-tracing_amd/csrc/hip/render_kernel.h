@@ -57,6 +57,10 @@ hipError_t LaunchRenderStream(const DeviceScene &sc, const RenderJob &job, float
 hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
                         hipStream_t stream, uint32_t n_cus, const char **variant);
 
+// Multi-GPU gather: scatters one rank's packed tiles (device memory) into a device frame.
+hipError_t LaunchUnpackTiles(const float *packed, float *frame, uint32_t tile_first, uint32_t tile_stride, uint32_t n_tiles,
+                             uint32_t tiles_x, uint32_t width, uint32_t height, hipStream_t stream);
+
 // Unit kernels for diagnostics and parity tests (one query per lane).
 hipError_t LaunchIntersect(const DeviceScene &sc, uint32_t n, const float *rays, const uint32_t *seeds, float *out,
                            uint32_t *seeds_out, bool reference_walk, hipStream_t stream);

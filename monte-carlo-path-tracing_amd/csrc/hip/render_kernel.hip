@@ -195,4 +195,32 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     return Launch<kAll | kV, false>(sc, job, out, nullptr, stream, n_cus);
 }
 
+// Tiles of one rank's packed block (64 pixels x 3 floats per tile, tile t = first + k * stride) -> their
+// pixels of the frame.  One lane per float: both sides are touched in runs of 24 consecutive floats (a
+// tile row), the packed side fully coalesced.
+__global__ void __launch_bounds__(kBlockSize) unpack_tiles_kernel(const float *__restrict__ packed, float *__restrict__ frame,
+                                                                  uint32_t tile_first, uint32_t tile_stride, uint32_t n_tiles,
+                                                                  uint32_t tiles_x, uint32_t width, uint32_t height)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; // float index in the packed block
+    if (i >= n_tiles * 192u)
+        return;
+    const uint32_t k = i / 192u, within = i % 192u, r = within / 3u, c = within % 3u;
+    const uint32_t t = tile_first + k * tile_stride;
+    const uint32_t x = (t % tiles_x) * 8u + (r & 7u), y = (t / tiles_x) * 8u + (r >> 3);
+    if (x < width && y < height)
+        frame[3 * (static_cast<size_t>(y) * width + x) + c] = packed[i];
+}
+
+hipError_t LaunchUnpackTiles(const float *packed, float *frame, uint32_t tile_first, uint32_t tile_stride, uint32_t n_tiles,
+                             uint32_t tiles_x, uint32_t width, uint32_t height, hipStream_t stream)
+{
+    if (n_tiles == 0)
+        return hipSuccess;
+    const uint32_t n = n_tiles * 192u;
+    hipLaunchKernelGGL(unpack_tiles_kernel, dim3((n + kBlockSize - 1) / kBlockSize), dim3(kBlockSize), 0, stream, packed, frame,
+                       tile_first, tile_stride, n_tiles, tiles_x, width, height);
+    return hipGetLastError();
+}
+
 } // namespace mcpt

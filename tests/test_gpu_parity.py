@@ -310,3 +310,40 @@ def test_walk_schedule_does_not_change_the_image(pkg, scenes):
     with pytest.raises(pkg.capi.McptError, match="64 lanes"):
         r.set_walk_schedule(65, 0)
     r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, 1])
+def test_tiled_renderer_in_cpp_equals_plain_draw(pkg, flags):
+    """mcpt_tiled_renderer_* (the C++ multi-GPU host: one commit, a renderer per device, grouped ncclSend /
+    ncclRecv gather, device-side scatter) on this box's single GPU: without and WITH the forced RCCL route
+    (MCPT_TILED_ALWAYS_GATHER: rank 0 sends its packed tiles to itself through librccl) the frame is the plain
+    draw's bit for bit; edge tiles included (film not a multiple of 8)."""
+    cfg = pkg.capi.Config.builtin("cornell-box").set_film(203, 117, 6)
+    r = pkg.capi.Renderer(cfg, device=0)
+    plain, _ = r.draw()
+    r.close()
+    t = pkg.capi.TiledRenderer(cfg, devices=(0,), flags=flags)
+    try:
+        frame, st = t.draw()
+        again, _ = t.draw()
+    finally:
+        t.close()
+    assert st["samples"] == 203 * 117 * 6 and st["kernel_milliseconds"] > 0
+    np.testing.assert_array_equal(frame, plain)
+    np.testing.assert_array_equal(again, plain)
+
+
+@pytest.mark.gpu
+def test_cli_gpus_switch(pkg, tmp_path):
+    """`mcpt_cli --gpus N` with every visible device (1 on the test box: takes the single-renderer route;
+    N > 1 the tiled one) writes the library's frame."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "mcpt_cli")
+    n = pkg.capi.device_count()
+    out = tmp_path / "f.f32"
+    r = subprocess.run([exe, "-i", "builtin:cornell-box", "-w", "72", "-h", "40", "-s", "4", "--gpus", str(n), "-o", str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    want, _ = pkg.capi.Renderer(pkg.capi.Config.builtin("cornell-box").set_film(72, 40, 4)).draw()
+    np.testing.assert_array_equal(np.fromfile(out, dtype=np.float32).reshape(40, 72, 3), want)

@@ -60,6 +60,31 @@ def test_no_cpu_fallback(pkg, lib):
         pkg.capi.Renderer(pkg.capi.Config.builtin("cornell-box").set_film(8, 8, 1))
 
 
+@pytest.mark.parametrize("name", ["cornell_96_spp32", "rough_dielectric_envmap", "volpath_medium_mixed", "masked_area_flat",
+                                  "terrain_directional"])
+def test_host_library_renders_the_golden_frames(name, pkg, lib):
+    """libmcpt_host.so (include/mcpt_host.h; what `mcpt_cli --cpu` runs): the product's kernel body on host threads,
+    fed through mcpt_config_serialize, gives the compiled reference's frames bit for bit."""
+    scene = cases(pkg.scenes)[name]
+    golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
+    frame, seconds = pkg.capi.host_render(pkg.capi.Config.from_scene(scene))
+    assert seconds > 0 and np.array_equal(frame, golden)
+
+
+def test_tiled_renderer_needs_a_gpu_and_valid_devices(pkg, lib):
+    import torch
+    cfg = pkg.capi.Config.builtin("cornell-box").set_film(16, 16, 1)
+    if not torch.cuda.is_available():
+        assert pkg.capi.device_count() == 0
+        with pytest.raises(pkg.capi.McptError, match="GPU only|HIP"):
+            pkg.capi.TiledRenderer(cfg, devices=(0,))
+    else:
+        with pytest.raises(pkg.capi.McptError, match="listed twice"):
+            pkg.capi.TiledRenderer(cfg, devices=(0, 0))
+        with pytest.raises(pkg.capi.McptError, match="invalid HIP device"):
+            pkg.capi.TiledRenderer(cfg, devices=(0, 99))
+
+
 def test_bad_input_is_rejected(pkg, lib, tmp_path):
     with pytest.raises(pkg.capi.McptError):
         pkg.capi.Config.from_mcsd_bytes(b"not a scene")

@@ -814,9 +814,19 @@ def run_cli(pkg, *args):
     return subprocess.run([exe, *map(str, args)], capture_output=True, text=True, timeout=120)
 
 
-def test_cli_refuses_cpu_and_reports_errors(pkg, tmp_path):
-    r = run_cli(pkg, "--cpu", "-i", "builtin:cornell-box")
-    assert r.returncode == 2 and "GPU only" in r.stderr
+def test_cli_cpu_switch_is_baseline_config_1(pkg, tmp_path):
+    """BASELINE config 1 / the reference's `--cpu` (apps/main.cpp:130-137): cornell-box on the CPU path.  The CLI
+    runs the kernel body on host threads through libmcpt_host.so; the frame is the compiled reference's golden
+    frame bit for bit (cornell 64x64 spp 8, the SURVEY section 0 anchor)."""
+    out = tmp_path / "cpu.f32"
+    r = run_cli(pkg, "--cpu", "-i", "builtin:cornell-box", "-w", 64, "-h", 64, "-s", 8, "-o", out)
+    assert r.returncode == 0, r.stderr
+    assert "host threads" in r.stderr
+    golden = np.load(os.path.join(os.path.dirname(__file__), "golden", "cornell_64_spp8.npz"))["frame"]
+    np.testing.assert_array_equal(np.fromfile(out, dtype=np.float32).reshape(64, 64, 3), golden)
+
+
+def test_cli_reports_errors(pkg, tmp_path):
     r = run_cli(pkg, "-i", tmp_path / "missing.xml")
     assert r.returncode == 1 and "cannot find config file" in r.stderr
     r = run_cli(pkg)

@@ -20,8 +20,9 @@ def main():
     ap.add_argument("--film", type=int, nargs=3, default=None, metavar=("W", "H", "SPP"))
     ap.add_argument("--draws", type=int, default=2)
     ap.add_argument("--counted", action="store_true", help="also run the counting instantiation once")
-    ap.add_argument("--kernel", choices=["stream", "lanes"], default="stream",
-                    help="stream kernel (default) or the lane-owns-a-path kernel")
+    ap.add_argument("--kernel", choices=["auto", "stream", "lanes"], default="auto",
+                    help="kernel formulation: the library's choice by scene class (default), the stream "
+                         "kernel, or the lane-owns-a-path kernel")
     a = ap.parse_args()
     from _pkg import load_package
     pkg = load_package()
@@ -42,7 +43,7 @@ def main():
         cfg.set_film(*a.film)
     w, h, spp = cfg.film()
     r = capi.Renderer(cfg)
-    r.set_kernel(a.kernel == "stream")
+    r.set_kernel({"auto": -1, "stream": 1, "lanes": 0}[a.kernel])
     out = {"scene": a.scene, "film": [w, h, spp], "info": r.info()}
     for _ in range(a.draws):
         _, st = r.draw()
