@@ -184,6 +184,11 @@ def main():
                          "cutting the workload's own film over the GPUs")
     ap.add_argument("--kernel", choices=["auto", "stream", "lanes"], default="auto",
                     help="kernel formulation (default: the library's choice by scene class)")
+    ap.add_argument("--rng", choices=["reference", "pcg"], default="reference",
+                    help="reference: the reference's per-pixel random stream (the graded mode, frames comparable per "
+                         "pixel).  pcg: throughput mode — an independent PCG-hashed stream per (pixel, sample), the "
+                         "samples of a pixel spread over lanes; compared with the CPU image by RMSE only")
+    ap.add_argument("--sample-split", type=int, default=0, help="--rng pcg: lanes per pixel (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes")
     ap.add_argument("--force-gather", action="store_true",
@@ -227,6 +232,8 @@ def main():
     def make_renderer(spp):
         r = pkg.capi.Renderer(pkg.workloads.config(name, W, H, spp), device=local_rank)
         r.set_kernel(kernel_mode)
+        if args.rng == "pcg":
+            r.set_rng(1, seed=1, sample_split=args.sample_split)
         return r
 
     renderer = make_renderer(SPP)
@@ -280,7 +287,8 @@ def main():
             "config": {"workload": f"{name}: {pkg.workloads.DESCRIPTION[name]}"
                                    + ("" if (W, H, SPP) == pkg.workloads.WORKLOADS[name][1] else f" — film overridden: {W}x{H} spp={SPP}"),
                        "baseline_config_index": pkg.workloads.WORKLOADS[name][2],
-                       "rng": "reference stream (Tea + LCG per pixel)",
+                       "rng": ("reference stream (Tea + LCG per pixel)" if args.rng == "reference" else
+                               "THROUGHPUT MODE, not per-pixel comparable: independent PCG-hashed stream per (pixel, sample)"),
                        "kernel": kernel_name,
                        "partition": f"8x8 tiles round-robin over {world} GPU(s)"
                                     + (", one RCCL gather to rank 0" if world > 1 else ""),
@@ -320,7 +328,7 @@ def main():
                 "kernel": kernel_name, "kernel_ms": kernel_ms, "per_sample": per_sample, "walk": walk, "hbm": hbm,
                 "scene": {"walk_nodes": scene_info["walk_nodes"], "primitives": scene_info["primitives"],
                           "geometry_bytes": scene_info["geometry_bytes"]}}
-        pmc = None if (args.no_pmc or world > 1) else pmc_leg(name, (W, H, SPP), kernel_name)
+        pmc = None if (args.no_pmc or world > 1 or args.rng != "reference") else pmc_leg(name, (W, H, SPP), kernel_name)
         if pmc and pmc["counters"].get("SQ_INSTS_VALU") and pmc["kernel_ns"]:
             c = pmc["counters"]
             pmc_ms = pmc["kernel_ns"] * 1e-6
@@ -376,11 +384,14 @@ def main():
                 out["cpu_baseline_port"] = recs["port"]
             rg = pkg.capi.Renderer(pkg.workloads.config(name, cw, ch, cspp), device=local_rank)
             rg.set_kernel(kernel_mode)
+            if args.rng == "pcg":
+                rg.set_rng(1, seed=1, sample_split=args.sample_split)
             gpu_frame, _ = rg.draw()
             rg.close()
             d = gpu_frame.astype(np.float64) - cpu_frame.astype(np.float64)
             l2 = np.sqrt((d ** 2).sum(axis=2))
-            out["parity"] = {"vs": "port", "film": [cw, ch, cspp],
+            out["parity"] = {"vs": "port", "film": [cw, ch, cspp], "rng": args.rng,
+                             "mean_gpu": float(gpu_frame.mean()), "mean_cpu": float(cpu_frame.mean()),
                              "rmse": float(np.sqrt((d ** 2).mean())), "mean_l2": float(l2.mean()),
                              "max_l2": float(l2.max()), "frac_gt_1e-3": float((l2 > 1e-3).mean()),
                              "frac_exact": float((l2 == 0).mean())}

@@ -148,6 +148,14 @@ int mcpt_renderer_info(const mcpt_renderer *r, uint64_t info[9]);
  * during the walk). */
 int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order);
 
+/* Self-check of the production ray query on THIS scene and film: renders the frame twice — ordered walk of the
+ * SAH hierarchy (what draws use) and the reference's trees in the reference's order — and compares them bit for
+ * bit.  The ordered walk's tie / sliver radii (csrc/host/commit.cpp) are bounds on the rounding error of the
+ * watertight triangle test; a scene outside them would show up here as n_differing > 0 instead of silently
+ * leaving the reference image.  first_pixel (y * width + x, 0xFFFFFFFF if none) and max_abs_diff may be NULL.
+ * Costs two draws (the reference-order one is several times slower).  No reference counterpart. */
+int mcpt_renderer_check_walks(mcpt_renderer *r, uint64_t *n_differing, uint32_t *first_pixel, float *max_abs_diff);
+
 /* Tuning knob of the vote-scheduled ordered walk (scenes of >= 2048 primitives; the image does not
  * depend on it): a wavefront leaves its box-test phase for the primitive tests as soon as fewer than
  * `leave_below` lanes are still searching, or as soon as `leave_at` lanes hold a primitive (0 = never
@@ -170,6 +178,20 @@ int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint
  *          the lanes' registers (experiments; instantiated for few scene classes, otherwise falls back to mode 0).
  *   mode 0: the lane-owns-a-path state machine (csrc/path_core.h, round 1's kernel). */
 int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_t refill_at);
+/* Which random streams later draws use.  No reference counterpart for mode 1.
+ *   mode 0 (default): the reference's — Tea-seeded LCG per pixel, threaded through ALL samples of the pixel
+ *          (reference src/renderer/renderer.cpp:62-81, include/csrt/utils/math.hpp:43-63).  Frames are the CPU
+ *          reference's bit for bit; the samples of a pixel are inherently sequential, so a pixel is one lane's work.
+ *   mode 1: THROUGHPUT mode, not per-pixel comparable with the reference: every (pixel, sample) starts its own
+ *          stream from a PCG hash (RXS-M-XS) of (seed, pixel, sample index) — same pixel jitter, same generator
+ *          step inside the sample, same estimator — so the samples of a pixel are independent and are spread over
+ *          `sample_split` lanes (samples k, k + K, ...; 0 = as many as fill the GPU twice, in powers of two up to
+ *          64); a second kernel adds the lanes' sums in lane order (deterministic).  What it buys: small films and
+ *          small per-GPU tile shares still fill the GPU (strong scaling beyond one pixel per lane), and the tail
+ *          of a frame shortens.  Graded by mean-square error against a converged image, not per pixel.  Runs the
+ *          lane-owns-a-path kernel; whole frames or packed tile ranges. */
+int mcpt_renderer_set_rng(mcpt_renderer *r, int mode, uint32_t seed, uint32_t sample_split);
+
 /* Name of the kernel instantiation the last draw launched ("" before the first draw); renderer-owned string. */
 const char *mcpt_renderer_last_kernel(const mcpt_renderer *r);
 

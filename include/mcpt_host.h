@@ -22,6 +22,12 @@ extern "C" {
  * seconds (may be NULL): wall time of the pixel loop, commit excluded.  Returns 0 or non-zero with a message in
  * mcpt_host_last_error(). */
 int mcpt_host_render(const void *mcsd_bytes, size_t size, int threads, float *frame, double *seconds);
+/* The same for the 8x8 tiles tile_first, tile_first + tile_stride, ... (tile_count of them, 0 = all that exist;
+ * mcpt_tile_range of include/mcpt.h): packed == 0 writes their pixels into a full frame, packed != 0 writes the
+ * tiles back to back, 64 pixels x 3 floats each, pixels outside the image untouched — byte for byte what
+ * mcpt_renderer_draw_device produces on the GPU for the same range. */
+int mcpt_host_render_tiles(const void *mcsd_bytes, size_t size, int threads, uint32_t tile_first, uint32_t tile_stride,
+                           uint32_t tile_count, int packed, float *frame, double *seconds);
 const char *mcpt_host_last_error(void);
 
 #ifdef __cplusplus

@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmcpt_hip.so")
+LIB_PATH = os.environ.get("MCPT_LIB") or os.path.join(HERE, "libmcpt_hip.so")   # MCPT_LIB: experiment builds
 CSRC = os.path.join(HERE, "csrc")
 
 
@@ -93,8 +93,11 @@ def lib():
     L.mcpt_renderer_table.argtypes = [vp, cp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
     L.mcpt_renderer_info.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     L.mcpt_renderer_set_walk.argtypes = [vp, ctypes.c_int]
+    L.mcpt_renderer_check_walks.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(u32),
+                                            ctypes.POINTER(ctypes.c_float)]
     L.mcpt_renderer_set_walk_schedule.argtypes = [vp, u32, u32]
     L.mcpt_renderer_set_kernel.argtypes = [vp, i32, u32, u32]
+    L.mcpt_renderer_set_rng.argtypes = [vp, i32, u32, u32]
     L.mcpt_renderer_last_kernel.argtypes = [vp]
     L.mcpt_renderer_last_kernel.restype = cp
     L.mcpt_debug_lbvh_build.argtypes = [u32, vp, vp, i32, vp, vp, ctypes.POINTER(ctypes.c_double)]
@@ -128,7 +131,7 @@ EXPORTED_SYMBOLS = [
     "mcpt_renderer_draw", "mcpt_renderer_draw_device", "mcpt_renderer_draw_counted",
     "mcpt_renderer_tile_count", "mcpt_tile_range_size", "mcpt_unpack_tiles",
     "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_set_walk", "mcpt_renderer_set_walk_schedule",
-    "mcpt_renderer_set_kernel", "mcpt_renderer_last_kernel",
+    "mcpt_renderer_set_kernel", "mcpt_renderer_last_kernel", "mcpt_renderer_check_walks", "mcpt_renderer_set_rng",
     "mcpt_renderer_destroy",
     "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_trace_pixel",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
@@ -302,11 +305,24 @@ class Renderer:
         _check(lib().mcpt_renderer_set_walk(self._h, 1 if reference_order else 0))
         return self
 
+    def check_walks(self):
+        """Both ray queries on this film, compared bit for bit: (pixels that differ, first such pixel or None,
+        largest absolute difference)."""
+        n, first, worst = ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_float()
+        _check(lib().mcpt_renderer_check_walks(self._h, ctypes.byref(n), ctypes.byref(first), ctypes.byref(worst)))
+        return n.value, (None if first.value == 0xFFFFFFFF else first.value), worst.value
+
     def set_kernel(self, stream, slots: int = 0, refill_at: int = 0):
         """-1 (default): by scene class; True / 1: the stream kernel (workgroup-local ray pool) wherever the scene
         allows it; False / 0: the lane-owns-a-path kernel; 2: stream with `slots` slots per workgroup in memory.
         The image does not depend on it."""
         _check(lib().mcpt_renderer_set_kernel(self._h, int(stream), slots, refill_at))   # 2: slots in memory
+        return self
+
+    def set_rng(self, mode: int, seed: int = 0, sample_split: int = 0):
+        """0: the reference's random stream (default; frames comparable per pixel).  1: throughput mode — an
+        independent PCG-hashed stream per (pixel, sample), samples of a pixel spread over `sample_split` lanes."""
+        _check(lib().mcpt_renderer_set_rng(self._h, mode, seed, sample_split))
         return self
 
     def last_kernel(self) -> str:
@@ -369,22 +385,32 @@ class TiledRenderer:
 HOST_LIB_PATH = os.path.join(HERE, "libmcpt_host.so")
 
 
-def host_render(config: Config, threads: int = 0):
+def host_render(config: Config, threads: int = 0, rng: TileRange = None, packed: bool = False, out: np.ndarray = None):
     """The optional host build of the kernel body (include/mcpt_host.h; what `mcpt_cli --cpu` runs):
-    (frame, seconds).  A separate shared object — libmcpt_hip.so has no CPU path."""
+    (frame, seconds).  A separate shared object — libmcpt_hip.so has no CPU path.  With `rng` only that tile
+    range is rendered — into `out` / a zeroed full frame, or with packed=True into a packed tile buffer
+    (tiles x 64 x 3), exactly as mcpt_renderer_draw_device lays it out on the GPU."""
     if not os.path.exists(HOST_LIB_PATH):
         raise McptError(f"{HOST_LIB_PATH} is not built")
     H = ctypes.CDLL(HOST_LIB_PATH)
-    H.mcpt_host_render.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
-                                   ctypes.POINTER(ctypes.c_double)]
+    H.mcpt_host_render_tiles.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32,
+                                         ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
     H.mcpt_host_last_error.restype = ctypes.c_char_p
     w, h, _ = config.film()
     raw = config.serialize()
-    frame = np.empty((h, w, 3), dtype=np.float32)
+    rng = rng or TileRange(0, 1, 0)
+    if out is None:
+        if packed:
+            tiles = ((w + 7) // 8) * ((h + 7) // 8)
+            out = np.zeros((lib().mcpt_tile_range_size(tiles, ctypes.byref(rng)), 64, 3), dtype=np.float32)
+        else:
+            out = np.zeros((h, w, 3), dtype=np.float32)
+    assert out.dtype == np.float32 and out.flags.c_contiguous
     sec = ctypes.c_double()
-    if H.mcpt_host_render(raw, len(raw), threads, frame.ctypes.data, ctypes.byref(sec)) != 0:
+    if H.mcpt_host_render_tiles(raw, len(raw), threads, rng.tile_first, rng.tile_stride, rng.tile_count, int(packed),
+                                out.ctypes.data, ctypes.byref(sec)) != 0:
         raise McptError(H.mcpt_host_last_error().decode(errors="replace"))
-    return frame, sec.value
+    return out, sec.value
 
 
 def unpack_tiles(packed: np.ndarray, rng: TileRange, width: int, height: int, frame: np.ndarray):

@@ -5,6 +5,7 @@
 #include "mcpt.h"
 
 #include <chrono>
+#include <cmath>
 #include <dlfcn.h>
 #include <mutex>
 #include <thread>
@@ -120,11 +121,19 @@ struct mcpt_renderer
     // Renderer is not reentrant either, renderer.cpp:17-22)
     uint32_t *scratch_dev = nullptr;
     size_t scratch_words = 0;
+    // mcpt_renderer_set_rng: 0 = the reference's stream (one LCG per pixel through all its samples), 1 = an
+    // independent stream per (pixel, sample), the samples of a pixel spread over `sample_split` lanes (0 = auto)
+    int rng_mode = 0;
+    uint32_t rng_seed = 0, sample_split = 0;
+    float *planes_dev = nullptr; // partial sums of the split samples
+    size_t planes_floats = 0;
 
     ~mcpt_renderer()
     {
         if (scratch_dev)
             (void)hipFree(scratch_dev);
+        if (planes_dev)
+            (void)hipFree(planes_dev);
         if (frame_dev)
             (void)hipFree(frame_dev);
         if (counters_dev)
@@ -263,6 +272,44 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     job.tiles_x = r->TilesX();
     job.packed = packed ? 1u : 0u;
     job.reference_walk = r->reference_walk ? 1u : 0u;
+    job.sample_split = 1;
+    float *render_target = out_device;
+    const uint32_t out_pixels = packed ? job.n_items : static_cast<uint32_t>(r->flat.camera.width) * r->flat.camera.height;
+    if (r->rng_mode == 1 && job.n_items != 0)
+    {
+        job.independent_samples = 1, job.rng_seed = r->rng_seed;
+        uint32_t split = r->sample_split;
+        if (split == 0)
+        {
+            // auto: enough (pixel, sample-subset) items for two rounds of the GPU's resident lanes (4 wavefronts per
+            // SIMD), in powers of two
+            const uint64_t want = 2ull * r->n_cus * 1024ull;
+            for (split = 1; uint64_t(job.n_items) * split < want && split < 64; split *= 2)
+                ;
+        }
+        split = std::max(1u, std::min(split, r->flat.camera.spp));
+        job.sample_split = split;
+        if (split > 1)
+        {
+            job.plane_stride = out_pixels;
+            const size_t need = size_t(split) * out_pixels * 3;
+            if (need > r->planes_floats)
+            {
+                if (r->planes_dev)
+                {
+                    Check(hipDeviceSynchronize(), "wait before growing the sample planes");
+                    Check(hipFree(r->planes_dev), "free sample planes");
+                    r->planes_dev = nullptr, r->planes_floats = 0;
+                }
+                Check(hipMalloc(reinterpret_cast<void **>(&r->planes_dev), need * sizeof(float)), "allocate sample planes");
+                r->planes_floats = need;
+            }
+            render_target = r->planes_dev;
+            if (!packed && n_tiles != r->Tiles())
+                // a partial tile range into a full frame: pixels of other ranges must stay untouched by the reduction
+                throw std::runtime_error("the independent-sample mode with split samples draws whole frames or packed tile ranges.");
+        }
+    }
     mcpt::TraceCounters *counters = nullptr;
     if (counted)
     {
@@ -281,7 +328,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     // matpreview 1.3x) and loses where the whole scene sits in LDS and the lane-owns-a-path kernel is already
     // VALU-bound (cornell 0.77x, volumetric-caustic 0.5x): DESIGN.md section 3
     const bool auto_stream = r->kernel_mode == -1 && !mcpt::StreamPrefersLanes(r->dev);
-    if ((r->kernel_mode > 0 || auto_stream) && job.n_items != 0 && mcpt::StreamSupports(r->dev, job))
+    if ((r->kernel_mode > 0 || auto_stream) && job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && r->rng_mode == 0)
     {
         const hipError_t planned = mcpt::PlanRenderStream(r->dev, job, counted, r->n_cus, &plan, &variant);
         if (planned == hipSuccess)
@@ -308,8 +355,14 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     if (streamed)
         Check(mcpt::LaunchRenderStream(r->dev, job, out_device, counters, stream, r->scratch_dev, plan), "launch stream kernel");
     else
-        Check(mcpt::LaunchRender(r->dev, job, out_device, counters, stream, r->n_cus, &variant), "launch render kernel");
+        Check(mcpt::LaunchRender(r->dev, job, render_target, counters, stream, r->n_cus, &variant), "launch render kernel");
+    if (job.sample_split > 1)
+        Check(mcpt::LaunchReduceSamplePlanes(r->planes_dev, out_device, out_pixels, job.sample_split, job.plane_stride,
+                                             r->flat.camera.spp_inv, stream),
+              "reduce sample planes");
     r->variant = variant;
+    if (r->rng_mode == 1)
+        r->variant += ", independent samples x" + std::to_string(job.sample_split);
     if (timed)
         Check(hipEventRecord(r->ev_end, stream), "record event");
     if (blocking)
@@ -759,6 +812,43 @@ int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order)
     return 0;
 }
 
+int mcpt_renderer_check_walks(mcpt_renderer *r, uint64_t *n_differing, uint32_t *first_pixel, float *max_abs_diff)
+{
+    if (!r || !n_differing)
+        return Fail("null argument");
+    const bool saved = r->reference_walk;
+    const size_t n = static_cast<size_t>(r->flat.camera.width) * r->flat.camera.height;
+    std::vector<float> ordered(3 * n), reference(3 * n);
+    r->reference_walk = false;
+    int rc = DrawToHost(r, ordered.data(), nullptr, false);
+    r->reference_walk = true;
+    if (rc == 0)
+        rc = DrawToHost(r, reference.data(), nullptr, false);
+    r->reference_walk = saved;
+    if (rc != 0)
+        return rc;
+    uint64_t differing = 0;
+    uint32_t first = 0xFFFFFFFFu;
+    float worst = 0.0f;
+    for (size_t p = 0; p < n; ++p)
+        if (std::memcmp(&ordered[3 * p], &reference[3 * p], 3 * sizeof(float)) != 0)
+        {
+            if (differing++ == 0)
+                first = static_cast<uint32_t>(p);
+            for (int c = 0; c < 3; ++c)
+            {
+                const float d = std::fabs(ordered[3 * p + c] - reference[3 * p + c]);
+                worst = d > worst || d != d ? d : worst;
+            }
+        }
+    *n_differing = differing;
+    if (first_pixel)
+        *first_pixel = first;
+    if (max_abs_diff)
+        *max_abs_diff = worst;
+    return 0;
+}
+
 int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_t refill_at)
 {
     if (!r)
@@ -768,6 +858,22 @@ int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_
     if (slots % 256u != 0 || slots > 4096u || refill_at > 64u)
         return Fail("mcpt_renderer_set_kernel: slots is a multiple of 256 up to 4096, refill_at at most 64");
     r->kernel_mode = mode, r->stream_slots = slots, r->stream_refill = refill_at;
+    return 0;
+}
+
+int mcpt_renderer_set_rng(mcpt_renderer *r, int mode, uint32_t seed, uint32_t sample_split)
+{
+    if (!r)
+        return Fail("null argument");
+    if (mode != 0 && mode != 1)
+        return Fail("mcpt_renderer_set_rng: mode is 0 (reference stream) or 1 (independent PCG-hashed stream per sample)");
+    if (mode == 0 && sample_split > 1)
+        return Fail("mcpt_renderer_set_rng: the reference stream is sequential over a pixel's samples and cannot be split");
+    if (sample_split > 1024)
+        return Fail("mcpt_renderer_set_rng: sample_split at most 1024");
+    if (mode == 1 && r->flat.integrator.has_masks)
+        ; // (fine: the reference-order walk draws from whatever stream the path carries)
+    r->rng_mode = mode, r->rng_seed = seed, r->sample_split = sample_split;
     return 0;
 }
 

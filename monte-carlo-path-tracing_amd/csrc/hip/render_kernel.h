@@ -26,6 +26,10 @@ struct RenderJob
     uint32_t tiles_x;     // tiles per image row
     uint32_t packed;      // 0: write frame layout, 1: write packed tile layout
     uint32_t reference_walk; // 1: force the reference-order walk (validation); masks force it anyway
+    // independent-sample RNG mode (mcpt_renderer_set_rng; lane-owns-a-path kernel only).  sample_split = K >= 1:
+    // work item q = k * n_items + item renders samples k, k + K, ... of the item's pixel; with K > 1 `out` holds K
+    // planes of `plane_stride` pixels of UNNORMALISED sums that ReduceSamplePlanes folds into the frame.
+    uint32_t independent_samples, rng_seed, sample_split, plane_stride;
 };
 
 // ---- stream kernel (stream_core.h, stream_kernel_impl.h) ------------------------------------------
@@ -56,6 +60,10 @@ hipError_t LaunchRenderStream(const DeviceScene &sc, const RenderJob &job, float
 
 hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
                         hipStream_t stream, uint32_t n_cus, const char **variant);
+
+// frame[p] = (planes[0][p] + ... + planes[K-1][p]) / spp for p < n_pixels (3 floats each), planes K x plane_stride pixels.
+hipError_t LaunchReduceSamplePlanes(const float *planes, float *frame, uint32_t n_pixels, uint32_t split, uint32_t plane_stride,
+                                    float spp_inv, hipStream_t stream);
 
 // Multi-GPU gather: scatters one rank's packed tiles (device memory) into a device frame.
 hipError_t LaunchUnpackTiles(const float *packed, float *frame, uint32_t tile_first, uint32_t tile_stride, uint32_t n_tiles,

@@ -223,4 +223,30 @@ hipError_t LaunchUnpackTiles(const float *packed, float *frame, uint32_t tile_fi
     return hipGetLastError();
 }
 
+// Independent-sample RNG mode with the samples of a pixel spread over `split` lanes: the lanes' unnormalised
+// sums, added in lane order (deterministic), times 1 / spp.
+__global__ void __launch_bounds__(kBlockSize) reduce_sample_planes_kernel(const float *__restrict__ planes, float *__restrict__ frame,
+                                                                          uint32_t n_floats, uint32_t split, size_t plane_floats,
+                                                                          float spp_inv)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_floats)
+        return;
+    float sum = planes[i];
+    for (uint32_t k = 1; k < split; ++k)
+        sum += planes[k * plane_floats + i];
+    frame[i] = sum * spp_inv;
+}
+
+hipError_t LaunchReduceSamplePlanes(const float *planes, float *frame, uint32_t n_pixels, uint32_t split, uint32_t plane_stride,
+                                    float spp_inv, hipStream_t stream)
+{
+    const uint32_t n = n_pixels * 3u;
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(reduce_sample_planes_kernel, dim3((n + kBlockSize - 1) / kBlockSize), dim3(kBlockSize), 0, stream, planes,
+                       frame, n, split, static_cast<size_t>(plane_stride) * 3u, spp_inv);
+    return hipGetLastError();
+}
+
 } // namespace mcpt

@@ -109,36 +109,41 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     st.stack = reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + threadIdx.x;
     bool has_pixel = false;
     uint32_t slot = 0; // where this pixel's result goes
+    // reference RNG mode: split == 1, one item per pixel.  Independent-sample mode: item q = k * n_items + pixel
+    // item, samples k, k + split, ... (all uniform values: no cost in the reference mode)
+    const uint32_t split = job.sample_split ? job.sample_split : 1u, n_work = job.n_items * split;
+    const bool independent = job.independent_samples != 0;
     for (;;)
     {
         if (!has_pixel)
         {
-            if (q >= job.n_items)
+            if (q >= n_work)
                 break;
+            const uint32_t k = split == 1 ? 0u : q / job.n_items, item = q - k * job.n_items;
             // item -> tile -> pixel
-            const uint32_t local_tile = q >> 6, r = q & 63u;
+            const uint32_t local_tile = item >> 6, r = item & 63u;
             const uint32_t tile = job.tile_first + local_tile * job.tile_stride;
             const uint32_t x = (tile % job.tiles_x) * 8u + (r & 7u), y = (tile / job.tiles_x) * 8u + (r >> 3);
-            const uint32_t item = q;
             q += stride;
             if (x >= width || y >= height)
                 continue; // padding of an edge tile
             const uint32_t pixel = y * width + x;
             start_pixel(st, pixel);
-            slot = job.packed ? item : pixel;
+            st.sample = k;
+            slot = (job.packed ? item : pixel) + k * job.plane_stride;
             has_pixel = true;
         }
         if (!st.alive)
         {
             if (st.sample >= sc.camera.spp)
             {
-                const V3 c = pixel_value(sc, st);
+                const V3 c = split == 1 ? pixel_value(sc, st) : st.pixel_sum;
                 float *dst = out + 3 * static_cast<size_t>(slot);
                 dst[0] = c.x, dst[1] = c.y, dst[2] = c.z;
                 has_pixel = false;
                 continue;
             }
-            start_sample(sc, st);
+            start_sample(sc, st, split, independent, job.rng_seed);
             if (kCount)
                 ++local.samples;
         }
@@ -186,7 +191,7 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
         return err;
     if (per_cu < 1)
         per_cu = 1;
-    uint32_t blocks = (job.n_items + kBlockSize - 1) / kBlockSize;
+    uint32_t blocks = (job.n_items * (job.sample_split ? job.sample_split : 1u) + kBlockSize - 1) / kBlockSize;
     const uint32_t resident = max_blocks * static_cast<uint32_t>(per_cu);
     if (blocks > resident)
         blocks = resident;

@@ -97,8 +97,12 @@ MCPT_HD void start_pixel(PathState &st, uint32_t pixel)
     st.pixel_sum = V3{0, 0, 0};
 }
 
-// renderer.cpp:68-76: stratified-in-x / van der Corput-in-y jitter, pinhole ray
-MCPT_HD void start_sample(const DeviceScene &sc, PathState &st)
+// renderer.cpp:68-76: stratified-in-x / van der Corput-in-y jitter, pinhole ray.
+// `step` / `independent_seed`: the independent-sample RNG mode (mcpt_renderer_set_rng): the lane renders samples
+// s, s + step, ... of the pixel, and each sample starts its own random stream from a PCG hash of (seed, pixel,
+// sample) instead of continuing the pixel's — so the samples of a pixel can be spread over lanes.  The defaults
+// are the reference: one stream per pixel, every sample.
+MCPT_HD void start_sample(const DeviceScene &sc, PathState &st, uint32_t step = 1, bool independent = false, uint32_t seed = 0)
 {
     const CameraRec &cam = sc.camera;
     const uint32_t i = st.pixel % static_cast<uint32_t>(cam.width), j = st.pixel / static_cast<uint32_t>(cam.width);
@@ -113,7 +117,9 @@ MCPT_HD void start_sample(const DeviceScene &sc, PathState &st)
     st.depth = 0;
     st.pdf_sample = 0;
     st.medium = kNone;
-    ++st.sample;
+    if (independent)
+        st.rng = pcg_hash(pcg_hash(pcg_hash(seed) + st.pixel) + s);
+    st.sample += step;
 }
 
 // renderer.cpp:77-80: clamp each sample to 1 BEFORE averaging (quirk Q3)

@@ -149,6 +149,15 @@ MCPT_HD float lcg_next(uint32_t &state)
     return static_cast<float>(state & 0x00ffffffu) / static_cast<float>(0x01000000u);
 }
 
+// PCG output hash (O'Neill's RXS-M-XS 32-bit permutation over one LCG step): seeds of the independent-sample
+// RNG mode (no reference counterpart; the reference threads one LCG through all samples of a pixel).
+MCPT_HD uint32_t pcg_hash(uint32_t v)
+{
+    const uint32_t state = v * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+
 // Base-2 radical inverse with the reference's float index update
 // (`index *= base_inv`, math.hpp:36-38).
 MCPT_HD float radical_inverse2(uint32_t index)

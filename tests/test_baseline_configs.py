@@ -125,3 +125,21 @@ def test_baseline_config_full_size_properties(pkg, name):
     print(name, "kernels:", lanes_kernel, "|", stream_kernel, "stream kernel ms", st2["kernel_milliseconds"])
     print(name, "full size", (w, h, spp), "kernel ms", stats["kernel_milliseconds"],
           "Msamples/s", w * h * spp / stats["kernel_milliseconds"] / 1e3)
+
+
+WALK_CHECK = {"cornell": (512, 512, 16), "dragon": (320, 180, 8), "matpreview-rc": (256, 256, 16),
+              "matpreview-rd": (256, 256, 16), "volumetric": (640, 360, 16)}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_baseline_config_walk_self_check(pkg, name):
+    """mcpt_renderer_check_walks on every BASELINE configuration: the production ordered walk and the
+    reference-order walk give the same frame bit for bit (full-size runs: tests/full_size_walk_check.py,
+    profiles/r02_walk_self_check.json)."""
+    r = pkg.capi.Renderer(pkg.workloads.config(name, *WALK_CHECK[name]), device=0)
+    try:
+        n, first, worst = r.check_walks()
+    finally:
+        r.close()
+    assert n == 0, f"{n} pixels differ, first {first}, max |diff| {worst}"

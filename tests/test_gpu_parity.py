@@ -347,3 +347,74 @@ def test_cli_gpus_switch(pkg, tmp_path):
     assert r.returncode == 0, r.stderr
     want, _ = pkg.capi.Renderer(pkg.capi.Config.builtin("cornell-box").set_film(72, 40, 4)).draw()
     np.testing.assert_array_equal(np.fromfile(out, dtype=np.float32).reshape(40, 72, 3), want)
+
+
+# ---- throughput RNG mode (mcpt_renderer_set_rng mode 1): graded statistically, not per pixel -------------
+@pytest.mark.gpu
+def test_independent_sample_mode_is_an_unbiased_twin_of_the_reference_stream(pkg):
+    """Mode 1 gives every (pixel, sample) its own PCG-hashed stream.  Same estimator, different random numbers:
+    against the reference-stream frame at the same spp it must differ like two independent estimates do —
+    (a) frame means agree, (b) the RMSE between mode 1 and the reference stream is what two mode-1 frames with
+    different seeds differ by, (c) averaging more samples shrinks the difference to a converged frame."""
+    cfg = pkg.capi.Config.builtin("cornell-box").set_film(128, 128, 128)
+    r = pkg.capi.Renderer(cfg, device=0)
+    try:
+        ref, _ = r.draw()
+        a, _ = r.set_rng(1, seed=1).draw()
+        kernel = r.last_kernel()
+        b, _ = r.set_rng(1, seed=2).draw()
+        a_again, _ = r.set_rng(1, seed=1).draw()
+        ref_again, _ = r.set_rng(0).draw()
+    finally:
+        r.close()
+    assert "independent samples" in kernel
+    np.testing.assert_array_equal(ref, ref_again)        # switching back restores the reference stream bit for bit
+    np.testing.assert_array_equal(a, a_again)            # deterministic for a seed
+    assert not np.array_equal(a, b)
+    rmse = lambda x, y: float(np.sqrt(((x.astype(np.float64) - y) ** 2).mean()))
+    assert abs(a.mean() - ref.mean()) < 2e-3 * ref.mean(), (a.mean(), ref.mean())
+    between_seeds, to_reference = rmse(a, b), rmse(a, ref)
+    assert 0.75 < to_reference / between_seeds < 1.33, (to_reference, between_seeds)
+    converged = (a.astype(np.float64) + b) / 2
+    assert rmse(converged, ref) < 0.9 * to_reference
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("split", [1, 2, 8, 0])
+def test_sample_split_does_not_change_the_estimate(pkg, split):
+    """The samples of a pixel spread over K lanes (K = 1, 2, 8, auto): the same samples are drawn, only the
+    order of the float additions differs (per-lane partial sums, added in lane order)."""
+    cfg = pkg.capi.Config.builtin("cornell-box").set_film(96, 64, 32)
+    r = pkg.capi.Renderer(cfg, device=0)
+    try:
+        one, _ = r.set_rng(1, seed=7, sample_split=1).draw()
+        got, st = r.set_rng(1, seed=7, sample_split=split).draw()
+        kernel = r.last_kernel()
+        # packed tile ranges of two ranks compose to the same frame
+        import torch
+        composed = np.zeros_like(got)
+        for rank in range(2):
+            rng = pkg.capi.TileRange(rank, 2, 0)
+            buf = torch.zeros(r.tiles_in(rng) * 64 * 3, dtype=torch.float32, device="cuda:0")
+            r.draw_device(buf.data_ptr(), rng, packed=True)
+            pkg.capi.unpack_tiles(buf.cpu().numpy(), rng, 96, 64, composed)
+    finally:
+        r.close()
+    assert st["samples"] == 96 * 64 * 32
+    np.testing.assert_allclose(got, one, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(composed, one, rtol=0, atol=2e-6)
+    if split == 0:
+        assert "x32" in kernel or "x64" in kernel or "x16" in kernel, kernel   # a small film is split widely
+
+
+@pytest.mark.gpu
+def test_rng_mode_arguments(pkg):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a renderer (GPU)")
+    r = pkg.capi.Renderer(pkg.capi.Config.builtin("cornell-box").set_film(16, 16, 2), device=0)
+    with pytest.raises(pkg.capi.McptError, match="cannot be split"):
+        r.set_rng(0, 0, 4)
+    with pytest.raises(pkg.capi.McptError, match="mode is 0"):
+        r.set_rng(3)
+    r.close()

@@ -49,6 +49,62 @@ def test_gather_of_tiles_rebuilds_the_frame(world, pkg, oracle, mcsd_file, tmp_p
     assert np.array_equal(got, want)
 
 
+def _product_worker(rank, world, port, mcsd_path, width, height, out_path):
+    """Like _worker, but the rank's packed tile block is written by the PRODUCT's tile writer — the kernel body's
+    host build (libmcpt_host.so, mcpt_host_render_tiles), the same enumeration of tiles and the same packed layout as
+    the HIP kernel's — not derived from a full frame."""
+    sys.path[:0] = [ROOT]
+    import torch
+    import torch.distributed as dist
+    from _pkg import load_package
+    pkg = load_package()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fg = pkg.tiling.FrameGather(world, rank, width, height, torch.device("cpu"))
+    packed = np.full((fg.max_tiles, 64, 3), -1.0, dtype=np.float32)   # poison: padding must never reach the frame
+    cfg = pkg.capi.Config.load_mcsd(mcsd_path)
+    rng = pkg.capi.TileRange(rank, world, 0)
+    n_tiles = len(pkg.tiling.rank_tiles(rank, world, width, height))
+    block = np.ascontiguousarray(packed[:n_tiles])
+    pkg.capi.host_render(cfg, threads=2, rng=rng, packed=True, out=block)
+    packed[:n_tiles] = block
+    fg.packed.copy_(torch.from_numpy(packed.reshape(-1)))
+    frame = fg.gather()
+    if rank == 0:
+        np.save(out_path, frame.numpy().reshape(height, width, 3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_of_the_products_own_packed_tiles(world, pkg, mcsd_file, tmp_path):
+    """World-2 / world-3 gloo run fed by the product's packed-tile writer (host build of the kernel body): the
+    gathered frame equals the compiled reference's golden frame bit for bit."""
+    import torch.multiprocessing as mp
+    from golden_cases import cases
+    scene = cases(pkg.scenes)["cornell_64_spp8"]
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "cornell_64_spp8.npz"))["frame"]
+    path = mcsd_file(scene)
+    out = str(tmp_path / "frame.npy")
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_product_worker, args=(world, port, path, 64, 64, out), nprocs=world, join=True)
+    assert np.array_equal(np.load(out), golden)
+
+
+def test_host_tile_writer_matches_full_frame(pkg):
+    """mcpt_host_render_tiles: frame layout and packed layout of three ranks' tile ranges (edge tiles in both
+    directions) compose to the full-frame render."""
+    cfg = pkg.capi.Config.builtin("cornell-box").set_film(44, 29, 2)
+    full, _ = pkg.capi.host_render(cfg)
+    composed, from_packed = np.zeros_like(full), np.zeros_like(full)
+    for rank in range(3):
+        rng = pkg.capi.TileRange(rank, 3, 0)
+        pkg.capi.host_render(cfg, rng=rng, out=composed)
+        block, _ = pkg.capi.host_render(cfg, rng=rng, packed=True)
+        pkg.capi.unpack_tiles(block, rng, 44, 29, from_packed)
+    assert np.array_equal(composed, full) and np.array_equal(from_packed, full)
+
+
 def test_partition_covers_every_pixel_once(pkg):
     for world in (1, 2, 3, 8):
         for (w, h) in ((512, 512), (1280, 720), (21, 13)):
