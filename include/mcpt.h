@@ -165,9 +165,11 @@ int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint
 
 /* Which kernel formulation later draws use; the image does not depend on it (tests assert the frames are
  * bit-identical).  Replaces the reference's megakernel dispatch (src/renderer/renderer.cpp:88-95).
- *   mode -1 (default): by scene class — the stream kernel for scenes whose traversal data does not fit LDS
- *          (meshes: long, uneven walks), the lane-owns-a-path kernel for the few-KB scenes (cornell-box,
- *          volumetric-caustic) where it is already VALU-bound and faster.
+ *   mode -1 (default): the lane-owns-a-path kernel for the few-KB scenes whose traversal data sits in LDS
+ *          (cornell-box, volumetric-caustic: it is VALU-bound there and faster); for every other scene the
+ *          renderer's FIRST draw calibrates — both formulations render a sample of the frame's tiles at a few
+ *          spp, the faster one is kept (they are within +-20 % of each other and the winner depends on the scene:
+ *          DESIGN.md section 3).  mcpt_renderer_last_kernel reports the choice and the two timings.
  *   mode 1: the STREAM kernel (csrc/stream_core.h) — a workgroup owns `slots` path slots (0 = built-in
  *          choice, otherwise a multiple of 256) whose rays go through a workgroup-local pool: emitted rays are
  *          compacted by wavefront ballot / prefix count, a lane that finishes a ray fetches the next one

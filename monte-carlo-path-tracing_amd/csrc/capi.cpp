@@ -10,6 +10,7 @@
 #include <mutex>
 #include <thread>
 #include <functional>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -116,6 +117,10 @@ struct mcpt_renderer
     // mcpt_renderer_set_kernel: -1 = by scene class (the default), 1 / 2 = stream kernel where the scene allows
     // it, 0 = lane-owns-a-path kernel
     int kernel_mode = -1;
+    // kernel_mode -1: which formulation the first draw's calibration found faster on THIS scene (-1 = not yet
+    // calibrated, 0 = lane-owns-a-path, 1 = stream), and what it measured
+    int auto_choice = -1;
+    float auto_ms[2] = {0, 0};
     uint32_t stream_slots = 0, stream_refill = 0;
     // slot storage of the stream kernel's workgroups; one draw at a time per renderer (the reference's
     // Renderer is not reentrant either, renderer.cpp:17-22)
@@ -259,6 +264,47 @@ uint32_t RangeSize(uint32_t tiles_total, const mcpt_tile_range &range)
     return range.tile_count == 0 ? available : (range.tile_count < available ? range.tile_count : available);
 }
 
+void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, bool packed, hipStream_t stream,
+          bool blocking, bool counted, mcpt_stats *stats);
+
+// Times both kernel formulations on a sample of the frame (every k-th tile so that about 8192 tiles = two rounds of
+// the GPU's lanes take part, at most 8 spp) and records the faster one in r->auto_choice.  Blocking; runs once per
+// renderer, costs well under 1 % of a BASELINE-size frame.
+void Calibrate(mcpt_renderer *r, hipStream_t stream)
+{
+    const uint32_t tiles = r->Tiles();
+    const uint32_t step = std::max(1u, tiles / 8192u);
+    const mcpt_tile_range sample{0, step, 0};
+    const uint32_t n = (tiles + step - 1) / step;
+    float *scratch = nullptr;
+    Check(hipMalloc(reinterpret_cast<void **>(&scratch), size_t(n) * 192 * sizeof(float)), "allocate calibration tiles");
+    const uint32_t spp = r->dev.camera.spp;
+    const float spp_inv = r->dev.camera.spp_inv;
+    const uint32_t few = std::min(spp, 8u);
+    r->dev.camera.spp = few, r->dev.camera.spp_inv = 1.0f / static_cast<float>(few);
+    const int saved_mode = r->kernel_mode;
+    try
+    {
+        for (int pass = 0; pass < 2; ++pass) // pass 0 warms the caches and the code objects up
+            for (int mode = 0; mode < 2; ++mode)
+            {
+                r->kernel_mode = mode;
+                mcpt_stats st{};
+                Draw(r, scratch, sample, true, stream, true, false, &st);
+                r->auto_ms[mode] = static_cast<float>(st.kernel_milliseconds);
+            }
+    }
+    catch (...)
+    {
+        r->kernel_mode = saved_mode, r->dev.camera.spp = spp, r->dev.camera.spp_inv = spp_inv;
+        (void)hipFree(scratch);
+        throw;
+    }
+    r->kernel_mode = saved_mode, r->dev.camera.spp = spp, r->dev.camera.spp_inv = spp_inv;
+    (void)hipFree(scratch);
+    r->auto_choice = r->auto_ms[1] < r->auto_ms[0] ? 1 : 0;
+}
+
 // Enqueues one render launch; optionally waits and reports timings.
 void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, bool packed, hipStream_t stream,
           bool blocking, bool counted, mcpt_stats *stats)
@@ -327,7 +373,18 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     // by scene class: the stream kernel wins where walks are long and uneven (meshes: dragon stand-in 1.4x,
     // matpreview 1.3x) and loses where the whole scene sits in LDS and the lane-owns-a-path kernel is already
     // VALU-bound (cornell 0.77x, volumetric-caustic 0.5x): DESIGN.md section 3
-    const bool auto_stream = r->kernel_mode == -1 && !mcpt::StreamPrefersLanes(r->dev);
+    // kernel_mode -1: small scenes (traversal data in LDS) always take the lane-owns-a-path kernel (VALU-bound there,
+    // the stream kernel measured 0.5-0.77x); for the others the two formulations are within +-20 % of each other
+    // and which one wins depends on the scene (dragon 1.20x, matpreview 1.07-1.11x for the stream kernel;
+    // classroom 0.88x, dining-room 0.86x), so the first draw CALIBRATES: both kernels render every k-th tile at a
+    // few spp into a scratch frame, the faster one is kept for this renderer (measure, don't guess).
+    if (r->kernel_mode == -1 && r->auto_choice < 0 && !counted)
+    {
+        r->auto_choice = 0;
+        if (!mcpt::StreamPrefersLanes(r->dev) && job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && r->rng_mode == 0)
+            Calibrate(r, stream);
+    }
+    const bool auto_stream = r->kernel_mode == -1 && r->auto_choice == 1;
     if ((r->kernel_mode > 0 || auto_stream) && job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && r->rng_mode == 0)
     {
         const hipError_t planned = mcpt::PlanRenderStream(r->dev, job, counted, r->n_cus, &plan, &variant);
@@ -361,6 +418,12 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                                              r->flat.camera.spp_inv, stream),
               "reduce sample planes");
     r->variant = variant;
+    if (r->kernel_mode == -1 && r->auto_ms[1] > 0.0f)
+    {
+        char note[96];
+        std::snprintf(note, sizeof note, " [calibrated on this scene: lanes %.3f ms, stream %.3f ms]", r->auto_ms[0], r->auto_ms[1]);
+        r->variant += note;
+    }
     if (r->rng_mode == 1)
         r->variant += ", independent samples x" + std::to_string(job.sample_split);
     if (timed)
@@ -858,6 +921,7 @@ int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_
     if (slots % 256u != 0 || slots > 4096u || refill_at > 64u)
         return Fail("mcpt_renderer_set_kernel: slots is a multiple of 256 up to 4096, refill_at at most 64");
     r->kernel_mode = mode, r->stream_slots = slots, r->stream_refill = refill_at;
+    r->auto_choice = -1; // (mode -1 calibrates again at the next draw)
     return 0;
 }
 

@@ -42,10 +42,13 @@ struct StreamControl // LDS, double-buffered by round parity
 #ifndef MCPT_STREAM_WAVES_SMALL_FULL
 #define MCPT_STREAM_WAVES_SMALL_FULL 3
 #endif
+#ifndef MCPT_STREAM_WAVES_MEMORY
+#define MCPT_STREAM_WAVES_MEMORY 2
+#endif
 template <uint32_t kFeatures, bool kLdsGeometry, bool kRegs>
 struct StreamBudget
 {
-    static constexpr int kWavesPerSimd = !kRegs ? 2
+    static constexpr int kWavesPerSimd = !kRegs ? MCPT_STREAM_WAVES_MEMORY
                                          : !kLdsGeometry ? MCPT_STREAM_WAVES_MESH
                                          : (kFeatures & (kFeatVolPath | kFeatAnalytic | kFeatMicrofacet)) ? MCPT_STREAM_WAVES_SMALL_FULL
                                                                                                         : 4;

@@ -26,6 +26,7 @@ GROUPS = [   # SQ has 8 slots per pass, TCC 4 (FETCH_SIZE takes 3, WRITE_SIZE 2)
     ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum"],
     ["FETCH_SIZE"],
     ["WRITE_SIZE"],
+    ["SQC_ICACHE_REQ", "SQC_ICACHE_HITS", "SQC_ICACHE_MISSES", "SQC_ICACHE_MISSES_DUPLICATE", "SQ_IFETCH", "SQ_IFETCH_LEVEL"],
 ]
 
 
@@ -36,12 +37,16 @@ def main():
     ap.add_argument("--workdir", default="gpurun_out/pmc_passes")
     ap.add_argument("--command", default=None,
                     help="profile this command instead of bench.py (e.g. 'python tools/render_scene.py standin:blob-field')")
+    ap.add_argument("--groups", default=None, help="comma-separated indices of the counter groups to run (default: all)")
     ap.add_argument("rest", nargs="*")
     a = ap.parse_args()
     env = dict(os.environ, TMPDIR="/tmp")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     counters, kernels, failed = {}, set(), []
+    wanted = None if a.groups is None else {int(x) for x in a.groups.split(",")}
     for gi, group in enumerate(GROUPS):
+        if wanted is not None and gi not in wanted:
+            continue
         d = os.path.join(a.workdir, f"pass{gi}")
         os.makedirs(d, exist_ok=True)
         target = (a.command.split() if a.command else
@@ -76,6 +81,10 @@ def main():
         for k in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_BRANCH"):
             if k in c:
                 derived[k.lower() + "_per_valu"] = c[k] / c["SQ_INSTS_VALU"]
+    if c.get("SQC_ICACHE_REQ"):
+        derived["icache_miss_rate"] = c.get("SQC_ICACHE_MISSES", 0.0) / c["SQC_ICACHE_REQ"]
+        if c.get("SQ_IFETCH"):
+            derived["ifetch_level_per_fetch"] = c.get("SQ_IFETCH_LEVEL", 0.0) / c["SQ_IFETCH"]
     if "FETCH_SIZE" in c:
         derived["hbm_read_bytes_note"] = "FETCH_SIZE/WRITE_SIZE are in KiB; apply the guide's gfx950 correction"
         derived["fetch_kib"] = c["FETCH_SIZE"]
