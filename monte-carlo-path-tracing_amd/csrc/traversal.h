@@ -554,6 +554,10 @@ MCPT_HD bool is_leading_lane()
 #endif
 }
 
+#ifndef MCPT_SIGN_ADDRESSED_NODES
+#define MCPT_SIGN_ADDRESSED_NODES 1 // measured: cornell 992 -> 1007 Msamples/s, frame unchanged (profiles/r02_experiments)
+#endif
+
 // Loop shape ("while-while"): an inner loop of pure node steps runs until the lane
 // holds a primitive or has run out of work, then the primitive test runs.  On the
 // GPU the wavefront therefore stays in the node phase until EVERY lane holds a
@@ -571,13 +575,14 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
     stack[0] = kWalkDone;
     uint32_t depth = 1; // entries on the stack
     uint32_t cur = 0;   // the top node
+#if MCPT_SIGN_ADDRESSED_NODES && defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t near_x = ray.dir_rcp.x > 0 ? 0u : 4u, near_y = ray.dir_rcp.y > 0 ? 0u : 4u, near_z = ray.dir_rcp.z > 0 ? 0u : 4u;
+#endif
     for (;;)
     {
         // ---- node steps until the lane holds a primitive or runs out of work ----
         while (!(cur & kWalkLeaf))
         {
-            const float4 *n = sc.walk_nodes + 4 * static_cast<size_t>(cur);
-            const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
             if (kCount)
             {
                 stats.node_tests += 2;
@@ -585,8 +590,39 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
                     ++stats.wave_node_steps;
             }
             float enter0, enter1;
-            const bool hit0 = box_enter(n0, n1, ray, enter0), hit1 = box_enter(n2, n3, ray, enter1);
-            const uint32_t ref0 = as_uint(n0.w), ref1 = as_uint(n1.w);
+            bool hit0, hit1;
+            uint32_t ref0, ref1;
+#if MCPT_SIGN_ADDRESSED_NODES && defined(__HIP_DEVICE_COMPILE__)
+            {
+                // (this walk runs on hierarchies staged in LDS.)  The slab test needs, per axis, the box plane the
+                // ray enters through and the one it leaves through; which of lo / hi that is depends on the sign of
+                // the ray's direction only.  Instead of loading the whole record and SELECTING (12 v_cndmask per
+                // node step, a 4-cycle VALU class), the lane READS the right words: the record is 16 words
+                // {lo0 ref0 | hi0 ref1 | lo1 - | hi1 -}, the entry plane of axis k is word k + near_k, near_k = 0 or 4.
+                // Same operands, same arithmetic; the selects become LDS addresses.
+                const float *w = reinterpret_cast<const float *>(sc.walk_nodes) + 16 * static_cast<size_t>(cur);
+                const float *wnx = w + near_x, *wfx = w + (4u - near_x), *wny = w + near_y + 1, *wfy = w + (5u - near_y),
+                            *wnz = w + near_z + 2, *wfz = w + (6u - near_z);
+                const float nx0 = (wnx[0] - ray.origin.x) * ray.dir_rcp.x, fx0 = (wfx[0] - ray.origin.x) * ray.dir_rcp.x;
+                const float ny0 = (wny[0] - ray.origin.y) * ray.dir_rcp.y, fy0 = (wfy[0] - ray.origin.y) * ray.dir_rcp.y;
+                const float nz0 = (wnz[0] - ray.origin.z) * ray.dir_rcp.z, fz0 = (wfz[0] - ray.origin.z) * ray.dir_rcp.z;
+                const float nx1 = (wnx[8] - ray.origin.x) * ray.dir_rcp.x, fx1 = (wfx[8] - ray.origin.x) * ray.dir_rcp.x;
+                const float ny1 = (wny[8] - ray.origin.y) * ray.dir_rcp.y, fy1 = (wfy[8] - ray.origin.y) * ray.dir_rcp.y;
+                const float nz1 = (wnz[8] - ray.origin.z) * ray.dir_rcp.z, fz1 = (wfz[8] - ray.origin.z) * ray.dir_rcp.z;
+                enter0 = fmaxf(fmaxf(fmaxf(kEpsDistance, nx0), ny0), nz0);
+                enter1 = fmaxf(fmaxf(fmaxf(kEpsDistance, nx1), ny1), nz1);
+                hit0 = enter0 <= fminf(fminf(fminf(ray.t_max, fx0), fy0), fz0);
+                hit1 = enter1 <= fminf(fminf(fminf(ray.t_max, fx1), fy1), fz1);
+                ref0 = as_uint(w[3]), ref1 = as_uint(w[7]);
+            }
+#else
+            {
+                const float4 *n = sc.walk_nodes + 4 * static_cast<size_t>(cur);
+                const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+                hit0 = box_enter(n0, n1, ray, enter0), hit1 = box_enter(n2, n3, ray, enter1);
+                ref0 = as_uint(n0.w), ref1 = as_uint(n1.w);
+            }
+#endif
             // both hit: continue with the nearer child, postpone the other; one hit: go
             // there; none: take the most recently postponed reference.  Branch free: the
             // postponed reference is ALWAYS stored at the top (it only becomes part of the
