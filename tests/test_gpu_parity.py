@@ -267,10 +267,11 @@ def test_reference_side_binding_renders_the_same_frame(pkg, mcsd_file, tmp_path)
 def test_device_pixel_trace_matches_the_host_build(pkg, mcsd_file):
     """mcpt_debug_trace_pixel: the per-step record of a pixel on the device against the CPU build
     of the same kernel body (tests/emu): same primitives, same LCG states, same depths, rays
-    and throughput within a few roundings (device libm).  This is the tool that showed why the
-    reference's classroom scene cannot match per pixel between ANY two float implementations:
-    a last-bit difference in a scattered direction grows ~30-100x per bounce among its thin
-    curved furniture parts."""
+    and throughput.  This is the tool that showed, in round 1, why the reference's classroom scene
+    did not match per pixel: a last-bit difference of the device's libm in a scattered direction grew
+    ~30-100x per bounce among its thin curved furniture parts; with glibc's algorithms on the device
+    (csrc/glibc_libm.h) the difference is gone and that scene is bit-exact too
+    (profiles/r02_real_scenes_bit_exact.json)."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
     import emu
