@@ -167,9 +167,10 @@ int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint
  * bit-identical).  Replaces the reference's megakernel dispatch (src/renderer/renderer.cpp:88-95).
  *   mode -1 (default): the lane-owns-a-path kernel for the few-KB scenes whose traversal data sits in LDS
  *          (cornell-box, volumetric-caustic: it is VALU-bound there and faster); for every other scene the
- *          renderer's FIRST draw calibrates — both formulations render a sample of the frame's tiles at a few
- *          spp, the faster one is kept (they are within +-20 % of each other and the winner depends on the scene:
- *          DESIGN.md section 3).  mcpt_renderer_last_kernel reports the choice and the two timings.
+ *          renderer's FIRST draw calibrates — lanes kernel with fixed lists, lanes kernel with the work counter and
+ *          stream kernel with the work counter render a sample of the frame's tiles at a few spp, the fastest is kept
+ *          (they are within +-25 % of each other and the winner depends on the scene: DESIGN.md section 3).
+ *          mcpt_renderer_last_kernel reports the choice and the three timings.
  *   mode 1: the STREAM kernel (csrc/stream_core.h) — a workgroup owns `slots` path slots (0 = built-in
  *          choice, otherwise a multiple of 256) whose rays go through a workgroup-local pool: emitted rays are
  *          compacted by wavefront ballot / prefix count, a lane that finishes a ray fetches the next one
@@ -180,6 +181,28 @@ int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint
  *          the lanes' registers (experiments; instantiated for few scene classes, otherwise falls back to mode 0).
  *   mode 0: the lane-owns-a-path state machine (csrc/path_core.h, round 1's kernel). */
 int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_t refill_at);
+/* How the pixels of a draw reach the lanes; the image does not depend on it.  0: every lane walks a fixed list
+ * (item q, q + launched lanes, ...).  1: a work counter in HBM — a lane that has finished a pixel takes the next
+ * item nobody has taken yet (one atomic per wavefront and fetch), in image (tile) order.  Pixels cost very
+ * different amounts (a camera ray that leaves the scene against a 17-bounce path through glass), and with fixed
+ * lists a frame lasts as long as the unluckiest wavefront's list: dragon/scene.xml 698 -> 969, matpreview 363 ->
+ * 491 / 231 -> 338, volumetric-caustic 767 -> 855 Msamples/s at full size.  -1 (default): 1 for the scenes whose
+ * hierarchy sits in LDS; for the others part of the first draw's calibration (see mcpt_renderer_set_kernel) —
+ * the reference's dining-room is 15 % faster with fixed lists.  No reference counterpart (its CPU back end hands
+ * out 64-pixel patches dynamically, renderer.cpp:688-699; its CUDA back end launches one thread per pixel). */
+int mcpt_renderer_set_work_distribution(mcpt_renderer *r, int mode);
+
+/* Primary-visibility pre-pass (csrc/hip/primary_kernel.hip): the camera ray of sample s of pixel p is a function of
+ * (p, s) alone — stratified in x, van der Corput in y, no random number (reference src/renderer/renderer.cpp:68-76) —
+ * so the closest hits of ALL camera rays of a draw are computed first by a lean kernel (one lane per (pixel, sample),
+ * coherent wavefronts), and the render kernels start every sample at its first vertex.  Same image, bit for bit; the
+ * first of the closest rays of every sample leaves the sequential per-pixel chain.  Costs 8 bytes of HBM per sample of
+ * the frame.  mode -1 (default): on for scenes whose hierarchy does not sit in LDS, where the scene allows it (no
+ * opacity masks, not the reference-order validation walk, no split samples) — dragon/scene.xml 1.4x, the reference's
+ * dining-room 1.07x, matpreview +-0; the LDS-resident scenes lose 4-5 % to it; 0: off; 1: on wherever allowed.  Replaces the camera-ray part of the first
+ * Scene::Intersect of ShadePath (src/renderer/integrators/path.cpp:18-21). */
+int mcpt_renderer_set_prepass(mcpt_renderer *r, int mode);
+
 /* Which random streams later draws use.  No reference counterpart for mode 1.
  *   mode 0 (default): the reference's — Tea-seeded LCG per pixel, threaded through ALL samples of the pixel
  *          (reference src/renderer/renderer.cpp:62-81, include/csrt/utils/math.hpp:43-63).  Frames are the CPU

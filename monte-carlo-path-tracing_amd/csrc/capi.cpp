@@ -120,7 +120,7 @@ struct mcpt_renderer
     // kernel_mode -1: which formulation the first draw's calibration found faster on THIS scene (-1 = not yet
     // calibrated, 0 = lane-owns-a-path, 1 = stream), and what it measured
     int auto_choice = -1;
-    float auto_ms[2] = {0, 0};
+    float auto_ms[3] = {0, 0, 0}; // lanes + fixed lists, lanes + work counter, stream + work counter
     uint32_t stream_slots = 0, stream_refill = 0;
     // slot storage of the stream kernel's workgroups; one draw at a time per renderer (the reference's
     // Renderer is not reentrant either, renderer.cpp:17-22)
@@ -132,6 +132,12 @@ struct mcpt_renderer
     uint32_t rng_seed = 0, sample_split = 0;
     float *planes_dev = nullptr; // partial sums of the split samples
     size_t planes_floats = 0;
+    // mcpt_renderer_set_prepass: -1 = the library's choice, 0 = off, 1 = on wherever the scene allows it
+    int prepass_mode = -1;
+    uint32_t *prehit_dev = nullptr; // camera-ray hits of the whole frame, 2 words per (pixel, sample)
+    size_t prehit_words = 0;
+    uint32_t *work_counter_dev = nullptr; // RenderJob::work_counter (dynamic work distribution), zeroed before every launch
+    int work_mode = -1;                   // mcpt_renderer_set_work_distribution: -1 library's choice, 0 fixed lists, 1 work counter
 
     ~mcpt_renderer()
     {
@@ -139,6 +145,10 @@ struct mcpt_renderer
             (void)hipFree(scratch_dev);
         if (planes_dev)
             (void)hipFree(planes_dev);
+        if (prehit_dev)
+            (void)hipFree(prehit_dev);
+        if (work_counter_dev)
+            (void)hipFree(work_counter_dev);
         if (frame_dev)
             (void)hipFree(frame_dev);
         if (counters_dev)
@@ -267,10 +277,19 @@ uint32_t RangeSize(uint32_t tiles_total, const mcpt_tile_range &range)
 void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, bool packed, hipStream_t stream,
           bool blocking, bool counted, mcpt_stats *stats);
 
-// Times both kernel formulations on a sample of the frame (every k-th tile so that about 8192 tiles = two rounds of
-// the GPU's lanes take part, at most 8 spp) and records the faster one in r->auto_choice.  Blocking; runs once per
-// renderer, costs well under 1 % of a BASELINE-size frame.
-void Calibrate(mcpt_renderer *r, hipStream_t stream)
+// Times the candidate configurations of a scene outside LDS on a sample of the frame (every k-th tile so that about
+// 8192 tiles = two rounds of the GPU's lanes take part, at most 8 spp) and records the fastest in r->auto_choice:
+//   0 lane-owns-a-path kernel, fixed per-lane pixel lists     1 the same with the work counter
+//   2 stream kernel with the work counter
+// (each with the camera-ray pre-pass when the scene allows it).  Blocking; once per renderer; about 1 % of a
+// BASELINE-size frame.
+struct AutoCandidate
+{
+    int kernel, work;
+};
+constexpr AutoCandidate kAutoCandidates[3] = {{0, 0}, {0, 1}, {1, 1}};
+
+void Calibrate(mcpt_renderer *r, hipStream_t stream, bool stream_allowed)
 {
     const uint32_t tiles = r->Tiles();
     const uint32_t step = std::max(1u, tiles / 8192u);
@@ -282,27 +301,35 @@ void Calibrate(mcpt_renderer *r, hipStream_t stream)
     const float spp_inv = r->dev.camera.spp_inv;
     const uint32_t few = std::min(spp, 8u);
     r->dev.camera.spp = few, r->dev.camera.spp_inv = 1.0f / static_cast<float>(few);
-    const int saved_mode = r->kernel_mode;
+    const int saved_kernel = r->kernel_mode, saved_work = r->work_mode;
     try
     {
         for (int pass = 0; pass < 2; ++pass) // pass 0 warms the caches and the code objects up
-            for (int mode = 0; mode < 2; ++mode)
+            for (int c = 0; c < 3; ++c)
             {
-                r->kernel_mode = mode;
+                if (kAutoCandidates[c].kernel == 1 && !stream_allowed)
+                {
+                    r->auto_ms[c] = 0.0f;
+                    continue;
+                }
+                r->kernel_mode = kAutoCandidates[c].kernel, r->work_mode = kAutoCandidates[c].work;
                 mcpt_stats st{};
                 Draw(r, scratch, sample, true, stream, true, false, &st);
-                r->auto_ms[mode] = static_cast<float>(st.kernel_milliseconds);
+                r->auto_ms[c] = static_cast<float>(st.kernel_milliseconds);
             }
     }
     catch (...)
     {
-        r->kernel_mode = saved_mode, r->dev.camera.spp = spp, r->dev.camera.spp_inv = spp_inv;
+        r->kernel_mode = saved_kernel, r->work_mode = saved_work, r->dev.camera.spp = spp, r->dev.camera.spp_inv = spp_inv;
         (void)hipFree(scratch);
         throw;
     }
-    r->kernel_mode = saved_mode, r->dev.camera.spp = spp, r->dev.camera.spp_inv = spp_inv;
+    r->kernel_mode = saved_kernel, r->work_mode = saved_work, r->dev.camera.spp = spp, r->dev.camera.spp_inv = spp_inv;
     (void)hipFree(scratch);
-    r->auto_choice = r->auto_ms[1] < r->auto_ms[0] ? 1 : 0;
+    r->auto_choice = 0;
+    for (int c = 1; c < 3; ++c)
+        if (r->auto_ms[c] > 0.0f && r->auto_ms[c] < r->auto_ms[r->auto_choice])
+            r->auto_choice = c;
 }
 
 // Enqueues one render launch; optionally waits and reports timings.
@@ -373,18 +400,23 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     // by scene class: the stream kernel wins where walks are long and uneven (meshes: dragon stand-in 1.4x,
     // matpreview 1.3x) and loses where the whole scene sits in LDS and the lane-owns-a-path kernel is already
     // VALU-bound (cornell 0.77x, volumetric-caustic 0.5x): DESIGN.md section 3
-    // kernel_mode -1: small scenes (traversal data in LDS) always take the lane-owns-a-path kernel (VALU-bound there,
-    // the stream kernel measured 0.5-0.77x); for the others the two formulations are within +-20 % of each other
-    // and which one wins depends on the scene (dragon 1.20x, matpreview 1.07-1.11x for the stream kernel;
-    // classroom 0.88x, dining-room 0.86x), so the first draw CALIBRATES: both kernels render every k-th tile at a
-    // few spp into a scratch frame, the faster one is kept for this renderer (measure, don't guess).
-    if (r->kernel_mode == -1 && r->auto_choice < 0 && !counted)
+    // The library's choices (kernel_mode -1, work_mode -1).  Small scenes (traversal data in LDS): the lane-owns-a-path
+    // kernel (VALU-bound there; the stream kernel measured 0.5-0.77x) with the work counter (volumetric-caustic +11 %,
+    // cornell +-0).  Every other scene: formulation and work distribution are within +-25 % of each other and the winner
+    // depends on the scene (full size, Msamples/s, lanes fixed / lanes counter / stream counter: dragon 601 / 614 / 969,
+    // matpreview-rc 364 / 411 / 491, classroom 163 / 159 / 131, dining-room 72 / 63 / 69), so the renderer's first draw
+    // CALIBRATES on a sample of the frame and keeps the fastest (measure, don't guess).
+    const bool small_scene = mcpt::StreamPrefersLanes(r->dev);
+    const bool can_stream = job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && r->rng_mode == 0;
+    if ((r->kernel_mode == -1 || r->work_mode == -1) && r->auto_choice < 0 && !counted)
     {
-        r->auto_choice = 0;
-        if (!mcpt::StreamPrefersLanes(r->dev) && job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && r->rng_mode == 0)
-            Calibrate(r, stream);
+        r->auto_choice = 1; // lanes + work counter
+        if (!small_scene && r->kernel_mode == -1 && r->work_mode == -1 && job.n_items != 0)
+            Calibrate(r, stream, can_stream);
     }
-    const bool auto_stream = r->kernel_mode == -1 && r->auto_choice == 1;
+    const int choice = r->auto_choice < 0 ? 1 : r->auto_choice;
+    const bool auto_stream = r->kernel_mode == -1 && kAutoCandidates[choice].kernel == 1 && !small_scene;
+    const bool dynamic_work = r->work_mode == -1 ? kAutoCandidates[choice].work == 1 : r->work_mode == 1;
     if ((r->kernel_mode > 0 || auto_stream) && job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && r->rng_mode == 0)
     {
         const hipError_t planned = mcpt::PlanRenderStream(r->dev, job, counted, r->n_cus, &plan, &variant);
@@ -407,8 +439,41 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         else if (planned != hipErrorNotSupported && planned != hipErrorOutOfMemory)
             Check(planned, "plan the stream kernel");
     }
+    if (dynamic_work)
+    {
+        if (!r->work_counter_dev)
+            Check(hipMalloc(reinterpret_cast<void **>(&r->work_counter_dev), sizeof(uint32_t)), "allocate work counter");
+        Check(hipMemsetAsync(r->work_counter_dev, 0, sizeof(uint32_t), stream), "clear work counter");
+        job.work_counter = r->work_counter_dev;
+    }
     if (timed)
         Check(hipEventRecord(r->ev_begin, stream), "record event");
+    // primary-visibility pre-pass: every camera ray of the job ahead of the sample chains (hip/primary_kernel.hip);
+    // inside the timed region.  The buffer covers the whole frame (8 B per sample), capped at 32 GiB of the 288.
+    r->dev.prehit = nullptr;
+    // (mode -1: scenes outside LDS only — the LDS-resident ones trace their coherent camera rays in-kernel at LDS
+    //  latency, and the pre-pass costs them 4-5 %: cornell 1040 -> 999, volumetric-caustic 855 -> 800 Msamples/s)
+    if ((r->prepass_mode == 1 || (r->prepass_mode == -1 && !small_scene)) && job.n_items != 0 &&
+        mcpt::PrimaryPrepassSupports(r->dev, job))
+    {
+        const size_t words = size_t(r->flat.camera.width) * r->flat.camera.height * r->dev.camera.spp * 2;
+        if (words * sizeof(uint32_t) <= (size_t(32) << 30))
+        {
+            if (words > r->prehit_words)
+            {
+                if (r->prehit_dev)
+                {
+                    Check(hipDeviceSynchronize(), "wait before growing the pre-pass buffer");
+                    Check(hipFree(r->prehit_dev), "free pre-pass buffer");
+                    r->prehit_dev = nullptr, r->prehit_words = 0;
+                }
+                Check(hipMalloc(reinterpret_cast<void **>(&r->prehit_dev), words * sizeof(uint32_t)), "allocate pre-pass buffer");
+                r->prehit_words = words;
+            }
+            Check(mcpt::LaunchPrimaryPrepass(r->dev, job, r->prehit_dev, counters, stream, r->n_cus), "launch pre-pass kernel");
+            r->dev.prehit = r->prehit_dev;
+        }
+    }
     if (streamed)
         Check(mcpt::LaunchRenderStream(r->dev, job, out_device, counters, stream, r->scratch_dev, plan), "launch stream kernel");
     else
@@ -418,14 +483,20 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                                              r->flat.camera.spp_inv, stream),
               "reduce sample planes");
     r->variant = variant;
-    if (r->kernel_mode == -1 && r->auto_ms[1] > 0.0f)
+    if (r->dev.prehit)
+        r->variant += " + camera-ray pre-pass";
+    if (dynamic_work)
+        r->variant += ", work counter";
+    if (r->kernel_mode == -1 && r->work_mode == -1 && r->auto_ms[0] > 0.0f)
     {
-        char note[96];
-        std::snprintf(note, sizeof note, " [calibrated on this scene: lanes %.3f ms, stream %.3f ms]", r->auto_ms[0], r->auto_ms[1]);
+        char note[160];
+        std::snprintf(note, sizeof note, " [calibrated on this scene: lanes fixed lists %.3f ms, lanes work counter %.3f ms, stream %.3f ms]",
+                      r->auto_ms[0], r->auto_ms[1], r->auto_ms[2]);
         r->variant += note;
     }
     if (r->rng_mode == 1)
         r->variant += ", independent samples x" + std::to_string(job.sample_split);
+    r->dev.prehit = nullptr; // (the unit kernels launched with r->dev never use it)
     if (timed)
         Check(hipEventRecord(r->ev_end, stream), "record event");
     if (blocking)
@@ -922,6 +993,28 @@ int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_
         return Fail("mcpt_renderer_set_kernel: slots is a multiple of 256 up to 4096, refill_at at most 64");
     r->kernel_mode = mode, r->stream_slots = slots, r->stream_refill = refill_at;
     r->auto_choice = -1; // (mode -1 calibrates again at the next draw)
+    return 0;
+}
+
+int mcpt_renderer_set_work_distribution(mcpt_renderer *r, int mode)
+{
+    if (!r)
+        return Fail("null argument");
+    if (mode < -1 || mode > 1)
+        return Fail("mcpt_renderer_set_work_distribution: mode is -1 (the library's choice), 0 (fixed per-lane pixel lists) or 1 (work counter)");
+    r->work_mode = mode;
+    r->auto_choice = -1;
+    return 0;
+}
+
+int mcpt_renderer_set_prepass(mcpt_renderer *r, int mode)
+{
+    if (!r)
+        return Fail("null argument");
+    if (mode < -1 || mode > 1)
+        return Fail("mcpt_renderer_set_prepass: mode is -1 (the library's choice), 0 (off) or 1 (on where the scene allows it)");
+    r->prepass_mode = mode;
+    r->auto_choice = -1;
     return 0;
 }
 

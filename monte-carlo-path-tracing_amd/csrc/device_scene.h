@@ -267,6 +267,12 @@ struct DeviceScene
     const float *env_tables;
     const float *lut_brdf;   // kLutRes * kLutRes
     const float *lut_albedo; // kLutRes
+    // Primary-visibility pre-pass (hip/primary_kernel.hip), or null: the closest hit of the CAMERA ray of sample s of
+    // pixel p, two words at 2 (p * spp + s): primitive (kNone: miss) and instance.  The camera ray of a sample is a
+    // function of (pixel, sample index) only — stratified in x, van der Corput in y, no random number
+    // (renderer.cpp:68-76) — so all of a frame's camera rays can be traced ahead of the per-pixel sample chains, by
+    // a lean kernel with coherent wavefronts, and the chains start every sample at its first vertex.
+    const uint32_t *prehit;
 };
 
 // Counters of the measurement mode: totals over a launch.

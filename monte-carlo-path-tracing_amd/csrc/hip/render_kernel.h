@@ -30,6 +30,13 @@ struct RenderJob
     // work item q = k * n_items + item renders samples k, k + K, ... of the item's pixel; with K > 1 `out` holds K
     // planes of `plane_stride` pixels of UNNORMALISED sums that ReduceSamplePlanes folds into the frame.
     uint32_t independent_samples, rng_seed, sample_split, plane_stride;
+    // Dynamic work distribution (null: every lane walks its fixed list q, q + stride, ...): a zeroed counter in HBM;
+    // a lane that has finished a pixel takes the next item not yet handed out (one atomic per wavefront and fetch).
+    // Pixels cost very different amounts (a camera ray that leaves the scene against a 17-bounce path on glass), and
+    // with fixed lists the frame lasts as long as the unluckiest wavefront's list.  Items are handed out in image (tile)
+    // order: lanes that fetch at about the same time work on neighbouring pixels (a permuted order — tiles far apart —
+    // was measured: matpreview 400 against 436 Msamples/s, the locality is worth more than the spread).
+    uint32_t *work_counter;
 };
 
 // ---- stream kernel (stream_core.h, stream_kernel_impl.h) ------------------------------------------
@@ -60,6 +67,14 @@ hipError_t LaunchRenderStream(const DeviceScene &sc, const RenderJob &job, float
 
 hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
                         hipStream_t stream, uint32_t n_cus, const char **variant);
+
+// Primary-visibility pre-pass (hip/primary_kernel.hip): the closest hit of every camera ray of the job's pixels into
+// `prehit` (2 words per (pixel, sample) of the WHOLE frame: width * height * spp * 2 words); the render kernels use it
+// when DeviceScene::prehit points to it.  Not for scenes with opacity masks, the reference-order validation walk, or
+// split samples.
+bool PrimaryPrepassSupports(const DeviceScene &sc, const RenderJob &job);
+hipError_t LaunchPrimaryPrepass(const DeviceScene &sc, const RenderJob &job, uint32_t *prehit, TraceCounters *counters,
+                                hipStream_t stream, uint32_t n_cus);
 
 // frame[p] = (planes[0][p] + ... + planes[K-1][p]) / spp for p < n_pixels (3 floats each), planes K x plane_stride pixels.
 hipError_t LaunchReduceSamplePlanes(const float *planes, float *frame, uint32_t n_pixels, uint32_t split, uint32_t plane_stride,

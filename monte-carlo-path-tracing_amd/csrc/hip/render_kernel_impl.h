@@ -124,7 +124,9 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
             const uint32_t local_tile = item >> 6, r = item & 63u;
             const uint32_t tile = job.tile_first + local_tile * job.tile_stride;
             const uint32_t x = (tile % job.tiles_x) * 8u + (r & 7u), y = (tile / job.tiles_x) * 8u + (r >> 3);
-            q += stride;
+            // the lane's NEXT item: the first one nobody has taken yet (the launch's lanes start on items 0 .. stride-1),
+            // or, without a counter, the next of its fixed list
+            q = job.work_counter ? stride + wave_reserve(job.work_counter, true) : q + stride;
             if (x >= width || y >= height)
                 continue; // padding of an edge tile
             const uint32_t pixel = y * width + x;

@@ -114,10 +114,11 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         pixel = y * width + x;
         return x < width && y < height;
     };
-    // gives the slot the first pixel of its sequence at or after item q
+    // gives the slot the first pixel of its sequence at or after item q (fixed lists q, q + stride, ...), or — with the
+    // job's work counter — the first item nobody has taken yet (all lanes of the wavefront call this together)
     auto assign = [&](StreamSlot<S> &s, uint32_t q)
     {
-        for (;; q += stride)
+        for (;; q = job.work_counter ? stride + wave_reserve(job.work_counter, true) : q + stride)
         {
             if (q >= job.n_items)
             {
@@ -170,7 +171,7 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
                 const V3 c = pixel_value(sc, s.st);
                 float *dst = out + 3 * static_cast<size_t>(job.packed ? s.item : s.st.pixel);
                 dst[0] = c.x, dst[1] = c.y, dst[2] = c.z;
-                assign(s, s.item + stride);
+                assign(s, job.work_counter ? stride + wave_reserve(job.work_counter, true) : s.item + stride);
             }
         };
         auto list_rays = [&](const StreamSlot<S> &s, uint32_t i)

@@ -358,8 +358,19 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
     Ray ray = make_ray(st.origin, st.dir);
     HitRaw raw;
     TraceStats ts{0, 0, 0, 0};
-    const bool hit_valid = trace<C, false>(sc, st.stack, ray, st.rng, raw, ts, cnt != nullptr);
-    if (cnt)
+    bool hit_valid;
+    const bool known = C::kOrdered && st.primary && sc.prehit != nullptr; // the pre-pass traced this camera ray
+    if (known)
+    {
+        const uint32_t *rec = sc.prehit + 2 * (static_cast<size_t>(st.pixel) * sc.camera.spp + (st.sample - 1u)); // (start_sample advanced it; the pre-pass is not combined with split samples)
+        const uint32_t prim = rec[0];
+        hit_valid = prim != kNone;
+        if (hit_valid)
+            hit_from_record<C::kAnalytic>(sc, rec[1], prim, ray, raw);
+    }
+    else
+        hit_valid = trace<C, false>(sc, st.stack, ray, st.rng, raw, ts, cnt != nullptr);
+    if (cnt && !known)
     {
         ++cnt->closest_rays, cnt->node_tests += ts.node_tests, cnt->prim_tests += ts.prim_tests;
         cnt->wave_node_steps += ts.wave_node_steps, cnt->wave_prim_steps += ts.wave_prim_steps;

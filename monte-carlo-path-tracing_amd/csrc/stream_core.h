@@ -411,6 +411,9 @@ enum StreamShadeResult : uint32_t
 };
 
 // One slot, one round.  Call again after handling kStreamPixelDone.
+// With the primary-visibility pre-pass (sc.prehit) a new sample's camera ray is not emitted: its hit is known, the
+// sample's first vertex is shaded at once — and if the sample ends there (a camera ray that leaves the scene, an
+// emitter seen directly, ...) the next sample starts in the same call.
 template <class C, uint32_t S>
 MCPT_HD StreamShadeResult stream_shade(const DeviceScene &sc, StreamSlot<S> &s, LaneCounters *cnt)
 {
@@ -420,15 +423,23 @@ MCPT_HD StreamShadeResult stream_shade(const DeviceScene &sc, StreamSlot<S> &s, 
         return kStreamContinue;
     stream_fold(s);
     s.flags &= ~(kSlotExtRay | (kSlotShadow0 * ((1u << S) - 1u)));
+    bool at_vertex = false; // a hit record waits to be shaded: the traced extension ray's, or a camera ray's from the pre-pass
     if (s.flags & kSlotEnded)
     {
         s.flags &= ~kSlotEnded;
         finish_sample(st);
     }
-    else if (st.alive)
-        stream_vertex<C, S>(sc, s, cnt);
-    if (!st.alive && !(s.flags & kSlotEnded))
+    else
+        at_vertex = st.alive;
+    for (;;) // (ONE call site of stream_vertex: the shading code is inlined once)
     {
+        if (at_vertex)
+        {
+            stream_vertex<C, S>(sc, s, cnt); // alive with its next ray, ended (waiting for shadow answers), or finished
+            at_vertex = false;
+        }
+        if (st.alive || (s.flags & kSlotEnded))
+            break;
         if (st.sample >= sc.camera.spp)
         {
             stream_pack(s);
@@ -437,6 +448,18 @@ MCPT_HD StreamShadeResult stream_shade(const DeviceScene &sc, StreamSlot<S> &s, 
         start_sample(sc, st);
         if (cnt)
             ++cnt->samples;
+        if (sc.prehit == nullptr)
+            break;
+        const uint32_t *rec = sc.prehit + 2 * (static_cast<size_t>(st.pixel) * sc.camera.spp + (st.sample - 1u));
+        const uint32_t prim = rec[0];
+        s.hit_valid = prim != kNone, s.hit_t = kMaxFloat;
+        if (s.hit_valid)
+        {
+            Ray ray = make_ray(st.origin, st.dir);
+            hit_from_record<C::kAnalytic>(sc, rec[1], prim, ray, s.hit);
+            s.hit_t = ray.t_max;
+        }
+        at_vertex = true;
     }
     if (st.alive)
         s.flags |= kSlotExtRay;
@@ -607,42 +630,6 @@ MCPT_HD void stream_save(const StreamStore &m, uint32_t i, const StreamSlot<S> &
 
 // ---- trace ------------------------------------------------------------------------------------
 // Wavefront helpers (a "wavefront" of the host build is one lane).
-MCPT_HD uint32_t lane_rank_among(bool p, uint32_t &total) // index of this lane among the lanes where p holds
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned long long mask = __ballot(p);
-    total = static_cast<uint32_t>(__popcll(mask));
-    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
-#else
-    total = p ? 1u : 0u;
-    return 0u;
-#endif
-}
-
-// One counter bump for all lanes of the wavefront where p holds: returns this lane's index in the
-// reserved range [base, base + n).  (One LDS atomic per wavefront instead of one per lane.)
-MCPT_HD uint32_t wave_reserve(uint32_t *counter, bool p)
-{
-    uint32_t n;
-    const uint32_t rank = lane_rank_among(p, n);
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t base = 0;
-    if (p && rank == 0)
-        base = atomicAdd(counter, n);
-    const unsigned long long mask = __ballot(p);
-    if (mask == 0)
-        return 0;
-    base = __builtin_amdgcn_readlane(base, __ffsll(static_cast<long long>(mask)) - 1);
-    return base + rank;
-#else
-    if (!p)
-        return 0;
-    const uint32_t base = *counter;
-    *counter += n;
-    return base + rank;
-#endif
-}
-
 // The ray list of a round: extension rays (closest queries, the long ones) are listed from the front,
 // shadow rays behind them, so that the pool is drained longest-first.
 struct StreamRayList

@@ -544,6 +544,35 @@ MCPT_HD bool test_slot(const DeviceScene &sc, uint32_t slot, Ray &ray, HitRaw &h
     return take;
 }
 
+// The hit record of a closest query whose WINNER is already known (primary-visibility pre-pass): the winner's own
+// test on the same ray gives the same barycentrics / object-space point, side and distance as it did inside the
+// walk (test_slot copies exactly these values when it accepts a primitive).  Sets ray.t_max to the distance.
+template <bool kAnalytic>
+MCPT_HD void hit_from_record(const DeviceScene &sc, uint32_t inst, uint32_t prim, Ray &ray, HitRaw &hit)
+{
+    SlotHit h;
+    if (!kAnalytic || sc.instances[inst].kind == kInstTriangles)
+        h = triangle_probe(sc.tri_pos + 3 * static_cast<size_t>(prim), ray); // (walk_prims holds copies of these vertices)
+    else
+    {
+        const InstanceRec &rec = sc.instances[inst];
+        Ray probe = ray;
+        probe.t_max = kMaxFloat;
+        HitRaw cand;
+        cand.a = cand.b = cand.c = 0.0f, cand.inside = false;
+        uint32_t unused_rng = 0;
+        if (rec.kind == kInstSphere)
+            h.hit = sphere_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, probe, unused_rng, cand);
+        else if (rec.kind == kInstDisk)
+            h.hit = disk_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, probe, unused_rng, cand);
+        else
+            h.hit = cylinder_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, probe, unused_rng, cand);
+        h.t = probe.t_max, h.a = cand.a, h.b = cand.b, h.c = cand.c, h.inside = cand.inside;
+    }
+    hit.inst = inst, hit.prim = prim, hit.a = h.a, hit.b = h.b, hit.c = h.c, hit.inside = h.inside;
+    ray.t_max = h.t;
+}
+
 // True for exactly one of the currently active lanes of the wavefront.
 MCPT_HD bool is_leading_lane()
 {
@@ -663,6 +692,43 @@ MCPT_HD uint32_t lanes_where(bool p)
     return static_cast<uint32_t>(__popcll(__ballot(p)));
 #else
     return p ? 1u : 0u;
+#endif
+}
+
+// Wavefront aggregation helpers (a "wavefront" of the host build is one lane).
+MCPT_HD uint32_t lane_rank_among(bool p, uint32_t &total) // index of this lane among the lanes where p holds
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long mask = __ballot(p);
+    total = static_cast<uint32_t>(__popcll(mask));
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+#else
+    total = p ? 1u : 0u;
+    return 0u;
+#endif
+}
+
+// One counter bump for all lanes of the wavefront where p holds: returns this lane's index in the
+// reserved range [base, base + n).  (One LDS atomic per wavefront instead of one per lane.)
+MCPT_HD uint32_t wave_reserve(uint32_t *counter, bool p)
+{
+    uint32_t n;
+    const uint32_t rank = lane_rank_among(p, n);
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t base = 0;
+    if (p && rank == 0)
+        base = atomicAdd(counter, n);
+    const unsigned long long mask = __ballot(p);
+    if (mask == 0)
+        return 0;
+    base = __builtin_amdgcn_readlane(base, __ffsll(static_cast<long long>(mask)) - 1);
+    return base + rank;
+#else
+    if (!p)
+        return 0;
+    const uint32_t base = *counter;
+    *counter += n;
+    return base + rank;
 #endif
 }
 

@@ -419,3 +419,56 @@ def test_rng_mode_arguments(pkg):
     with pytest.raises(pkg.capi.McptError, match="mode is 0"):
         r.set_rng(3)
     r.close()
+
+
+# ---- scheduling choices that must not change a single bit: kernel formulation x work distribution x pre-pass ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell_96_spp32", "rough_dielectric_envmap", "volpath_medium_mixed", "terrain_directional",
+                                  "rough_plastic_constant_cyl"])
+def test_scheduling_choices_do_not_change_the_image(name, pkg, scenes):
+    """Lane-owns-a-path vs stream kernel, fixed per-lane pixel lists vs the work counter, camera rays traced in the
+    sample chain vs by the primary-visibility pre-pass: 8 combinations, one frame — the compiled reference's golden."""
+    golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
+    try:
+        seen = set()
+        for kernel in (0, 1):
+            for work in (0, 1):
+                for prepass in (0, 1):
+                    frame, _ = r.set_kernel(kernel).set_work_distribution(work).set_prepass(prepass).draw()
+                    seen.add(r.last_kernel())
+                    assert np.array_equal(frame, golden), (kernel, work, prepass, r.last_kernel())
+        assert any("pre-pass" in k for k in seen) and any("work counter" in k for k in seen), seen
+        frame, _ = r.set_kernel(-1).set_work_distribution(-1).set_prepass(-1).draw()   # the library's own choice
+        assert np.array_equal(frame, golden), r.last_kernel()
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
+def test_prepass_is_not_used_where_the_camera_ray_consumes_random_numbers(pkg, scenes):
+    """An opacity mask draws a random number during the walk (bsdf.cpp:272-276): the camera ray's hit is part of the
+    pixel's random chain there, so the pre-pass must stay off even when asked for — and the frame is the golden."""
+    golden = np.load(os.path.join(GOLDEN, "masked_area_flat.npz"))["frame"]
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes["masked_area_flat"]), device=0)
+    try:
+        frame, _ = r.set_prepass(1).draw()
+        assert "pre-pass" not in r.last_kernel()
+        assert np.array_equal(frame, golden)
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
+def test_calibration_reports_its_measurements(pkg):
+    """A scene outside LDS: the first draw times three configurations on a sample of the frame and says so."""
+    scene = pkg.scenes.material_preview("rough_conductor", "envmap", "mesh", 160, 120, 8)
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
+    try:
+        assert r.info()["primitives"] >= 2048
+        a, _ = r.draw()
+        assert "calibrated on this scene" in r.last_kernel()
+        b, _ = r.set_kernel(0).set_work_distribution(0).set_prepass(0).draw()
+        assert np.array_equal(a, b)
+    finally:
+        r.close()
