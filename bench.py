@@ -87,7 +87,7 @@ def stream_bandwidth(torch, device):
     return out
 
 
-def pmc_leg(workload, film, kernel_hint, timeout_s=300):
+def pmc_leg(workload, film, choice, timeout_s=300):
     """Hardware counters of the render kernel for one full-size launch of the workload: rocprofv3 runs
     tools/render_scene.py (one draw) once per counter group.  Returns None when rocprofv3 is not there."""
     if shutil.which("rocprofv3") is None:
@@ -100,7 +100,8 @@ def pmc_leg(workload, film, kernel_hint, timeout_s=300):
         for gi, group in enumerate(PMC_GROUPS):
             d = os.path.join(tmp, f"pass{gi}")
             target = [sys.executable, os.path.join(ROOT, "tools", "render_scene.py"), f"workload:{workload}",
-                      "--film", *map(str, film), "--draws", "1"]
+                      "--film", *map(str, film), "--draws", "1", "--kernel-mode", str(choice[0]), "--work", str(choice[1]),
+                      "--prepass", str(choice[2])]   # the timed run's (calibrated) choice, made explicit: no calibration launches
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", *group, "--output-format", "csv", "-d", d, "-o", "p",
                    "--", *target]
             try:
@@ -114,17 +115,18 @@ def pmc_leg(workload, film, kernel_hint, timeout_s=300):
                 continue
             for row in csv.DictReader(open(files[0])):
                 name = row["Kernel_Name"]
-                if "render_kernel" not in name and "stream_kernel" not in name:
+                if "render_kernel" not in name and "stream_kernel" not in name and "primary_kernel" not in name:
                     continue
                 kernels.add(name.split("(")[0][-90:])
                 counters[row["Counter_Name"]] = counters.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
             for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "render_kernel" in row["Kernel_Name"] or "stream_kernel" in row["Kernel_Name"]:
+                    if any(k in row["Kernel_Name"] for k in ("render_kernel", "stream_kernel", "primary_kernel")):
                         if gi == 0:
                             duration_ns.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    # one draw = [camera-ray pre-pass +] render kernel: the step's kernel time is their sum
     return {"counters": counters, "kernels": sorted(kernels), "failed": failed,
-            "kernel_ns": float(np.mean(duration_ns)) if duration_ns else None}
+            "kernel_ns": float(np.sum(duration_ns)) if duration_ns else None}
 
 
 def cpu_baseline(pkg, workload, W, H, SPP, budget_s=12.0):
@@ -278,6 +280,7 @@ def main():
         elapsed = float(t.item())
     kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # same stream as the launches
     kernel_name = renderer.last_kernel()
+    choice = renderer.last_choice()   # (kernel, work distribution, pre-pass) the timed steps ran
 
     # The same job in the THROUGHPUT mode (independent PCG-hashed stream per (pixel, sample), the samples of a
     # pixel spread over lanes): reported next to `value`, never as `value`.  With the reference stream a pixel's
@@ -328,6 +331,7 @@ def main():
         # GPU and its share of the tiles, kernel time from one more (blocking) draw of that share.
         count_spp = min(SPP, 16)
         rc = make_renderer(count_spp)
+        rc.set_kernel(choice[0]).set_work_distribution(choice[1]).set_prepass(choice[2])
         _, counts = rc.draw(counted=True)
         scene_info = rc.info()
         rc.close()
@@ -357,7 +361,7 @@ def main():
                 "kernel": kernel_name, "kernel_ms": kernel_ms, "per_sample": per_sample, "walk": walk, "hbm": hbm,
                 "scene": {"walk_nodes": scene_info["walk_nodes"], "primitives": scene_info["primitives"],
                           "geometry_bytes": scene_info["geometry_bytes"]}}
-        pmc = None if (args.no_pmc or world > 1 or args.rng != "reference") else pmc_leg(name, (W, H, SPP), kernel_name)
+        pmc = None if (args.no_pmc or world > 1 or args.rng != "reference") else pmc_leg(name, (W, H, SPP), choice)
         if pmc and pmc["counters"].get("SQ_INSTS_VALU") and pmc["kernel_ns"]:
             c = pmc["counters"]
             pmc_ms = pmc["kernel_ns"] * 1e-6
@@ -398,7 +402,8 @@ def main():
                                 % (100 * issue, 100 * lanes))
             roof["pmc"] = {"kernels": pmc["kernels"], "failed": pmc["failed"],
                            "command": "rocprofv3 --kernel-trace --pmc <group> -- python tools/render_scene.py "
-                                      f"workload:{name} --film {W} {H} {SPP} --draws 1 (one pass per group)"}
+                                      f"workload:{name} --film {W} {H} {SPP} --draws 1 --kernel-mode {choice[0]} --work {choice[1]} "
+                                      f"--prepass {choice[2]} (one pass per group; counters and durations summed over the draw's kernels)"}
         else:
             roof["note"] = ("no counter pass (rocprofv3 absent, --no-pmc or N > 1): algorithmic bytes (32 B/box test, "
                             "36 B/primitive test, 132 B/shaded hit, 12 B/pixel) over the kernel time against the "
@@ -425,6 +430,9 @@ def main():
                              "max_l2": float(l2.max()), "frac_gt_1e-3": float((l2 > 1e-3).mean()),
                              "frac_exact": float((l2 == 0).mean())}
         print(json.dumps(out))
+    if args.force_gather:
+        step()   # (the throughput-mode loop above left its own frame in the gather buffer)
+        sync()
     if rank == 0 and args.force_gather:
         # the gathered frame must be the plain full-frame draw, bit for bit
         plain, _ = renderer.draw()

@@ -181,6 +181,10 @@ int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint
  *          the lanes' registers (experiments; instantiated for few scene classes, otherwise falls back to mode 0).
  *   mode 0: the lane-owns-a-path state machine (csrc/path_core.h, round 1's kernel). */
 int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_t refill_at);
+/* What the last draw actually ran, as arguments for mcpt_renderer_set_kernel / _set_work_distribution / _set_prepass
+ * (so that a second renderer, a profiler run, ... can repeat the calibrated choice without calibrating). */
+int mcpt_renderer_last_choice(const mcpt_renderer *r, int *kernel, int *work_distribution, int *prepass);
+
 /* How the pixels of a draw reach the lanes; the image does not depend on it.  0: every lane walks a fixed list
  * (item q, q + launched lanes, ...).  1: a work counter in HBM — a lane that has finished a pixel takes the next
  * item nobody has taken yet (one atomic per wavefront and fetch), in image (tile) order.  Pixels cost very

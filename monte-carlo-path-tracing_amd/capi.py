@@ -100,6 +100,7 @@ def lib():
     L.mcpt_renderer_set_rng.argtypes = [vp, i32, u32, u32]
     L.mcpt_renderer_set_prepass.argtypes = [vp, i32]
     L.mcpt_renderer_set_work_distribution.argtypes = [vp, i32]
+    L.mcpt_renderer_last_choice.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.mcpt_renderer_last_kernel.argtypes = [vp]
     L.mcpt_renderer_last_kernel.restype = cp
     L.mcpt_debug_lbvh_build.argtypes = [u32, vp, vp, i32, vp, vp, ctypes.POINTER(ctypes.c_double)]
@@ -133,7 +134,7 @@ EXPORTED_SYMBOLS = [
     "mcpt_renderer_draw", "mcpt_renderer_draw_device", "mcpt_renderer_draw_counted",
     "mcpt_renderer_tile_count", "mcpt_tile_range_size", "mcpt_unpack_tiles",
     "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_set_walk", "mcpt_renderer_set_walk_schedule",
-    "mcpt_renderer_set_kernel", "mcpt_renderer_last_kernel", "mcpt_renderer_check_walks", "mcpt_renderer_set_rng", "mcpt_renderer_set_prepass", "mcpt_renderer_set_work_distribution",
+    "mcpt_renderer_set_kernel", "mcpt_renderer_last_kernel", "mcpt_renderer_check_walks", "mcpt_renderer_set_rng", "mcpt_renderer_set_prepass", "mcpt_renderer_set_work_distribution", "mcpt_renderer_last_choice",
     "mcpt_renderer_destroy",
     "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_trace_pixel",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
@@ -326,6 +327,12 @@ class Renderer:
         independent PCG-hashed stream per (pixel, sample), samples of a pixel spread over `sample_split` lanes."""
         _check(lib().mcpt_renderer_set_rng(self._h, mode, seed, sample_split))
         return self
+
+    def last_choice(self):
+        """(kernel, work distribution, pre-pass) the last draw ran — arguments for the three setters."""
+        k, w, p = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(lib().mcpt_renderer_last_choice(self._h, ctypes.byref(k), ctypes.byref(w), ctypes.byref(p)))
+        return k.value, w.value, p.value
 
     def set_work_distribution(self, mode: int):
         """-1 library's choice (default), 0 fixed per-lane pixel lists, 1 work counter (dynamic).  Image unchanged."""

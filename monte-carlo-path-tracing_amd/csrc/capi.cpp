@@ -121,6 +121,7 @@ struct mcpt_renderer
     // calibrated, 0 = lane-owns-a-path, 1 = stream), and what it measured
     int auto_choice = -1;
     float auto_ms[3] = {0, 0, 0}; // lanes + fixed lists, lanes + work counter, stream + work counter
+    int last_kernel = 0, last_work = 0, last_prepass = 0; // what the last draw actually ran (mcpt_renderer_last_choice)
     uint32_t stream_slots = 0, stream_refill = 0;
     // slot storage of the stream kernel's workgroups; one draw at a time per renderer (the reference's
     // Renderer is not reentrant either, renderer.cpp:17-22)
@@ -483,6 +484,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                                              r->flat.camera.spp_inv, stream),
               "reduce sample planes");
     r->variant = variant;
+    r->last_kernel = streamed ? (r->kernel_mode == 2 ? 2 : 1) : 0, r->last_work = dynamic_work ? 1 : 0, r->last_prepass = r->dev.prehit ? 1 : 0;
     if (r->dev.prehit)
         r->variant += " + camera-ray pre-pass";
     if (dynamic_work)
@@ -1035,6 +1037,19 @@ int mcpt_renderer_set_rng(mcpt_renderer *r, int mode, uint32_t seed, uint32_t sa
 }
 
 const char *mcpt_renderer_last_kernel(const mcpt_renderer *r) { return r ? r->variant.c_str() : ""; }
+
+int mcpt_renderer_last_choice(const mcpt_renderer *r, int *kernel, int *work_distribution, int *prepass)
+{
+    if (!r)
+        return Fail("null argument");
+    if (kernel)
+        *kernel = r->last_kernel;
+    if (work_distribution)
+        *work_distribution = r->last_work;
+    if (prepass)
+        *prepass = r->last_prepass;
+    return 0;
+}
 
 int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint32_t leave_at)
 {

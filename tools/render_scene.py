@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--kernel", choices=["auto", "stream", "lanes"], default="auto",
                     help="kernel formulation: the library's choice by scene class (default), the stream "
                          "kernel, or the lane-owns-a-path kernel")
+    ap.add_argument("--work", type=int, default=-1, help="work distribution: -1 library's choice, 0 fixed lists, 1 work counter")
+    ap.add_argument("--prepass", type=int, default=-1, help="camera-ray pre-pass: -1 library's choice, 0 off, 1 on")
+    ap.add_argument("--kernel-mode", type=int, default=None, help="numeric kernel mode (overrides --kernel)")
     a = ap.parse_args()
     from _pkg import load_package
     pkg = load_package()
@@ -43,7 +46,8 @@ def main():
         cfg.set_film(*a.film)
     w, h, spp = cfg.film()
     r = capi.Renderer(cfg)
-    r.set_kernel({"auto": -1, "stream": 1, "lanes": 0}[a.kernel])
+    r.set_kernel({"auto": -1, "stream": 1, "lanes": 0}[a.kernel] if a.kernel_mode is None else a.kernel_mode)
+    r.set_work_distribution(a.work).set_prepass(a.prepass)
     out = {"scene": a.scene, "film": [w, h, spp], "info": r.info()}
     for _ in range(a.draws):
         _, st = r.draw()
