@@ -117,7 +117,7 @@ def pmc_leg(workload, film, choice, timeout_s=300):
                 name = row["Kernel_Name"]
                 if "render_kernel" not in name and "stream_kernel" not in name and "primary_kernel" not in name:
                     continue
-                kernels.add(name.split("(")[0][-90:])
+                kernels.add(name.replace("(anonymous namespace)::", "").split("(")[0][-90:])
                 counters[row["Counter_Name"]] = counters.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
             for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):

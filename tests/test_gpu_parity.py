@@ -462,7 +462,7 @@ def test_prepass_is_not_used_where_the_camera_ray_consumes_random_numbers(pkg, s
 @pytest.mark.gpu
 def test_calibration_reports_its_measurements(pkg):
     """A scene outside LDS: the first draw times three configurations on a sample of the frame and says so."""
-    scene = pkg.scenes.material_preview("rough_conductor", "envmap", "mesh", 160, 120, 8)
+    scene = pkg.scenes.terrain_scene(64, 160, 120, 8)
     r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
     try:
         assert r.info()["primitives"] >= 2048
