@@ -1,7 +1,9 @@
 """Differential campaign on the GPU (not collected by pytest; run by hand: python tests/gpu_campaign.py <seed> ...).
 Random scenes (test_random_combinations' generator with more
 seeds, plus mesh resolutions on both sides of the 2048-primitive switch to the vote walk, supplied
-tangents, object transforms), both walks, plain and counting kernels, against the oracle.  Round-1 result: profiles/r01_gpu_campaign.json."""
+tangents, object transforms), both walks, plain and counting kernels, against the oracle.  Round-1 result: profiles/r01_gpu_campaign.json.
+Round 2: every frame must EQUAL the oracle's (bit-exact device libm), and so must the frames of the other scheduling
+choices: stream kernel, work counter, camera-ray pre-pass (profiles/r02_gpu_campaign.json)."""
 import sys, time, importlib, tempfile, os, json, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -42,14 +44,20 @@ for seed in seeds:
         path = os.path.join(tmp, 's.mcsd'); M.dump(scene, path)
         want, _ = orc.render(path)
         r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
-        a, _ = r.draw(); c, _ = r.draw(counted=True); r.set_walk(True); b, _ = r.draw(); r.close()
+        a, _ = r.draw(); c, _ = r.draw(counted=True)
+        others = []
+        for kernel, work, prepass in ((0, 0, 0), (1, 1, 1), (0, 1, 1), (1, 0, 0)):
+            f, _ = r.set_kernel(kernel).set_work_distribution(work).set_prepass(prepass).draw()
+            others.append(bool(np.array_equal(f, a)))
+        r.set_kernel(-1).set_work_distribution(-1).set_prepass(-1)
+        r.set_walk(True); b, _ = r.draw(); r.close()
         n += 1
         d = np.abs(a.astype(np.float64) - want)
-        ok = np.array_equal(a, b) and np.array_equal(a, c) and np.isfinite(a).all() and d.mean() <= 4e-3 and np.median(d) <= 1e-6
+        ok = np.array_equal(a, b) and np.array_equal(a, c) and np.isfinite(a).all() and np.array_equal(a, want) and all(others)
         worst = max(worst, float(d.mean()))
         if not ok:
             bad.append({'seed': seed, 'name': name, 'walks_equal': bool(np.array_equal(a, b)), 'counted_equal': bool(np.array_equal(a, c)),
-                        'finite': bool(np.isfinite(a).all()), 'mean': float(d.mean()), 'median': float(np.median(d)), 'max': float(d.max())})
+                        'finite': bool(np.isfinite(a).all()), 'equals_oracle': bool(np.array_equal(a, want)), 'scheduling_choices_equal': others, 'mean': float(d.mean()), 'median': float(np.median(d)), 'max': float(d.max())})
             print('BAD', bad[-1], flush=True)
     print('seed', seed, 'done; scenes', n, 'bad', len(bad), 'elapsed', round(time.time() - t0), flush=True)
 json.dump({'scenes': n, 'bad': bad, 'worst_mean': worst}, open(os.path.join(ROOT, 'gpurun_out', 'campaign.json'), 'w'), indent=1)
