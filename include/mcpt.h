@@ -272,6 +272,14 @@ int mcpt_debug_intersect(mcpt_renderer *r, uint32_t n, const float *rays, const 
 int mcpt_debug_bsdf(mcpt_renderer *r, uint32_t id_bsdf, int mode, uint32_t n, const float *records,
                     const uint32_t *seeds, float *out, uint32_t *seeds_out);
 
+/* Experiment: closest-hit rate of a LEAN trace-only kernel (walk state only; csrc/hip/trace_rate_kernel.hip) on n rays
+ * (origin[3] dir[3], host memory).  mode 0: one ray per lane; mode 1: persistent wavefronts that re-fill free lanes
+ * from a global queue (refill_at lanes free, 0 = 16).  waves_per_simd: 4 or 8 (launch bound).  found[i] = primitive
+ * hit (0xFFFFFFFF: none); milliseconds = the trace kernel alone.  Triangle scenes without opacity masks.  It bounds
+ * what a multi-kernel wavefront formulation could gain; no render path uses it. */
+int mcpt_debug_trace_rate(mcpt_renderer *r, uint32_t n, const float *rays, int mode, int waves_per_simd, uint32_t refill_at,
+                          uint32_t *found, float *milliseconds);
+
 /* Diagnostics: the steps of one pixel (index y * width + x) on the device, one lane, all of the
  * pixel's samples: 16 floats per step = ray origin[3], direction[3], largest throughput
  * component after the step, primitive hit (-1: none), distance, shadow queries, last shadow

@@ -107,6 +107,7 @@ def lib():
     L.mcpt_debug_intersect.argtypes = [vp, u32, vp, vp, vp, vp]
     L.mcpt_debug_bsdf.argtypes = [vp, u32, i32, u32, vp, vp, vp, vp]
     L.mcpt_debug_trace_pixel.argtypes = [vp, u32, u32, vp, vp]
+    L.mcpt_debug_trace_rate.argtypes = [vp, u32, vp, i32, i32, u32, vp, ctypes.POINTER(ctypes.c_float)]
     L.mcpt_renderer_destroy.argtypes = [vp]
     L.mcpt_renderer_destroy.restype = None
     L.mcpt_write_image.argtypes = [cp, vp, i32, i32]
@@ -136,7 +137,7 @@ EXPORTED_SYMBOLS = [
     "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_set_walk", "mcpt_renderer_set_walk_schedule",
     "mcpt_renderer_set_kernel", "mcpt_renderer_last_kernel", "mcpt_renderer_check_walks", "mcpt_renderer_set_rng", "mcpt_renderer_set_prepass", "mcpt_renderer_set_work_distribution", "mcpt_renderer_last_choice",
     "mcpt_renderer_destroy",
-    "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_trace_pixel",
+    "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_trace_pixel", "mcpt_debug_trace_rate",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
     "mcpt_config_serialize", "mcpt_tiled_renderer_create", "mcpt_tiled_renderer_draw",
     "mcpt_tiled_renderer_set_kernel", "mcpt_tiled_renderer_destroy", "mcpt_render_tiled", "mcpt_device_count",
@@ -288,6 +289,15 @@ class Renderer:
         _check(lib().mcpt_debug_trace_pixel(self._h, y * self.width + x, capacity, out.ctypes.data, n.ctypes.data))
         steps = out[:int(n[0])]
         return steps, steps[:, 11].copy().view(np.uint32)
+
+    def trace_rate(self, rays, mode, waves_per_simd=4, refill_at=0):
+        """Experiment kernel (mcpt.h): (found[n] uint32 primitive or 0xFFFFFFFF, milliseconds of the lean trace kernel)."""
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
+        found = np.zeros(len(rays), dtype=np.uint32)
+        ms = ctypes.c_float()
+        _check(lib().mcpt_debug_trace_rate(self._h, len(rays), rays.ctypes.data, mode, waves_per_simd, refill_at, found.ctypes.data,
+                                           ctypes.byref(ms)))
+        return found, ms.value
 
     def table(self, what: str) -> np.ndarray:
         data, count = ctypes.c_void_p(), ctypes.c_size_t()

@@ -1124,6 +1124,35 @@ int mcpt_debug_bsdf(mcpt_renderer *r, uint32_t id_bsdf, int mode, uint32_t n, co
                    { return mcpt::LaunchBsdf(r->dev, n, id_bsdf, mode, a, b, c, d, nullptr); });
 }
 
+int mcpt_debug_trace_rate(mcpt_renderer *r, uint32_t n, const float *rays, int mode, int waves_per_simd, uint32_t refill_at,
+                          uint32_t *found, float *milliseconds)
+{
+    if (!r || !rays || !found || !milliseconds || n == 0)
+        return Fail("invalid argument");
+    if ((r->flat.features & mcpt::kFeatAnalytic) != 0 || r->flat.integrator.has_masks)
+        return Fail("mcpt_debug_trace_rate: triangle scenes without opacity masks only");
+    float *d_rays = nullptr;
+    uint32_t *d_found = nullptr;
+    int rc = 0;
+    try
+    {
+        Check(hipSetDevice(r->device), "select device");
+        Check(hipMalloc(reinterpret_cast<void **>(&d_rays), size_t(n) * 24), "allocate");
+        Check(hipMalloc(reinterpret_cast<void **>(&d_found), size_t(n) * 4), "allocate");
+        Check(hipMemcpy(d_rays, rays, size_t(n) * 24, hipMemcpyHostToDevice), "upload");
+        Check(mcpt::RunTraceRate(r->dev, n, d_rays, mode, waves_per_simd, refill_at ? refill_at : 16u, r->n_cus, d_found, milliseconds,
+                                 nullptr),
+              "trace-rate kernel");
+        Check(hipMemcpy(found, d_found, size_t(n) * 4, hipMemcpyDeviceToHost), "download");
+    }
+    catch (const std::exception &e)
+    {
+        rc = Fail(e.what());
+    }
+    (void)hipFree(d_rays), (void)hipFree(d_found);
+    return rc;
+}
+
 int mcpt_debug_trace_pixel(mcpt_renderer *r, uint32_t pixel, uint32_t capacity, float *out, uint32_t *n_steps)
 {
     if (!r || !out || !n_steps)

@@ -84,6 +84,10 @@ hipError_t LaunchReduceSamplePlanes(const float *planes, float *frame, uint32_t 
 hipError_t LaunchUnpackTiles(const float *packed, float *frame, uint32_t tile_first, uint32_t tile_stride, uint32_t n_tiles,
                              uint32_t tiles_x, uint32_t width, uint32_t height, hipStream_t stream);
 
+// Experiment (hip/trace_rate_kernel.hip): closest-hit rate of a lean trace-only kernel on a batch of rays in HBM.
+hipError_t RunTraceRate(const DeviceScene &sc, uint32_t n, const float *rays_dev, int mode, int waves, uint32_t refill_at, uint32_t n_cus,
+                        uint32_t *found_dev, float *milliseconds, hipStream_t stream);
+
 // Unit kernels for diagnostics and parity tests (one query per lane).
 hipError_t LaunchIntersect(const DeviceScene &sc, uint32_t n, const float *rays, const uint32_t *seeds, float *out,
                            uint32_t *seeds_out, bool reference_walk, hipStream_t stream);
