@@ -179,6 +179,13 @@ int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint
  *          to mode 0.
  *   mode 2: the stream kernel with `slots` (> 256) slots per workgroup whose path state lives in memory instead of
  *          the lanes' registers (experiments; instantiated for few scene classes, otherwise falls back to mode 0).
+ *   mode 3: the MULTI-KERNEL wavefront formulation (csrc/hip/wavefront_kernels.hip): one path slot per pixel of the draw in
+ *          HBM, a frame = rounds of two launches — a shade kernel (one lane per slot; emitted rays compacted by wavefront
+ *          ballot / prefix count into ray queues) and a lean trace kernel (one lane per queued ray, walk state only,
+ *          2-3x the ray rate of the walk inside the single-kernel formulations) — until a round queues no ray.  Same
+ *          frame.  Blocking (the host decides when to stop).  Instantiated for surface materials with one shadow ray per
+ *          vertex (otherwise falls back); measured slower than mode 1 on the BASELINE scenes, so
+ *          the library never picks it by itself.
  *   mode 0: the lane-owns-a-path state machine (csrc/path_core.h, round 1's kernel). */
 int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_t refill_at);
 /* What the last draw actually ran, as arguments for mcpt_renderer_set_kernel / _set_work_distribution / _set_prepass

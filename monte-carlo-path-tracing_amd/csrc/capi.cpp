@@ -137,6 +137,10 @@ struct mcpt_renderer
     int prepass_mode = -1;
     uint32_t *prehit_dev = nullptr; // camera-ray hits of the whole frame, 2 words per (pixel, sample)
     size_t prehit_words = 0;
+    // multi-kernel wavefront formulation (mcpt_renderer_set_kernel mode 3): slot storage, ray lists, counters
+    uint32_t *wf_dev = nullptr;
+    size_t wf_words = 0;
+    uint32_t wf_rounds = 0; // rounds of the last wavefront draw
     uint32_t *work_counter_dev = nullptr; // RenderJob::work_counter (dynamic work distribution), zeroed before every launch
     int work_mode = -1;                   // mcpt_renderer_set_work_distribution: -1 library's choice, 0 fixed lists, 1 work counter
 
@@ -150,6 +154,8 @@ struct mcpt_renderer
             (void)hipFree(prehit_dev);
         if (work_counter_dev)
             (void)hipFree(work_counter_dev);
+        if (wf_dev)
+            (void)hipFree(wf_dev);
         if (frame_dev)
             (void)hipFree(frame_dev);
         if (counters_dev)
@@ -333,6 +339,56 @@ void Calibrate(mcpt_renderer *r, hipStream_t stream, bool stream_allowed)
             r->auto_choice = c;
 }
 
+// One frame in the multi-kernel wavefront formulation: rounds of (shade launch, trace launch) until a round lists no
+// ray.  The host only has to know when to stop: it launches rounds in batches and reads the last round's ray count
+// after each batch (a finished frame costs at most one batch of empty rounds, about a millisecond).  Blocking.
+uint32_t DrawWavefront(mcpt_renderer *r, const mcpt::RenderJob &job, float *out_device, hipStream_t stream)
+{
+    const uint32_t n_slots = job.n_items;
+    size_t cold = 0, hot = 0, ids = 0;
+    mcpt::WavefrontSizes(r->dev, n_slots, &cold, &hot, &ids);
+    const uint32_t n_counters = mcpt::WavefrontCounterWords();
+    const size_t words = cold + hot + ids + n_counters;
+    if (words > r->wf_words)
+    {
+        if (r->wf_dev)
+        {
+            Check(hipDeviceSynchronize(), "wait before growing the wavefront storage");
+            Check(hipFree(r->wf_dev), "free wavefront storage");
+            r->wf_dev = nullptr, r->wf_words = 0;
+        }
+        Check(hipMalloc(reinterpret_cast<void **>(&r->wf_dev), words * sizeof(uint32_t)), "allocate wavefront storage");
+        r->wf_words = words;
+    }
+    uint32_t *cold_dev = r->wf_dev, *hot_dev = cold_dev + cold, *ids_dev = hot_dev + hot, *counters = ids_dev + ids;
+    Check(hipMemsetAsync(counters, 0, n_counters * sizeof(uint32_t), stream), "clear wavefront counters");
+    std::vector<uint32_t> listed(n_counters / 2);
+    constexpr uint32_t kBatch = 32;
+    uint32_t round = 0;
+    for (;;)
+    {
+        uint32_t parity = 0;
+        for (uint32_t k = 0; k < kBatch; ++k, ++round)
+        {
+            parity = round & 1u;
+            Check(mcpt::LaunchWavefrontRound(r->dev, job, out_device, cold_dev, hot_dev, ids_dev, counters, n_slots, round == 0, parity,
+                                             stream),
+                  "launch wavefront round");
+        }
+        Check(hipMemcpyAsync(listed.data(), counters + parity * listed.size(), listed.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, stream),
+              "read ray counts");
+        Check(hipStreamSynchronize(stream), "wavefront rounds");
+        uint64_t total = 0;
+        for (uint32_t c : listed)
+            total += c;
+        if (total == 0)
+            break; // the last round listed no ray: every slot has finished its pixel
+        if (round > (1u << 24))
+            throw std::runtime_error("the wavefront renderer does not terminate.");
+    }
+    return round;
+}
+
 // Enqueues one render launch; optionally waits and reports timings.
 void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, bool packed, hipStream_t stream,
           bool blocking, bool counted, mcpt_stats *stats)
@@ -475,7 +531,13 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             r->dev.prehit = r->prehit_dev;
         }
     }
-    if (streamed)
+    const bool wavefront = r->kernel_mode == 3 && !counted && r->rng_mode == 0 && mcpt::WavefrontSupports(r->dev, job);
+    if (wavefront)
+    {
+        r->wf_rounds = DrawWavefront(r, job, out_device, stream);
+        variant = "wavefront (shade / trace launches) surface-materials";
+    }
+    else if (streamed)
         Check(mcpt::LaunchRenderStream(r->dev, job, out_device, counters, stream, r->scratch_dev, plan), "launch stream kernel");
     else
         Check(mcpt::LaunchRender(r->dev, job, render_target, counters, stream, r->n_cus, &variant), "launch render kernel");
@@ -484,7 +546,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                                              r->flat.camera.spp_inv, stream),
               "reduce sample planes");
     r->variant = variant;
-    r->last_kernel = streamed ? (r->kernel_mode == 2 ? 2 : 1) : 0, r->last_work = dynamic_work ? 1 : 0, r->last_prepass = r->dev.prehit ? 1 : 0;
+    r->last_kernel = wavefront ? 3 : streamed ? (r->kernel_mode == 2 ? 2 : 1) : 0, r->last_work = dynamic_work ? 1 : 0, r->last_prepass = r->dev.prehit ? 1 : 0;
     if (r->dev.prehit)
         r->variant += " + camera-ray pre-pass";
     if (dynamic_work)
@@ -989,8 +1051,8 @@ int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_
 {
     if (!r)
         return Fail("null argument");
-    if (mode < -1 || mode > 2)
-        return Fail("mcpt_renderer_set_kernel: mode is -1 (by scene class), 0 (lane-owns-a-path), 1 (stream) or 2 (stream, slots in memory)");
+    if (mode < -1 || mode > 3)
+        return Fail("mcpt_renderer_set_kernel: mode is -1 (the library's choice), 0 (lane-owns-a-path), 1 (stream), 2 (stream, slots in memory) or 3 (multi-kernel wavefront)");
     if (slots % 256u != 0 || slots > 4096u || refill_at > 64u)
         return Fail("mcpt_renderer_set_kernel: slots is a multiple of 256 up to 4096, refill_at at most 64");
     r->kernel_mode = mode, r->stream_slots = slots, r->stream_refill = refill_at;

@@ -84,6 +84,15 @@ hipError_t LaunchReduceSamplePlanes(const float *planes, float *frame, uint32_t 
 hipError_t LaunchUnpackTiles(const float *packed, float *frame, uint32_t tile_first, uint32_t tile_stride, uint32_t n_tiles,
                              uint32_t tiles_x, uint32_t width, uint32_t height, hipStream_t stream);
 
+// ---- multi-kernel wavefront formulation (hip/wavefront_kernels.hip) --------------------------------------
+// One slot per item of the job, path state in HBM; a frame = rounds of (shade launch, trace launch) until a round lists
+// no ray.  counters: WavefrontCounterWords() words, zero before the first round.  Buffers sized by WavefrontSizes (32-bit words).
+bool WavefrontSupports(const DeviceScene &sc, const RenderJob &job);
+void WavefrontSizes(const DeviceScene &sc, uint32_t n_slots, size_t *cold_words, size_t *hot_words, size_t *id_words);
+uint32_t WavefrontCounterWords(); // two round parities x two ray kinds x the queues; the last round's half sums to 0 when the frame is done
+hipError_t LaunchWavefrontRound(const DeviceScene &sc, const RenderJob &job, float *out, uint32_t *cold, uint32_t *hot, uint32_t *ids,
+                                uint32_t *counters, uint32_t n_slots, bool first_round, uint32_t parity, hipStream_t stream);
+
 // Experiment (hip/trace_rate_kernel.hip): closest-hit rate of a lean trace-only kernel on a batch of rays in HBM.
 hipError_t RunTraceRate(const DeviceScene &sc, uint32_t n, const float *rays_dev, int mode, int waves, uint32_t refill_at, uint32_t n_cus,
                         uint32_t *found_dev, float *milliseconds, hipStream_t stream);

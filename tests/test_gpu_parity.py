@@ -439,6 +439,15 @@ def test_scheduling_choices_do_not_change_the_image(name, pkg, scenes):
                     seen.add(r.last_kernel())
                     assert np.array_equal(frame, golden), (kernel, work, prepass, r.last_kernel())
         assert any("pre-pass" in k for k in seen) and any("work counter" in k for k in seen), seen
+        # the multi-kernel wavefront formulation (shade / trace launches over path slots in HBM) where it is instantiated:
+        # surface materials, one shadow ray per vertex, no opacity masks
+        for prepass in (0, 1):
+            frame, _ = r.set_kernel(3).set_prepass(prepass).draw()
+            if "wavefront" in r.last_kernel():
+                seen.add("wavefront")
+            assert np.array_equal(frame, golden), (3, prepass, r.last_kernel())
+        if name in ("cornell_96_spp32", "rough_dielectric_envmap", "terrain_directional"):
+            assert "wavefront" in seen
         frame, _ = r.set_kernel(-1).set_work_distribution(-1).set_prepass(-1).draw()   # the library's own choice
         assert np.array_equal(frame, golden), r.last_kernel()
     finally:
