@@ -158,3 +158,30 @@ def test_device_lbvh_builder_on_a_mesh(pkg):
     d_links, d_geom, d_sec = pkg.capi.lbvh_build(boxes, areas, on_device=True)
     print(f"terrain {len(boxes)} triangles: host {h_sec * 1e3:.1f} ms, device {d_sec * 1e3:.2f} ms")
     assert np.array_equal(h_links, d_links) and np.array_equal(h_geom.view(np.uint32), d_geom.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_lean_trace_kernel_experiment_agrees_with_the_unit_query(pkg):
+    """mcpt_debug_trace_rate (the lean trace-only kernels behind DESIGN.md section 9's measurement): one ray per lane and
+    the queue re-fill variant name the same primitive for every ray, the one mcpt_debug_intersect names."""
+    scene = pkg.scenes.terrain_scene(48, 64, 48, 1)
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
+    try:
+        rng = np.random.default_rng(5)
+        n = 20000
+        origins = np.tile(np.array([[0.0, 2.2, 4.5]], np.float32), (n, 1)) + rng.normal(size=(n, 3)).astype(np.float32) * 0.3
+        dirs = np.array([[0.0, -0.45, -1.0]], np.float32) + rng.normal(size=(n, 3)).astype(np.float32) * 0.35
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        rays = np.concatenate([origins, dirs], axis=1)
+        a, ms_a = r.trace_rate(rays, 0, 8)
+        b, ms_b = r.trace_rate(rays, 1, 4, 16)
+        c, _ = r.trace_rate(rays, 1, 8, 32)
+        out, _ = r.debug_intersect(origins, dirs)
+    finally:
+        r.close()
+    assert ms_a > 0 and ms_b > 0
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(a, c)
+    hit = out[:, 0] > 0
+    assert 0.2 < hit.mean() < 1.0
+    np.testing.assert_array_equal(a != 0xFFFFFFFF, hit)

@@ -866,6 +866,36 @@ def test_cli_xml_to_exr(pkg, tmp_path):
 
 
 @pytest.mark.gpu
+def test_xml_scene_on_the_gpu_equals_the_oracle(pkg, tmp_path):
+    """A Mitsuba-style XML scene through the product's front end (mcpt_config_load_xml), rendered on the GPU, against
+    the ORACLE's frame of the same configuration: equality (the front end's output is what the oracle is fed, as MCSD)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import checkers
+    body = """<bsdf type="roughconductor" id="metal"><string name="material" value="Cu"/><float name="alpha" value="0.2"/></bsdf>
+    <bsdf type="diffuse" id="grey"><rgb name="reflectance" value="0.6"/></bsdf>
+    <shape type="sphere"><float name="radius" value="0.7"/><point name="center" x="0" y="0" z="3"/><ref id="metal"/></shape>
+    <shape type="rectangle"><transform name="toWorld"><scale value="4"/><rotate x="1" angle="90"/><translate y="-0.7"/></transform>
+        <ref id="grey"/></shape>
+    <shape type="rectangle"><transform name="toWorld"><scale value="0.5"/><rotate x="1" angle="-90"/><translate y="2.5" z="3"/></transform>
+        <emitter type="area"><rgb name="radiance" value="12"/></emitter></shape>
+    <emitter type="constant"><rgb name="radiance" value="0.3"/></emitter>"""
+    xml = tmp_path / "scene.xml"
+    xml.write_text(scene_xml(body))
+    cfg = pkg.capi.Config.load_xml(xml).set_film(64, 40, 16)
+    mcsd = tmp_path / "scene.mcsd"
+    cfg.save_mcsd(mcsd)
+    want, _ = checkers.Oracle().render(str(mcsd))
+    r = pkg.capi.Renderer(cfg, device=0)
+    try:
+        frame, _ = r.draw()
+    finally:
+        r.close()
+    assert want.mean() > 0.05
+    np.testing.assert_array_equal(frame, want)
+
+
+@pytest.mark.gpu
 def test_cli_renders_like_the_library(pkg, tmp_path):
     scene = pkg.scenes.cornell_box(48, 48, 4)
     path = tmp_path / "s.mcsd"
