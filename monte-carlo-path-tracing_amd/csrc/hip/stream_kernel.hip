@@ -76,12 +76,12 @@ hipError_t PlanRenderStream(const DeviceScene &sc, const RenderJob &job, bool co
     *name = k.name;
     // Launch shape.  Small scenes: 2 slots per lane keep two workgroups on a CU (LDS: traversal data + stacks +
     // hot fields), which measured best; meshes: 2 slots per lane, everything but the stacks and the ray list in
-    // cached global memory.  A wavefront refills when a quarter of its lanes are free.
+    // cached global memory.  A wavefront refills when 24 of its lanes are free.
     if (cfg->slots == 0)
         cfg->slots = 2 * kBlockSize;
     cfg->slots = ((cfg->slots + kBlockSize - 1) / kBlockSize) * kBlockSize;
     if (cfg->refill_at == 0)
-        cfg->refill_at = 16;
+        cfg->refill_at = 24; // (swept 8 .. 64 with the work counter and the pre-pass: flat from 16 to 32, -12 % at 64, -9 % at 8 on dragon)
     return k.plan(sc, job, n_cus, *cfg);
 }
 
