@@ -464,7 +464,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     // matpreview-rc 364 / 411 / 491, classroom 163 / 159 / 131, dining-room 72 / 63 / 69), so the renderer's first draw
     // CALIBRATES on a sample of the frame and keeps the fastest (measure, don't guess).
     const bool small_scene = mcpt::StreamPrefersLanes(r->dev);
-    const bool can_stream = job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && r->rng_mode == 0;
+    const bool can_stream = job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && (r->rng_mode == 0 || job.sample_split <= 1);
     if ((r->kernel_mode == -1 || r->work_mode == -1) && r->auto_choice < 0 && !counted)
     {
         r->auto_choice = 1; // lanes + work counter
@@ -474,7 +474,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     const int choice = r->auto_choice < 0 ? 1 : r->auto_choice;
     const bool auto_stream = r->kernel_mode == -1 && kAutoCandidates[choice].kernel == 1 && !small_scene;
     const bool dynamic_work = r->work_mode == -1 ? kAutoCandidates[choice].work == 1 : r->work_mode == 1;
-    if ((r->kernel_mode > 0 || auto_stream) && job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && r->rng_mode == 0)
+    if ((r->kernel_mode > 0 || auto_stream) && can_stream)
     {
         const hipError_t planned = mcpt::PlanRenderStream(r->dev, job, counted, r->n_cus, &plan, &variant);
         if (planned == hipSuccess)

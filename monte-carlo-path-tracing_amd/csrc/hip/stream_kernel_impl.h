@@ -166,7 +166,7 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         // wavefront and kind)
         auto shade_slot = [&](StreamSlot<S> &s, uint32_t i)
         {
-            while (stream_shade<C, S>(sc, s, cnt) == kStreamPixelDone)
+            while (stream_shade<C, S>(sc, s, cnt, job.independent_samples != 0, job.rng_seed) == kStreamPixelDone)
             {
                 const V3 c = pixel_value(sc, s.st);
                 float *dst = out + 3 * static_cast<size_t>(job.packed ? s.item : s.st.pixel);

@@ -414,8 +414,11 @@ enum StreamShadeResult : uint32_t
 // With the primary-visibility pre-pass (sc.prehit) a new sample's camera ray is not emitted: its hit is known, the
 // sample's first vertex is shaded at once — and if the sample ends there (a camera ray that leaves the scene, an
 // emitter seen directly, ...) the next sample starts in the same call.
+// `independent` / `seed`: the independent-sample RNG mode (mcpt_renderer_set_rng) without split samples — every sample
+// starts its own PCG-hashed stream (path_core.h::start_sample).
 template <class C, uint32_t S>
-MCPT_HD StreamShadeResult stream_shade(const DeviceScene &sc, StreamSlot<S> &s, LaneCounters *cnt)
+MCPT_HD StreamShadeResult stream_shade(const DeviceScene &sc, StreamSlot<S> &s, LaneCounters *cnt, bool independent = false,
+                                       uint32_t seed = 0)
 {
     PathState &st = s.st;
     stream_unpack(s);
@@ -445,7 +448,7 @@ MCPT_HD StreamShadeResult stream_shade(const DeviceScene &sc, StreamSlot<S> &s, 
             stream_pack(s);
             return kStreamPixelDone;
         }
-        start_sample(sc, st);
+        start_sample(sc, st, 1, independent, seed);
         if (cnt)
             ++cnt->samples;
         if (sc.prehit == nullptr)

@@ -409,6 +409,27 @@ def test_sample_split_does_not_change_the_estimate(pkg, split):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["rough_dielectric_envmap", "terrain_directional"])
+def test_independent_sample_mode_is_the_same_frame_in_both_kernel_formulations(name, pkg, scenes):
+    """Mode 1 without split samples runs in the stream kernel too: per (seed, pixel, sample) streams make the frame a
+    function of the seed only, so lanes kernel == stream kernel bit for bit, with and without the pre-pass."""
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
+    try:
+        r.set_rng(1, seed=11, sample_split=1)
+        lanes, _ = r.set_kernel(0).set_prepass(0).draw()
+        assert "stream" not in r.last_kernel()
+        for prepass in (0, 1):
+            got, _ = r.set_kernel(1).set_work_distribution(1).set_prepass(prepass).draw()
+            assert "stream" in r.last_kernel() and "independent" in r.last_kernel(), r.last_kernel()
+            assert np.array_equal(got, lanes), (prepass, r.last_kernel())
+        split, _ = r.set_rng(1, seed=11, sample_split=4).set_kernel(1).draw()     # split samples: the lanes kernel
+        assert "stream" not in r.last_kernel()
+        np.testing.assert_allclose(split, lanes, rtol=0, atol=2e-6)
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
 def test_rng_mode_arguments(pkg):
     import torch
     if not torch.cuda.is_available():
