@@ -168,9 +168,9 @@ int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint
  *   mode -1 (default): the lane-owns-a-path kernel for the few-KB scenes whose traversal data sits in LDS
  *          (cornell-box, volumetric-caustic: it is VALU-bound there and faster); for every other scene the
  *          renderer's FIRST draw calibrates — lanes kernel with fixed lists, lanes kernel with the work counter and
- *          stream kernel with the work counter render a sample of the frame's tiles at a few spp, the fastest is kept
+ *          stream kernel with the work counter (workgroup rounds, wavefront rounds: modes 1 and 4) render a sample of the frame's tiles at a few spp, the fastest is kept
  *          (they are within +-25 % of each other and the winner depends on the scene: DESIGN.md section 3).
- *          mcpt_renderer_last_kernel reports the choice and the three timings.
+ *          mcpt_renderer_last_kernel reports the choice and the four timings.
  *   mode 1: the STREAM kernel (csrc/stream_core.h) — a workgroup owns `slots` path slots (0 = built-in
  *          choice, otherwise a multiple of 256) whose rays go through a workgroup-local pool: emitted rays are
  *          compacted by wavefront ballot / prefix count, a lane that finishes a ray fetches the next one
@@ -186,6 +186,11 @@ int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint
  *          frame.  Blocking (the host decides when to stop).  Instantiated for surface materials with one shadow ray per
  *          vertex (otherwise falls back); measured slower than mode 1 on the BASELINE scenes, so
  *          the library never picks it by itself.
+ *   mode 4: mode 1 (one slot per lane) with WAVEFRONT rounds: each wavefront of a workgroup alternates its shade and
+ *          trace phases alone — own ray list, no workgroup barrier — so no wavefront waits for the longest ray of the
+ *          other three; its shadow rays fill only its own free lanes.  Faster than mode 1 on matpreview (+10 %) and the
+ *          interior scenes (+9 .. +21 %), slower on dragon/scene.xml (-14 %): the fourth candidate of mode -1's
+ *          calibration.  Same frame.
  *   mode 0: the lane-owns-a-path state machine (csrc/path_core.h, round 1's kernel). */
 int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_t refill_at);
 /* What the last draw actually ran, as arguments for mcpt_renderer_set_kernel / _set_work_distribution / _set_prepass

@@ -120,7 +120,7 @@ struct mcpt_renderer
     // kernel_mode -1: which formulation the first draw's calibration found faster on THIS scene (-1 = not yet
     // calibrated, 0 = lane-owns-a-path, 1 = stream), and what it measured
     int auto_choice = -1;
-    float auto_ms[3] = {0, 0, 0}; // lanes + fixed lists, lanes + work counter, stream + work counter
+    float auto_ms[4] = {0, 0, 0, 0}; // lanes + fixed lists, lanes + work counter, stream + work counter (workgroup rounds, wavefront rounds)
     int last_kernel = 0, last_work = 0, last_prepass = 0; // what the last draw actually ran (mcpt_renderer_last_choice)
     uint32_t stream_slots = 0, stream_refill = 0;
     // slot storage of the stream kernel's workgroups; one draw at a time per renderer (the reference's
@@ -294,7 +294,8 @@ struct AutoCandidate
 {
     int kernel, work;
 };
-constexpr AutoCandidate kAutoCandidates[3] = {{0, 0}, {0, 1}, {1, 1}};
+constexpr int kAutoCount = 4;
+constexpr AutoCandidate kAutoCandidates[kAutoCount] = {{0, 0}, {0, 1}, {1, 1}, {4, 1}};
 
 void Calibrate(mcpt_renderer *r, hipStream_t stream, bool stream_allowed)
 {
@@ -312,9 +313,9 @@ void Calibrate(mcpt_renderer *r, hipStream_t stream, bool stream_allowed)
     try
     {
         for (int pass = 0; pass < 2; ++pass) // pass 0 warms the caches and the code objects up
-            for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < kAutoCount; ++c)
             {
-                if (kAutoCandidates[c].kernel == 1 && !stream_allowed)
+                if (kAutoCandidates[c].kernel != 0 && !stream_allowed)
                 {
                     r->auto_ms[c] = 0.0f;
                     continue;
@@ -334,7 +335,7 @@ void Calibrate(mcpt_renderer *r, hipStream_t stream, bool stream_allowed)
     r->kernel_mode = saved_kernel, r->work_mode = saved_work, r->dev.camera.spp = spp, r->dev.camera.spp_inv = spp_inv;
     (void)hipFree(scratch);
     r->auto_choice = 0;
-    for (int c = 1; c < 3; ++c)
+    for (int c = 1; c < kAutoCount; ++c)
         if (r->auto_ms[c] > 0.0f && r->auto_ms[c] < r->auto_ms[r->auto_choice])
             r->auto_choice = c;
 }
@@ -453,6 +454,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     const char *variant = "";
     mcpt::StreamLaunch plan{};
     plan.slots = r->stream_slots, plan.refill_at = r->stream_refill, plan.slots_in_memory = r->kernel_mode == 2 ? 1u : 0u;
+    plan.wave_local = r->kernel_mode == 4 ? 1u : 0u;
     bool streamed = false;
     // by scene class: the stream kernel wins where walks are long and uneven (meshes: dragon stand-in 1.4x,
     // matpreview 1.3x) and loses where the whole scene sits in LDS and the lane-owns-a-path kernel is already
@@ -472,9 +474,11 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             Calibrate(r, stream, can_stream);
     }
     const int choice = r->auto_choice < 0 ? 1 : r->auto_choice;
-    const bool auto_stream = r->kernel_mode == -1 && kAutoCandidates[choice].kernel == 1 && !small_scene;
+    const bool auto_stream = r->kernel_mode == -1 && kAutoCandidates[choice].kernel != 0 && !small_scene;
+    if (auto_stream)
+        plan.wave_local = kAutoCandidates[choice].kernel == 4 ? 1u : 0u;
     const bool dynamic_work = r->work_mode == -1 ? kAutoCandidates[choice].work == 1 : r->work_mode == 1;
-    if ((r->kernel_mode > 0 || auto_stream) && can_stream)
+    if (((r->kernel_mode > 0 && r->kernel_mode != 3) || auto_stream) && can_stream)
     {
         const hipError_t planned = mcpt::PlanRenderStream(r->dev, job, counted, r->n_cus, &plan, &variant);
         if (planned == hipSuccess)
@@ -546,16 +550,20 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                                              r->flat.camera.spp_inv, stream),
               "reduce sample planes");
     r->variant = variant;
-    r->last_kernel = wavefront ? 3 : streamed ? (r->kernel_mode == 2 ? 2 : 1) : 0, r->last_work = dynamic_work ? 1 : 0, r->last_prepass = r->dev.prehit ? 1 : 0;
+    r->last_kernel = wavefront ? 3 : streamed ? (plan.slots_in_memory ? 2 : plan.wave_local ? 4 : 1) : 0, r->last_work = dynamic_work ? 1 : 0, r->last_prepass = r->dev.prehit ? 1 : 0;
+    if (streamed && !wavefront && plan.wave_local)
+        r->variant += ", wavefront rounds";
     if (r->dev.prehit)
         r->variant += " + camera-ray pre-pass";
     if (dynamic_work)
         r->variant += ", work counter";
     if (r->kernel_mode == -1 && r->work_mode == -1 && r->auto_ms[0] > 0.0f)
     {
-        char note[160];
-        std::snprintf(note, sizeof note, " [calibrated on this scene: lanes fixed lists %.3f ms, lanes work counter %.3f ms, stream %.3f ms]",
-                      r->auto_ms[0], r->auto_ms[1], r->auto_ms[2]);
+        char note[256];
+        std::snprintf(note, sizeof note,
+                      " [calibrated on this scene: lanes fixed lists %.3f ms, lanes work counter %.3f ms, stream %.3f ms, stream "
+                      "wavefront rounds %.3f ms]",
+                      r->auto_ms[0], r->auto_ms[1], r->auto_ms[2], r->auto_ms[3]);
         r->variant += note;
     }
     if (r->rng_mode == 1)
@@ -1051,8 +1059,8 @@ int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_
 {
     if (!r)
         return Fail("null argument");
-    if (mode < -1 || mode > 3)
-        return Fail("mcpt_renderer_set_kernel: mode is -1 (the library's choice), 0 (lane-owns-a-path), 1 (stream), 2 (stream, slots in memory) or 3 (multi-kernel wavefront)");
+    if (mode < -1 || mode > 4)
+        return Fail("mcpt_renderer_set_kernel: mode is -1 (the library's choice), 0 (lane-owns-a-path), 1 (stream), 2 (stream, slots in memory), 3 (multi-kernel wavefront) or 4 (stream, wavefront rounds)");
     if (slots % 256u != 0 || slots > 4096u || refill_at > 64u)
         return Fail("mcpt_renderer_set_kernel: slots is a multiple of 256 up to 4096, refill_at at most 64");
     r->kernel_mode = mode, r->stream_slots = slots, r->stream_refill = refill_at;

@@ -45,6 +45,7 @@ struct RenderJob
 struct StreamLaunch
 {
     uint32_t slots_in_memory; // input: 0 = one slot per lane, path state in registers; 1 = `slots` slots per workgroup in memory
+    uint32_t wave_local; // input (one slot per lane only): 1 = every wavefront runs its rounds alone, no workgroup barrier
     uint32_t slots;      // path slots per workgroup (a multiple of 256)
     uint32_t refill_at;  // a wavefront fetches new rays when this many of its lanes are free
     uint32_t blocks, blocks_per_cu, lds_bytes;

@@ -77,6 +77,8 @@ hipError_t PlanRenderStream(const DeviceScene &sc, const RenderJob &job, bool co
     // Launch shape.  Small scenes: 2 slots per lane keep two workgroups on a CU (LDS: traversal data + stacks +
     // hot fields), which measured best; meshes: 2 slots per lane, everything but the stacks and the ray list in
     // cached global memory.  A wavefront refills when 24 of its lanes are free.
+    if (cfg->slots_in_memory)
+        cfg->wave_local = 0;
     if (cfg->slots == 0)
         cfg->slots = 2 * kBlockSize;
     cfg->slots = ((cfg->slots + kBlockSize - 1) / kBlockSize) * kBlockSize;

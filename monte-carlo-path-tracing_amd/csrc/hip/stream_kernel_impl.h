@@ -45,6 +45,13 @@ struct StreamControl // LDS, double-buffered by round parity
 #ifndef MCPT_STREAM_WAVES_MEMORY
 #define MCPT_STREAM_WAVES_MEMORY 2
 #endif
+// One slot per lane (kRegs) with StreamLaunch::wave_local: every wavefront of the workgroup runs its rounds on its own
+// — its own ray list and control words, no workgroup barrier in the round loop.  The shadow rays of a wavefront then
+// fill only that wavefront's free lanes, and no wavefront waits for the longest ray of the other three.  Which of the
+// two is faster depends on the scene (full size, Msamples/s, workgroup rounds -> wavefront rounds: matpreview 444 -> 489
+// and 315 -> 346, classroom 125 -> 137, dining-room 63 -> 77, dragon/scene.xml 920 -> 794): the renderer's calibration
+// times both.
+constexpr uint32_t kStreamWaves = kBlockSize / 64u;
 template <uint32_t kFeatures, bool kLdsGeometry, bool kRegs>
 struct StreamBudget
 {
@@ -62,6 +69,8 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
               uint32_t *__restrict__ scratch, const StreamLaunch cfg)
 {
     using C = Config<kFeatures>;
+    const bool kWaveLocal = kRegs && cfg.wave_local != 0; // (uniform over the launch)
+    const uint32_t wave = kWaveLocal ? threadIdx.x >> 6 : 0u;
     extern __shared__ float4 lds_geometry[];
     DeviceScene sc = sc_in;
     uint32_t n_staged = 0;
@@ -98,10 +107,23 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     }
     else
         m.hot = region + (kRegs ? 0u : stream_cold_words(S)) * P;
-    uint32_t *ids = lds_words;
-    StreamControl *ctrl = reinterpret_cast<StreamControl *>(lds_words + (1u + S) * P);
-    if (threadIdx.x == 0)
-        *ctrl = StreamControl{};
+    // (wave-local: the wavefront's S x 64 shadow-ray entries sit where the workgroup's list has them, behind P)
+    uint32_t *ids = lds_words + wave * S * 64u;
+    StreamControl *ctrl = reinterpret_cast<StreamControl *>(lds_words + (1u + S) * P) + wave;
+    if (threadIdx.x < kStreamWaves)
+        reinterpret_cast<StreamControl *>(lds_words + (1u + S) * P)[threadIdx.x] = StreamControl{};
+    // between the phases of a round: the workgroup's barrier, or — wave-local — only the memory order (the lanes of a
+    // wavefront run in lock step; what they wrote for each other must have landed)
+    auto phase_sync = [&]()
+    {
+        if (kWaveLocal)
+        {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+        else
+            __syncthreads();
+    };
 
     const uint32_t width = static_cast<uint32_t>(sc.camera.width), height = static_cast<uint32_t>(sc.camera.height);
     const uint32_t stride = gridDim.x * P;
@@ -221,19 +243,24 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
                 list_rays(s, i);
             }
         const unsigned long long t1 = now();
-        __syncthreads();
+        phase_sync();
         const unsigned long long t2 = now();
         const uint32_t n_ext = ctrl->n_ext[p], n_shadow = ctrl->n_shadow[p];
         if (kRegs)
         {
             // (with the extension rays in registers the ray list only says whether shadow rays exist: the
             //  workgroup is done when no lane has a ray of either kind)
-            if (__syncthreads_or(own.active ? 1 : 0) == 0 && n_ext + n_shadow == 0)
+            if (kWaveLocal)
+            {
+                if (lanes_where(own.active) == 0 && n_ext + n_shadow == 0)
+                    break;
+            }
+            else if (__syncthreads_or(own.active ? 1 : 0) == 0 && n_ext + n_shadow == 0)
                 break;
         }
         else if (n_ext + n_shadow == 0)
             break; // every slot is exhausted
-        if (threadIdx.x == 0)
+        if (kWaveLocal ? (threadIdx.x & 63u) == 0 : threadIdx.x == 0)
             ctrl->n_ext[p ^ 1u] = 0, ctrl->n_shadow[p ^ 1u] = 0, ctrl->next[p ^ 1u] = 0;
         // ---- trace -------------------------------------------------------------------------------
         const StreamRayList list{ids, n_ext, n_shadow, &ctrl->next[p]};
@@ -241,7 +268,7 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         if (kRegs)
             mine.hit_valid = own.found, mine.hit = own.hit, mine.hit_t = own.t;
         const unsigned long long t3 = now();
-        __syncthreads();
+        phase_sync();
         if (kCount)
             t_shade += t1 - t0, t_trace += t3 - t2, t_wait += (t2 - t1) + (now() - t3), ++n_rounds;
     }
@@ -275,7 +302,7 @@ inline size_t StreamLdsBytes(const DeviceScene &sc, bool lds_geometry, bool hot_
     size_t vecs = 0;
     if (lds_geometry)
         vecs = 2ull * sc.integrator.n_nodes + 6ull * sc.integrator.n_prims + 4ull * sc.integrator.n_walk_nodes;
-    size_t words = size_t(sc.integrator.walk_depth) * kBlockSize + (1u + S) * size_t(slots) + sizeof(StreamControl) / 4;
+    size_t words = size_t(sc.integrator.walk_depth) * kBlockSize + (1u + S) * size_t(slots) + kStreamWaves * sizeof(StreamControl) / 4;
     if (hot_in_lds)
         words += size_t(stream_hot_words(S)) * slots;
     return vecs * sizeof(float4) + words * sizeof(uint32_t);

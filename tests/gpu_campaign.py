@@ -46,7 +46,7 @@ for seed in seeds:
         r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
         a, _ = r.draw(); c, _ = r.draw(counted=True)
         others = []
-        for kernel, work, prepass in ((0, 0, 0), (1, 1, 1), (0, 1, 1), (1, 0, 0)):
+        for kernel, work, prepass in ((0, 0, 0), (1, 1, 1), (0, 1, 1), (1, 0, 0), (4, 1, 1), (4, 0, 0)):
             f, _ = r.set_kernel(kernel).set_work_distribution(work).set_prepass(prepass).draw()
             others.append(bool(np.array_equal(f, a)))
         r.set_kernel(-1).set_work_distribution(-1).set_prepass(-1)

@@ -453,7 +453,7 @@ def test_scheduling_choices_do_not_change_the_image(name, pkg, scenes):
     r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
     try:
         seen = set()
-        for kernel in (0, 1):
+        for kernel in (0, 1, 4):
             for work in (0, 1):
                 for prepass in (0, 1):
                     frame, _ = r.set_kernel(kernel).set_work_distribution(work).set_prepass(prepass).draw()
@@ -464,7 +464,7 @@ def test_scheduling_choices_do_not_change_the_image(name, pkg, scenes):
         # surface materials, one shadow ray per vertex, no opacity masks
         for prepass in (0, 1):
             frame, _ = r.set_kernel(3).set_prepass(prepass).draw()
-            if "wavefront" in r.last_kernel():
+            if "wavefront (shade" in r.last_kernel():
                 seen.add("wavefront")
             assert np.array_equal(frame, golden), (3, prepass, r.last_kernel())
         if name in ("cornell_96_spp32", "rough_dielectric_envmap", "terrain_directional"):
@@ -491,13 +491,13 @@ def test_prepass_is_not_used_where_the_camera_ray_consumes_random_numbers(pkg, s
 
 @pytest.mark.gpu
 def test_calibration_reports_its_measurements(pkg):
-    """A scene outside LDS: the first draw times three configurations on a sample of the frame and says so."""
+    """A scene outside LDS: the first draw times four configurations on a sample of the frame and says so."""
     scene = pkg.scenes.terrain_scene(64, 160, 120, 8)
     r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
     try:
         assert r.info()["primitives"] >= 2048
         a, _ = r.draw()
-        assert "calibrated on this scene" in r.last_kernel()
+        assert "calibrated on this scene" in r.last_kernel() and "stream wavefront rounds" in r.last_kernel()
         b, _ = r.set_kernel(0).set_work_distribution(0).set_prepass(0).draw()
         assert np.array_equal(a, b)
     finally:
