@@ -692,6 +692,10 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
     // A lane is SEARCHING (cur is a node), HOLDING (cur is a primitive slot) or FREE (cur == kWalkDone: its ray is
     // finished and waits to be retired, or it has none).
     const uint32_t n_lanes = lanes_where(true);
+    // the first fetch of a round does not wait for `refill_at` free lanes: lanes without an own ray take listed rays at
+    // once, so that a round's shadow rays run NEXT TO its extension rays, not behind them (a frame can be as long as
+    // its longest pixel's chain of rounds: dragon/scene.xml)
+    uint32_t fetch_at = own ? 1u : refill_at;
     for (;;)
     {
         // ---- node phase: a tight loop of node steps (walk_ordered, traversal.h) that runs while the lanes that
@@ -703,7 +707,7 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
             if (n_searching == 0)
                 break;
             const uint32_t n_free = lanes_where(cur == kWalkDone), n_holding = n_lanes - n_searching - n_free;
-            if (n_holding > n_searching || (!pool_empty && n_free >= refill_at))
+            if (n_holding > n_searching || (!pool_empty && n_free >= fetch_at))
                 break; // (each exit is followed by progress below: a primitive phase or a fetch)
             if (searching)
             {
@@ -746,8 +750,9 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
         }
         // ---- retire finished rays, fetch new ones ----
         const uint32_t n_free = lanes_where(cur == kWalkDone);
-        if (n_free == n_lanes || (n_free >= refill_at && !pool_empty))
+        if (n_free == n_lanes || (n_free >= fetch_at && !pool_empty))
         {
+            fetch_at = refill_at;
             if (my != kNone && cur == kWalkDone)
             {
                 if (my == kOwnRayId)
