@@ -233,6 +233,14 @@ int mcpt_renderer_set_prepass(mcpt_renderer *r, int mode);
  *          lane-owns-a-path kernel; whole frames or packed tile ranges. */
 int mcpt_renderer_set_rng(mcpt_renderer *r, int mode, uint32_t seed, uint32_t sample_split);
 
+/* Small jobs (fewer pixels than the GPU holds lanes: a rank's share of a strong-scaling run, a thumbnail).  The
+ * reference's one RNG stream per pixel makes a pixel's samples a sequential chain, so such a job lasts as long as one
+ * chain however many lanes idle.  The launcher therefore SPREADS it: only every `lanes_per_path`-th lane of a wavefront
+ * takes pixels, all wavefront slots of the GPU are used, and each wavefront executes the (fewer) diverged instructions
+ * of fewer paths — the chain gets shorter.  0 (default): the launcher's choice (the sparsest power of two up to 8 that
+ * still fits the resident lanes; 1 for jobs that fill the GPU); 1: dense; 2 .. 64: as given.  Same frame. */
+int mcpt_renderer_set_lane_spread(mcpt_renderer *r, uint32_t lanes_per_path);
+
 /* Name of the kernel instantiation the last draw launched ("" before the first draw); renderer-owned string. */
 const char *mcpt_renderer_last_kernel(const mcpt_renderer *r);
 

@@ -135,6 +135,8 @@ struct mcpt_renderer
     size_t planes_floats = 0;
     // mcpt_renderer_set_prepass: -1 = the library's choice, 0 = off, 1 = on wherever the scene allows it
     int prepass_mode = -1;
+    uint32_t lane_spread = 0; // mcpt_renderer_set_lane_spread: 0 = the launcher's choice
+    uint32_t *hit_counters_dev = nullptr; // RenderJob::hit_counters, zeroed before every pre-pass
     uint32_t *prehit_dev = nullptr; // camera-ray hits of the whole frame, 2 words per (pixel, sample)
     size_t prehit_words = 0;
     // multi-kernel wavefront formulation (mcpt_renderer_set_kernel mode 3): slot storage, ray lists, counters
@@ -152,6 +154,8 @@ struct mcpt_renderer
             (void)hipFree(planes_dev);
         if (prehit_dev)
             (void)hipFree(prehit_dev);
+        if (hit_counters_dev)
+            (void)hipFree(hit_counters_dev);
         if (work_counter_dev)
             (void)hipFree(work_counter_dev);
         if (wf_dev)
@@ -404,6 +408,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     job.packed = packed ? 1u : 0u;
     job.reference_walk = r->reference_walk ? 1u : 0u;
     job.sample_split = 1;
+    job.lane_spread = r->lane_spread;
     float *render_target = out_device;
     const uint32_t out_pixels = packed ? job.n_items : static_cast<uint32_t>(r->flat.camera.width) * r->flat.camera.height;
     if (r->rng_mode == 1 && job.n_items != 0)
@@ -466,6 +471,17 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     // matpreview-rc 364 / 411 / 491, classroom 163 / 159 / 131, dining-room 72 / 63 / 69), so the renderer's first draw
     // CALIBRATES on a sample of the frame and keeps the fastest (measure, don't guess).
     const bool small_scene = mcpt::StreamPrefersLanes(r->dev);
+    // (decided here because the stream kernel's launch shape depends on it: with a pre-pass the kernel sizes its lane
+    //  spread from the pre-pass's hit count)
+    const size_t prehit_need = size_t(r->flat.camera.width) * r->flat.camera.height * r->dev.camera.spp * 2;
+    const bool prepass = (r->prepass_mode == 1 || (r->prepass_mode == -1 && !small_scene)) && job.n_items != 0 &&
+                         mcpt::PrimaryPrepassSupports(r->dev, job) && prehit_need * sizeof(uint32_t) <= (size_t(32) << 30);
+    if (prepass)
+    {
+        if (!r->hit_counters_dev)
+            Check(hipMalloc(reinterpret_cast<void **>(&r->hit_counters_dev), mcpt::kHitCounters * sizeof(uint32_t)), "allocate hit counters");
+        job.hit_counters = r->hit_counters_dev;
+    }
     const bool can_stream = job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && (r->rng_mode == 0 || job.sample_split <= 1);
     if ((r->kernel_mode == -1 || r->work_mode == -1) && r->auto_choice < 0 && !counted)
     {
@@ -514,11 +530,10 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     r->dev.prehit = nullptr;
     // (mode -1: scenes outside LDS only — the LDS-resident ones trace their coherent camera rays in-kernel at LDS
     //  latency, and the pre-pass costs them 4-5 %: cornell 1040 -> 999, volumetric-caustic 855 -> 800 Msamples/s)
-    if ((r->prepass_mode == 1 || (r->prepass_mode == -1 && !small_scene)) && job.n_items != 0 &&
-        mcpt::PrimaryPrepassSupports(r->dev, job))
+    if (prepass)
     {
-        const size_t words = size_t(r->flat.camera.width) * r->flat.camera.height * r->dev.camera.spp * 2;
-        if (words * sizeof(uint32_t) <= (size_t(32) << 30))
+        const size_t words = prehit_need;
+        Check(hipMemsetAsync(r->hit_counters_dev, 0, mcpt::kHitCounters * sizeof(uint32_t), stream), "clear hit counters");
         {
             if (words > r->prehit_words)
             {
@@ -553,6 +568,13 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     r->last_kernel = wavefront ? 3 : streamed ? (plan.slots_in_memory ? 2 : plan.wave_local ? 4 : 1) : 0, r->last_work = dynamic_work ? 1 : 0, r->last_prepass = r->dev.prehit ? 1 : 0;
     if (streamed && !wavefront && plan.wave_local)
         r->variant += ", wavefront rounds";
+    if (streamed && !wavefront && !plan.slots_in_memory)
+    {
+        if (plan.lane_spread == 0)
+            r->variant += ", lane spread from the pre-pass's hit count";
+        else if (plan.lane_spread > 1)
+            r->variant += ", 1 path per " + std::to_string(plan.lane_spread) + " lanes";
+    }
     if (r->dev.prehit)
         r->variant += " + camera-ray pre-pass";
     if (dynamic_work)
@@ -1087,6 +1109,16 @@ int mcpt_renderer_set_prepass(mcpt_renderer *r, int mode)
         return Fail("mcpt_renderer_set_prepass: mode is -1 (the library's choice), 0 (off) or 1 (on where the scene allows it)");
     r->prepass_mode = mode;
     r->auto_choice = -1;
+    return 0;
+}
+
+int mcpt_renderer_set_lane_spread(mcpt_renderer *r, uint32_t lanes_per_path)
+{
+    if (!r)
+        return Fail("null argument");
+    if (lanes_per_path > 64 || (lanes_per_path & (lanes_per_path - 1u)) != 0)
+        return Fail("mcpt_renderer_set_lane_spread: 0 (the library's choice) or a power of two up to 64");
+    r->lane_spread = lanes_per_path;
     return 0;
 }
 

@@ -38,7 +38,11 @@ __global__ void __launch_bounds__(kBlockSize) primary_kernel(const DeviceScene s
     const unsigned long long total = static_cast<unsigned long long>(job.n_items) * spp;
     const unsigned long long stride = static_cast<unsigned long long>(gridDim.x) * blockDim.x;
     TraceStats ts{0, 0, 0, 0};
-    uint32_t rays = 0;
+    uint32_t rays = 0, hits = 0;
+    __shared__ uint32_t block_hits;
+    if (threadIdx.x == 0)
+        block_hits = 0;
+    __syncthreads();
     for (unsigned long long q = static_cast<unsigned long long>(blockIdx.x) * blockDim.x + threadIdx.x; q < total; q += stride)
     {
         const uint32_t item = static_cast<uint32_t>(q / spp), s = static_cast<uint32_t>(q - static_cast<unsigned long long>(item) * spp);
@@ -57,6 +61,17 @@ __global__ void __launch_bounds__(kBlockSize) primary_kernel(const DeviceScene s
         uint32_t *rec = prehit + 2 * (static_cast<size_t>(st.pixel) * spp + s);
         rec[0] = found ? hit.prim : kNone, rec[1] = found ? hit.inst : 0u;
         ++rays;
+        hits += found ? 1u : 0u;
+    }
+    if (job.hit_counters)
+    {
+        // camera rays of this launch that hit something: per workgroup through LDS, one global add per workgroup
+        const uint32_t wave_hits = lanes_sum(hits);
+        if ((threadIdx.x & 63u) == 0 && wave_hits)
+            atomicAdd(&block_hits, wave_hits);
+        __syncthreads();
+        if (threadIdx.x == 0 && block_hits)
+            atomicAdd(&job.hit_counters[blockIdx.x % kHitCounters], block_hits);
     }
     if (kCount)
     {

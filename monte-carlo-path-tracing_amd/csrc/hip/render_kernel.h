@@ -10,6 +10,14 @@ namespace mcpt
 {
 
 constexpr int kBlockSize = 256;
+constexpr uint32_t kHitCounters = 32;
+// lane_spread from the job's EXPENSIVE pixels (camera ray hits something): the largest power of two with
+// spread <= kSpreadNum / kSpreadDen * launched lanes / expensive pixels.  Fitted to rank-share measurements
+// (profiles/r02_experiments/lane_spread_rank_shares.json): the best spread leaves 2-3 expensive pixels per active lane.
+#ifndef MCPT_SPREAD_NUM
+#define MCPT_SPREAD_NUM 3
+#endif
+constexpr uint32_t kSpreadNum = MCPT_SPREAD_NUM, kSpreadDen = 1, kMaxStreamSpread = 16;
 // Traversal data (both hierarchies + triangle positions) up to this size is staged
 // in LDS, next to the traversal stacks (walk_depth x 256 x 4 B per workgroup):
 // 4 workgroups per CU x (24 KiB + stacks) leaves room in the 160 KiB of a CU.
@@ -36,6 +44,14 @@ struct RenderJob
     // with fixed lists the frame lasts as long as the unluckiest wavefront's list.  Items are handed out in image (tile)
     // order: lanes that fetch at about the same time work on neighbouring pixels (a permuted order — tiles far apart —
     // was measured: matpreview 400 against 436 Msamples/s, the locality is worth more than the spread).
+    // Lanes per item slot.  A job with fewer items than the GPU holds lanes (a rank's share of a strong-scaling run) is
+    // spread: only every lane_spread-th lane takes items, so that every wavefront slot of the GPU is used and each
+    // wavefront carries fewer paths — fewer diverged instructions per wavefront, and a pixel's chain of samples (the
+    // reference's one RNG stream per pixel makes it sequential) gets shorter.  0: the launcher's choice; 1: dense.
+    uint32_t lane_spread;
+    // kHitCounters words (may be null): the pre-pass adds the number of camera rays that hit something — what the
+    // expensive part of the job is.  The stream kernel sizes lane_spread from it (lane_spread 0 only).
+    uint32_t *hit_counters;
     uint32_t *work_counter;
 };
 
@@ -45,6 +61,7 @@ struct RenderJob
 struct StreamLaunch
 {
     uint32_t slots_in_memory; // input: 0 = one slot per lane, path state in registers; 1 = `slots` slots per workgroup in memory
+    uint32_t lane_spread; // output: RenderJob::lane_spread as resolved by the plan (one slot per lane only)
     uint32_t wave_local; // input (one slot per lane only): 1 = every wavefront runs its rounds alone, no workgroup barrier
     uint32_t slots;      // path slots per workgroup (a multiple of 256)
     uint32_t refill_at;  // a wavefront fetches new rays when this many of its lanes are free

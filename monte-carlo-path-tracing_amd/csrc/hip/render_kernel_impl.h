@@ -97,8 +97,11 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         }
         n_staged = n_node_vec + n_tri_vec + n_walk_vec + n_slot_vec;
     }
-    const uint32_t stride = gridDim.x * blockDim.x;
-    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    // (lane_spread is a power of two up to 64: the lanes 0, spread, 2 spread, ... of a wavefront take items)
+    const uint32_t spread = job.lane_spread ? job.lane_spread : 1u;
+    const uint32_t stride = gridDim.x * blockDim.x / spread;
+    const uint32_t lane_id = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t q = lane_id / spread;
     const uint32_t width = static_cast<uint32_t>(sc.camera.width), height = static_cast<uint32_t>(sc.camera.height);
 
     LaneCounters local{};
@@ -113,6 +116,8 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     // item, samples k, k + split, ... (all uniform values: no cost in the reference mode)
     const uint32_t split = job.sample_split ? job.sample_split : 1u, n_work = job.n_items * split;
     const bool independent = job.independent_samples != 0;
+    if (lane_id % spread != 0)
+        q = n_work;
     for (;;)
     {
         if (!has_pixel)
@@ -193,14 +198,20 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
         return err;
     if (per_cu < 1)
         per_cu = 1;
-    uint32_t blocks = (job.n_items * (job.sample_split ? job.sample_split : 1u) + kBlockSize - 1) / kBlockSize;
+    const uint32_t n_work = job.n_items * (job.sample_split ? job.sample_split : 1u);
     const uint32_t resident = max_blocks * static_cast<uint32_t>(per_cu);
+    RenderJob spread_job = job;
+    // (measured on rank shares of cornell-box and volumetric-caustic: this kernel's wavefronts execute nearly the same
+    //  instructions with 8 paths as with 64 — dense is the default; cornell's 1/8 share gains 8 % at spread 2 - 4)
+    if (spread_job.lane_spread == 0)
+        spread_job.lane_spread = 1;
+    uint64_t blocks = (uint64_t(n_work) * spread_job.lane_spread + kBlockSize - 1) / kBlockSize;
     if (blocks > resident)
         blocks = resident;
     if (blocks == 0)
         return hipSuccess;
-    hipLaunchKernelGGL((render_kernel<kFeatures, kCount, kLdsGeometry>), dim3(blocks), dim3(kBlockSize), lds_bytes,
-                       stream, sc, job, out, counters);
+    hipLaunchKernelGGL((render_kernel<kFeatures, kCount, kLdsGeometry>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlockSize),
+                       lds_bytes, stream, sc, spread_job, out, counters);
     return hipGetLastError();
 }
 

@@ -126,7 +126,22 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     };
 
     const uint32_t width = static_cast<uint32_t>(sc.camera.width), height = static_cast<uint32_t>(sc.camera.height);
-    const uint32_t stride = gridDim.x * P;
+    // (one slot per lane: RenderJob::lane_spread — only every spread-th lane takes pixels)
+    uint32_t spread = kRegs && cfg.lane_spread ? cfg.lane_spread : 1u;
+    if (kRegs && cfg.lane_spread == 0 && job.hit_counters)
+    {
+        // the plan left the choice to the launch: from the pre-pass's count of camera rays that hit something
+        // (expensive pixels = hits / spp, at most the job's pixels)
+        unsigned long long hits = 0;
+        for (uint32_t k = 0; k < kHitCounters; ++k)
+            hits += job.hit_counters[k];
+        unsigned long long expensive = hits / sc_in.camera.spp;
+        expensive = expensive > job.n_items ? job.n_items : expensive < 1 ? 1 : expensive;
+        const unsigned long long lanes = static_cast<unsigned long long>(gridDim.x) * P;
+        while (spread < kMaxStreamSpread && 2ull * spread * expensive * kSpreadDen <= lanes * kSpreadNum)
+            spread *= 2;
+    }
+    const uint32_t stride = gridDim.x * P / spread;
     // item -> tile -> pixel; false for the padding of an edge tile
     auto pixel_of = [&](uint32_t q, uint32_t &pixel) -> bool
     {
@@ -164,7 +179,10 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     if (kRegs)
     {
         mine.flags = 0;
-        assign(mine, blockIdx.x * P + threadIdx.x);
+        if (threadIdx.x % spread != 0)
+            mine.flags |= kSlotExhausted;
+        else
+            assign(mine, (blockIdx.x * P + threadIdx.x) / spread);
     }
     else
         for (uint32_t i = threadIdx.x; i < P; i += kBlockSize)
@@ -329,9 +347,25 @@ hipError_t PlanStream(const DeviceScene &sc, const RenderJob &job, uint32_t n_cu
         return err;
     if (per_cu < 1)
         return hipErrorOutOfMemory; // does not fit: the caller falls back to fewer slots or the other kernel
-    uint32_t blocks = (job.n_items + cfg.slots - 1) / cfg.slots;
     const uint32_t resident = n_cus * static_cast<uint32_t>(per_cu);
-    cfg.blocks = blocks > resident ? resident : blocks;
+    cfg.lane_spread = 1;
+    uint64_t blocks = (uint64_t(job.n_items) + cfg.slots - 1) / cfg.slots;
+    if (kRegs)
+    {
+        cfg.lane_spread = job.lane_spread;
+        if (cfg.lane_spread == 0 && job.hit_counters)
+            blocks = resident; // the kernel sizes the spread from the pre-pass's hit count: every resident slot is launched
+        else
+        {
+            // no pre-pass: every pixel of the job counts as expensive
+            if (cfg.lane_spread == 0)
+                for (cfg.lane_spread = 1; cfg.lane_spread < kMaxStreamSpread &&
+                                          2ull * cfg.lane_spread * job.n_items * kSpreadDen <= uint64_t(resident) * cfg.slots * kSpreadNum;)
+                    cfg.lane_spread *= 2;
+            blocks = (uint64_t(job.n_items) * cfg.lane_spread + cfg.slots - 1) / cfg.slots;
+        }
+    }
+    cfg.blocks = blocks > resident ? resident : static_cast<uint32_t>(blocks);
     cfg.blocks_per_cu = static_cast<uint32_t>(per_cu);
     return hipSuccess;
 }

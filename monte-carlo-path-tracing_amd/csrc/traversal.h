@@ -695,6 +695,17 @@ MCPT_HD uint32_t lanes_where(bool p)
 #endif
 }
 
+// Sum of `v` over the lanes of the wavefront (the value itself on the host).
+MCPT_HD uint32_t lanes_sum(uint32_t v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_xor(v, off, 64);
+#endif
+    return v;
+}
+
 // Wavefront aggregation helpers (a "wavefront" of the host build is one lane).
 MCPT_HD uint32_t lane_rank_among(bool p, uint32_t &total) // index of this lane among the lanes where p holds
 {
