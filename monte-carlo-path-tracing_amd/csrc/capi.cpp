@@ -482,7 +482,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             Check(hipMalloc(reinterpret_cast<void **>(&r->hit_counters_dev), mcpt::kHitCounters * sizeof(uint32_t)), "allocate hit counters");
         job.hit_counters = r->hit_counters_dev;
     }
-    const bool can_stream = job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && (r->rng_mode == 0 || job.sample_split <= 1);
+    const bool can_stream = job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && (job.sample_split <= 1 || r->kernel_mode != 2);
     if ((r->kernel_mode == -1 || r->work_mode == -1) && r->auto_choice < 0 && !counted)
     {
         r->auto_choice = 1; // lanes + work counter
@@ -557,7 +557,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         variant = "wavefront (shade / trace launches) surface-materials";
     }
     else if (streamed)
-        Check(mcpt::LaunchRenderStream(r->dev, job, out_device, counters, stream, r->scratch_dev, plan), "launch stream kernel");
+        Check(mcpt::LaunchRenderStream(r->dev, job, render_target, counters, stream, r->scratch_dev, plan), "launch stream kernel");
     else
         Check(mcpt::LaunchRender(r->dev, job, render_target, counters, stream, r->n_cus, &variant), "launch render kernel");
     if (job.sample_split > 1)

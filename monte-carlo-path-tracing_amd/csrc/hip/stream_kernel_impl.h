@@ -126,6 +126,9 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     };
 
     const uint32_t width = static_cast<uint32_t>(sc.camera.width), height = static_cast<uint32_t>(sc.camera.height);
+    // independent-sample mode with split samples: item q = k * n_items + pixel item, the slot renders samples k, k + split,
+    // ... of that pixel into plane k (uniform values; split == 1 in the reference mode)
+    const uint32_t split = job.sample_split ? job.sample_split : 1u, n_work = job.n_items * split;
     // (one slot per lane: RenderJob::lane_spread — only every spread-th lane takes pixels)
     uint32_t spread = kRegs && cfg.lane_spread ? cfg.lane_spread : 1u;
     if (kRegs && cfg.lane_spread == 0 && job.hit_counters)
@@ -136,7 +139,7 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         for (uint32_t k = 0; k < kHitCounters; ++k)
             hits += job.hit_counters[k];
         unsigned long long expensive = hits / sc_in.camera.spp;
-        expensive = expensive > job.n_items ? job.n_items : expensive < 1 ? 1 : expensive;
+        expensive = (expensive > job.n_items ? job.n_items : expensive < 1 ? 1 : expensive) * split;
         const unsigned long long lanes = static_cast<unsigned long long>(gridDim.x) * P;
         while (spread < kMaxStreamSpread && 2ull * spread * expensive * kSpreadDen <= lanes * kSpreadNum)
             spread *= 2;
@@ -157,16 +160,18 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     {
         for (;; q = job.work_counter ? stride + wave_reserve(job.work_counter, true) : q + stride)
         {
-            if (q >= job.n_items)
+            if (q >= n_work)
             {
                 s.flags |= kSlotExhausted;
                 return;
             }
+            const uint32_t k = split == 1 ? 0u : q / job.n_items;
             uint32_t pixel;
-            if (pixel_of(q, pixel))
+            if (pixel_of(q - k * job.n_items, pixel))
             {
                 s.item = q;
                 start_pixel(s.st, pixel);
+                s.st.sample = k;
                 return;
             }
         }
@@ -206,10 +211,12 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         // wavefront and kind)
         auto shade_slot = [&](StreamSlot<S> &s, uint32_t i)
         {
-            while (stream_shade<C, S>(sc, s, cnt, job.independent_samples != 0, job.rng_seed) == kStreamPixelDone)
+            while (stream_shade<C, S>(sc, s, cnt, job.independent_samples != 0, job.rng_seed, split) == kStreamPixelDone)
             {
-                const V3 c = pixel_value(sc, s.st);
-                float *dst = out + 3 * static_cast<size_t>(job.packed ? s.item : s.st.pixel);
+                const uint32_t k = split == 1 ? 0u : s.item / job.n_items;
+                const V3 c = split == 1 ? pixel_value(sc, s.st) : s.st.pixel_sum; // (planes hold unnormalised partial sums)
+                float *dst = out + 3 * (static_cast<size_t>(job.packed ? s.item - k * job.n_items : s.st.pixel) +
+                                        static_cast<size_t>(k) * job.plane_stride);
                 dst[0] = c.x, dst[1] = c.y, dst[2] = c.z;
                 assign(s, job.work_counter ? stride + wave_reserve(job.work_counter, true) : s.item + stride);
             }
@@ -349,7 +356,8 @@ hipError_t PlanStream(const DeviceScene &sc, const RenderJob &job, uint32_t n_cu
         return hipErrorOutOfMemory; // does not fit: the caller falls back to fewer slots or the other kernel
     const uint32_t resident = n_cus * static_cast<uint32_t>(per_cu);
     cfg.lane_spread = 1;
-    uint64_t blocks = (uint64_t(job.n_items) + cfg.slots - 1) / cfg.slots;
+    const uint64_t n_work = uint64_t(job.n_items) * (job.sample_split ? job.sample_split : 1u);
+    uint64_t blocks = (n_work + cfg.slots - 1) / cfg.slots;
     if (kRegs)
     {
         cfg.lane_spread = job.lane_spread;
@@ -360,9 +368,9 @@ hipError_t PlanStream(const DeviceScene &sc, const RenderJob &job, uint32_t n_cu
             // no pre-pass: every pixel of the job counts as expensive
             if (cfg.lane_spread == 0)
                 for (cfg.lane_spread = 1; cfg.lane_spread < kMaxStreamSpread &&
-                                          2ull * cfg.lane_spread * job.n_items * kSpreadDen <= uint64_t(resident) * cfg.slots * kSpreadNum;)
+                                          2ull * cfg.lane_spread * n_work * kSpreadDen <= uint64_t(resident) * cfg.slots * kSpreadNum;)
                     cfg.lane_spread *= 2;
-            blocks = (uint64_t(job.n_items) * cfg.lane_spread + cfg.slots - 1) / cfg.slots;
+            blocks = (n_work * cfg.lane_spread + cfg.slots - 1) / cfg.slots;
         }
     }
     cfg.blocks = blocks > resident ? resident : static_cast<uint32_t>(blocks);

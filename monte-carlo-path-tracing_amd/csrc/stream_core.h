@@ -418,7 +418,7 @@ enum StreamShadeResult : uint32_t
 // starts its own PCG-hashed stream (path_core.h::start_sample).
 template <class C, uint32_t S>
 MCPT_HD StreamShadeResult stream_shade(const DeviceScene &sc, StreamSlot<S> &s, LaneCounters *cnt, bool independent = false,
-                                       uint32_t seed = 0)
+                                       uint32_t seed = 0, uint32_t step = 1)
 {
     PathState &st = s.st;
     stream_unpack(s);
@@ -448,7 +448,7 @@ MCPT_HD StreamShadeResult stream_shade(const DeviceScene &sc, StreamSlot<S> &s, 
             stream_pack(s);
             return kStreamPixelDone;
         }
-        start_sample(sc, st, 1, independent, seed);
+        start_sample(sc, st, step, independent, seed);
         if (cnt)
             ++cnt->samples;
         if (sc.prehit == nullptr)

@@ -411,7 +411,7 @@ def test_sample_split_does_not_change_the_estimate(pkg, split):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["rough_dielectric_envmap", "terrain_directional"])
 def test_independent_sample_mode_is_the_same_frame_in_both_kernel_formulations(name, pkg, scenes):
-    """Mode 1 without split samples runs in the stream kernel too: per (seed, pixel, sample) streams make the frame a
+    """Mode 1 runs in the stream kernel too (with and without split samples): per (seed, pixel, sample) streams make the frame a
     function of the seed only, so lanes kernel == stream kernel bit for bit, with and without the pre-pass."""
     r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
     try:
@@ -422,9 +422,13 @@ def test_independent_sample_mode_is_the_same_frame_in_both_kernel_formulations(n
             got, _ = r.set_kernel(1).set_work_distribution(1).set_prepass(prepass).draw()
             assert "stream" in r.last_kernel() and "independent" in r.last_kernel(), r.last_kernel()
             assert np.array_equal(got, lanes), (prepass, r.last_kernel())
-        split, _ = r.set_rng(1, seed=11, sample_split=4).set_kernel(1).draw()     # split samples: the lanes kernel
+        # split samples (k, k + 4, ... per lane; partial-sum planes + reduce): both formulations, the same planes
+        split_stream, _ = r.set_rng(1, seed=11, sample_split=4).set_kernel(1).draw()
+        assert "stream" in r.last_kernel() and "x4" in r.last_kernel(), r.last_kernel()
+        split_lanes, _ = r.set_kernel(0).draw()
         assert "stream" not in r.last_kernel()
-        np.testing.assert_allclose(split, lanes, rtol=0, atol=2e-6)
+        assert np.array_equal(split_stream, split_lanes)
+        np.testing.assert_allclose(split_stream, lanes, rtol=0, atol=2e-6)
     finally:
         r.close()
 
@@ -485,6 +489,28 @@ def test_prepass_is_not_used_where_the_camera_ray_consumes_random_numbers(pkg, s
         frame, _ = r.set_prepass(1).draw()
         assert "pre-pass" not in r.last_kernel()
         assert np.array_equal(frame, golden)
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell_96_spp32", "terrain_directional", "rough_dielectric_envmap"])
+def test_lane_spread_does_not_change_the_image(name, pkg, scenes):
+    """Small jobs run on every n-th lane (mcpt_renderer_set_lane_spread; with a pre-pass the stream kernel sizes n from
+    the camera rays that hit something): scheduling only — the golden frame for every n, kernel and work distribution."""
+    golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
+    try:
+        seen = set()
+        for kernel in (0, 1, 4):
+            for spread in (0, 1, 2, 16, 64):
+                for work, prepass in ((1, 1), (0, 0)):
+                    frame, st = r.set_kernel(kernel).set_lane_spread(spread).set_work_distribution(work).set_prepass(prepass).draw()
+                    seen.add(r.last_kernel())
+                    assert np.array_equal(frame, golden), (kernel, spread, work, prepass, r.last_kernel())
+        assert any("1 path per 16 lanes" in k for k in seen) and any("from the pre-pass's hit count" in k for k in seen), seen
+        with pytest.raises(pkg.capi.McptError, match="power of two"):
+            r.set_lane_spread(3)
     finally:
         r.close()
 
