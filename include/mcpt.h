@@ -214,7 +214,7 @@ int mcpt_renderer_set_work_distribution(mcpt_renderer *r, int mode);
  * coherent wavefronts), and the render kernels start every sample at its first vertex.  Same image, bit for bit; the
  * first of the closest rays of every sample leaves the sequential per-pixel chain.  Costs 8 bytes of HBM per sample of
  * the frame.  mode -1 (default): on for scenes whose hierarchy does not sit in LDS, where the scene allows it (no
- * opacity masks, not the reference-order validation walk, no split samples) — dragon/scene.xml 1.4x, the reference's
+ * opacity masks, not the reference-order validation walk) — dragon/scene.xml 1.4x, the reference's
  * dining-room 1.07x, matpreview +-0; the LDS-resident scenes lose 4-5 % to it; 0: off; 1: on wherever allowed.  Replaces the camera-ray part of the first
  * Scene::Intersect of ShadePath (src/renderer/integrators/path.cpp:18-21). */
 int mcpt_renderer_set_prepass(mcpt_renderer *r, int mode);
@@ -226,12 +226,22 @@ int mcpt_renderer_set_prepass(mcpt_renderer *r, int mode);
  *   mode 1: THROUGHPUT mode, not per-pixel comparable with the reference: every (pixel, sample) starts its own
  *          stream from a PCG hash (RXS-M-XS) of (seed, pixel, sample index) — same pixel jitter, same generator
  *          step inside the sample, same estimator — so the samples of a pixel are independent and are spread over
- *          `sample_split` lanes (samples k, k + K, ...; 0 = as many as fill the GPU twice, in powers of two up to
- *          64); a second kernel adds the lanes' sums in lane order (deterministic).  What it buys: small films and
- *          small per-GPU tile shares still fill the GPU (strong scaling beyond one pixel per lane), and the tail
- *          of a frame shortens.  Graded by mean-square error against a converged image, not per pixel.  Runs the
- *          lane-owns-a-path kernel; whole frames or packed tile ranges. */
+ *          `sample_split` lanes (samples k, k + K, ...; 0 = 16 (pixel, sample-subset) items per resident lane, in
+ *          powers of two up to 32); a second kernel adds the lanes' sums in lane order (deterministic).  What it
+ *          buys: small films and small per-GPU tile shares still fill the GPU (strong scaling beyond one pixel per
+ *          lane), and short items handed out by the work counter balance what whole-pixel chains cannot (whole
+ *          frames on one GPU: cornell-box 64 -> 45 ms, dragon/scene.xml 200 -> 92 ms).  Graded by mean-square error
+ *          against a converged image, not per pixel.  Both kernel formulations, with the camera-ray pre-pass; whole
+ *          frames or packed tile ranges. */
 int mcpt_renderer_set_rng(mcpt_renderer *r, int mode, uint32_t seed, uint32_t sample_split);
+
+/* Which pixels the 64 lanes of a wavefront of the lane-owns-a-path kernel render.  0: one 8x8 tile (neighbouring camera
+ * rays).  1: transposed — 64 different tiles, one pixel each.  -1 (default): transposed when the scene's traversal data
+ * sits in LDS and the draw gives every lane at most one pixel — then nothing can be re-balanced while the frame runs, it
+ * lasts as long as its slowest wavefront, and a wavefront that holds an average mix of pixels (and thins out as its cheap
+ * ones finish) is faster than one that holds a tile of expensive ones: cornell-box 512x512 spp 256 65.3 -> 61.0 ms.
+ * Same frame. */
+int mcpt_renderer_set_pixel_order(mcpt_renderer *r, int mode);
 
 /* Small jobs (fewer pixels than the GPU holds lanes: a rank's share of a strong-scaling run, a thumbnail).  The
  * reference's one RNG stream per pixel makes a pixel's samples a sequential chain, so such a job lasts as long as one

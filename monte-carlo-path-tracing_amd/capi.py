@@ -100,6 +100,7 @@ def lib():
     L.mcpt_renderer_set_rng.argtypes = [vp, i32, u32, u32]
     L.mcpt_renderer_set_prepass.argtypes = [vp, i32]
     L.mcpt_renderer_set_lane_spread.argtypes = [vp, u32]
+    L.mcpt_renderer_set_pixel_order.argtypes = [vp, i32]
     L.mcpt_renderer_set_work_distribution.argtypes = [vp, i32]
     L.mcpt_renderer_last_choice.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.mcpt_renderer_last_kernel.argtypes = [vp]
@@ -136,7 +137,7 @@ EXPORTED_SYMBOLS = [
     "mcpt_renderer_draw", "mcpt_renderer_draw_device", "mcpt_renderer_draw_counted",
     "mcpt_renderer_tile_count", "mcpt_tile_range_size", "mcpt_unpack_tiles",
     "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_set_walk", "mcpt_renderer_set_walk_schedule",
-    "mcpt_renderer_set_kernel", "mcpt_renderer_last_kernel", "mcpt_renderer_check_walks", "mcpt_renderer_set_rng", "mcpt_renderer_set_prepass", "mcpt_renderer_set_lane_spread", "mcpt_renderer_set_work_distribution", "mcpt_renderer_last_choice",
+    "mcpt_renderer_set_kernel", "mcpt_renderer_last_kernel", "mcpt_renderer_check_walks", "mcpt_renderer_set_rng", "mcpt_renderer_set_prepass", "mcpt_renderer_set_lane_spread", "mcpt_renderer_set_pixel_order", "mcpt_renderer_set_work_distribution", "mcpt_renderer_last_choice",
     "mcpt_renderer_destroy",
     "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_trace_pixel", "mcpt_debug_trace_rate",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
@@ -354,6 +355,11 @@ class Renderer:
         """Primary-visibility pre-pass (all camera rays ahead of the sample chains): -1 library's choice (default),
         0 off, 1 on where the scene allows it.  The image does not depend on it."""
         _check(lib().mcpt_renderer_set_prepass(self._h, mode))
+        return self
+
+    def set_pixel_order(self, mode: int):
+        """Lanes kernel: -1 library's choice, 0 a wavefront renders one 8x8 tile, 1 transposed (64 tiles).  Same frame."""
+        _check(lib().mcpt_renderer_set_pixel_order(self._h, mode))
         return self
 
     def set_lane_spread(self, lanes_per_path: int):

@@ -136,6 +136,7 @@ struct mcpt_renderer
     // mcpt_renderer_set_prepass: -1 = the library's choice, 0 = off, 1 = on wherever the scene allows it
     int prepass_mode = -1;
     uint32_t lane_spread = 0; // mcpt_renderer_set_lane_spread: 0 = the launcher's choice
+    int pixel_order = -1;     // mcpt_renderer_set_pixel_order: -1 the launcher's choice, 0 tiles, 1 transposed
     uint32_t *hit_counters_dev = nullptr; // RenderJob::hit_counters, zeroed before every pre-pass
     uint32_t *prehit_dev = nullptr; // camera-ray hits of the whole frame, 2 words per (pixel, sample)
     size_t prehit_words = 0;
@@ -415,6 +416,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     job.reference_walk = r->reference_walk ? 1u : 0u;
     job.sample_split = 1;
     job.lane_spread = r->lane_spread;
+    job.scatter = r->pixel_order < 0 ? mcpt::kScatterAuto : static_cast<uint32_t>(r->pixel_order);
     float *render_target = out_device;
     const uint32_t out_pixels = packed ? job.n_items : static_cast<uint32_t>(r->flat.camera.width) * r->flat.camera.height;
     if (r->rng_mode == 1 && job.n_items != 0)
@@ -423,10 +425,13 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         uint32_t split = r->sample_split;
         if (split == 0)
         {
-            // auto: enough (pixel, sample-subset) items for two rounds of the GPU's resident lanes (4 wavefronts per
-            // SIMD), in powers of two
-            const uint64_t want = 2ull * r->n_cus * 1024ull;
-            for (split = 1; uint64_t(job.n_items) * split < want && split < 64; split *= 2)
+            // auto: 16 (pixel, sample-subset) items per resident lane (4 wavefronts per SIMD), in powers of two up to 32.
+            // Short items handed out by the work counter balance what whole-pixel chains cannot: swept on one GPU
+            // (profiles/r02_experiments/independent_samples_split_sweep.json), whole frame, split 1 -> best: cornell 64.3
+            // -> 44.6 ms (16), dragon/scene.xml 200 -> 92 ms (4 and up), matpreview 251 -> 214 ms (32); 1/8 rank shares
+            // 40.8 -> 7.2, 91 -> 11.6, 122 -> 30.8 ms (32).
+            const uint64_t want = 16ull * r->n_cus * 1024ull;
+            for (split = 1; uint64_t(job.n_items) * split < want && split < 32; split *= 2)
                 ;
         }
         split = std::max(1u, std::min(split, r->flat.camera.spp));
@@ -554,6 +559,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             }
             Check(mcpt::LaunchPrimaryPrepass(r->dev, job, r->prehit_dev, counters, stream, r->n_cus), "launch pre-pass kernel");
             r->dev.prehit = r->prehit_dev;
+            r->dev.prehit_step = job.sample_split ? job.sample_split : 1u;
         }
     }
     const bool wavefront = r->kernel_mode == 3 && !counted && r->rng_mode == 0 && mcpt::WavefrontSupports(r->dev, job);
@@ -574,6 +580,8 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     r->last_kernel = wavefront ? 3 : streamed ? (plan.slots_in_memory ? 2 : plan.wave_local ? 4 : 1) : 0, r->last_work = dynamic_work ? 1 : 0, r->last_prepass = r->dev.prehit ? 1 : 0;
     if (streamed && !wavefront && plan.wave_local)
         r->variant += ", wavefront rounds";
+    if (!streamed && !wavefront && mcpt::LastLaunchTransposed())
+        r->variant += ", transposed pixel order";
     if (streamed && !wavefront && !plan.slots_in_memory)
     {
         if (plan.lane_spread == 0)
@@ -1115,6 +1123,16 @@ int mcpt_renderer_set_prepass(mcpt_renderer *r, int mode)
         return Fail("mcpt_renderer_set_prepass: mode is -1 (the library's choice), 0 (off) or 1 (on where the scene allows it)");
     r->prepass_mode = mode;
     r->auto_choice = -1;
+    return 0;
+}
+
+int mcpt_renderer_set_pixel_order(mcpt_renderer *r, int mode)
+{
+    if (!r)
+        return Fail("null argument");
+    if (mode < -1 || mode > 1)
+        return Fail("mcpt_renderer_set_pixel_order: mode is -1 (the library's choice), 0 (a wavefront renders a tile) or 1 (transposed)");
+    r->pixel_order = mode;
     return 0;
 }
 

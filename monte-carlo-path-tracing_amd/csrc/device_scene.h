@@ -273,6 +273,7 @@ struct DeviceScene
     // (renderer.cpp:68-76) — so all of a frame's camera rays can be traced ahead of the per-pixel sample chains, by
     // a lean kernel with coherent wavefronts, and the chains start every sample at its first vertex.
     const uint32_t *prehit;
+    uint32_t prehit_step; // start_sample's step of the launch that reads prehit (split samples; 1 otherwise)
 };
 
 // Counters of the measurement mode: totals over a launch.

@@ -113,7 +113,7 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, uint32_t *prehit,
 bool PrimaryPrepassSupports(const DeviceScene &sc, const RenderJob &job)
 {
     // (an opacity mask draws a random number during the walk: the camera ray's hit is then part of the chain)
-    return !job.reference_walk && !sc.integrator.has_masks && sc.integrator.n_walk_nodes != 0 && job.sample_split <= 1;
+    return !job.reference_walk && !sc.integrator.has_masks && sc.integrator.n_walk_nodes != 0;
 }
 
 hipError_t LaunchPrimaryPrepass(const DeviceScene &sc, const RenderJob &job, uint32_t *prehit, TraceCounters *counters,

@@ -11,6 +11,8 @@ namespace mcpt
 
 constexpr int kBlockSize = 256;
 constexpr uint32_t kHitCounters = 32;
+constexpr uint32_t kScatterAuto = 0xFFFFFFFFu;
+bool LastLaunchTransposed(); // what the calling thread's last LaunchRender chose (for the kernel description)
 // lane_spread from the job's EXPENSIVE pixels (camera ray hits something): the largest power of two with
 // spread <= kSpreadNum / kSpreadDen * launched lanes / expensive pixels.  Fitted to rank-share measurements
 // (profiles/r02_experiments/lane_spread_rank_shares.json): the best spread leaves 2-3 expensive pixels per active lane.
@@ -49,6 +51,14 @@ struct RenderJob
     // wavefront carries fewer paths — fewer diverged instructions per wavefront, and a pixel's chain of samples (the
     // reference's one RNG stream per pixel makes it sequential) gets shorter.  0: the launcher's choice; 1: dense.
     uint32_t lane_spread;
+    // Pixel order of the lane-owns-a-path kernel.  0: item q (the 64 lanes of a wavefront render one 8x8 tile).
+    // 1: TRANSPOSED — lane l of the w-th wavefront's worth of items takes item l * (items / 64) + w: 64 different tiles.
+    // kScatterAuto: the launcher's choice — transposed when the traversal data sits in LDS (no locality to lose) and the
+    // job gives every lane at most one pixel (nothing left for the work counter to balance): a frame then lasts as long
+    // as its slowest wavefront, and a tile of expensive pixels makes a slow one; transposed, every wavefront holds the
+    // same mix and thins out as its cheap pixels finish (cornell 512x512: 65.3 -> 61.0 ms; volumetric-caustic, 3.5
+    // pixels per lane: 140 -> 149 ms, so not there).
+    uint32_t scatter;
     // kHitCounters words (may be null): the pre-pass adds the number of camera rays that hit something — what the
     // expensive part of the job is.  The stream kernel sizes lane_spread from it (lane_spread 0 only).
     uint32_t *hit_counters;
@@ -88,8 +98,8 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
 
 // Primary-visibility pre-pass (hip/primary_kernel.hip): the closest hit of every camera ray of the job's pixels into
 // `prehit` (2 words per (pixel, sample) of the WHOLE frame: width * height * spp * 2 words); the render kernels use it
-// when DeviceScene::prehit points to it.  Not for scenes with opacity masks, the reference-order validation walk, or
-// split samples.
+// when DeviceScene::prehit points to it.  Not for scenes with opacity masks or the reference-order validation walk.
+// (With split samples DeviceScene::prehit_step is the launch's sample step.)
 bool PrimaryPrepassSupports(const DeviceScene &sc, const RenderJob &job);
 hipError_t LaunchPrimaryPrepass(const DeviceScene &sc, const RenderJob &job, uint32_t *prehit, TraceCounters *counters,
                                 hipStream_t stream, uint32_t n_cus);

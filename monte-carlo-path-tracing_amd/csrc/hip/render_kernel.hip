@@ -138,6 +138,13 @@ hipError_t LaunchBsdf(const DeviceScene &sc, uint32_t n, uint32_t id_bsdf, int m
 // reference-order walk, which exists only in the full instantiation.  The two
 // LDS-resident instantiations (tiny scenes) use the plain ordered walk, all others
 // the vote-scheduled one (its threshold comes from the commit: 0 for small scenes).
+namespace
+{
+thread_local bool g_last_transposed = false;
+}
+void NoteTransposed(bool transposed) { g_last_transposed = transposed; }
+bool LastLaunchTransposed() { return g_last_transposed; }
+
 hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
                         hipStream_t stream, uint32_t n_cus, const char **variant)
 {

@@ -124,7 +124,9 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         {
             if (q >= n_work)
                 break;
-            const uint32_t k = split == 1 ? 0u : q / job.n_items, item = q - k * job.n_items;
+            // (n_work is a multiple of 64: whole tiles)
+            const uint32_t qs = job.scatter ? (q & 63u) * (n_work >> 6) + (q >> 6) : q;
+            const uint32_t k = split == 1 ? 0u : qs / job.n_items, item = qs - k * job.n_items;
             // item -> tile -> pixel
             const uint32_t local_tile = item >> 6, r = item & 63u;
             const uint32_t tile = job.tile_first + local_tile * job.tile_stride;
@@ -184,6 +186,8 @@ inline size_t StagedBytes(const DeviceScene &sc, bool ordered)
     return vecs * sizeof(float4);
 }
 
+void NoteTransposed(bool transposed);
+
 template <uint32_t kFeatures, bool kCount, bool kLdsGeometry = false>
 hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters, hipStream_t stream,
                   uint32_t max_blocks)
@@ -205,6 +209,9 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
     //  instructions with 8 paths as with 64 — dense is the default; cornell's 1/8 share gains 8 % at spread 2 - 4)
     if (spread_job.lane_spread == 0)
         spread_job.lane_spread = 1;
+    if (spread_job.scatter == kScatterAuto)
+        spread_job.scatter = kLdsGeometry && uint64_t(n_work) <= uint64_t(resident) * kBlockSize ? 1u : 0u;
+    NoteTransposed(spread_job.scatter != 0);
     uint64_t blocks = (uint64_t(n_work) * spread_job.lane_spread + kBlockSize - 1) / kBlockSize;
     if (blocks > resident)
         blocks = resident;

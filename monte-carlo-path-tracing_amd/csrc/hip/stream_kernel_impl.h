@@ -360,7 +360,9 @@ hipError_t PlanStream(const DeviceScene &sc, const RenderJob &job, uint32_t n_cu
     uint64_t blocks = (n_work + cfg.slots - 1) / cfg.slots;
     if (kRegs)
     {
-        cfg.lane_spread = job.lane_spread;
+        // (the automatic spread is for the scenes outside LDS: latency-bound rounds.  With the hierarchy in LDS the
+        //  kernel is VALU-bound and idle lanes are not free: cornell 776 -> 519 Msamples/s at 1 path per 2 lanes)
+        cfg.lane_spread = job.lane_spread ? job.lane_spread : kLdsGeometry ? 1u : 0u;
         if (cfg.lane_spread == 0 && job.hit_counters)
             blocks = resident; // the kernel sizes the spread from the pre-pass's hit count: every resident slot is launched
         else

@@ -362,7 +362,7 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
     const bool known = C::kOrdered && st.primary && sc.prehit != nullptr; // the pre-pass traced this camera ray
     if (known)
     {
-        const uint32_t *rec = sc.prehit + 2 * (static_cast<size_t>(st.pixel) * sc.camera.spp + (st.sample - 1u)); // (start_sample advanced it; the pre-pass is not combined with split samples)
+        const uint32_t *rec = sc.prehit + 2 * (static_cast<size_t>(st.pixel) * sc.camera.spp + (st.sample - sc.prehit_step)); // (start_sample advanced it)
         const uint32_t prim = rec[0];
         hit_valid = prim != kNone;
         if (hit_valid)

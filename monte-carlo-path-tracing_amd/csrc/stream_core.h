@@ -453,7 +453,7 @@ MCPT_HD StreamShadeResult stream_shade(const DeviceScene &sc, StreamSlot<S> &s, 
             ++cnt->samples;
         if (sc.prehit == nullptr)
             break;
-        const uint32_t *rec = sc.prehit + 2 * (static_cast<size_t>(st.pixel) * sc.camera.spp + (st.sample - 1u));
+        const uint32_t *rec = sc.prehit + 2 * (static_cast<size_t>(st.pixel) * sc.camera.spp + (st.sample - step));
         const uint32_t prim = rec[0];
         s.hit_valid = prim != kNone, s.hit_t = kMaxFloat;
         if (s.hit_valid)
