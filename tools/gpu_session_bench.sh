@@ -17,6 +17,6 @@ for w in ${WORKLOADS:-cornell dragon matpreview-rc matpreview-rd volumetric}; do
 done
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- \
-      python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pmc > $GRAFT_REPO_ROOT/$OUT/prof_stdout.txt 2>&1)
+      python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pmc --no-throughput-mode > $GRAFT_REPO_ROOT/$OUT/prof_stdout.txt 2>&1)
   find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -r head -5
 fi
