@@ -289,7 +289,7 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
             ctrl->n_ext[p ^ 1u] = 0, ctrl->n_shadow[p ^ 1u] = 0, ctrl->next[p ^ 1u] = 0;
         // ---- trace -------------------------------------------------------------------------------
         const StreamRayList list{ids, n_ext, n_shadow, &ctrl->next[p]};
-        stream_trace<C, kCount>(sc, m, list, stack, cfg.refill_at, cnt, kRegs ? &own : nullptr);
+        stream_trace<C, kCount, !kRegs>(sc, m, list, stack, cfg.refill_at, cnt, kRegs ? &own : nullptr);
         if (kRegs)
             mine.hit_valid = own.found, mine.hit = own.hit, mine.hit_t = own.t;
         const unsigned long long t3 = now();

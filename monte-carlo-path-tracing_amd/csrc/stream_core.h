@@ -661,7 +661,9 @@ struct OwnRay
 };
 constexpr uint32_t kOwnRayId = 0xFFFFFFFEu;
 
-template <class C, bool kCount>
+// kListHasExt = false: the list holds shadow rays only (one slot per lane: every extension ray is its lane's own) — the
+// retire / fetch code of listed extension rays is not compiled in.
+template <class C, bool kCount, bool kListHasExt = true>
 MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const StreamRayList &list, uint32_t *stack,
                           uint32_t refill_at, LaneCounters *cnt, OwnRay *own = nullptr)
 {
@@ -759,7 +761,7 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
                 {
                     own->found = best.found, own->hit = hit, own->t = best.found ? best.best_t : kMaxFloat;
                 }
-                else if (kind == 0)
+                else if (kListHasExt && kind == 0)
                 {
                     m.hot[kHotPrim * P + slot] = best.found ? hit.prim : kNone;
                     if (best.found)
@@ -783,11 +785,11 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
             const uint32_t k = wave_reserve(list.next, want);
             if (want && k < total)
             {
-                my = list.ids[k < list.n_ext ? k : P + (k - list.n_ext)];
-                kind = (my >= P ? 1u : 0u) + (my >= 2u * P ? 1u : 0u), slot = my - kind * P;
+                my = kListHasExt ? list.ids[k < list.n_ext ? k : P + (k - list.n_ext)] : list.ids[P + k];
+                kind = kListHasExt ? (my >= P ? 1u : 0u) + (my >= 2u * P ? 1u : 0u) : (my >= 2u * P ? 2u : 1u), slot = my - kind * P;
                 V3 o, d;
                 float t_max = kMaxFloat;
-                if (kind == 0)
+                if (kListHasExt && kind == 0)
                     o = stream_get3(m.hot, P, kHotA, slot), d = stream_get3(m.hot, P, kHotDir, slot);
                 else
                 {
