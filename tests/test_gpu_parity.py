@@ -429,6 +429,18 @@ def test_independent_sample_mode_is_the_same_frame_in_both_kernel_formulations(n
         assert "stream" not in r.last_kernel()
         assert np.array_equal(split_stream, split_lanes)
         np.testing.assert_allclose(split_stream, lanes, rtol=0, atol=2e-6)
+        # ... and as packed tile ranges of two ranks (what bench.py --gpus 2 gathers), stream kernel, split samples
+        import torch
+        r.set_kernel(1)
+        h, w = split_stream.shape[:2]
+        composed = np.zeros_like(split_stream)
+        for rank in range(2):
+            rng = pkg.capi.TileRange(rank, 2, 0)
+            buf = torch.zeros(r.tiles_in(rng) * 64 * 3, dtype=torch.float32, device="cuda:0")
+            r.draw_device(buf.data_ptr(), rng, packed=True)
+            assert "stream" in r.last_kernel(), r.last_kernel()
+            pkg.capi.unpack_tiles(buf.cpu().numpy(), rng, w, h, composed)
+        assert np.array_equal(composed, split_stream)
     finally:
         r.close()
 
