@@ -198,8 +198,9 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
         *variant = "surface-materials";
         return Launch<kSurface | kV, false>(sc, job, out, nullptr, stream, n_cus);
     }
-    *variant = "all";
-    return Launch<kAll | kV, false>(sc, job, out, nullptr, stream, n_cus);
+    *variant = lds ? "all+lds" : "all";
+    return lds ? Launch<kAll | kO, false, true>(sc, job, out, nullptr, stream, n_cus)
+               : Launch<kAll | kV, false>(sc, job, out, nullptr, stream, n_cus);
 }
 
 // Tiles of one rank's packed block (64 pixels x 3 floats per tile, tile t = first + k * stride) -> their
