@@ -48,7 +48,11 @@ struct Budget
     // volumetric scenes than at 2 (208 VGPRs), slower again at 4 (-3 %) and 6 (-24 %); the
     // surface-materials instantiation (matpreview) is fastest at 6 (rough dielectric +25 %,
     // rough conductor +3 % over its natural 168 VGPRs)
-    static constexpr int kWavesPerSimd = (kFeatures & (kFeatVolPath | kFeatAnalytic)) ? 3
+    // (the same instantiation with the hierarchy in LDS, volumetric-caustic at 2 / 3 / 4 per SIMD: 779 / 913 / 890 Msamples/s)
+#ifndef MCPT_FULL_LDS_WAVES
+#define MCPT_FULL_LDS_WAVES 3
+#endif
+    static constexpr int kWavesPerSimd = (kFeatures & (kFeatVolPath | kFeatAnalytic)) ? (kLdsGeometry ? MCPT_FULL_LDS_WAVES : 3)
 #ifdef MCPT_EXPERIMENT_MICROFACET_WAVES
                                          : (kFeatures & kFeatMicrofacet)              ? MCPT_EXPERIMENT_MICROFACET_WAVES
 #else
