@@ -211,8 +211,11 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
     RenderJob spread_job = job;
     // (measured on rank shares of cornell-box and volumetric-caustic: this kernel's wavefronts execute nearly the same
     //  instructions with 8 paths as with 64 — dense is the default; cornell's 1/8 share gains 8 % at spread 2 - 4)
+    //  — except the diffuse LDS instantiations on a quarter of the lanes or less: 1 path per 2 lanes, cornell's 1/4 and
+    //  1/8 shares 43.6 -> 38.8 and 41.2 -> 38.8 ms; its 1/2 share 42.8 -> 53.0 ms, so not there)
     if (spread_job.lane_spread == 0)
-        spread_job.lane_spread = 1;
+        spread_job.lane_spread =
+            kLdsGeometry && (kFeatures & kAll & ~kFeatEmitters) == 0 && uint64_t(n_work) * 4u <= uint64_t(resident) * kBlockSize ? 2u : 1u;
     if (spread_job.scatter == kScatterAuto)
         // (measured on the diffuse instantiations; volumetric-caustic lost 6 % with it at 3.5 pixels per lane)
         spread_job.scatter = kLdsGeometry && (kFeatures & kAll & ~kFeatEmitters) == 0 &&
