@@ -2,23 +2,32 @@
 """Benchmark of the render hot path on MI355X.
 
     python bench.py [--workload cornell|dragon|matpreview-rc|matpreview-rd|volumetric]
-                    [--gpus N] [--steps K] [--warmup W] [--weak]
+                    [--gpus N] [--steps K] [--warmup W] [--weak] [--no-also]
 
 A "step" is one complete render of the workload's frame (all pixels, all spp) with the scene already
-resident in HBM and the frame left in HBM.  The workloads are the configurations BASELINE.json names, at
-their stated film sizes (monte-carlo-path-tracing_amd/workloads.py); the default is configs[1], cornell-box
-512x512 spp 256.  For N > 1 (launched by torch.distributed.run, one rank per GPU) the frame's 8x8 tiles are
-dealt round-robin to the ranks, every rank renders its tiles into a packed device buffer and ONE RCCL gather
-brings them to rank 0, which scatters them into the frame — all inside the timed region.  The film is the
-workload's own for every N: the total work is fixed ("strong" scaling).  `--weak` (cornell only) grows the
-film side with sqrt(N) instead, so that every GPU renders 512x512 pixels' worth of tiles.
+resident in HBM.  At N = 1 a step is the BLOCKING drop-in call, `mcpt_renderer_draw` = csrt::Renderer::Draw
+(t_render includes the final device-to-host copy of the frame; the host buffer is
+pinned).  The workloads are the configurations BASELINE.json names, at their stated film sizes
+(monte-carlo-path-tracing_amd/workloads.py); the default is configs[1], cornell-box 512x512 spp 256, and the
+default N = 1 line carries an `also` block with north_star's SECOND target, dragon/scene.xml 1280x720 spp 256,
+measured the same way in the same process (value, ms_per_step, first_draw_ms, roofline with counters,
+cpu_baseline, parity).  For N > 1 (launched by torch.distributed.run, one rank per GPU) the frame's 8x8 tiles
+are dealt round-robin to the ranks, every rank renders its tiles into a packed device buffer, ONE RCCL gather
+brings them to rank 0, which scatters them into the frame and copies it to the host — all inside the timed
+region.  The film is the workload's own for every N: the total work is fixed ("strong" scaling).  `--weak`
+(cornell only) grows the film side with sqrt(N) instead.
 
-Rank 0 prints one JSON line: metric Msamples/s (W*H*spp / t / 1e6, whole job) plus
+Rank 0 prints ONE JSON line: metric Msamples/s (W*H*spp / t / 1e6, whole job) plus
+  first_draw_ms what the FIRST draw of a fresh renderer costs (buffer allocation and, for scenes outside
+                LDS, the calibration of the kernel configuration): what a one-shot `mcpt_cli` run pays.
   roofline      the render kernel against the roof that binds it.  Counts per sample come from the kernel's
                 counting instantiation (run outside the timed region), the kernel time from HIP events on the
                 launch stream, hardware counters from rocprofv3 --pmc passes that bench.py runs on the same
                 workload right after the timed region (one pass per counter group, --kernel-trace only), the
-                HBM stream bandwidth from a device copy / reduction timed in this process.
+                HBM stream bandwidth from a device copy / reduction timed in this process.  `valu` holds BOTH
+                readings of the VALU roof: `frac_at_16_lanes_per_clk` (SQ's accounting: a wave64 instruction
+                takes 4 issue cycles) and `frac_at_32_lanes_per_clk` (the guide's: 2 cycles), and — where the
+                counters exist — the instruction-class mix that decides between them.
   cpu_baseline  at N = 1: the compiled reference (oracle/_ref, "reference") and the oracle port ("port") timed
                 on this host's cores on a bounded sample of the same workload, and `parity`: the GPU frame
                 against that CPU frame at the same film / spp.
@@ -48,7 +57,17 @@ PMC_GROUPS = [
      "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"],
     ["FETCH_SIZE"],
     ["WRITE_SIZE"],
+    # instruction-class mix (optional: a box whose rocprofv3 lacks one of these reports the pass under `failed`)
+    ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
+     "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_SALU", "SQ_INSTS_VMEM"],
 ]
+KERNEL_WORDS = ("render_kernel", "stream_kernel", "primary_kernel", "queued_")
+# Issue cost per wave64 VALU instruction by class, from this repository's microbenchmark on MI355X
+# (tools/microbench/valu_rate.hip, profiles/r02_experiments/valu_issue_rate_microbench.jsonl): plain fp32
+# add / sub / mul, moves and bit operations issue every ~2.7 cycles per SIMD, compares / selects / min / max / fma /
+# conversions / integer multiplies every ~4.5, transcendentals (rcp, sqrt, ...) every ~8.5.
+CLASS_CYCLES = {"SQ_INSTS_VALU_ADD_F32": 2.7, "SQ_INSTS_VALU_MUL_F32": 2.7, "SQ_INSTS_VALU_FMA_F32": 4.5,
+                "SQ_INSTS_VALU_TRANS_F32": 8.5, "SQ_INSTS_VALU_INT32": 2.7, "SQ_INSTS_VALU_CVT": 4.5}
 
 
 def algorithmic_bytes_per_sample(counts, spp):
@@ -115,13 +134,13 @@ def pmc_leg(workload, film, choice, timeout_s=300):
                 continue
             for row in csv.DictReader(open(files[0])):
                 name = row["Kernel_Name"]
-                if "render_kernel" not in name and "stream_kernel" not in name and "primary_kernel" not in name:
+                if not any(k in name for k in KERNEL_WORDS):
                     continue
                 kernels.add(name.replace("(anonymous namespace)::", "").split("(")[0][-90:])
                 counters[row["Counter_Name"]] = counters.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
             for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if any(k in row["Kernel_Name"] for k in ("render_kernel", "stream_kernel", "primary_kernel")):
+                    if any(k in row["Kernel_Name"] for k in KERNEL_WORDS):
                         if gi == 0:
                             duration_ns.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
     # one draw = [camera-ray pre-pass +] render kernel: the step's kernel time is their sum
@@ -171,6 +190,280 @@ def cpu_baseline(pkg, workload, W, H, SPP, budget_s=12.0):
     return recs, frame, (w, h, spp)
 
 
+def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device, primary):
+    """One workload, measured: the timed loop, the throughput-mode loop (primary line only), roofline, CPU baseline
+    and parity.  Returns the JSON record on rank 0 (None elsewhere)."""
+    W, H, SPP = film
+    weak = args.weak and world > 1
+    use_gather = world > 1 or args.force_gather
+    kernel_mode = {"auto": -1, "stream": 1, "lanes": 0, "queued": 5}[args.kernel]
+
+    def make_renderer(spp):
+        r = pkg.capi.Renderer(pkg.workloads.config(name, W, H, spp), device=local_rank)
+        r.set_kernel(kernel_mode)
+        if args.rng == "pcg":
+            r.set_rng(1, seed=1, sample_split=args.sample_split)
+        return r
+
+    renderer = make_renderer(SPP)
+    rng = pkg.capi.TileRange(rank, world, 0)
+    assert renderer.tiles_in(rng) == len(pkg.tiling.rank_tiles(rank, world, W, H))
+    stream = torch.cuda.current_stream().cuda_stream
+    # the caller's frame: host memory (pinned), like the buffer csrt::RayTracer hands to Renderer::Draw
+    host = torch.empty(H * W * 3, dtype=torch.float32, pin_memory=True)
+    host_np = host.numpy().reshape(H, W, 3)
+    fg = pkg.tiling.FrameGather(world, rank, W, H, device) if use_gather else None
+    kernel_ms_steps = []
+
+    def step(record=False):
+        if not use_gather:
+            st = renderer.draw_into(host_np)   # blocking; device-to-host copy of the frame included
+            if record:
+                kernel_ms_steps.append(st["kernel_milliseconds"])
+        else:
+            renderer.draw_device(fg.packed.data_ptr(), rng, packed=True, stream=stream, blocking=False)
+            fg.gather()
+            if rank == 0:
+                host.copy_(fg.frame, non_blocking=True)
+
+    def sync():
+        if use_gather:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # First draw of a fresh renderer: buffer allocation and — scenes outside LDS, library's choice of kernel — the
+    # calibration of the kernel configuration.  Reported (`first_draw_ms`), not part of a step.
+    sync()
+    t_first = time.perf_counter()
+    step()
+    sync()
+    first_draw_ms = 1e3 * (time.perf_counter() - t_first)
+    for _ in range(args.warmup):
+        step()
+    sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step(record=True)
+    ev1.record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # HIP events on the launch stream: inside the library around every draw's launches (N = 1), around the loop (N > 1)
+    kernel_ms = float(np.mean(kernel_ms_steps)) if kernel_ms_steps else ev0.elapsed_time(ev1) / max(args.steps, 1)
+    kernel_name = renderer.last_kernel()
+    choice = renderer.last_choice()   # (kernel, work distribution, pre-pass) the timed steps ran
+    gather_ms = None
+    if use_gather:
+        # the exchange step alone: one more gather of the blocks already rendered
+        sync()
+        g0 = time.perf_counter()
+        fg.gather()
+        sync()
+        gather_ms = 1e3 * (time.perf_counter() - g0)
+
+    # The same job in the THROUGHPUT mode (independent PCG-hashed stream per (pixel, sample), the samples of a
+    # pixel spread over lanes): reported next to `value`, never as `value`.  With the reference stream a pixel's
+    # samples are one sequential chain, so a GPU whose tile share is below one pixel per lane cannot go faster
+    # than one wavefront's chain (DESIGN.md section 7); this mode has no such floor.
+    throughput = None
+    if args.rng == "reference" and not args.no_throughput_mode and primary:
+        renderer.set_rng(1, seed=1, sample_split=args.sample_split)
+        for _ in range(max(args.warmup, 1)):
+            step()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        e2 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([e2], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e2 = float(t.item())
+        throughput = {"value": W * H * SPP * args.steps / e2 / 1e6, "unit": "Msamples/s", "ms_per_step": 1e3 * e2 / args.steps,
+                      "rng": "independent PCG-hashed stream per (pixel, sample); not per-pixel comparable with the reference",
+                      "kernel": renderer.last_kernel()}
+        renderer.set_rng(0)
+
+    # per-rank kernel time of its share (N > 1): one more blocking draw on every rank, gathered to rank 0
+    rank_kernel_ms = None
+    if world > 1:
+        st = renderer.draw_device(fg.packed.data_ptr(), rng, packed=True, stream=stream, blocking=True)
+        mine = torch.tensor([st["kernel_milliseconds"]], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_kernel_ms = [float(v.item()) for v in every]
+        kernel_ms = rank_kernel_ms[0]
+
+    out = None
+    if rank == 0:
+        samples = W * H * SPP
+        value = samples * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Msamples/sec (W*H*spp/s)", "value": value, "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "first_draw_ms": first_draw_ms,
+            "config": {"workload": f"{name}: {pkg.workloads.DESCRIPTION[name]}"
+                                   + ("" if (W, H, SPP) == pkg.workloads.WORKLOADS[name][1] else f" — film overridden: {W}x{H} spp={SPP}"),
+                       "baseline_config_index": pkg.workloads.WORKLOADS[name][2],
+                       "step": ("blocking mcpt_renderer_draw into a pinned host frame (device-to-host copy included)" if not use_gather else
+                                "per rank: asynchronous draw of its tiles + ONE gather; rank 0: scatter + device-to-host copy of the frame"),
+                       "rng": ("reference stream (Tea + LCG per pixel)" if args.rng == "reference" else
+                               "THROUGHPUT MODE, not per-pixel comparable: independent PCG-hashed stream per (pixel, sample)"),
+                       "kernel": kernel_name,
+                       "partition": f"8x8 tiles round-robin over {world} GPU(s)"
+                                    + (", one RCCL gather to rank 0" if world > 1 else ""),
+                       "film": (f"{W}x{H}: side scaled with sqrt(N) so that every GPU renders 512x512 pixels' worth "
+                                "of tiles (weak scaling)") if weak else f"{W}x{H}"},
+        }
+        if rank_kernel_ms is not None:
+            out["per_rank_kernel_ms"] = rank_kernel_ms
+        if gather_ms is not None:
+            out["gather_ms"] = gather_ms
+        if throughput:
+            out["throughput_mode"] = throughput
+        # ---- roofline of the render kernel (everything below is outside the timed region).  N > 1: rank 0's
+        # GPU and its share of the tiles.
+        count_spp = min(SPP, 16)
+        rc = make_renderer(count_spp)
+        count_choice = choice if choice[0] != 5 else (1, 1, choice[2])   # (the queued renderer has no counting build: its rays are the stream kernel's)
+        rc.set_kernel(count_choice[0]).set_work_distribution(count_choice[1]).set_prepass(count_choice[2])
+        _, counts = rc.draw(counted=True)
+        scene_info = rc.info()
+        rc.close()
+        rank_samples = samples if world == 1 else len(pkg.tiling.rank_tiles(0, world, W, H)) * 64 * SPP
+        b_per_sample = algorithmic_bytes_per_sample(counts, SPP)
+        algorithmic_bytes = b_per_sample * rank_samples
+        algorithmic_gbs = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
+        props = torch.cuda.get_device_properties(device)
+        n_simd = props.multi_processor_count * 4
+        clock_ghz = getattr(props, "clock_rate", 2.4e6) / 1e6   # (fallback only: cycles come from GRBM_GUI_ACTIVE)
+        bw = stream_bandwidth(torch, device)
+        hbm_peak = max(bw["copy_gbs"], bw["read_gbs"])
+        rays = counts["closest_rays"] + counts["shadow_rays"]
+        per_sample = {k: counts[k] / counts["samples"] for k in
+                      ("closest_rays", "shadow_rays", "node_tests", "prim_tests", "shaded_hits")}
+        walk = {"rays_per_s": rays / counts["samples"] * rank_samples / (kernel_ms * 1e-3),
+                "node_phase_lane_util": (counts["node_tests"] / 2) / (64.0 * max(counts["wave_node_steps"], 1)),
+                "prim_phase_lane_util": counts["prim_tests"] / (64.0 * max(counts["wave_prim_steps"], 1))}
+        hbm = {"algorithmic_gbs": algorithmic_gbs, "bytes_per_sample": b_per_sample,
+               "stream_peak_gbs": hbm_peak, "stream_copy_gbs": bw["copy_gbs"], "stream_read_gbs": bw["read_gbs"],
+               "spec_peak_gbs": HBM_SPEC_GBS, "frac_algorithmic_of_stream_peak": algorithmic_gbs / hbm_peak,
+               "frac_algorithmic_of_spec": algorithmic_gbs / HBM_SPEC_GBS}
+        roof = {"bound": "hbm", "achieved": algorithmic_gbs, "peak": hbm_peak, "unit": "GB/s",
+                "frac": algorithmic_gbs / hbm_peak, "traffic": None,
+                "kernel": kernel_name, "kernel_ms": kernel_ms, "per_sample": per_sample, "walk": walk, "hbm": hbm,
+                "scene": {"walk_nodes": scene_info["walk_nodes"], "primitives": scene_info["primitives"],
+                          "geometry_bytes": scene_info["geometry_bytes"]}}
+        pmc = None if (args.no_pmc or world > 1 or args.rng != "reference") else pmc_leg(name, (W, H, SPP), choice)
+        if pmc and pmc["counters"].get("SQ_INSTS_VALU") and pmc["kernel_ns"]:
+            c = pmc["counters"]
+            pmc_ms = pmc["kernel_ns"] * 1e-6
+            cycles = c["GRBM_GUI_ACTIVE"] / N_XCD if c.get("GRBM_GUI_ACTIVE") else pmc_ms * 1e-3 * clock_ghz * 1e9
+            issue = c["SQ_INSTS_VALU"] * 4.0 / (n_simd * cycles)
+            lanes = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+            valu_peak = n_simd * VALU_LANES_PER_SIMD * cycles / (pmc_ms * 1e-3) / 1e12   # T lane-ops/s at the measured clock
+            valu = {"issue_frac": issue, "lane_util": lanes, "useful_frac": issue * lanes,
+                    # the two readings of the VALU roof: SQ accounts a wave64 instruction at 4 issue cycles (16 lanes / clk /
+                    # SIMD); the CDNA4 guide gives 2 cycles (32 lanes / clk / SIMD).  The truth depends on the instruction
+                    # mix (this repository's microbenchmark: plain add / mul / mov 2.7, fma / cmp / cndmask / cvt 4.5 cycles).
+                    "frac_at_16_lanes_per_clk": issue * lanes, "frac_at_32_lanes_per_clk": 0.5 * issue * lanes,
+                    "issue_frac_at_2_cycles": 0.5 * issue,
+                    "valu_insts_per_sample": c["SQ_INSTS_VALU"] / samples,
+                    "wait_any_per_wave_cycle": c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0),
+                    "peak_tlaneops": valu_peak, "achieved_tlaneops": valu_peak * issue * lanes,
+                    "pmc_kernel_ms": pmc_ms, "cycles": cycles}
+            mix = {k: c[k] for k in CLASS_CYCLES if k in c}
+            if mix:
+                classified = sum(mix.values())
+                other = max(c["SQ_INSTS_VALU"] - classified, 0.0)   # compares, selects, min / max, moves, bit operations, packed, fp64
+                est_cycles = sum(v * CLASS_CYCLES[k] for k, v in mix.items()) + other * 4.5
+                valu["class_mix"] = dict({k.replace("SQ_INSTS_VALU_", "").lower(): v / c["SQ_INSTS_VALU"] for k, v in mix.items()},
+                                         other=other / c["SQ_INSTS_VALU"])
+                valu["issue_frac_by_class_cycles"] = est_cycles / (n_simd * cycles)
+                valu["frac_by_class_cycles"] = est_cycles / (n_simd * cycles) * lanes
+                for k in ("SQ_INSTS_SALU", "SQ_INSTS_VMEM"):
+                    if k in c:
+                        valu[k.lower() + "_per_valu"] = c[k] / c["SQ_INSTS_VALU"]
+            roof["valu"] = valu
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                # rocprofv3 reports KiB; FETCH_SIZE counts 64-byte requests where gfx950 moves 128 (guide's
+                # gfx950 note): doubled
+                traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+                roof["traffic"] = traffic
+                hbm.update(measured_gbs=traffic / (pmc_ms * 1e-3) / 1e9,
+                           measured_frac_of_stream_peak=traffic / (pmc_ms * 1e-3) / 1e9 / hbm_peak,
+                           measured_frac_of_spec=traffic / (pmc_ms * 1e-3) / 1e9 / HBM_SPEC_GBS,
+                           traffic_over_algorithmic=traffic / algorithmic_bytes,
+                           fetch_bytes=2.0 * c["FETCH_SIZE"] * 1024.0, write_bytes=c["WRITE_SIZE"] * 1024.0)
+            # the roof the kernel is closest to: VALU issue slots or HBM bytes actually moved
+            if issue >= hbm.get("measured_frac_of_stream_peak", 0.0):
+                roof.update(bound="valu", achieved=valu["achieved_tlaneops"], peak=valu_peak, unit="Tlane-op/s",
+                            frac=issue * lanes)
+                roof["note"] = ("VALU-issue bound: %.0f %% of the issue slots of the %d SIMDs are taken (SQ's 4-cycle accounting; "
+                                "%.0f %% at the guide's 2 cycles per instruction), %.0f %% of the lanes of those instructions do "
+                                "work -> frac = useful fp32 lane-operations / peak, between %.2f (32 lanes / clk / SIMD) and %.2f "
+                                "(16; reported as `frac`); no FMA: the arithmetic contract forbids contraction.  HBM moves %s per "
+                                "launch against %s of algorithmic bytes: the walk's data comes from LDS / cache."
+                                % (100 * issue, n_simd, 50 * issue, 100 * lanes, 0.5 * issue * lanes, issue * lanes,
+                                   "%.3g MB" % (roof["traffic"] / 1e6) if roof["traffic"] else "?",
+                                   "%.3g GB" % (algorithmic_bytes / 1e9)))
+            else:
+                roof.update(achieved=hbm["measured_gbs"], frac=hbm["measured_frac_of_stream_peak"])
+                roof["note"] = ("memory bound: achieved = HBM bytes moved per launch (PMC) / kernel time, peak = stream "
+                                "bandwidth measured in this process; VALU issue %.0f %% x lane utilisation %.0f %%"
+                                % (100 * issue, 100 * lanes))
+            roof["pmc"] = {"kernels": pmc["kernels"], "failed": pmc["failed"],
+                           "command": "rocprofv3 --kernel-trace --pmc <group> -- python tools/render_scene.py "
+                                      f"workload:{name} --film {W} {H} {SPP} --draws 1 --kernel-mode {choice[0]} --work {choice[1]} "
+                                      f"--prepass {choice[2]} (one pass per group; counters and durations summed over the draw's kernels)"}
+        else:
+            roof["note"] = ("no counter pass (rocprofv3 absent, --no-pmc or N > 1): algorithmic bytes (32 B/box test, "
+                            "36 B/primitive test, 132 B/shaded hit, 12 B/pixel) over the kernel time against the "
+                            "measured stream bandwidth")
+            if pmc:
+                roof["pmc"] = {"failed": pmc["failed"]}
+        out["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            recs, cpu_frame, (cw, ch, cspp) = cpu_baseline(pkg, name, W, H, SPP, budget_s=12.0 if primary else 8.0)
+            out["cpu_baseline"] = recs.get("reference", recs["port"])
+            if "reference" in recs:
+                out["cpu_baseline_port"] = recs["port"]
+            rg = pkg.capi.Renderer(pkg.workloads.config(name, cw, ch, cspp), device=local_rank)
+            rg.set_kernel(kernel_mode)
+            if args.rng == "pcg":
+                rg.set_rng(1, seed=1, sample_split=args.sample_split)
+            gpu_frame, _ = rg.draw()
+            rg.close()
+            d = gpu_frame.astype(np.float64) - cpu_frame.astype(np.float64)
+            l2 = np.sqrt((d ** 2).sum(axis=2))
+            out["parity"] = {"vs": "port", "film": [cw, ch, cspp], "rng": args.rng,
+                             "mean_gpu": float(gpu_frame.mean()), "mean_cpu": float(cpu_frame.mean()),
+                             "rmse": float(np.sqrt((d ** 2).mean())), "mean_l2": float(l2.mean()),
+                             "max_l2": float(l2.max()), "frac_gt_1e-3": float((l2 > 1e-3).mean()),
+                             "frac_exact": float((l2 == 0).mean())}
+    if args.force_gather and primary:
+        step()   # (the throughput-mode loop above left its own frame in the gather buffer)
+        sync()
+        if rank == 0:
+            # the gathered frame must be the plain full-frame draw, bit for bit
+            plain, _ = renderer.draw()
+            same = bool(np.array_equal(fg.frame.cpu().numpy().reshape(H, W, 3), plain))
+            print(json.dumps({"force_gather_frame_equals_plain_draw": same}), file=sys.stderr)
+            if not same:
+                sys.exit(3)
+    renderer.close()
+    del host
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,8 +477,8 @@ def main():
     ap.add_argument("--weak", action="store_true",
                     help="N > 1, cornell: grow the film side with sqrt(N) (per-GPU work fixed) instead of "
                          "cutting the workload's own film over the GPUs")
-    ap.add_argument("--kernel", choices=["auto", "stream", "lanes"], default="auto",
-                    help="kernel formulation (default: the library's choice by scene class)")
+    ap.add_argument("--kernel", choices=["auto", "stream", "lanes", "queued"], default="auto",
+                    help="kernel formulation (default: the library's choice by scene class / first-draw calibration)")
     ap.add_argument("--rng", choices=["reference", "pcg"], default="reference",
                     help="reference: the reference's per-pixel random stream (the graded mode, frames comparable per "
                          "pixel).  pcg: throughput mode — an independent PCG-hashed stream per (pixel, sample), the "
@@ -196,6 +489,9 @@ def main():
                          "default reference-stream run reports next to `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes")
+    ap.add_argument("--no-also", action="store_true",
+                    help="N = 1, default workload: skip the `also` block (dragon/scene.xml 1280x720 spp 256, north_star's "
+                         "second target, measured in the same process)")
     ap.add_argument("--force-gather", action="store_true",
                     help="take the multi-GPU code path (RCCL process group, packed tiles, gather, scatter) "
                          "even with one rank: lets a 1-GPU box exercise it")
@@ -221,8 +517,7 @@ def main():
 
     name = args.workload
     W, H, SPP = pkg.workloads.WORKLOADS[name][1]
-    weak = args.weak and world > 1
-    if weak:
+    if args.weak and world > 1:
         if name != "cornell" or args.width or args.height:
             raise SystemExit("--weak is defined for the cornell workload's square film only")
         # the largest square film (side a multiple of the 8-pixel tile) whose per-rank share still fits the
@@ -231,221 +526,16 @@ def main():
         while -(-((side // 8) ** 2) // world) * 64 > 512 * 512:
             side -= 8
         W = H = side
-    W, H, SPP = args.width or W, args.height or H, args.spp or SPP
-    kernel_mode = {"auto": -1, "stream": 1, "lanes": 0}[args.kernel]
-
-    def make_renderer(spp):
-        r = pkg.capi.Renderer(pkg.workloads.config(name, W, H, spp), device=local_rank)
-        r.set_kernel(kernel_mode)
-        if args.rng == "pcg":
-            r.set_rng(1, seed=1, sample_split=args.sample_split)
-        return r
-
-    renderer = make_renderer(SPP)
-    rng = pkg.capi.TileRange(rank, world, 0)
-    assert renderer.tiles_in(rng) == len(pkg.tiling.rank_tiles(rank, world, W, H))
-    stream = torch.cuda.current_stream().cuda_stream
-
-    if not use_gather:
-        frame = torch.zeros(H * W * 3, dtype=torch.float32, device=device)
-    else:
-        fg = pkg.tiling.FrameGather(world, rank, W, H, device)
-
-    def step():
-        if not use_gather:
-            renderer.draw_device(frame.data_ptr(), rng, packed=False, stream=stream, blocking=False)
-        else:
-            renderer.draw_device(fg.packed.data_ptr(), rng, packed=True, stream=stream, blocking=False)
-            fg.gather()
-
-    def sync():
-        if use_gather:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # Renderer set-up, not a step: the first draw of a renderer calibrates its kernel configuration on a sample of the
-    # frame and allocates its buffers (camera-ray pre-pass, work counter) — like the commit and the upload it happens
-    # once per renderer, before any warm-up or timed step (also with --warmup 0).
-    step()
-    sync()
-    for _ in range(args.warmup):
-        step()
-    sync()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms = ev0.elapsed_time(ev1) / max(args.steps, 1)  # same stream as the launches
-    kernel_name = renderer.last_kernel()
-    choice = renderer.last_choice()   # (kernel, work distribution, pre-pass) the timed steps ran
-
-    # The same job in the THROUGHPUT mode (independent PCG-hashed stream per (pixel, sample), the samples of a
-    # pixel spread over lanes): reported next to `value`, never as `value`.  With the reference stream a pixel's
-    # samples are one sequential chain, so a GPU whose tile share is below one pixel per lane cannot go faster
-    # than one wavefront's chain; this mode has no such floor.
-    throughput = None
-    if args.rng == "reference" and not args.no_throughput_mode:
-        renderer.set_rng(1, seed=1, sample_split=args.sample_split)
-        for _ in range(max(args.warmup, 1)):
-            step()
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sync()
-        e2 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([e2], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            e2 = float(t.item())
-        throughput = {"value": W * H * SPP * args.steps / e2 / 1e6, "unit": "Msamples/s", "ms_per_step": 1e3 * e2 / args.steps,
-                      "rng": "independent PCG-hashed stream per (pixel, sample); not per-pixel comparable with the reference",
-                      "kernel": renderer.last_kernel()}
-        renderer.set_rng(0)
-
+    film = (args.width or W, args.height or H, args.spp or SPP)
+    out = measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device, primary=True)
+    default_run = name == "cornell" and film == pkg.workloads.WORKLOADS["cornell"][1] and args.rng == "reference"
+    if world == 1 and not use_gather and default_run and not args.no_also:
+        # north_star's second target in the same driver-run line
+        also = measure(pkg, torch, dist, args, "dragon", pkg.workloads.WORKLOADS["dragon"][1], world, rank, local_rank, device,
+                       primary=False)
+        out["also"] = {"dragon": also}
     if rank == 0:
-        samples = W * H * SPP
-        value = samples * args.steps / elapsed / 1e6
-        out = {
-            "metric": "Msamples/sec (W*H*spp/s)", "value": value, "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{name}: {pkg.workloads.DESCRIPTION[name]}"
-                                   + ("" if (W, H, SPP) == pkg.workloads.WORKLOADS[name][1] else f" — film overridden: {W}x{H} spp={SPP}"),
-                       "baseline_config_index": pkg.workloads.WORKLOADS[name][2],
-                       "rng": ("reference stream (Tea + LCG per pixel)" if args.rng == "reference" else
-                               "THROUGHPUT MODE, not per-pixel comparable: independent PCG-hashed stream per (pixel, sample)"),
-                       "kernel": kernel_name,
-                       "partition": f"8x8 tiles round-robin over {world} GPU(s)"
-                                    + (", one RCCL gather to rank 0" if world > 1 else ""),
-                       "film": (f"{W}x{H}: side scaled with sqrt(N) so that every GPU renders 512x512 pixels' worth "
-                                "of tiles (weak scaling)") if weak else f"{W}x{H}"},
-        }
-        if throughput:
-            out["throughput_mode"] = throughput
-        # ---- roofline of the render kernel (everything below is outside the timed region).  N > 1: rank 0's
-        # GPU and its share of the tiles, kernel time from one more (blocking) draw of that share.
-        count_spp = min(SPP, 16)
-        rc = make_renderer(count_spp)
-        rc.set_kernel(choice[0]).set_work_distribution(choice[1]).set_prepass(choice[2])
-        _, counts = rc.draw(counted=True)
-        scene_info = rc.info()
-        rc.close()
-        if world > 1:
-            st = renderer.draw_device(fg.packed.data_ptr(), rng, packed=True, stream=stream, blocking=True)
-            kernel_ms = st["kernel_milliseconds"]
-        rank_samples = samples if world == 1 else len(pkg.tiling.rank_tiles(0, world, W, H)) * 64 * SPP
-        b_per_sample = algorithmic_bytes_per_sample(counts, SPP)
-        algorithmic_bytes = b_per_sample * rank_samples
-        algorithmic_gbs = algorithmic_bytes / (kernel_ms * 1e-3) / 1e9
-        props = torch.cuda.get_device_properties(device)
-        n_simd = props.multi_processor_count * 4
-        clock_ghz = getattr(props, "clock_rate", 2.4e6) / 1e6   # (fallback only: cycles come from GRBM_GUI_ACTIVE)
-        bw = stream_bandwidth(torch, device)
-        hbm_peak = max(bw["copy_gbs"], bw["read_gbs"])
-        rays = counts["closest_rays"] + counts["shadow_rays"]
-        per_sample = {k: counts[k] / counts["samples"] for k in
-                      ("closest_rays", "shadow_rays", "node_tests", "prim_tests", "shaded_hits")}
-        walk = {"rays_per_s": rays / counts["samples"] * rank_samples / (kernel_ms * 1e-3),
-                "node_phase_lane_util": (counts["node_tests"] / 2) / (64.0 * max(counts["wave_node_steps"], 1)),
-                "prim_phase_lane_util": counts["prim_tests"] / (64.0 * max(counts["wave_prim_steps"], 1))}
-        hbm = {"algorithmic_gbs": algorithmic_gbs, "bytes_per_sample": b_per_sample,
-               "stream_peak_gbs": hbm_peak, "stream_copy_gbs": bw["copy_gbs"], "stream_read_gbs": bw["read_gbs"],
-               "spec_peak_gbs": HBM_SPEC_GBS, "frac_algorithmic_of_stream_peak": algorithmic_gbs / hbm_peak}
-        roof = {"bound": "hbm", "achieved": algorithmic_gbs, "peak": hbm_peak, "unit": "GB/s",
-                "frac": algorithmic_gbs / hbm_peak, "traffic": None,
-                "kernel": kernel_name, "kernel_ms": kernel_ms, "per_sample": per_sample, "walk": walk, "hbm": hbm,
-                "scene": {"walk_nodes": scene_info["walk_nodes"], "primitives": scene_info["primitives"],
-                          "geometry_bytes": scene_info["geometry_bytes"]}}
-        pmc = None if (args.no_pmc or world > 1 or args.rng != "reference") else pmc_leg(name, (W, H, SPP), choice)
-        if pmc and pmc["counters"].get("SQ_INSTS_VALU") and pmc["kernel_ns"]:
-            c = pmc["counters"]
-            pmc_ms = pmc["kernel_ns"] * 1e-6
-            cycles = c["GRBM_GUI_ACTIVE"] / N_XCD if c.get("GRBM_GUI_ACTIVE") else pmc_ms * 1e-3 * clock_ghz * 1e9
-            issue = c["SQ_INSTS_VALU"] * 4.0 / (n_simd * cycles)
-            lanes = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
-            valu_peak = n_simd * VALU_LANES_PER_SIMD * cycles / (pmc_ms * 1e-3) / 1e12   # T lane-ops/s at the measured clock
-            valu = {"issue_frac": issue, "lane_util": lanes, "useful_frac": issue * lanes,
-                    "valu_insts_per_sample": c["SQ_INSTS_VALU"] / samples,
-                    "wait_any_per_wave_cycle": c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0),
-                    "peak_tlaneops": valu_peak, "achieved_tlaneops": valu_peak * issue * lanes,
-                    "pmc_kernel_ms": pmc_ms, "cycles": cycles}
-            roof["valu"] = valu
-            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                # rocprofv3 reports KiB; FETCH_SIZE counts 64-byte requests where gfx950 moves 128 (guide's
-                # gfx950 note): doubled
-                traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
-                roof["traffic"] = traffic
-                hbm.update(measured_gbs=traffic / (pmc_ms * 1e-3) / 1e9,
-                           measured_frac_of_stream_peak=traffic / (pmc_ms * 1e-3) / 1e9 / hbm_peak,
-                           traffic_over_algorithmic=traffic / algorithmic_bytes,
-                           fetch_bytes=2.0 * c["FETCH_SIZE"] * 1024.0, write_bytes=c["WRITE_SIZE"] * 1024.0)
-            # the roof the kernel is closest to: VALU issue slots or HBM bytes actually moved
-            if issue >= hbm.get("measured_frac_of_stream_peak", 0.0):
-                roof.update(bound="valu", achieved=valu["achieved_tlaneops"], peak=valu_peak, unit="Tlane-op/s",
-                            frac=issue * lanes)
-                roof["note"] = ("VALU-issue bound: %.0f %% of the issue slots of the %d SIMDs are taken, %.0f %% of the "
-                                "lanes of those instructions do work -> frac = useful fp32 lane-operations / peak (no FMA: "
-                                "the arithmetic contract forbids contraction).  HBM moves %s per launch against %s of "
-                                "algorithmic bytes: the walk's data comes from LDS / cache."
-                                % (100 * issue, n_simd, 100 * lanes,
-                                   "%.3g MB" % (roof["traffic"] / 1e6) if roof["traffic"] else "?",
-                                   "%.3g GB" % (algorithmic_bytes / 1e9)))
-            else:
-                roof.update(achieved=hbm["measured_gbs"], frac=hbm["measured_frac_of_stream_peak"])
-                roof["note"] = ("memory bound: achieved = HBM bytes moved per launch (PMC) / kernel time, peak = stream "
-                                "bandwidth measured in this process; VALU issue %.0f %% x lane utilisation %.0f %%"
-                                % (100 * issue, 100 * lanes))
-            roof["pmc"] = {"kernels": pmc["kernels"], "failed": pmc["failed"],
-                           "command": "rocprofv3 --kernel-trace --pmc <group> -- python tools/render_scene.py "
-                                      f"workload:{name} --film {W} {H} {SPP} --draws 1 --kernel-mode {choice[0]} --work {choice[1]} "
-                                      f"--prepass {choice[2]} (one pass per group; counters and durations summed over the draw's kernels)"}
-        else:
-            roof["note"] = ("no counter pass (rocprofv3 absent, --no-pmc or N > 1): algorithmic bytes (32 B/box test, "
-                            "36 B/primitive test, 132 B/shaded hit, 12 B/pixel) over the kernel time against the "
-                            "measured stream bandwidth")
-            if pmc:
-                roof["pmc"] = {"failed": pmc["failed"]}
-        out["roofline"] = roof
-        if world == 1 and not args.no_cpu_baseline:
-            recs, cpu_frame, (cw, ch, cspp) = cpu_baseline(pkg, name, W, H, SPP)
-            out["cpu_baseline"] = recs.get("reference", recs["port"])
-            if "reference" in recs:
-                out["cpu_baseline_port"] = recs["port"]
-            rg = pkg.capi.Renderer(pkg.workloads.config(name, cw, ch, cspp), device=local_rank)
-            rg.set_kernel(kernel_mode)
-            if args.rng == "pcg":
-                rg.set_rng(1, seed=1, sample_split=args.sample_split)
-            gpu_frame, _ = rg.draw()
-            rg.close()
-            d = gpu_frame.astype(np.float64) - cpu_frame.astype(np.float64)
-            l2 = np.sqrt((d ** 2).sum(axis=2))
-            out["parity"] = {"vs": "port", "film": [cw, ch, cspp], "rng": args.rng,
-                             "mean_gpu": float(gpu_frame.mean()), "mean_cpu": float(cpu_frame.mean()),
-                             "rmse": float(np.sqrt((d ** 2).mean())), "mean_l2": float(l2.mean()),
-                             "max_l2": float(l2.max()), "frac_gt_1e-3": float((l2 > 1e-3).mean()),
-                             "frac_exact": float((l2 == 0).mean())}
         print(json.dumps(out))
-    if args.force_gather:
-        step()   # (the throughput-mode loop above left its own frame in the gather buffer)
-        sync()
-    if rank == 0 and args.force_gather:
-        # the gathered frame must be the plain full-frame draw, bit for bit
-        plain, _ = renderer.draw()
-        same = bool(np.array_equal(fg.frame.cpu().numpy().reshape(H, W, 3), plain))
-        print(json.dumps({"force_gather_frame_equals_plain_draw": same}), file=sys.stderr)
-        if not same:
-            sys.exit(3)
-    renderer.close()
     if use_gather:
         dist.destroy_process_group()
 

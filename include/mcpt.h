@@ -266,6 +266,10 @@ const char *mcpt_renderer_last_kernel(const mcpt_renderer *r);
  * flags: MCPT_TILED_ALWAYS_GATHER takes the RCCL route even with one device (tests on a 1-GPU box). */
 typedef struct mcpt_tiled_renderer mcpt_tiled_renderer;
 #define MCPT_TILED_ALWAYS_GATHER 1u
+/* Test switch: `devices` may list one device several times — N logical ranks (a renderer, a stream and a packed
+ * block each) on fewer GPUs.  Real RCCL refuses such a communicator; the environment variable MCPT_RCCL_LIBRARY
+ * names a library to bind in its place (tests/rccl_shim: the seven entry points over hipMemcpyAsync). */
+#define MCPT_TILED_LOGICAL_RANKS 2u
 int mcpt_tiled_renderer_create(const mcpt_config *cfg, int n_devices, const int *devices, unsigned flags,
                                mcpt_tiled_renderer **out);
 /* Blocking; `frame` is a HOST buffer of width*height*3 floats.  stats (may be NULL): wall time of the call, the

@@ -249,6 +249,15 @@ class Renderer:
         _check(fn(self._h, frame.ctypes.data, ctypes.byref(st)))
         return frame, st.as_dict()
 
+    def draw_into(self, frame: np.ndarray, counted=False):
+        """Renderer::Draw(float*) into the caller's host buffer (h x w x 3 float32, C order): blocking, the
+        device-to-host copy of the frame included.  Returns the stats dict."""
+        assert frame.dtype == np.float32 and frame.flags.c_contiguous and frame.size == self.height * self.width * 3
+        st = Stats()
+        fn = lib().mcpt_renderer_draw_counted if counted else lib().mcpt_renderer_draw
+        _check(fn(self._h, frame.ctypes.data, ctypes.byref(st)))
+        return st.as_dict()
+
     def tiles_in(self, rng: TileRange) -> int:
         return lib().mcpt_tile_range_size(self.tiles_total, ctypes.byref(rng))
 
@@ -391,6 +400,7 @@ def device_count() -> int:
 
 
 TILED_ALWAYS_GATHER = 1
+TILED_LOGICAL_RANKS = 2   # test switch: one device listed several times (needs MCPT_RCCL_LIBRARY = tests/rccl_shim)
 
 
 class TiledRenderer:

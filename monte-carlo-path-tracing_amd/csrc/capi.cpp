@@ -250,12 +250,19 @@ struct Rccl
         std::call_once(once, []
                        {
             void *h = nullptr;
-            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-                if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr)
-                    break;
+            // MCPT_RCCL_LIBRARY: a library to bind instead (tests drive N logical ranks on a 1-GPU box through a shim
+            // that implements the seven entry points with hipMemcpyAsync: tests/rccl_shim)
+            const char *override_path = std::getenv("MCPT_RCCL_LIBRARY");
+            if (override_path && *override_path)
+                h = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+            else
+                for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                    if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) != nullptr)
+                        break;
             if (!h)
             {
-                problem = std::string("cannot load librccl.so.1 (") + dlerror() + ")";
+                const char *why = dlerror();
+                problem = std::string("cannot load ") + (override_path && *override_path ? override_path : "librccl.so.1") + " (" + (why ? why : "?") + ")";
                 return;
             }
             auto bind = [&](auto &fn, const char *symbol)
@@ -302,6 +309,24 @@ struct AutoCandidate
 constexpr int kAutoCount = 4;
 constexpr AutoCandidate kAutoCandidates[kAutoCount] = {{0, 0}, {0, 1}, {1, 1}, {4, 1}};
 
+void Calibrate(mcpt_renderer *r, hipStream_t stream, bool stream_allowed);
+
+// Runs the first-draw calibration now if a draw of `range` would (the library's choices, a scene outside LDS).
+// Returns whether the renderer holds a calibrated choice afterwards.
+bool EnsureCalibrated(mcpt_renderer *r, const mcpt_tile_range &range, hipStream_t stream)
+{
+    if (r->auto_choice >= 0)
+        return true;
+    if (r->kernel_mode != -1 || mcpt::StreamPrefersLanes(r->dev) || RangeSize(r->Tiles(), range) == 0)
+        return false;
+    mcpt::RenderJob job{};
+    job.n_items = RangeSize(r->Tiles(), range) * 64u;
+    job.reference_walk = r->reference_walk ? 1u : 0u;
+    r->auto_choice = r->work_mode == 0 ? 0 : 1;
+    Calibrate(r, stream, mcpt::StreamSupports(r->dev, job));
+    return true;
+}
+
 void Calibrate(mcpt_renderer *r, hipStream_t stream, bool stream_allowed)
 {
     const uint32_t tiles = r->Tiles();
@@ -314,13 +339,18 @@ void Calibrate(mcpt_renderer *r, hipStream_t stream, bool stream_allowed)
     const float spp_inv = r->dev.camera.spp_inv;
     const uint32_t few = std::min(spp, 8u);
     r->dev.camera.spp = few, r->dev.camera.spp_inv = 1.0f / static_cast<float>(few);
-    const int saved_kernel = r->kernel_mode, saved_work = r->work_mode;
+    const int saved_kernel = r->kernel_mode, saved_work = r->work_mode, saved_rng = r->rng_mode;
+    // The timing draws run in the reference-stream mode whatever the renderer is set to: they rank kernel formulations,
+    // and a nested draw in the independent-sample mode would re-size (free) the sample planes the OUTER draw has already
+    // taken a pointer to.
+    r->rng_mode = 0;
     try
     {
         for (int pass = 0; pass < 2; ++pass) // pass 0 warms the caches and the code objects up
             for (int c = 0; c < kAutoCount; ++c)
             {
-                if (kAutoCandidates[c].kernel != 0 && !stream_allowed)
+                // (a fixed work distribution — mcpt_renderer_set_work_distribution — restricts the candidates to it)
+                if ((kAutoCandidates[c].kernel != 0 && !stream_allowed) || (saved_work != -1 && kAutoCandidates[c].work != saved_work))
                 {
                     r->auto_ms[c] = 0.0f;
                     continue;
@@ -333,16 +363,18 @@ void Calibrate(mcpt_renderer *r, hipStream_t stream, bool stream_allowed)
     }
     catch (...)
     {
-        r->kernel_mode = saved_kernel, r->work_mode = saved_work, r->dev.camera.spp = spp, r->dev.camera.spp_inv = spp_inv;
+        r->kernel_mode = saved_kernel, r->work_mode = saved_work, r->rng_mode = saved_rng, r->dev.camera.spp = spp, r->dev.camera.spp_inv = spp_inv;
         (void)hipFree(scratch);
         throw;
     }
-    r->kernel_mode = saved_kernel, r->work_mode = saved_work, r->dev.camera.spp = spp, r->dev.camera.spp_inv = spp_inv;
+    r->kernel_mode = saved_kernel, r->work_mode = saved_work, r->rng_mode = saved_rng, r->dev.camera.spp = spp, r->dev.camera.spp_inv = spp_inv;
     (void)hipFree(scratch);
-    r->auto_choice = 0;
-    for (int c = 1; c < kAutoCount; ++c)
-        if (r->auto_ms[c] > 0.0f && r->auto_ms[c] < r->auto_ms[r->auto_choice])
+    r->auto_choice = -1;
+    for (int c = 0; c < kAutoCount; ++c)
+        if (r->auto_ms[c] > 0.0f && (r->auto_choice < 0 || r->auto_ms[c] < r->auto_ms[r->auto_choice]))
             r->auto_choice = c;
+    if (r->auto_choice < 0)
+        r->auto_choice = saved_work == 0 ? 0 : 1;
     // The sample is rendered at a few spp: it ranks throughput, not the length of a pixel's chain of rounds, which is
     // what the wavefront rounds shorten at full spp (dragon/scene.xml: 8.27 ms against 8.27 ms in the sample, 179 ms
     // against 250 ms for the frame).  With the lane spread they were the fastest on every scene measured, so they are
@@ -417,6 +449,15 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     job.sample_split = 1;
     job.lane_spread = r->lane_spread;
     job.scatter = r->pixel_order < 0 ? mcpt::kScatterAuto : static_cast<uint32_t>(r->pixel_order);
+    // The library's choices (kernel_mode -1): the first draw of a renderer calibrates — BEFORE this draw sizes any of its
+    // own buffers, because the calibration's nested draws re-size the renderer's scratch allocations.
+    const bool small_scene = mcpt::StreamPrefersLanes(r->dev);
+    if ((r->kernel_mode == -1 || r->work_mode == -1) && r->auto_choice < 0 && !counted)
+    {
+        r->auto_choice = r->work_mode == 0 ? 0 : 1; // lanes kernel, fixed lists / work counter
+        if (!small_scene && r->kernel_mode == -1 && job.n_items != 0)
+            Calibrate(r, stream, mcpt::StreamSupports(r->dev, job));
+    }
     float *render_target = out_device;
     const uint32_t out_pixels = packed ? job.n_items : static_cast<uint32_t>(r->flat.camera.width) * r->flat.camera.height;
     if (r->rng_mode == 1 && job.n_items != 0)
@@ -481,12 +522,28 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     // depends on the scene (full size, Msamples/s, lanes fixed / lanes counter / stream counter: dragon 601 / 614 / 969,
     // matpreview-rc 364 / 411 / 491, classroom 163 / 159 / 131, dining-room 72 / 63 / 69), so the renderer's first draw
     // CALIBRATES on a sample of the frame and keeps the fastest (measure, don't guess).
-    const bool small_scene = mcpt::StreamPrefersLanes(r->dev);
     // (decided here because the stream kernel's launch shape depends on it: with a pre-pass the kernel sizes its lane
     //  spread from the pre-pass's hit count)
     const size_t prehit_need = size_t(r->flat.camera.width) * r->flat.camera.height * r->dev.camera.spp * 2;
-    const bool prepass = (r->prepass_mode == 1 || (r->prepass_mode == -1 && !small_scene)) && job.n_items != 0 &&
-                         mcpt::PrimaryPrepassSupports(r->dev, job) && prehit_need * sizeof(uint32_t) <= (size_t(32) << 30);
+    bool prepass = (r->prepass_mode == 1 || (r->prepass_mode == -1 && !small_scene)) && job.n_items != 0 &&
+                   mcpt::PrimaryPrepassSupports(r->dev, job) && prehit_need * sizeof(uint32_t) <= (size_t(32) << 30);
+    if (prepass && prehit_need > r->prehit_words)
+    {
+        // 8 B per sample of the frame.  A failed allocation is not an error: the draw renders without the pre-pass.
+        if (r->prehit_dev)
+        {
+            Check(hipDeviceSynchronize(), "wait before growing the pre-pass buffer");
+            Check(hipFree(r->prehit_dev), "free pre-pass buffer");
+            r->prehit_dev = nullptr, r->prehit_words = 0;
+        }
+        if (hipMalloc(reinterpret_cast<void **>(&r->prehit_dev), prehit_need * sizeof(uint32_t)) == hipSuccess)
+            r->prehit_words = prehit_need;
+        else
+        {
+            (void)hipGetLastError(); // (clear the sticky error)
+            r->prehit_dev = nullptr, prepass = false;
+        }
+    }
     if (prepass)
     {
         if (!r->hit_counters_dev)
@@ -494,12 +551,6 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         job.hit_counters = r->hit_counters_dev;
     }
     const bool can_stream = job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && (job.sample_split <= 1 || r->kernel_mode != 2);
-    if ((r->kernel_mode == -1 || r->work_mode == -1) && r->auto_choice < 0 && !counted)
-    {
-        r->auto_choice = 1; // lanes + work counter
-        if (!small_scene && r->kernel_mode == -1 && r->work_mode == -1 && job.n_items != 0)
-            Calibrate(r, stream, can_stream);
-    }
     const int choice = r->auto_choice < 0 ? 1 : r->auto_choice;
     const bool auto_stream = r->kernel_mode == -1 && kAutoCandidates[choice].kernel != 0 && !small_scene;
     if (auto_stream)
@@ -543,20 +594,8 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     //  latency, and the pre-pass costs them 4-5 %: cornell 1040 -> 999, volumetric-caustic 855 -> 800 Msamples/s)
     if (prepass)
     {
-        const size_t words = prehit_need;
         Check(hipMemsetAsync(r->hit_counters_dev, 0, mcpt::kHitCounters * sizeof(uint32_t), stream), "clear hit counters");
         {
-            if (words > r->prehit_words)
-            {
-                if (r->prehit_dev)
-                {
-                    Check(hipDeviceSynchronize(), "wait before growing the pre-pass buffer");
-                    Check(hipFree(r->prehit_dev), "free pre-pass buffer");
-                    r->prehit_dev = nullptr, r->prehit_words = 0;
-                }
-                Check(hipMalloc(reinterpret_cast<void **>(&r->prehit_dev), words * sizeof(uint32_t)), "allocate pre-pass buffer");
-                r->prehit_words = words;
-            }
             Check(mcpt::LaunchPrimaryPrepass(r->dev, job, r->prehit_dev, counters, stream, r->n_cus), "launch pre-pass kernel");
             r->dev.prehit = r->prehit_dev;
             r->dev.prehit_step = job.sample_split ? job.sample_split : 1u;
@@ -901,7 +940,37 @@ int mcpt_renderer_create(const mcpt_config *cfg, int device, mcpt_renderer **out
         CheckDevice(device);
         Check(hipSetDevice(device), "select device");
         DeviceLbvh device_lbvh; // large meshes: reference-topology LBVH on the GPU (bit-identical)
-        *out = MakeRenderer(mcpt::CommitScene(cfg->scene, &device_lbvh), device).release();
+        std::unique_ptr<mcpt_renderer> r = MakeRenderer(mcpt::CommitScene(cfg->scene, &device_lbvh), device);
+        // MCPT_CHECK_WALKS=<spp> (opt-in): right after the commit, render the user's film at that many samples per pixel
+        // with the production ordered walk AND the reference-order walk and warn on stderr if a pixel differs — the tie
+        // radius and the sliver reach of the ordered walk are engineering bounds, this is the
+        // run-time check that a scene lies inside them.  The renderer is created either way.
+        if (const char *check = std::getenv("MCPT_CHECK_WALKS"))
+        {
+            const long want = std::strtol(check, nullptr, 10);
+            if (want > 0 && !r->flat.integrator.has_masks)
+            {
+                const uint32_t spp = r->dev.camera.spp, few = std::min<uint32_t>(spp, static_cast<uint32_t>(want));
+                const float spp_inv = r->dev.camera.spp_inv;
+                r->dev.camera.spp = r->flat.camera.spp = few, r->dev.camera.spp_inv = r->flat.camera.spp_inv = 1.0f / static_cast<float>(few);
+                uint64_t differing = 0;
+                uint32_t first = 0;
+                float worst = 0;
+                const int rc = mcpt_renderer_check_walks(r.get(), &differing, &first, &worst);
+                r->dev.camera.spp = r->flat.camera.spp = spp, r->dev.camera.spp_inv = r->flat.camera.spp_inv = spp_inv;
+                r->auto_choice = -1; // (the check's draws calibrated at the reduced spp: calibrate the real film again)
+                if (rc != 0)
+                    std::fprintf(stderr, "mcpt: MCPT_CHECK_WALKS could not run: %s\n", g_error.c_str());
+                else if (differing)
+                    std::fprintf(stderr,
+                                 "mcpt: WARNING: the ordered walk and the reference-order walk differ on %llu pixel(s) of this scene at %u spp "
+                                 "(first pixel %u, largest difference %g); use mcpt_renderer_set_walk(r, 1) for the reference's order.\n",
+                                 static_cast<unsigned long long>(differing), few, first, worst);
+                else
+                    std::fprintf(stderr, "mcpt: MCPT_CHECK_WALKS: both walks agree on every pixel at %u spp.\n", few);
+            }
+        }
+        *out = r.release();
         return 0;
     }
     catch (const std::exception &e)
@@ -1060,7 +1129,15 @@ int mcpt_renderer_check_walks(mcpt_renderer *r, uint64_t *n_differing, uint32_t 
         return Fail("null argument");
     const bool saved = r->reference_walk;
     const size_t n = static_cast<size_t>(r->flat.camera.width) * r->flat.camera.height;
-    std::vector<float> ordered(3 * n), reference(3 * n);
+    std::vector<float> ordered, reference;
+    try
+    {
+        ordered.resize(3 * n), reference.resize(3 * n);
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(std::string("mcpt_renderer_check_walks: ") + e.what());
+    }
     r->reference_walk = false;
     int rc = DrawToHost(r, ordered.data(), nullptr, false);
     r->reference_walk = true;
@@ -1339,7 +1416,7 @@ int mcpt_tiled_renderer_create(const mcpt_config *cfg, int n_devices, const int 
             devs[k] = devices ? devices[k] : k;
             CheckDevice(devs[k]);
             for (int j = 0; j < k; ++j)
-                if (devs[j] == devs[k])
+                if (devs[j] == devs[k] && !(flags & MCPT_TILED_LOGICAL_RANKS))
                     throw std::runtime_error("device " + std::to_string(devs[k]) + " is listed twice.");
         }
         std::unique_ptr<mcpt_tiled_renderer> t(new mcpt_tiled_renderer);
@@ -1409,6 +1486,22 @@ int mcpt_tiled_renderer_draw(mcpt_tiled_renderer *t, float *frame, mcpt_stats *s
         mcpt_renderer *r0 = t->ranks[0].get();
         const uint32_t tiles = r0->Tiles(), width = r0->flat.camera.width, height = r0->flat.camera.height;
         const size_t frame_floats = static_cast<size_t>(width) * height * 3;
+        // First draw: ONE rank calibrates its kernel configuration (blocking sample launches) and the others take its
+        // choice — same scene, same interleaved share of the tiles — instead of N calibrations one after the other.
+        for (uint32_t k = 1; k < n; ++k)
+        {
+            mcpt_renderer *r = t->ranks[k].get();
+            if (r0->auto_choice < 0 && k == 1)
+            {
+                Check(hipSetDevice(r0->device), "select device");
+                (void)EnsureCalibrated(r0, mcpt_tile_range{0, n, 0}, t->streams[0]);
+            }
+            if (r->auto_choice < 0 && r0->auto_choice >= 0 && r->kernel_mode == r0->kernel_mode && r->work_mode == r0->work_mode)
+            {
+                r->auto_choice = r0->auto_choice;
+                std::memcpy(r->auto_ms, r0->auto_ms, sizeof r->auto_ms);
+            }
+        }
         // every GPU starts on its tiles (asynchronous launches from this thread)
         for (uint32_t k = 0; k < n; ++k)
         {
@@ -1431,15 +1524,23 @@ int mcpt_tiled_renderer_draw(mcpt_tiled_renderer *t, float *frame, mcpt_stats *s
             for (uint32_t k = 0; k < n; ++k)
                 offset[k + 1] = offset[k] + static_cast<size_t>(RangeSize(tiles, mcpt_tile_range{k, n, 0})) * 192;
             rccl.Check(rccl.GroupStart(), "start the gather");
-            for (uint32_t k = 0; k < n; ++k)
+            try
             {
-                const size_t count = offset[k + 1] - offset[k];
-                if (count == 0)
-                    continue;
-                rccl.Check(rccl.Send(t->packed[k], count, Rccl::kFloat32, 0, t->comms[k], t->streams[k]), "send tiles");
-                rccl.Check(rccl.Recv(t->gathered + offset[k], count, Rccl::kFloat32, static_cast<int>(k), t->comms[0],
-                                     t->streams[0]),
-                           "receive tiles");
+                for (uint32_t k = 0; k < n; ++k)
+                {
+                    const size_t count = offset[k + 1] - offset[k];
+                    if (count == 0)
+                        continue;
+                    rccl.Check(rccl.Send(t->packed[k], count, Rccl::kFloat32, 0, t->comms[k], t->streams[k]), "send tiles");
+                    rccl.Check(rccl.Recv(t->gathered + offset[k], count, Rccl::kFloat32, static_cast<int>(k), t->comms[0],
+                                         t->streams[0]),
+                               "receive tiles");
+                }
+            }
+            catch (...)
+            {
+                (void)rccl.GroupEnd(); // never leave a group open on this thread: the next call would run inside it
+                throw;
             }
             rccl.Check(rccl.GroupEnd(), "finish the gather");
             Check(hipSetDevice(r0->device), "select device");
@@ -1472,6 +1573,10 @@ int mcpt_tiled_renderer_draw(mcpt_tiled_renderer *t, float *frame, mcpt_stats *s
     }
     catch (const std::exception &e)
     {
+        // launches of the other ranks may still be in flight: drain every stream before the caller retries or destroys
+        for (size_t k = 0; k < t->ranks.size(); ++k)
+            if (t->ranks[k] && hipSetDevice(t->ranks[k]->device) == hipSuccess && k < t->streams.size() && t->streams[k])
+                (void)hipStreamSynchronize(t->streams[k]);
         return Fail(std::string("error when draw.\n\t") + e.what());
     }
 }

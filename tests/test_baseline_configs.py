@@ -143,3 +143,42 @@ def test_baseline_config_walk_self_check(pkg, name):
     finally:
         r.close()
     assert n == 0, f"{n} pixels differ, first {first}, max |diff| {worst}"
+
+
+@pytest.mark.gpu
+def test_dragon_full_film_equals_the_oracle(pkg, oracle, tmp_path):
+    """north_star's second target at its own film: dragon/scene.xml 1280 x 720 spp 256 (831 580 triangles), GPU frame
+    == oracle frame, every pixel, bit for bit.  (About 11 s of oracle time on the GPU box's 256 host threads; a host
+    with few cores compares at spp 32 — equality holds at any spp, `u = s / spp` makes the two films different images.)"""
+    w, h, spp = pkg.workloads.WORKLOADS["dragon"][1]
+    if (os.cpu_count() or 1) < 64:
+        spp = 32
+    cfg = pkg.workloads.config("dragon", w, h, spp)
+    path = str(tmp_path / "dragon.mcsd")
+    cfg.save_mcsd(path)
+    frame, stats = _draw(pkg, cfg)
+    want, info = oracle.render(path)
+    print("dragon full film", (w, h, spp), "GPU kernel ms", stats["kernel_milliseconds"], "oracle seconds", info["seconds"])
+    assert frame.shape == want.shape == (h, w, 3)
+    differing = int((frame != want).any(axis=2).sum())
+    assert differing == 0, f"{differing} of {w * h} pixels differ, max |diff| {np.abs(frame - want).max()}"
+
+
+@pytest.mark.gpu
+def test_walk_check_at_renderer_creation(pkg):
+    """MCPT_CHECK_WALKS=<spp>: mcpt_renderer_create renders the film with both walks and reports on stderr; the renderer
+    works afterwards and its frame is the usual one."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, sys.argv[1]); from _pkg import load_package; pkg = load_package(); import hashlib\n"
+            "r = pkg.capi.Renderer(pkg.workloads.config('matpreview-rc', 96, 96, 8), device=0)\n"
+            "f, _ = r.draw(); print(hashlib.sha256(f.tobytes()).hexdigest())")
+    outs = []
+    for env in (dict(os.environ, MCPT_CHECK_WALKS="2"), {k: v for k, v in os.environ.items() if k != "MCPT_CHECK_WALKS"}):
+        r = subprocess.run([sys.executable, "-c", code, root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append((r.stdout.strip().splitlines()[-1], r.stderr))
+    assert "both walks agree on every pixel at 2 spp" in outs[0][1]
+    assert "MCPT_CHECK_WALKS" not in outs[1][1]
+    assert outs[0][0] == outs[1][0]

@@ -39,3 +39,24 @@ def test_matches_host_libm(checker, name):
     first = np.zeros(16, np.uint32)
     bad = checker.mcpt_libm_check(name.encode(), 61, first.ctypes.data, 16)
     assert bad == 0, f"{name}: {bad} arguments differ, first {[hex(v) for v in first[:min(bad, 16)]]}"
+
+
+@pytest.mark.gpu
+def test_device_evaluation_equals_the_host_libm_on_every_argument():
+    """The header as the GPU evaluates it: tests/libm/libm_device_sweep runs sinf cosf tanf acosf atanf for ALL 2^32
+    float bit patterns (and atan2f for 2^26 pairs) in a gfx950 kernel and compares, chunk by chunk, with what this
+    host's libm returns.  "device == host" is thereby tested, not inferred from frames.  It FAILS — not skips — on a
+    host whose libm is not the restated one (GNU libc 2.35 on an FMA-capable CPU): on such a box "the CPU reference
+    image of the same box" is not bit-equal to the GPU frame, and the suite must say so."""
+    import json
+    subprocess.run(["make", "-s", "-C", HERE, "libm_device_sweep"], check=True)
+    r = subprocess.run([os.path.join(HERE, "libm_device_sweep")], capture_output=True, text=True, timeout=900)
+    assert r.returncode in (0, 1), r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    print(json.dumps(rec))
+    host = f"glibc {_glibc() or '?'}, FMA {'yes' if 'fma' in open('/proc/cpuinfo').read() else 'NO'}"
+    bad = {k: v for k, v in rec.items() if isinstance(v, dict) and v["differing_chunks"]}
+    assert not bad, (f"device evaluation of csrc/glibc_libm.h differs from this host's libm ({host}; the restatement is of "
+                     f"glibc 2.35, FMA variant): {bad}")
+    for name in ("sinf", "cosf", "tanf", "acosf", "atanf"):
+        assert rec[name]["arguments"] == 2 ** 32

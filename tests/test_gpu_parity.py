@@ -335,6 +335,87 @@ def test_tiled_renderer_in_cpp_equals_plain_draw(pkg, flags):
     np.testing.assert_array_equal(again, plain)
 
 
+_LOGICAL_RANKS_SCRIPT = r"""
+import ctypes, json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from _pkg import load_package
+pkg = load_package()
+shim = ctypes.CDLL(os.environ["MCPT_RCCL_LIBRARY"])
+shim.mcpt_rccl_shim_stats.argtypes = [ctypes.POINTER(ctypes.c_ulonglong)] * 2
+out = {}
+for scene, film in (("cornell-box", (203, 117, 6)), ("cornell-box", (64, 64, 8))):
+    cfg = pkg.capi.Config.builtin(scene).set_film(*film)
+    r = pkg.capi.Renderer(cfg, device=0)
+    plain, _ = r.draw()
+    r.close()
+    for n in (2, 3, 8):
+        m0, b0 = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        shim.mcpt_rccl_shim_stats(ctypes.byref(m0), ctypes.byref(b0))
+        t = pkg.capi.TiledRenderer(cfg, devices=(0,) * n, flags=pkg.capi.TILED_LOGICAL_RANKS)
+        frame, st = t.draw()
+        again, _ = t.draw()
+        t.close()
+        m1, b1 = ctypes.c_ulonglong(), ctypes.c_ulonglong()
+        shim.mcpt_rccl_shim_stats(ctypes.byref(m1), ctypes.byref(b1))
+        tiles = ((film[0] + 7) // 8) * ((film[1] + 7) // 8)
+        out[f"{film[0]}x{film[1]}/{n}"] = {
+            "equal": bool(np.array_equal(frame, plain)), "again": bool(np.array_equal(again, plain)),
+            "messages": m1.value - m0.value, "bytes": b1.value - b0.value, "expect_bytes": 2 * tiles * 192 * 4,
+            "ranks_with_tiles": min(n, tiles), "samples": st["samples"]}
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.gpu
+def test_tiled_renderer_with_several_logical_ranks_through_the_rccl_shim(pkg):
+    """The C++ N-GPU host (capi.cpp: per-rank offsets, ONE grouped ncclSend / ncclRecv gather, per-rank unpack) with
+    N = 2, 3, 8 ranks on this box's single GPU: the device is listed N times (MCPT_TILED_LOGICAL_RANKS) and the seven RCCL
+    entry points come from tests/rccl_shim (MCPT_RCCL_LIBRARY), which turns every matched send / recv pair into a
+    device copy ordered between the two ranks' streams.  Frame == plain draw bit for bit (edge tiles: 203 x 117 is no
+    multiple of 8), every rank that has tiles sent exactly one message per draw, and the bytes moved are the frame's
+    packed tiles.  In a subprocess: the RCCL binding is process-wide and the other tests use the real library."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim_dir = os.path.join(root, "tests", "rccl_shim")
+    subprocess.run(["make", "-C", shim_dir], check=True, capture_output=True)
+    env = dict(os.environ, MCPT_RCCL_LIBRARY=os.path.join(shim_dir, "librccl_shim.so"))
+    r = subprocess.run([sys.executable, "-c", _LOGICAL_RANKS_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(out) == 6
+    for key, rec in out.items():
+        assert rec["equal"] and rec["again"], (key, rec)
+        assert rec["messages"] == 2 * rec["ranks_with_tiles"], (key, rec)   # two draws
+        assert rec["bytes"] == rec["expect_bytes"], (key, rec)
+
+
+@pytest.mark.gpu
+def test_first_draw_in_the_independent_sample_mode_on_a_mesh(pkg):
+    """Regression (round-2 advisor finding): a renderer whose FIRST draw is in the independent-sample mode with split
+    samples on a scene outside LDS calibrates inside that draw; the calibration's nested draws used to re-size the sample
+    planes the outer draw had already taken a pointer to.  A 100 x 100 film (tiles * 64 > pixels) and a packed 1/8 tile
+    share, first draw == second draw."""
+    cfg = pkg.capi.Config.from_scene(pkg.scenes.terrain_scene(n=96, width=100, height=100, spp=8))
+    for rng, packed in ((pkg.capi.TileRange(0, 1, 0), False), (pkg.capi.TileRange(0, 8, 0), True)):
+        r = pkg.capi.Renderer(cfg, device=0)
+        if r.info()["geometry_bytes"] <= 24 * 1024:
+            r.close()
+            pytest.skip("needs a scene outside LDS")
+        r.set_rng(1, seed=3, sample_split=0)
+        import torch
+        n = r.tiles_in(rng) * 64 if packed else 100 * 100
+        a = torch.zeros(n * 3, dtype=torch.float32, device="cuda:0")
+        b = torch.zeros(n * 3, dtype=torch.float32, device="cuda:0")
+        r.draw_device(a.data_ptr(), rng, packed=packed, stream=0, blocking=True)
+        r.draw_device(b.data_ptr(), rng, packed=packed, stream=0, blocking=True)
+        r.close()
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b)
+
+
 @pytest.mark.gpu
 def test_cli_gpus_switch(pkg, tmp_path):
     """`mcpt_cli --gpus N` with every visible device (1 on the test box: takes the single-renderer route;
