@@ -539,16 +539,24 @@ MCPT_HD void plastic_eval(const ShadeTables &T, const BsdfRec &b, BsdfQuery &q) 
 }
 
 // ---- dispatch (bsdf.cpp:188-236) --------------------------------------------
-template <bool kMicrofacet>
+// kOnly: 0 = whatever kind the record says (the single-kernel formulations); a BsdfKind = the caller guarantees that
+// kind (the queued renderer's per-material shade launches, hip/queued_kernels.hip: only that model is compiled in);
+// kBsdfNoCode = the caller never reaches a BSDF (its launch shades misses, emitters and pass-through surfaces).
+constexpr uint32_t kBsdfNoCode = 0xFFu;
+
+template <bool kMicrofacet, uint32_t kOnly = 0>
 MCPT_HD void bsdf_sample(const ShadeTables &T, const BsdfRec &b, uint32_t &rng, BsdfQuery &q)
 {
-    if (!kMicrofacet || b.kind == kBsdfDiffuse)
+    if (kOnly == kBsdfNoCode)
+        return;
+    const uint32_t kind = kOnly ? kOnly : b.kind;
+    if (!kMicrofacet || kind == kBsdfDiffuse)
     {
-        if (b.kind == kBsdfDiffuse)
+        if (kind == kBsdfDiffuse)
             diffuse_sample(T, b, rng, q);
         return;
     }
-    switch (b.kind)
+    switch (kind)
     {
     case kBsdfRoughDiffuse: rough_diffuse_sample(T, b, rng, q); break;
     case kBsdfConductor: conductor_sample(T, b, rng, q); break;
@@ -559,16 +567,19 @@ MCPT_HD void bsdf_sample(const ShadeTables &T, const BsdfRec &b, uint32_t &rng, 
     }
 }
 
-template <bool kMicrofacet>
+template <bool kMicrofacet, uint32_t kOnly = 0>
 MCPT_HD void bsdf_eval(const ShadeTables &T, const BsdfRec &b, BsdfQuery &q)
 {
-    if (!kMicrofacet || b.kind == kBsdfDiffuse)
+    if (kOnly == kBsdfNoCode)
+        return;
+    const uint32_t kind = kOnly ? kOnly : b.kind;
+    if (!kMicrofacet || kind == kBsdfDiffuse)
     {
-        if (b.kind == kBsdfDiffuse)
+        if (kind == kBsdfDiffuse)
             diffuse_eval(T, b, q);
         return;
     }
-    switch (b.kind)
+    switch (kind)
     {
     case kBsdfRoughDiffuse: rough_diffuse_eval(T, b, q); break;
     case kBsdfConductor: conductor_eval(T, b, q); break;

@@ -144,6 +144,11 @@ struct mcpt_renderer
     uint32_t *wf_dev = nullptr;
     size_t wf_words = 0;
     uint32_t wf_rounds = 0; // rounds of the last wavefront draw
+    // queued renderer (mcpt_renderer_set_kernel mode 5): slot pool, ray queues, shade queues, counters — one allocation
+    uint32_t *queued_dev = nullptr;
+    size_t queued_words = 0;
+    uint32_t queued_slots = 0; // mcpt_renderer_set_kernel's `slots` in mode 5 is the pool size in units of 4096 slots (0 = one slot per pixel)
+    uint32_t *queued_host = nullptr; // pinned: the counter block read back after every batch of rounds
     uint32_t *work_counter_dev = nullptr; // RenderJob::work_counter (dynamic work distribution), zeroed before every launch
     int work_mode = -1;                   // mcpt_renderer_set_work_distribution: -1 library's choice, 0 fixed lists, 1 work counter
 
@@ -161,6 +166,10 @@ struct mcpt_renderer
             (void)hipFree(work_counter_dev);
         if (wf_dev)
             (void)hipFree(wf_dev);
+        if (queued_dev)
+            (void)hipFree(queued_dev);
+        if (queued_host)
+            (void)hipHostFree(queued_host);
         if (frame_dev)
             (void)hipFree(frame_dev);
         if (counters_dev)
@@ -433,6 +442,59 @@ uint32_t DrawWavefront(mcpt_renderer *r, const mcpt::RenderJob &job, float *out_
     return round;
 }
 
+// One frame in the queued formulation (queue_core.h, hip/queued_kernels.*): round 0 starts every slot, then rounds of
+// (trace launch, one shade launch per material group) until a round queues nothing.  The host only has to know when to
+// stop: it launches rounds in batches and reads the last round's queue counters after each batch.  Blocking.
+uint32_t DrawQueued(mcpt_renderer *r, const mcpt::RenderJob &job, float *out_device, hipStream_t stream)
+{
+    const uint32_t groups = mcpt::QueuedGroups(r->flat.bsdfs.data(), r->flat.bsdfs.size(), true);
+    // pool size: one slot per pixel of the job unless the caller asked for a smaller pool — the reference's one random
+    // stream per pixel makes a pixel's samples a sequential chain of rounds, and a frame cannot be shorter than its
+    // longest chain: every pixel should start in round 0 when memory allows (96 B + queues per slot)
+    uint64_t want = job.n_items;
+    if (r->queued_slots)
+        want = std::min<uint64_t>(want, uint64_t(r->queued_slots) * 4096u);
+    want = std::min<uint64_t>(want, 1u << 26);
+    mcpt::QueuedSizes sz{};
+    mcpt::QueuedLayout(static_cast<uint32_t>(want), groups, &sz);
+    if (sz.total_words() > r->queued_words)
+    {
+        if (r->queued_dev)
+        {
+            Check(hipDeviceSynchronize(), "wait before growing the queue storage");
+            Check(hipFree(r->queued_dev), "free queue storage");
+            r->queued_dev = nullptr, r->queued_words = 0;
+        }
+        Check(hipMalloc(reinterpret_cast<void **>(&r->queued_dev), sz.total_words() * sizeof(uint32_t)), "allocate queue storage");
+        r->queued_words = sz.total_words();
+    }
+    if (!r->queued_host)
+        Check(hipHostMalloc(reinterpret_cast<void **>(&r->queued_host), sz.counter_words * sizeof(uint32_t), hipHostMallocDefault),
+              "allocate counter mirror");
+    uint32_t *counters = mcpt::QueuedCounters(r->queued_dev, sz);
+    Check(hipMemsetAsync(counters, 0, sz.counter_words * sizeof(uint32_t), stream), "clear queue counters");
+    const size_t half = sz.counter_words / 2;
+    constexpr uint32_t kBatch = 32;
+    uint32_t round = 0;
+    for (;;)
+    {
+        for (uint32_t k = 0; k < kBatch; ++k, ++round)
+            Check(mcpt::LaunchQueuedRound(r->dev, job, out_device, r->queued_dev, sz, groups, round, r->n_cus, stream), "launch queued round");
+        // what the last round (round - 1) queued for the next one lives in the counters of parity `round & 1`
+        Check(hipMemcpyAsync(r->queued_host, counters + (round & 1u) * half, half * sizeof(uint32_t), hipMemcpyDeviceToHost, stream),
+              "read queue counters");
+        Check(hipStreamSynchronize(stream), "queued rounds");
+        uint64_t total = 0;
+        for (size_t k = 0; k < half; k += 32) // (one counter per 128-byte line)
+            total += r->queued_host[k];
+        if (total == 0)
+            break;
+        if (round > (1u << 24))
+            throw std::runtime_error("the queued renderer does not terminate.");
+    }
+    return round;
+}
+
 // Enqueues one render launch; optionally waits and reports timings.
 void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, bool packed, hipStream_t stream,
           bool blocking, bool counted, mcpt_stats *stats)
@@ -525,7 +587,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     // (decided here because the stream kernel's launch shape depends on it: with a pre-pass the kernel sizes its lane
     //  spread from the pre-pass's hit count)
     const size_t prehit_need = size_t(r->flat.camera.width) * r->flat.camera.height * r->dev.camera.spp * 2;
-    bool prepass = (r->prepass_mode == 1 || (r->prepass_mode == -1 && !small_scene)) && job.n_items != 0 &&
+    bool prepass = (r->prepass_mode == 1 || (r->prepass_mode == -1 && !small_scene) || (r->kernel_mode == 5 && r->prepass_mode != 0)) && job.n_items != 0 &&
                    mcpt::PrimaryPrepassSupports(r->dev, job) && prehit_need * sizeof(uint32_t) <= (size_t(32) << 30);
     if (prepass && prehit_need > r->prehit_words)
     {
@@ -555,8 +617,8 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     const bool auto_stream = r->kernel_mode == -1 && kAutoCandidates[choice].kernel != 0 && !small_scene;
     if (auto_stream)
         plan.wave_local = kAutoCandidates[choice].kernel == 4 ? 1u : 0u;
-    const bool dynamic_work = r->work_mode == -1 ? kAutoCandidates[choice].work == 1 : r->work_mode == 1;
-    if (((r->kernel_mode > 0 && r->kernel_mode != 3) || auto_stream) && can_stream)
+    const bool dynamic_work = r->kernel_mode == 5 || (r->work_mode == -1 ? kAutoCandidates[choice].work == 1 : r->work_mode == 1);
+    if (((r->kernel_mode > 0 && r->kernel_mode != 3 && r->kernel_mode != 5) || auto_stream) && can_stream)
     {
         const hipError_t planned = mcpt::PlanRenderStream(r->dev, job, counted, r->n_cus, &plan, &variant);
         if (planned == hipSuccess)
@@ -602,7 +664,14 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         }
     }
     const bool wavefront = r->kernel_mode == 3 && !counted && r->rng_mode == 0 && mcpt::WavefrontSupports(r->dev, job);
-    if (wavefront)
+    const bool queued = r->kernel_mode == 5 && !counted && r->rng_mode == 0 && r->dev.prehit != nullptr && dynamic_work &&
+                        mcpt::QueuedSupports(r->dev, job);
+    if (queued)
+    {
+        r->wf_rounds = DrawQueued(r, job, out_device, stream);
+        variant = "queued (trace launch + one shade launch per material group, slot pool)";
+    }
+    else if (wavefront)
     {
         r->wf_rounds = DrawWavefront(r, job, out_device, stream);
         variant = "wavefront (shade / trace launches) surface-materials";
@@ -616,12 +685,14 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                                              r->flat.camera.spp_inv, stream),
               "reduce sample planes");
     r->variant = variant;
-    r->last_kernel = wavefront ? 3 : streamed ? (plan.slots_in_memory ? 2 : plan.wave_local ? 4 : 1) : 0, r->last_work = dynamic_work ? 1 : 0, r->last_prepass = r->dev.prehit ? 1 : 0;
-    if (streamed && !wavefront && plan.wave_local)
+    r->last_kernel = queued ? 5 : wavefront ? 3 : streamed ? (plan.slots_in_memory ? 2 : plan.wave_local ? 4 : 1) : 0, r->last_work = dynamic_work ? 1 : 0, r->last_prepass = r->dev.prehit ? 1 : 0;
+    if (queued)
+        r->variant += ", " + std::to_string(r->wf_rounds) + " rounds";
+    if (streamed && !wavefront && !queued && plan.wave_local)
         r->variant += ", wavefront rounds";
-    if (!streamed && !wavefront && mcpt::LastLaunchTransposed())
+    if (!streamed && !wavefront && !queued && mcpt::LastLaunchTransposed())
         r->variant += ", transposed pixel order";
-    if (streamed && !wavefront && !plan.slots_in_memory)
+    if (streamed && !wavefront && !queued && !plan.slots_in_memory)
     {
         if (plan.lane_spread == 0)
             r->variant += ", lane spread from the pre-pass's hit count";
@@ -1172,8 +1243,15 @@ int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_
 {
     if (!r)
         return Fail("null argument");
-    if (mode < -1 || mode > 4)
-        return Fail("mcpt_renderer_set_kernel: mode is -1 (the library's choice), 0 (lane-owns-a-path), 1 (stream), 2 (stream, slots in memory), 3 (multi-kernel wavefront) or 4 (stream, wavefront rounds)");
+    if (mode < -1 || mode > 5)
+        return Fail("mcpt_renderer_set_kernel: mode is -1 (the library's choice), 0 (lane-owns-a-path), 1 (stream), 2 (stream, slots in memory), 3 (multi-kernel wavefront), 4 (stream, wavefront rounds) or 5 (queued: per-material shade launches)");
+    if (mode == 5)
+    {
+        // `slots`: size of the slot pool in units of 4096 slots (0 = one slot per pixel of the draw)
+        r->kernel_mode = mode, r->queued_slots = slots;
+        r->auto_choice = -1;
+        return 0;
+    }
     if (slots % 256u != 0 || slots > 4096u || refill_at > 64u)
         return Fail("mcpt_renderer_set_kernel: slots is a multiple of 256 up to 4096, refill_at at most 64");
     r->kernel_mode = mode, r->stream_slots = slots, r->stream_refill = refill_at;

@@ -121,6 +121,25 @@ uint32_t WavefrontCounterWords(); // two round parities x two ray kinds x the qu
 hipError_t LaunchWavefrontRound(const DeviceScene &sc, const RenderJob &job, float *out, uint32_t *cold, uint32_t *hot, uint32_t *ids,
                                 uint32_t *counters, uint32_t n_slots, bool first_round, uint32_t parity, hipStream_t stream);
 
+// ---- queued renderer (queue_core.h, hip/queued_kernels.*) ------------------------------------------------
+// Path slots (a pool: a finished slot takes the next unassigned pixel), ray queues and per-material shade queues in
+// HBM; a frame = round 0 (every slot starts) + rounds of (trace launch, one shade launch per material group) until a
+// round queues nothing.  The caller owns ONE buffer of QueuedSizes::total_words() words, zeroes the counter block
+// (QueuedCounters) and the job's work counter before round 0, and reads the counter block to find out when the frame
+// is finished: the frame is done when the block of parity (last round + 1) & 1 sums to zero.
+struct QueuedSizes
+{
+    uint32_t cap, n_slots, n_present;
+    size_t slot_words, ext_words, shadow_words, entry_words, counter_words;
+    size_t total_words() const { return slot_words + ext_words + shadow_words + entry_words + counter_words; }
+};
+bool QueuedSupports(const DeviceScene &sc, const RenderJob &job);
+uint32_t QueuedGroups(const BsdfRec *bsdfs, size_t n_bsdfs, bool any_instance_without_bsdf); // bit g: the scene needs group g's launch
+void QueuedLayout(uint32_t n_slots_wanted, uint32_t groups, QueuedSizes *sizes);
+uint32_t *QueuedCounters(uint32_t *base, const QueuedSizes &sizes);
+hipError_t LaunchQueuedRound(const DeviceScene &sc, const RenderJob &job, float *out, uint32_t *base, const QueuedSizes &sizes, uint32_t groups,
+                             uint32_t round, uint32_t n_cus, hipStream_t stream);
+
 // Experiment (hip/trace_rate_kernel.hip): closest-hit rate of a lean trace-only kernel on a batch of rays in HBM.
 hipError_t RunTraceRate(const DeviceScene &sc, uint32_t n, const float *rays_dev, int mode, int waves, uint32_t refill_at, uint32_t n_cus,
                         uint32_t *found_dev, float *milliseconds, hipStream_t stream);

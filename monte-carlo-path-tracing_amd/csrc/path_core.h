@@ -193,13 +193,13 @@ MCPT_HD BsdfQuery query_at(const Surface &s, V3 wo, V3 facing)
 }
 
 // path.cpp:238-266.  has_bsdf == false: pass-through surface, weight 1.
-template <class C>
+template <class C, uint32_t kOnly = 0>
 MCPT_HD BsdfQuery eval_at(const DeviceScene &sc, const Surface &s, uint32_t bsdf, V3 wi, V3 wo)
 {
     BsdfQuery q = query_at(s, wo, -wi);
     q.wi = wi;
     if (bsdf != kNone)
-        bsdf_eval<C::kMicrofacet>(shade_tables<C>(sc), sc.bsdfs[bsdf], q);
+        bsdf_eval<C::kMicrofacet, kOnly>(shade_tables<C>(sc), sc.bsdfs[bsdf], q);
     else
         q.pdf = 1, q.attenuation = V3{1, 1, 1}, q.valid = true;
     return q;

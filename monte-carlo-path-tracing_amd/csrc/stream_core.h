@@ -75,7 +75,7 @@ struct StreamSlot
 // Direct light at a vertex, deferred: draws the vertex's light-sampling numbers in the reference's
 // order, writes one shadow ray per contributing light and its estimate c[j].  Mirrors connect_lights
 // (path_core.h) statement by statement; what differs is only WHEN the occlusion answer is used.
-template <class C, uint32_t S>
+template <class C, uint32_t S, uint32_t kOnly = 0>
 MCPT_HD void stream_connect(const DeviceScene &sc, StreamSlot<S> &s, bool at_medium, const Surface &surf, V3 position)
 {
     PathState &st = s.st;
@@ -117,7 +117,7 @@ MCPT_HD void stream_connect(const DeviceScene &sc, StreamSlot<S> &s, bool at_med
                 return false;
             tr = m.attenuation / m.pdf;
         }
-        const BsdfQuery q = eval_at<C>(sc, surf, bsdf, wi, wo);
+        const BsdfQuery q = eval_at<C, kOnly>(sc, surf, bsdf, wi, wo);
         if (!q.valid)
             return false;
         att = q.attenuation, pdf = q.pdf;
@@ -224,7 +224,8 @@ MCPT_HD void stream_pack(StreamSlot<S> &s)
 // shadow queries deferred.  On return the slot is alive with its next extension ray in st.origin / st.dir
 // (kSlotExtRay), or the sample is finished (st.alive == false), or it has ENDED but waits for shadow rays
 // (kSlotEnded).
-template <class C, uint32_t S>
+// kOnly (bsdfs.h): the BSDF kind the caller guarantees for a surface with a BSDF that is not an emitter, or 0.
+template <class C, uint32_t S, uint32_t kOnly = 0>
 MCPT_HD void stream_vertex(const DeviceScene &sc, StreamSlot<S> &s, LaneCounters *cnt)
 {
     PathState &st = s.st;
@@ -352,7 +353,7 @@ MCPT_HD void stream_vertex(const DeviceScene &sc, StreamSlot<S> &s, LaneCounters
     const V3 vertex = st.in_medium ? st.origin : surf.position;
     s.thr_connect = st.throughput;
     s.flags |= kSlotPending;
-    stream_connect<C, S>(sc, s, st.in_medium, surf, vertex);
+    stream_connect<C, S, kOnly>(sc, s, st.in_medium, surf, vertex);
     const bool shadows_out = (s.flags & (kSlotShadow0 * ((1u << S) - 1u))) != 0;
     if (!shadows_out)
         stream_fold(s); // nothing to wait for: L += throughput * 0, as the reference does
@@ -377,7 +378,7 @@ MCPT_HD void stream_vertex(const DeviceScene &sc, StreamSlot<S> &s, LaneCounters
     {
         BsdfQuery q = query_at(surf, st.wo, st.wo);
         if (bsdf != kNone)
-            bsdf_sample<C::kMicrofacet>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
+            bsdf_sample<C::kMicrofacet, kOnly>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
         else
             q.wi = st.wo, q.pdf = 1.0f, q.attenuation = V3{1.0f, 1.0f, 1.0f}, q.valid = true;
         if (!q.valid)

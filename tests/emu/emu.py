@@ -58,6 +58,16 @@ class Emulator:
                         (int(c) for c in counters))) if counted else {}
         return frame, info
 
+    def render_queued(self, mcsd_path, width, height, n_slots=0):
+        """The queued formulation (csrc/queue_core.h) on the host: (frame, rounds)."""
+        self.lib.mcpt_emu_render_queued.restype = ctypes.c_int
+        self.lib.mcpt_emu_render_queued.argtypes = [ctypes.c_char_p, _f32p, ctypes.c_uint32, ctypes.c_void_p]
+        frame = np.zeros((height, width, 3), dtype=np.float32)
+        rounds = ctypes.c_uint32()
+        if self.lib.mcpt_emu_render_queued(str(mcsd_path).encode(), frame, n_slots, ctypes.byref(rounds)) != 0:
+            raise RuntimeError(self.lib.mcpt_emu_last_error().decode())
+        return frame, rounds.value
+
     ORDERED = 32      # feature bit of the ordered walk in a forced `variant`
     REFERENCE = -2    # `variant`: the launcher's pick, but with the reference-order walk
 

@@ -19,6 +19,7 @@
 #include "host/commit.hpp"
 #include "path_core.h"
 #include "stream_core.h"
+#include "queue_core.h"
 
 namespace
 {
@@ -146,10 +147,221 @@ void RenderAllStream(const DeviceScene &sc, float *frame, LaneCounters *total, u
         t.join();
 }
 
+// The QUEUED formulation (queue_core.h) on the host: one pool of slots, rounds of (trace every queued ray; shade every
+// material group's queue).  Same functions as the HIP kernels (hip/queued_kernels.*): queue_shade, queue_load / queue_save,
+// queue_take_entry, the contribution that travels with the shadow ray; only the queue bookkeeping is restated.  The
+// camera-ray pre-pass is computed first, like on the GPU.  Single-threaded rounds (the point is the logic, not speed).
+template <uint32_t kFeatures>
+void RenderAllQueued(DeviceScene sc, float *frame, uint32_t n_slots, uint32_t *rounds_out)
+{
+    using C = Config<kFeatures>;
+    const uint32_t w = static_cast<uint32_t>(sc.camera.width), h = static_cast<uint32_t>(sc.camera.height), spp = sc.camera.spp;
+    const uint32_t tiles_x = (w + 7) / 8, tiles_y = (h + 7) / 8, n_items = tiles_x * tiles_y * 64;
+    std::vector<uint32_t> stack(kWalkStackMax * kWalkStackStride);
+    // pre-pass: the closest hit of every camera ray
+    std::vector<uint32_t> prehit(size_t(2) * w * h * spp);
+    {
+        const unsigned workers = std::max(1u, std::thread::hardware_concurrency());
+        std::atomic<uint32_t> next{0};
+        auto work = [&]()
+        {
+            std::vector<uint32_t> st(kWalkStackMax * kWalkStackStride);
+            for (;;)
+            {
+                const uint32_t p = next.fetch_add(1);
+                if (p >= w * h)
+                    break;
+                for (uint32_t k = 0; k < spp; ++k)
+                {
+                    PathState ps;
+                    ps.pixel = p, ps.sample = k;
+                    start_sample(sc, ps);
+                    Ray ray = make_ray(ps.origin, ps.dir);
+                    HitRaw hit;
+                    TraceStats ts{0, 0, 0, 0};
+                    const bool found = walk_ordered<false, C::kAnalytic, false, C::kSlivers>(sc, st.data(), ray, hit, ts);
+                    prehit[2 * (size_t(p) * spp + k)] = found ? hit.prim : kNone, prehit[2 * (size_t(p) * spp + k) + 1] = found ? hit.inst : 0u;
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < workers; ++t)
+            pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool)
+            t.join();
+    }
+    sc.prehit = prehit.data(), sc.prehit_step = 1;
+    n_slots = std::max(1u, std::min(n_slots ? n_slots : n_items, n_items));
+    std::vector<uint32_t> slots(size_t(n_slots) * kQueueSlotWords, 0u);
+    struct Ext { V3 o, d; uint32_t id; };
+    struct Shadow { V3 o, d; float t_max; uint32_t id; V3 contribution; };
+    struct Entry { uint32_t w[kQueueEntryWords]; };
+    std::vector<Ext> ext, ext_next;
+    std::vector<Shadow> shadow, shadow_next;
+    std::vector<Entry> queue[2][kQueueGroups];
+    uint32_t work_counter = 0;
+    auto assign = [&](StreamSlot<1> &s, uint32_t item)
+    {
+        for (;; item = n_slots + work_counter++)
+        {
+            if (item >= n_items)
+            {
+                s.flags = kSlotExhausted;
+                return;
+            }
+            const uint32_t tile = item >> 6, r = item & 63u;
+            const uint32_t x = (tile % tiles_x) * 8u + (r & 7u), y = (tile / tiles_x) * 8u + (r >> 3);
+            if (x < w && y < h)
+            {
+                s.flags = 0;
+                start_pixel(s.st, y * w + x);
+                return;
+            }
+        }
+    };
+    // one slot in the launch of group g: what the lane of queued_shade does
+    auto shade_one = [&](auto group_tag, uint32_t id, const Entry *entry, uint32_t parity)
+    {
+        constexpr uint32_t kGroup = decltype(group_tag)::value;
+        StreamSlot<1> s{};
+        uint32_t *rec = slots.data() + size_t(id) * kQueueSlotWords;
+        if (!entry)
+        {
+            s.st.medium = kNone;
+            assign(s, id);
+        }
+        else
+        {
+            queue_load<C>(rec, s);
+            queue_take_entry(entry->w, s);
+        }
+        QueueRays rays{};
+        uint32_t budget = kQueueSamplesPerCall;
+        while (!(s.flags & kSlotExhausted) && queue_shade<C, kGroup>(sc, s, budget, rays, nullptr) == kQueuePixelDone)
+        {
+            const V3 v = pixel_value(sc, s.st);
+            frame[3 * size_t(s.st.pixel)] = v.x, frame[3 * size_t(s.st.pixel) + 1] = v.y, frame[3 * size_t(s.st.pixel) + 2] = v.z;
+            assign(s, n_slots + work_counter++);
+        }
+        if (s.flags & kSlotExhausted)
+            return;
+        queue_save<C>(rec, s);
+        if (rays.ext)
+            ext_next.push_back(Ext{s.st.origin, s.st.dir, id});
+        if (rays.shadow)
+            shadow_next.push_back(Shadow{s.sh_origin[0], s.sh_dir[0], s.sh_tmax[0], id | rays.shadow_id_bits, rays.contribution});
+        if (rays.requeue)
+        {
+            Entry e{};
+            e.w[0] = id, e.w[1] = kQueueNoHit;
+            queue[parity ^ 1u][rays.requeue_group].push_back(e);
+        }
+    };
+    auto shade_group = [&](uint32_t g, uint32_t id, const Entry *entry, uint32_t parity)
+    {
+        switch (g)
+        {
+        case 0: shade_one(std::integral_constant<uint32_t, 0>{}, id, entry, parity); break;
+        case 1: shade_one(std::integral_constant<uint32_t, 1>{}, id, entry, parity); break;
+        case 2: shade_one(std::integral_constant<uint32_t, 2>{}, id, entry, parity); break;
+        case 3: shade_one(std::integral_constant<uint32_t, 3>{}, id, entry, parity); break;
+        case 4: shade_one(std::integral_constant<uint32_t, 4>{}, id, entry, parity); break;
+        case 5: shade_one(std::integral_constant<uint32_t, 5>{}, id, entry, parity); break;
+        default: shade_one(std::integral_constant<uint32_t, 6>{}, id, entry, parity); break;
+        }
+    };
+    uint32_t round = 0;
+    for (uint32_t id = 0; id < n_slots; ++id) // round 0
+        shade_group(0, id, nullptr, 0);
+    for (round = 1;; ++round)
+    {
+        const uint32_t parity = round & 1u;
+        ext.swap(ext_next), shadow.swap(shadow_next);
+        ext_next.clear(), shadow_next.clear();
+        for (uint32_t g = 0; g < kQueueGroups; ++g)
+            queue[parity ^ 1u][g].clear(); // (what queued_trace zeroes)
+        size_t pending = ext.size() + shadow.size();
+        for (uint32_t g = 0; g < kQueueGroups; ++g)
+            pending += queue[parity][g].size();
+        if (pending == 0)
+            break;
+        // ---- trace ----
+        for (const Ext &r : ext)
+        {
+            Ray ray = make_ray(r.o, r.d);
+            HitRaw hit;
+            TraceStats ts{0, 0, 0, 0};
+            const bool found = walk_ordered<false, C::kAnalytic, false, C::kSlivers>(sc, stack.data(), ray, hit, ts);
+            Entry e{};
+            e.w[0] = r.id, e.w[1] = kNone;
+            uint32_t group = 0;
+            if (found)
+            {
+                group = queue_group_of_instance(sc, hit.inst);
+                e.w[1] = hit.prim, e.w[2] = hit.inst | (hit.inside ? 0x80000000u : 0u), e.w[3] = as_uint(hit.a), e.w[4] = as_uint(hit.b);
+                e.w[5] = as_uint(hit.c), e.w[6] = as_uint(ray.t_max);
+            }
+            queue[parity][group].push_back(e);
+        }
+        for (const Shadow &r : shadow)
+        {
+            Ray ray = make_ray(r.o, r.d);
+            ray.t_max = r.t_max;
+            HitRaw hit;
+            TraceStats ts{0, 0, 0, 0};
+            if (!walk_ordered<true, C::kAnalytic, false, C::kSlivers>(sc, stack.data(), ray, hit, ts))
+            {
+                uint32_t *L = slots.data() + size_t(r.id & kQueueSlotMask) * kQueueSlotWords + kQL;
+                L[0] = as_uint(as_float(L[0]) + r.contribution.x), L[1] = as_uint(as_float(L[1]) + r.contribution.y);
+                L[2] = as_uint(as_float(L[2]) + r.contribution.z);
+            }
+            if (r.id & kQueuePush)
+            {
+                Entry e{};
+                e.w[0] = r.id & kQueueSlotMask, e.w[1] = kQueueNoHit;
+                queue[parity][(r.id >> kQueueGroupShift) & 7u].push_back(e);
+            }
+        }
+        // ---- shade: one "launch" per group ----
+        for (uint32_t g = 0; g < kQueueGroups; ++g)
+            for (size_t k = 0; k < queue[parity][g].size(); ++k)
+            {
+                const Entry e = queue[parity][g][k];
+                shade_group(g, e.w[0], &e, parity);
+            }
+    }
+    if (rounds_out)
+        *rounds_out = round;
+}
+
 } // namespace
 
 extern "C"
 {
+
+// The queued formulation on the host (see RenderAllQueued).  Scenes the queued renderer accepts: surface paths on
+// triangle meshes without opacity masks, at most one shadow ray per vertex.  n_slots: size of the slot pool (0 = one per
+// work item).  rounds: number of rounds the frame took (may be null).
+int mcpt_emu_render_queued(const char *mcsd_path, float *frame, uint32_t n_slots, uint32_t *rounds)
+{
+    try
+    {
+        const FlatScene flat = CommitScene(mcsd::Load(mcsd_path));
+        const DeviceScene sc = flat.HostView();
+        const uint32_t n_shadow = flat.integrator.n_emitters + (flat.integrator.n_area_lights ? 1u : 0u);
+        constexpr uint32_t kSurfaceF = kFeatEmitters | kFeatTextures | kFeatMicrofacet;
+        if (flat.integrator.has_masks || n_shadow > 1 || flat.integrator.n_walk_nodes == 0 || (flat.features & ~kSurfaceF) != 0)
+            throw std::runtime_error("not a scene for the queued renderer (opacity masks, more than one light sample per vertex, volume paths, quadrics, or empty)");
+        RenderAllQueued<kSurfaceF | kFeatOrderedWalk | kFeatSlivers>(sc, frame, n_slots, rounds);
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return 1;
+    }
+}
 
 // The stream formulation on the host (see RenderAllStream).  The scene must be one the stream kernel
 // accepts: no opacity masks, at most kStreamMaxShadow shadow rays per vertex.

@@ -182,3 +182,33 @@ def test_walk_check_at_renderer_creation(pkg):
     assert "both walks agree on every pixel at 2 spp" in outs[0][1]
     assert "MCPT_CHECK_WALKS" not in outs[1][1]
     assert outs[0][0] == outs[1][0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dragon", "matpreview-rc", "matpreview-rd"])
+def test_queued_renderer_on_the_mesh_configurations(pkg, oracle, tmp_path, name):
+    """The queued renderer (mode 5) on the BASELINE mesh configurations: == oracle at the reduced film, and at a
+    quarter-size film == the stream kernel's frame (hash)."""
+    w, h, spp = REDUCED[name]
+    cfg = pkg.workloads.config(name, w, h, spp)
+    path = str(tmp_path / "scene.mcsd")
+    cfg.save_mcsd(path)
+    r = pkg.capi.Renderer(cfg, device=0)
+    try:
+        frame, _ = r.set_kernel(5).draw()
+        assert "queued" in r.last_kernel(), r.last_kernel()
+    finally:
+        r.close()
+    want, _ = oracle.render(path)
+    differing = int((frame != want).any(axis=2).sum())
+    assert differing == 0, f"{differing} pixels differ"
+    fw, fh, fspp = pkg.workloads.WORKLOADS[name][1]
+    r = pkg.capi.Renderer(pkg.workloads.config(name, fw // 2, fh // 2, max(fspp // 8, 8)), device=0)
+    try:
+        a, _ = r.set_kernel(5).draw()
+        queued_kernel = r.last_kernel()
+        b, _ = r.set_kernel(1).draw()
+    finally:
+        r.close()
+    assert "queued" in queued_kernel
+    assert hashlib.sha256(a.tobytes()).hexdigest() == hashlib.sha256(b.tobytes()).hexdigest()

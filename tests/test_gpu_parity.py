@@ -578,6 +578,69 @@ def test_scheduling_choices_do_not_change_the_image(name, pkg, scenes):
         r.close()
 
 
+QUEUED_CASES = ["cornell_64_spp8", "cornell_96_spp32", "rough_conductor_envmap", "rough_dielectric_envmap", "plastic_spot",
+                "bumpy_directional", "depth_limited", "terrain_directional"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", QUEUED_CASES)
+def test_queued_renderer_reproduces_the_goldens(name, pkg, scenes):
+    """mcpt_renderer_set_kernel mode 5 — the queued renderer (queue_core.h, hip/queued_kernels.*): path slots as
+    96-byte records in HBM, a trace launch that files every answered extension ray under the material group it hit,
+    one shade launch per group with that group's BSDF model only, direct light travelling with the shadow ray — gives
+    the compiled reference's golden frame bit for bit, with one slot per pixel AND with a pool of 4096 slots that take
+    pixel after pixel from the work counter; a second draw of the same renderer gives it again."""
+    golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
+    try:
+        for pool in (0, 1):
+            frame, st = r.set_kernel(5, slots=pool).draw()
+            assert "queued" in r.last_kernel(), r.last_kernel()
+            assert r.last_choice()[0] == 5
+            assert np.array_equal(frame, golden), (pool, r.last_kernel(), float(np.abs(frame - golden).max()))
+        again, _ = r.draw()
+        assert np.array_equal(again, golden)
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
+def test_queued_renderer_on_packed_tile_ranges(pkg, scenes):
+    """Two ranks' tile shares rendered by the queued renderer into packed buffers compose to the golden (the slot's
+    work item is recomputed from its pixel when the pixel is stored: queue_item_of_pixel); edge tiles included."""
+    import torch
+    cfg = pkg.capi.Config.builtin("cornell-box").set_film(203, 117, 6)
+    r = pkg.capi.Renderer(cfg, device=0)
+    try:
+        want, _ = r.draw()
+        r.set_kernel(5)
+        composed = np.zeros_like(want)
+        for rank in range(3):
+            rng = pkg.capi.TileRange(rank, 3, 0)
+            buf = torch.zeros(r.tiles_in(rng) * 64 * 3, dtype=torch.float32, device="cuda:0")
+            r.draw_device(buf.data_ptr(), rng, packed=True)
+            assert "queued" in r.last_kernel()
+            pkg.capi.unpack_tiles(buf.cpu().numpy(), rng, 203, 117, composed)
+        assert np.array_equal(composed, want)
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
+def test_queued_renderer_falls_back_where_it_is_not_instantiated(pkg, scenes):
+    """Volume paths, quadrics, opacity masks, more than one light sample per vertex: mode 5 renders with another
+    formulation (and the frame is still the golden)."""
+    for name in ("volpath_medium_mixed", "conductor_aniso_mixed", "masked_area_flat"):
+        golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
+        r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
+        try:
+            frame, _ = r.set_kernel(5).draw()
+            assert "queued" not in r.last_kernel()
+            assert np.array_equal(frame, golden), name
+        finally:
+            r.close()
+
+
 @pytest.mark.gpu
 def test_prepass_is_not_used_where_the_camera_ray_consumes_random_numbers(pkg, scenes):
     """An opacity mask draws a random number during the walk (bsdf.cpp:272-276): the camera ray's hit is part of the

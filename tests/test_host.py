@@ -333,6 +333,24 @@ def test_stream_formulation_emulated_matches_golden(name, slots, pkg, emulator, 
     assert np.array_equal(frame, golden), f"max diff {np.abs(frame - golden).max():.3e}"
 
 
+@pytest.mark.parametrize("slots", [0, 700])
+@pytest.mark.parametrize("name", sorted(MANIFEST["frames"]))
+def test_queued_formulation_emulated_matches_golden(name, slots, pkg, emulator, mcsd_file):
+    """csrc/queue_core.h on the host — a pool of path slots (one per pixel, or 700 that take pixel after pixel), rounds
+    of trace (the extension ray's answer goes to the shade queue of the material group it hit; an unoccluded shadow ray
+    adds the contribution it carries to its slot's radiance) and one shade pass per material group, each compiled with
+    that group's BSDF model only — reproduces the compiled reference's frames bit for bit."""
+    scene = cases(pkg.scenes)[name]
+    golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
+    try:
+        frame, rounds = emulator.render_queued(mcsd_file(scene), scene.camera.width, scene.camera.height, slots)
+    except RuntimeError as e:
+        assert "not a scene for the queued renderer" in str(e)
+        pytest.skip(str(e))
+    assert rounds > scene.camera.spp
+    assert np.array_equal(frame, golden), f"max diff {np.abs(frame - golden).max():.3e}"
+
+
 @pytest.mark.parametrize("strategy", [1, 2, 3])
 @pytest.mark.parametrize("name", ["cornell_64_spp8", "thin_dielectric_sun", "conductor_aniso_mixed",
                                   "volumetric_iso_64x36_spp8"])
