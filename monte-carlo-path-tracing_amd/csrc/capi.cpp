@@ -108,7 +108,8 @@ struct mcpt_renderer
     uint32_t n_cus = 0;
     mcpt::FlatScene flat;
     mcpt::DeviceScene dev{};
-    DeviceArray arrays[18];
+    DeviceArray arrays[20];
+    uint32_t *walk_spill_dev = nullptr; // DeviceScene::walk_spill (allocated when a launch may use the wide walk)
     bool reference_walk = false;           // mcpt_renderer_set_walk
     float *frame_dev = nullptr;            // scratch frame for mcpt_renderer_draw
     mcpt::TraceCounters *counters_dev = nullptr;
@@ -168,6 +169,8 @@ struct mcpt_renderer
             (void)hipFree(wf_dev);
         if (queued_dev)
             (void)hipFree(queued_dev);
+        if (walk_spill_dev)
+            (void)hipFree(walk_spill_dev);
         if (queued_host)
             (void)hipHostFree(queued_host);
         if (frame_dev)
@@ -216,6 +219,7 @@ std::unique_ptr<mcpt_renderer> MakeRenderer(mcpt::FlatScene flat, int device)
     d.node_area = r->arrays[k++].Upload(f.node_area, "upload node areas");
     d.walk_nodes = r->arrays[k++].Upload(f.walk_nodes, "upload walk hierarchy");
     d.walk_prims = r->arrays[k++].Upload(f.walk_prims, "upload walk primitives");
+    d.wide_nodes = r->arrays[k++].Upload(f.wide_nodes, "upload wide walk hierarchy");
     d.tri_pos = r->arrays[k++].Upload(f.tri_pos, "upload triangle positions");
     d.tri_attr = r->arrays[k++].Upload(f.tri_attr, "upload triangle attributes");
     d.instances = r->arrays[k++].Upload(f.instances, "upload instances");
@@ -293,6 +297,19 @@ struct Rccl
             throw std::runtime_error(std::string("RCCL error : \"") + GetErrorString(rc) + "\" when " + what + ".");
     }
 };
+
+// Backing store of the short traversal stacks (short_stack.h) of the launches that walk the 4-wide hierarchy: one column
+// of wide_stack entries per lane of a launch, up to kWalkSpillLanes lanes (launchers cap their grids at that).  Touched
+// only when a walk holds more than kWideRing postponed children.
+constexpr uint32_t kWalkSpillLanes = 1u << 21;
+void EnsureWalkSpill(mcpt_renderer *r)
+{
+    if (r->walk_spill_dev || r->flat.integrator.n_wide_nodes == 0)
+        return;
+    const size_t words = size_t(std::max(r->flat.integrator.wide_stack, 2u)) * kWalkSpillLanes;
+    Check(hipMalloc(reinterpret_cast<void **>(&r->walk_spill_dev), words * sizeof(uint32_t)), "allocate traversal-stack backing store");
+    r->dev.walk_spill = r->walk_spill_dev, r->dev.walk_spill_lanes = kWalkSpillLanes;
+}
 
 uint32_t RangeSize(uint32_t tiles_total, const mcpt_tile_range &range)
 {
@@ -456,7 +473,7 @@ uint32_t DrawQueued(mcpt_renderer *r, const mcpt::RenderJob &job, float *out_dev
         want = std::min<uint64_t>(want, uint64_t(r->queued_slots) * 4096u);
     want = std::min<uint64_t>(want, 1u << 26);
     mcpt::QueuedSizes sz{};
-    mcpt::QueuedLayout(static_cast<uint32_t>(want), groups, &sz);
+    mcpt::QueuedLayout(static_cast<uint32_t>(want), groups, r->dev.integrator.walk_depth, r->n_cus, &sz);
     if (sz.total_words() > r->queued_words)
     {
         if (r->queued_dev)
@@ -500,6 +517,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
           bool blocking, bool counted, mcpt_stats *stats)
 {
     Check(hipSetDevice(r->device), "select device");
+    EnsureWalkSpill(r);
     const uint32_t n_tiles = RangeSize(r->Tiles(), range);
     mcpt::RenderJob job{};
     job.n_items = n_tiles * 64u;
@@ -1140,6 +1158,8 @@ int mcpt_renderer_table(const mcpt_renderer *r, const char *what, const void **d
         return set(f.light_cdf.data(), f.light_cdf.size());
     if (w == "env_tables")
         return set(f.env_tables.data(), f.env_tables.size());
+    if (w == "camera") // eye, front, dx, dy (camera.cpp:26-37): 12 floats
+        return set(&f.camera.eye, 12);
     return Fail("unknown table '" + w + "'");
 }
 
@@ -1418,6 +1438,9 @@ int mcpt_debug_trace_rate(mcpt_renderer *r, uint32_t n, const float *rays, int m
     try
     {
         Check(hipSetDevice(r->device), "select device");
+        EnsureWalkSpill(r);
+        if (n > kWalkSpillLanes && mode == 3)
+            throw std::runtime_error("mcpt_debug_trace_rate: at most 2^21 rays in mode 3");
         Check(hipMalloc(reinterpret_cast<void **>(&d_rays), size_t(n) * 24), "allocate");
         Check(hipMalloc(reinterpret_cast<void **>(&d_found), size_t(n) * 4), "allocate");
         Check(hipMemcpy(d_rays, rays, size_t(n) * 24, hipMemcpyHostToDevice), "upload");

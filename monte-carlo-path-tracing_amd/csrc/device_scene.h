@@ -30,6 +30,14 @@
 //              The boxes of leaves are bit-identical to the reference's leaf
 //              boxes, interior boxes are exact unions: a primitive is reachable
 //              here under exactly the conditions it is in the reference's tree.
+//   wide_nodes 4 x uint4 per node (64 B) of the SAME hierarchy collapsed to four children per node, child boxes as
+//              8-bit offsets on the node's own grid (commit.cpp, BuildWideNodes):
+//                [0] = origin.xyz (float bits), biased exponents ex | ey << 8 | ez << 16 | n_children << 24
+//                [1] = child references 0..3 (node index, kWalkLeaf | slot, or kWalkDone for an unused slot)
+//                [2] = lo.x of children 0..3 (one byte each), lo.y, lo.z, hi.x     [3] = hi.y, hi.z, -, -
+//              plane = origin + 2^(e - 127) * q: decoded boxes contain the exact ones (verified with these very
+//              operations by the quantiser), so the walk reaches every primitive the exact hierarchy reaches; the exact
+//              leaf-box test at the primitive (test_slot, kLeafCheck) stops what the larger boxes let through.
 //   walk_prims 3 x float4 per slot: p0 | bits(global primitive), p1 | bits(instance),
 //              p2 | bits(rank of the primitive in the reference's visiting order)
 //   tri_pos    3 x float4 per triangle: p0, p1, p2 (w unused)  -> 36 B useful
@@ -67,6 +75,7 @@ constexpr uint32_t kWalkSliver = 0x80000000u; // walk_prims rank word: the trian
                                               // (commit.cpp); the low 31 bits are the rank
 constexpr uint32_t kWalkDepthMax = 56;      // bound on the ordered-walk tree depth
 constexpr uint32_t kWalkStackMax = kWalkDepthMax + 1; // stack entries: one per level + the sentinel
+constexpr uint32_t kWideRing = 16;      // entries per lane of the 4-wide walk's short stack that live in LDS (short_stack.h)
 constexpr int kLutRes = 128;            // kulla_conty.hpp:9
 
 struct Vec3f
@@ -212,6 +221,8 @@ struct IntegratorRec // reference integrator.hpp:31-69 (the scalar part)
     uint32_t id_sun, id_envmap;
     uint32_t n_tlas_nodes, n_nodes, n_instances, n_prims;
     uint32_t n_walk_nodes; // ordered-walk hierarchy (0 = empty scene)
+    uint32_t n_wide_nodes; // ... its 4-wide quantised form (wide_nodes)
+    uint32_t wide_stack;   // stack entries a walk of the wide form can need (sentinel included)
     uint32_t walk_depth;   // stack entries a lane needs: the tree's depth + 1 (sentinel)
     uint32_t has_masks;    // some BSDF carries an opacity map: the walk must keep the reference's order
     uint32_t walk_hold;    // ... or when at least this many lanes hold a primitive (0 = never for that reason)
@@ -239,6 +250,8 @@ enum SceneFeature : uint32_t
     kFeatVoteWalk = 1u << 6,
     // the scene has sliver triangles (IntegratorRec::walk_sliver_reach > 0): test_slot handles them
     kFeatSlivers = 1u << 7,
+    // the ordered walk runs on the 4-wide quantised hierarchy (wide_nodes) with a short stack (short_stack.h)
+    kFeatWideWalk = 1u << 8,
 };
 
 // Device view: raw pointers into HBM + the scalar records.
@@ -253,6 +266,9 @@ struct DeviceScene
     const float *node_area;    // 1 per node
     const float4 *walk_nodes;  // 4 per node of the ordered-walk hierarchy
     const float4 *walk_prims;  // 3 per slot
+    const uint4 *wide_nodes;   // 4 per node of the 4-wide quantised hierarchy (meshes: scenes outside LDS)
+    uint32_t *walk_spill;      // backing store of the short traversal stacks (short_stack.h): wide_stack x lanes of a launch
+    uint32_t walk_spill_lanes; // ... lanes it has room for
     const float4 *tri_pos;     // 3 per triangle slot (global primitive index)
     const float4 *tri_attr;    // 9 per triangle slot
     const InstanceRec *instances;

@@ -24,6 +24,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "../queue_core.h"
 #include "render_kernel.h"
 
@@ -37,6 +39,7 @@ constexpr uint32_t kQueueCounterKinds = 2 + kQueueGroups; // extension rays, sha
 struct QueueView
 {
     uint32_t *slots, *rays_ext, *rays_shadow, *entries, *counters;
+    uint32_t *spill;   // backing store of the trace launch's short traversal stacks (short_stack.h): walk_depth x lanes of the launch
     uint32_t cap;      // entries per sub-queue (a multiple of 64); slots = kSubQueues * cap
     uint32_t groups;   // bit g: the scene has vertices for group g's launch (bit 0 always)
     uint32_t n_present;
@@ -73,12 +76,9 @@ __device__ __forceinline__ void queue_push(const QueueView &qv, uint32_t parity,
     }
 }
 
-#ifndef MCPT_QUEUED_SHADE_WAVES
-#define MCPT_QUEUED_SHADE_WAVES 2 // wavefronts per SIMD the shade launches are compiled for (256 VGPRs: no spills)
-#endif
-
-template <uint32_t kFeatures, uint32_t kGroup>
-__global__ void __launch_bounds__(kBlockSize, MCPT_QUEUED_SHADE_WAVES)
+// kWaves: wavefronts per SIMD the launch is compiled for — 2 (256 VGPRs: no spills) or 4 (128 VGPRs)
+template <uint32_t kFeatures, uint32_t kGroup, int kWaves>
+__global__ void __launch_bounds__(kBlockSize, kWaves)
 queued_shade(const DeviceScene sc, const RenderJob job, float *__restrict__ out, const QueueView qv, uint32_t parity, uint32_t fresh)
 {
     using C = Config<kFeatures>;
@@ -178,7 +178,7 @@ queued_shade(const DeviceScene sc, const RenderJob job, float *__restrict__ out,
                 uint4 *dst = reinterpret_cast<uint4 *>(qv.rays_ext + (static_cast<size_t>(q) * qv.cap + pos) * kQueueExtWords);
                 const V3 o = s.st.origin, d = s.st.dir;
                 dst[0] = uint4{as_uint(o.x), as_uint(o.y), as_uint(o.z), as_uint(d.x)};
-                dst[1] = uint4{as_uint(d.y), as_uint(d.z), id, 0u};
+                dst[1] = uint4{as_uint(d.y), as_uint(d.z), id, rays.miss_group};
             }
         }
         if (__ballot(shadow))
@@ -220,14 +220,24 @@ hipError_t LaunchQueuedShadeGroup(const DeviceScene &sc, const RenderJob &job, f
                                   uint32_t n_cus, hipStream_t stream)
 {
     static thread_local uint32_t blocks = 0; // (per kernel instantiation)
+    static const int waves = []
+    {
+        const char *e = std::getenv("MCPT_QUEUED_SHADE_WAVES"); // (measurements)
+        return e && std::atoi(e) == 4 ? 4 : 2;
+    }();
     if (blocks == 0)
     {
-        const hipError_t err = QueuedGrid(queued_shade<kQueuedFeatures, kGroup>, 0, n_cus, &blocks);
+        const hipError_t err = waves == 4 ? QueuedGrid(queued_shade<kQueuedFeatures, kGroup, 4>, 0, n_cus, &blocks)
+                                          : QueuedGrid(queued_shade<kQueuedFeatures, kGroup, 2>, 0, n_cus, &blocks);
         if (err != hipSuccess)
             return err;
     }
-    hipLaunchKernelGGL((queued_shade<kQueuedFeatures, kGroup>), dim3(blocks), dim3(kBlockSize), 0, stream, sc, job, out, qv, parity,
-                       fresh ? 1u : 0u);
+    if (waves == 4)
+        hipLaunchKernelGGL((queued_shade<kQueuedFeatures, kGroup, 4>), dim3(blocks), dim3(kBlockSize), 0, stream, sc, job, out, qv, parity,
+                           fresh ? 1u : 0u);
+    else
+        hipLaunchKernelGGL((queued_shade<kQueuedFeatures, kGroup, 2>), dim3(blocks), dim3(kBlockSize), 0, stream, sc, job, out, qv, parity,
+                           fresh ? 1u : 0u);
     return hipGetLastError();
 }
 

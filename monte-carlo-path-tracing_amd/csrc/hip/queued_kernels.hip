@@ -1,5 +1,8 @@
 // Trace launch and host-side driver of the QUEUED renderer (queued_kernels.h, queue_core.h) for gfx950 (MI355X).
 #include "queued_kernels.h"
+#include "../short_stack.h"
+
+#include <cstdlib>
 
 namespace mcpt
 {
@@ -8,12 +11,18 @@ namespace
 {
 
 // One lane per queued ray; a wavefront works through its sub-queue's extension rays, then its shadow rays.
-// Walk state only: the traversal stack (LDS, lane-interleaved), the ray, the best hit.
-template <bool kAnalytic, bool kSlivers>
-__global__ void __launch_bounds__(kBlockSize) queued_trace(const DeviceScene sc, const QueueView qv, uint32_t parity)
+// Walk state only: the ray, the best hit, and a SHORT traversal stack (short_stack.h: 8 entries per lane in LDS = 8 KiB
+// per workgroup, older entries in HBM) — 8 wavefronts per SIMD where the full stacks allowed 5.
+constexpr uint32_t kTraceRing = 8;
+template <bool kAnalytic, bool kSlivers, int kWaves>
+__global__ void __launch_bounds__(kBlockSize, kWaves) queued_trace(const DeviceScene sc, const QueueView qv, uint32_t parity)
 {
-    extern __shared__ uint32_t lds_stacks[];
-    uint32_t *stack = lds_stacks + threadIdx.x;
+    __shared__ uint32_t lds_rings[kTraceRing * kBlockSize];
+    ShortStack<kTraceRing> stack;
+    stack.ring = lds_rings + threadIdx.x;
+    stack.spill = qv.spill + (static_cast<size_t>(blockIdx.x) * kBlockSize + threadIdx.x);
+    stack.spill_stride = gridDim.x * kBlockSize;
+    stack.base = 0;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (blockIdx.x * kBlockSize + threadIdx.x) >> 6, n_waves = gridDim.x * (kBlockSize / 64u);
     const uint32_t q = wave % kSubQueues, chunk_stride = n_waves / kSubQueues;
@@ -22,7 +31,6 @@ __global__ void __launch_bounds__(kBlockSize) queued_trace(const DeviceScene sc,
     if (blockIdx.x == 0)
         for (uint32_t k = threadIdx.x; k < kQueueCounterKinds * kSubQueues; k += kBlockSize)
             *queue_counter(qv, parity ^ 1u, k / kSubQueues, k % kSubQueues) = 0;
-    TraceStats ts{0, 0, 0, 0};
     // ---- extension rays: closest hit -> the shade queue of the material group that was hit ----
     const uint32_t n_ext = *queue_counter(qv, parity, 0, q);
     for (uint32_t c = wave / kSubQueues; c * 64u < n_ext; c += chunk_stride)
@@ -38,8 +46,9 @@ __global__ void __launch_bounds__(kBlockSize) queued_trace(const DeviceScene sc,
             id = r1.z;
             Ray ray = make_ray(V3{as_float(r0.x), as_float(r0.y), as_float(r0.z)}, V3{as_float(r0.w), as_float(r1.x), as_float(r1.y)});
             HitRaw hit;
-            const bool found = walk_ordered_vote<false, kAnalytic, false, kSlivers>(sc, stack, ray, hit, ts);
+            const bool found = walk_ordered_short<false, kAnalytic, kSlivers, kTraceRing>(sc, stack, ray, hit);
             e0.x = id;
+            group = r1.w; // where the slot goes if the ray left the scene
             if (found)
             {
                 group = queue_group_of_instance(sc, hit.inst);
@@ -50,8 +59,10 @@ __global__ void __launch_bounds__(kBlockSize) queued_trace(const DeviceScene sc,
         queue_push(qv, parity, q, mine, group, e0, e1);
     }
     // ---- shadow rays: any hit.  Unoccluded: the slot's radiance gains the ray's contribution ----
+    // (chunks dealt from the LAST wavefront of the sub-queue down: the wavefronts that got extension rays above are the
+    //  first ones)
     const uint32_t n_shadow = *queue_counter(qv, parity, 1, q);
-    for (uint32_t c = wave / kSubQueues; c * 64u < n_shadow; c += chunk_stride)
+    for (uint32_t c = chunk_stride - 1u - wave / kSubQueues; c * 64u < n_shadow; c += chunk_stride)
     {
         const uint32_t idx = c * 64u + lane;
         const bool mine = idx < n_shadow;
@@ -64,7 +75,7 @@ __global__ void __launch_bounds__(kBlockSize) queued_trace(const DeviceScene sc,
             Ray ray = make_ray(V3{as_float(r0.x), as_float(r0.y), as_float(r0.z)}, V3{as_float(r0.w), as_float(r1.x), as_float(r1.y)});
             ray.t_max = as_float(r1.z);
             HitRaw hit;
-            if (!walk_ordered_vote<true, kAnalytic, false, kSlivers>(sc, stack, ray, hit, ts))
+            if (!walk_ordered_short<true, kAnalytic, kSlivers, kTraceRing>(sc, stack, ray, hit))
             {
                 // L += throughput * direct (stream_fold / connect_lights): nobody else touches this slot's radiance
                 // during the launch
@@ -79,24 +90,40 @@ __global__ void __launch_bounds__(kBlockSize) queued_trace(const DeviceScene sc,
     }
 }
 
+// Wavefronts per SIMD the trace launch is compiled for and launched with: 8 (64 VGPRs, a few spills), 6 (80) or 5 (its
+// natural 88).  MCPT_QUEUED_TRACE_WAVES in the environment picks another one for measurements.
+int TraceWaves()
+{
+    static const int waves = []
+    {
+        const char *e = std::getenv("MCPT_QUEUED_TRACE_WAVES");
+        const int w = e ? std::atoi(e) : 8;
+        return w == 5 || w == 6 ? w : 8;
+    }();
+    return waves;
+}
+
 template <bool kAnalytic, bool kSlivers>
 hipError_t LaunchTrace(const DeviceScene &sc, const QueueView &qv, uint32_t parity, uint32_t n_cus, hipStream_t stream)
 {
-    const size_t lds_bytes = size_t(sc.integrator.walk_depth) * kBlockSize * sizeof(uint32_t);
-    static thread_local uint32_t blocks = 0;
-    static thread_local size_t blocks_for_lds = 0;
-    if (blocks == 0 || blocks_for_lds != lds_bytes)
+    const uint32_t blocks = QueuedTraceBlocks(n_cus);
+    switch (TraceWaves())
     {
-        const hipError_t err = QueuedGrid(queued_trace<kAnalytic, kSlivers>, lds_bytes, n_cus, &blocks);
-        if (err != hipSuccess)
-            return err;
-        blocks_for_lds = lds_bytes;
+    case 5: hipLaunchKernelGGL((queued_trace<kAnalytic, kSlivers, 5>), dim3(blocks), dim3(kBlockSize), 0, stream, sc, qv, parity); break;
+    case 6: hipLaunchKernelGGL((queued_trace<kAnalytic, kSlivers, 6>), dim3(blocks), dim3(kBlockSize), 0, stream, sc, qv, parity); break;
+    default: hipLaunchKernelGGL((queued_trace<kAnalytic, kSlivers, 8>), dim3(blocks), dim3(kBlockSize), 0, stream, sc, qv, parity); break;
     }
-    hipLaunchKernelGGL((queued_trace<kAnalytic, kSlivers>), dim3(blocks), dim3(kBlockSize), lds_bytes, stream, sc, qv, parity);
     return hipGetLastError();
 }
 
 } // namespace
+
+// Grid of the trace launch: every wavefront slot of the machine at 8 per SIMD, a multiple of kSubQueues wavefronts.
+uint32_t QueuedTraceBlocks(uint32_t n_cus)
+{
+    constexpr uint32_t kBlocksPerSet = kSubQueues / (kBlockSize / 64u);
+    return ((n_cus * static_cast<uint32_t>(TraceWaves()) + kBlocksPerSet - 1) / kBlocksPerSet) * kBlocksPerSet;
+}
 
 bool QueuedSupports(const DeviceScene &sc, const RenderJob &job)
 {
@@ -116,8 +143,9 @@ uint32_t QueuedGroups(const BsdfRec *bsdfs, size_t n_bsdfs, bool any_instance_wi
     return groups;
 }
 
-void QueuedLayout(uint32_t n_slots_wanted, uint32_t groups, QueuedSizes *sz)
+void QueuedLayout(uint32_t n_slots_wanted, uint32_t groups, uint32_t walk_depth, uint32_t n_cus, QueuedSizes *sz)
 {
+    sz->spill_words = size_t(walk_depth) * QueuedTraceBlocks(n_cus) * kBlockSize;
     uint32_t cap = (n_slots_wanted + kSubQueues - 1) / kSubQueues;
     cap = ((cap + 63u) / 64u) * 64u;
     if (cap == 0)
@@ -141,6 +169,7 @@ static QueueView MakeView(uint32_t *base, const QueuedSizes &sz, uint32_t groups
     qv.rays_shadow = qv.rays_ext + sz.ext_words;
     qv.entries = qv.rays_shadow + sz.shadow_words;
     qv.counters = qv.entries + sz.entry_words;
+    qv.spill = qv.counters + sz.counter_words;
     qv.cap = sz.cap, qv.groups = groups, qv.n_present = sz.n_present;
     uint32_t d = 0;
     for (uint32_t g = 0; g < kQueueGroups; ++g)

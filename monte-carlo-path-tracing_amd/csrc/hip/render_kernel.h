@@ -130,12 +130,13 @@ hipError_t LaunchWavefrontRound(const DeviceScene &sc, const RenderJob &job, flo
 struct QueuedSizes
 {
     uint32_t cap, n_slots, n_present;
-    size_t slot_words, ext_words, shadow_words, entry_words, counter_words;
-    size_t total_words() const { return slot_words + ext_words + shadow_words + entry_words + counter_words; }
+    size_t slot_words, ext_words, shadow_words, entry_words, counter_words, spill_words;
+    size_t total_words() const { return slot_words + ext_words + shadow_words + entry_words + counter_words + spill_words; }
 };
 bool QueuedSupports(const DeviceScene &sc, const RenderJob &job);
 uint32_t QueuedGroups(const BsdfRec *bsdfs, size_t n_bsdfs, bool any_instance_without_bsdf); // bit g: the scene needs group g's launch
-void QueuedLayout(uint32_t n_slots_wanted, uint32_t groups, QueuedSizes *sizes);
+void QueuedLayout(uint32_t n_slots_wanted, uint32_t groups, uint32_t walk_depth, uint32_t n_cus, QueuedSizes *sizes);
+uint32_t QueuedTraceBlocks(uint32_t n_cus);
 uint32_t *QueuedCounters(uint32_t *base, const QueuedSizes &sizes);
 hipError_t LaunchQueuedRound(const DeviceScene &sc, const RenderJob &job, float *out, uint32_t *base, const QueuedSizes &sizes, uint32_t groups,
                              uint32_t round, uint32_t n_cus, hipStream_t stream);

@@ -202,6 +202,151 @@ private:
 // traversal stack.
 int g_walk_tree_strategy = 0; // SetWalkTreeStrategyForTesting
 
+// ---- 4-wide, quantised form of the ordered-walk hierarchy (device_scene.h: wide_nodes) ----------
+// The mesh walk is bound by the number of 64-byte node records it pulls through L2 / Infinity Cache (a lean trace kernel
+// moves ~150 G records/s = 9.4 TB/s whatever its occupancy: DESIGN.md section 6), so the lever is records per ray: a
+// node that holds FOUR children in the same 64 bytes halves them.  The binary tree above is collapsed — a node takes its
+// grandchildren, largest surface first, until it has four children — and the children's boxes are stored as 8-bit
+// offsets on a per-node grid (origin + 2^e * q per axis).  Decoded boxes CONTAIN the binary tree's boxes, rounding
+// included: the quantiser verifies `origin + scale * q` with the device's own float operations and moves q outwards until
+// it does.  The slab test is monotone in the box, so every primitive the exact hierarchy reaches is reached here too;
+// what a larger box lets through in addition is stopped at the primitive by the exact leaf-box test
+// (traversal.h, test_slot: kLeafCheck), as it already is for slivers' grown boxes.  Answers unchanged.
+void BuildWideNodes(FlatScene &fs)
+{
+    IntegratorRec &ig = fs.integrator;
+    fs.wide_nodes.clear();
+    ig.n_wide_nodes = 0, ig.wide_stack = 1;
+    const uint32_t n_binary = ig.n_walk_nodes;
+    if (n_binary == 0)
+    {
+        fs.wide_nodes.assign(4, uint4{0, 0, 0, 0});
+        return;
+    }
+    struct Child
+    {
+        uint32_t ref; // binary node index, or kWalkLeaf | slot
+        Bounds box;
+    };
+    auto children_of = [&](uint32_t node, Child out[2]) -> int
+    {
+        const float4 *n = &fs.walk_nodes[4 * size_t(node)];
+        int k = 0;
+        uint32_t ref0, ref1;
+        std::memcpy(&ref0, &n[0].w, 4), std::memcpy(&ref1, &n[1].w, 4);
+        Bounds b0, b1;
+        b0.lo = V3{n[0].x, n[0].y, n[0].z}, b0.hi = V3{n[1].x, n[1].y, n[1].z};
+        b1.lo = V3{n[2].x, n[2].y, n[2].z}, b1.hi = V3{n[3].x, n[3].y, n[3].z};
+        if (!(b0.lo.x > b0.hi.x)) // (not the "never entered" box of the top node's second child)
+            out[k++] = Child{ref0, b0};
+        if (!(b1.lo.x > b1.hi.x))
+            out[k++] = Child{ref1, b1};
+        return k;
+    };
+    auto area = [](const Bounds &b)
+    {
+        const double dx = double(b.hi.x) - b.lo.x, dy = double(b.hi.y) - b.lo.y, dz = double(b.hi.z) - b.lo.z;
+        return dx * dy + dy * dz + dz * dx;
+    };
+    // breadth-first over the wide nodes: node k of `todo` becomes wide node k
+    struct Todo
+    {
+        uint32_t binary;     // the binary node whose subtree this wide node covers ...
+        uint32_t stack_above; // entries on a walk's stack when it arrives here (worst case over the path)
+    };
+    std::vector<Todo> todo{{0u, 1u}};
+    std::vector<uint4> &out = fs.wide_nodes;
+    uint32_t worst_stack = 1;
+    for (size_t k = 0; k < todo.size(); ++k)
+    {
+        Child kids[4];
+        int n = children_of(todo[k].binary, kids);
+        // take grandchildren, largest surface first, while there is room
+        for (;;)
+        {
+            int pick = -1;
+            double best = -1.0;
+            for (int i = 0; i < n; ++i)
+                if (!(kids[i].ref & kWalkLeaf) && area(kids[i].box) > best)
+                    best = area(kids[i].box), pick = i;
+            if (pick < 0 || n >= 4)
+                break;
+            Child grand[2];
+            const int g = children_of(kids[pick].ref, grand);
+            if (n - 1 + g > 4)
+                break;
+            kids[pick] = kids[n - 1], --n;
+            for (int i = 0; i < g; ++i)
+                kids[n++] = grand[i];
+        }
+        // the node's grid: origin = the children's common lower corner, scale = the power of two that spans the extent in 255 steps
+        Bounds all;
+        for (int i = 0; i < n; ++i)
+            all.Add(kids[i].box);
+        const float origin[3] = {all.lo.x, all.lo.y, all.lo.z}, top[3] = {all.hi.x, all.hi.y, all.hi.z};
+        uint32_t expo[3];
+        uint8_t qlo[4][3] = {}, qhi[4][3] = {};
+        for (int a = 0; a < 3; ++a)
+        {
+            // smallest scale = 2^e whose grid spans the extent in 255 steps AND whose decoded planes — evaluated exactly
+            // like the device evaluates them, origin + scale * float(q) — enclose every child
+            const float extent = top[a] - origin[a];
+            int e = extent > 0.0f ? std::max(-126, std::ilogb(extent) - 9) : -126;
+            for (;; ++e)
+            {
+                const float scale = std::ldexp(1.0f, e);
+                bool fits = origin[a] + scale * 255.0f >= top[a];
+                for (int i = 0; i < n && fits; ++i)
+                {
+                    const float lo = comp(kids[i].box.lo, a), hi = comp(kids[i].box.hi, a);
+                    int ql = static_cast<int>(std::floor((double(lo) - origin[a]) / scale)), qh = static_cast<int>(std::ceil((double(hi) - origin[a]) / scale));
+                    ql = std::min(std::max(ql, 0), 255), qh = std::min(std::max(qh, 0), 255);
+                    while (ql > 0 && !(origin[a] + scale * static_cast<float>(ql) <= lo))
+                        --ql;
+                    while (qh < 255 && !(origin[a] + scale * static_cast<float>(qh) >= hi))
+                        ++qh;
+                    fits = origin[a] + scale * static_cast<float>(ql) <= lo && origin[a] + scale * static_cast<float>(qh) >= hi;
+                    qlo[i][a] = static_cast<uint8_t>(ql), qhi[i][a] = static_cast<uint8_t>(qh);
+                }
+                if (fits || e >= 127)
+                    break;
+            }
+            expo[a] = static_cast<uint32_t>(e + 127);
+        }
+        uint32_t refs[4] = {kWalkDone, kWalkDone, kWalkDone, kWalkDone};
+        const uint32_t pushes = n > 0 ? static_cast<uint32_t>(n - 1) : 0u;
+        worst_stack = std::max(worst_stack, todo[k].stack_above + pushes);
+        for (int i = 0; i < n; ++i)
+        {
+            if (kids[i].ref & kWalkLeaf)
+                refs[i] = kids[i].ref;
+            else
+            {
+                refs[i] = static_cast<uint32_t>(todo.size());
+                todo.push_back(Todo{kids[i].ref, todo[k].stack_above + pushes});
+            }
+        }
+        auto bits = [](float f)
+        {
+            uint32_t u;
+            std::memcpy(&u, &f, 4);
+            return u;
+        };
+        auto plane_word = [&](const uint8_t q[4][3], int a)
+        { return uint32_t(q[0][a]) | (uint32_t(q[1][a]) << 8) | (uint32_t(q[2][a]) << 16) | (uint32_t(q[3][a]) << 24); };
+        // unused child slots: an inverted box (255 .. 0) and the "done" reference; `n` in the top byte of word 3
+        for (int i = n; i < 4; ++i)
+            for (int a = 0; a < 3; ++a)
+                qlo[i][a] = 255, qhi[i][a] = 0;
+        out.push_back(uint4{bits(origin[0]), bits(origin[1]), bits(origin[2]), expo[0] | (expo[1] << 8) | (expo[2] << 16) | (uint32_t(n) << 24)});
+        out.push_back(uint4{refs[0], refs[1], refs[2], refs[3]});
+        out.push_back(uint4{plane_word(qlo, 0), plane_word(qlo, 1), plane_word(qlo, 2), plane_word(qhi, 0)});
+        out.push_back(uint4{plane_word(qhi, 1), plane_word(qhi, 2), 0u, 0u});
+    }
+    ig.n_wide_nodes = static_cast<uint32_t>(todo.size());
+    ig.wide_stack = worst_stack + 1;
+}
+
 class WalkTreeBuilder
 {
 public:
@@ -735,6 +880,7 @@ DeviceScene FlatScene::HostView() const
     d.camera = camera, d.integrator = integrator, d.features = features;
     d.nodes = nodes.data(), d.node_area = node_area.data();
     d.walk_nodes = walk_nodes.data(), d.walk_prims = walk_prims.data();
+    d.wide_nodes = wide_nodes.data();
     d.tri_pos = tri_pos.data(), d.tri_attr = tri_attr.data();
     d.instances = instances.data(), d.analytic = analytic.data();
     d.light_inst = light_inst.data(), d.light_cdf = light_cdf.data();
@@ -1072,6 +1218,7 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
             fs.walk_prims.push_back(float4{p[1].x, p[1].y, p[1].z, Bits(prim_inst[prim])});
             fs.walk_prims.push_back(float4{p[2].x, p[2].y, p[2].z, Bits(rank[prim] | (sliver[prim] ? kWalkSliver : 0u))});
         }
+        BuildWideNodes(fs);
         fs.seconds_walk = seconds_since(t_walk);
     }
 
@@ -1391,6 +1538,8 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
         fs.walk_nodes.assign(4, float4{0, 0, 0, 0});
     if (fs.walk_prims.empty())
         fs.walk_prims.assign(3, float4{0, 0, 0, 0});
+    if (fs.wide_nodes.empty())
+        fs.wide_nodes.assign(4, uint4{0, 0, 0, 0});
     fs.seconds_total = seconds_since(t_begin);
     return fs;
 }

@@ -23,6 +23,7 @@ struct FlatScene
     std::vector<float> node_area;  // 1 per node
     std::vector<float4> walk_nodes; // 4 per node (ordered-walk hierarchy)
     std::vector<float4> walk_prims; // 3 per slot
+    std::vector<uint4> wide_nodes;  // 4 per node of the 4-wide quantised form of the ordered-walk hierarchy
     std::vector<float4> tri_pos;   // 3 per primitive slot
     std::vector<float4> tri_attr;  // 9 per primitive slot
     std::vector<InstanceRec> instances;

@@ -25,6 +25,7 @@
 #define MCPT_PATH_CORE_H
 
 #include "lights_media.h"
+#include "short_stack.h"
 #include "traversal.h"
 
 namespace mcpt
@@ -41,6 +42,7 @@ struct Config
     static constexpr bool kOrdered = (kFeatures & kFeatOrderedWalk) != 0; // which ray query runs (traversal.h)
     static constexpr bool kVote = (kFeatures & kFeatVoteWalk) != 0;       // ... scheduled by wavefront vote
     static constexpr bool kSlivers = (kFeatures & kFeatSlivers) != 0;     // ... with the sliver handling of test_slot
+    static constexpr bool kWide = (kFeatures & kFeatWideWalk) != 0;       // ... on the 4-wide quantised hierarchy
 };
 
 struct LaneCounters
@@ -141,6 +143,9 @@ MCPT_HD bool trace(const DeviceScene &sc, uint32_t *stack, Ray &r, uint32_t &rng
 {
     if (C::kOrdered)
     {
+        if (C::kWide)
+            return count ? walk_wide_vote<kAny, C::kAnalytic, true, C::kSlivers>(sc, stack, r, hit, ts)
+                         : walk_wide_vote<kAny, C::kAnalytic, false, C::kSlivers>(sc, stack, r, hit, ts);
         if (C::kVote)
             return count ? walk_ordered_vote<kAny, C::kAnalytic, true, C::kSlivers>(sc, stack, r, hit, ts)
                          : walk_ordered_vote<kAny, C::kAnalytic, false, C::kSlivers>(sc, stack, r, hit, ts);

@@ -62,7 +62,8 @@ constexpr uint32_t kSlotRequeue = 1u << 13; // the slot goes straight to another
 constexpr uint32_t kSlotFresh = 1u << 14;   // no pixel yet
 
 // ---- queue records ----------------------------------------------------------------------------
-// extension ray: origin, direction, slot                                            8 words
+// extension ray: origin, direction, slot, group of the shade queue the slot joins IF THE RAY MISSES        8 words
+//                (the launch that starts the slot's next sample: queue_group_after_end)
 // shadow ray:    origin, direction, t_max, id, contribution (3), -                  12 words
 //                id = slot | kQueuePush (the slot has no extension ray out: this lane queues it for shading) |
 //                     group << kQueueGroupShift (... in that group's queue)
@@ -76,6 +77,7 @@ struct QueueRays // what a shade call emits
     bool ext, shadow, requeue;
     uint32_t requeue_group;  // requeue: the group whose launch shades the slot's pending first vertex
     uint32_t shadow_id_bits; // kQueuePush | group << kQueueGroupShift, or 0
+    uint32_t miss_group;     // ext: the shade queue the slot joins if its extension ray leaves the scene
     V3 contribution;         // shadow: what the slot's radiance gains if the ray is unoccluded
 };
 
@@ -181,6 +183,7 @@ MCPT_HD QueueShadeResult queue_shade(const DeviceScene &sc, StreamSlot<1> &s, ui
     constexpr uint32_t kOnly = queue_kind_of_group(kGroup);
     PathState &st = s.st;
     out.ext = out.shadow = out.requeue = false, out.requeue_group = 0, out.shadow_id_bits = 0, out.contribution = V3{0, 0, 0};
+    out.miss_group = 0;
     stream_unpack(s);
     if (s.flags & kSlotExhausted)
         return kQueueContinue;
@@ -245,7 +248,13 @@ MCPT_HD QueueShadeResult queue_shade(const DeviceScene &sc, StreamSlot<1> &s, ui
     if (out.requeue)
         s.flags |= kSlotRequeue;
     if (out.ext)
+    {
         s.flags |= kSlotExtRay;
+        // a ray that leaves the scene ends the sample (every launch has that code: stream_vertex's miss branch); the
+        // launch that shades the NEXT sample's first vertex should be the one that does it, or the slot pays a round
+        // for the hand-over
+        out.miss_group = queue_group_after_end<C>(sc, st);
+    }
     if (out.shadow && !out.ext) // ended at a vertex whose shadow ray is out: that ray's lane queues the slot
         out.shadow_id_bits = kQueuePush | (queue_group_after_end<C>(sc, st) << kQueueGroupShift);
     stream_pack(s);

@@ -517,17 +517,6 @@ enum StreamCold : uint32_t
 };
 MCPT_HD constexpr uint32_t stream_cold_words(uint32_t S) { return kColdEstimates + 3u * S + 3u; } // + the ray origin (volpath)
 
-MCPT_HD float as_float(uint32_t u)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __uint_as_float(u);
-#else
-    float f;
-    __builtin_memcpy(&f, &u, 4);
-    return f;
-#endif
-}
-
 MCPT_HD V3 stream_get3(const uint32_t *base, uint32_t P, uint32_t field, uint32_t i)
 {
     return V3{as_float(base[field * P + i]), as_float(base[(field + 1) * P + i]), as_float(base[(field + 2) * P + i])};

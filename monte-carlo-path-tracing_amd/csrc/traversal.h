@@ -110,6 +110,17 @@ MCPT_HD uint32_t as_uint(float f)
 #endif
 }
 
+MCPT_HD float as_float(uint32_t u)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+
 // Opacity mask of an instance's BSDF (bsdf.cpp:272-276): may draw one number.
 template <bool kTextures>
 MCPT_HD bool masked_out(const DeviceScene &sc, uint32_t bsdf, V2 uv, uint32_t &rng)
@@ -464,7 +475,11 @@ struct ClosestState
 // (triangle.cpp:82) — and the later accepted one is kept.  This covers exact ties (shared
 // edges, two surfaces in one plane) and the case where a flat box's entry distance and
 // the triangle's own distance differ in the last bit.  Returns whether `hit` changed.
-template <bool kAny, bool kAnalytic, bool kSlivers = true>
+// kLeafCheck: the walk came here through a hierarchy whose boxes are LARGER than the exact ones (the 4-wide quantised
+// form, device_scene.h: wide_nodes).  The exact hierarchy tests a primitive only when its own leaf box lets the ray in
+// under the current bound; here that test is made explicitly, on the primitive's record, before the hit counts.  (A
+// sliver's leaf box is a grown one in both hierarchies and its own rules below decide: not re-tested here.)
+template <bool kAny, bool kAnalytic, bool kSlivers = true, bool kLeafCheck = false>
 MCPT_HD bool test_slot(const DeviceScene &sc, uint32_t slot, Ray &ray, HitRaw &hit, ClosestState &best)
 {
     const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(slot);
@@ -473,6 +488,11 @@ MCPT_HD bool test_slot(const DeviceScene &sc, uint32_t slot, Ray &ray, HitRaw &h
     if (!kAnalytic || sc.instances[inst].kind == kInstTriangles)
     {
         h = triangle_probe(p, ray);
+        if (kLeafCheck && h.hit && !(kSlivers && (rank & kWalkSliver)))
+        {
+            const V3 lo = vmin(vmin(xyz(p[0]), xyz(p[1])), xyz(p[2])), hi = vmax(vmax(xyz(p[0]), xyz(p[1])), xyz(p[2]));
+            h.hit = box_hit(float4{lo.x, lo.y, lo.z, 0.0f}, float4{hi.x, hi.y, hi.z, 0.0f}, ray); // triangle.cpp:9-15, bound = ray.t_max
+        }
     }
     else
     {
@@ -490,6 +510,8 @@ MCPT_HD bool test_slot(const DeviceScene &sc, uint32_t slot, Ray &ray, HitRaw &h
         else
             h.hit = cylinder_hit<false>(sc, sc.analytic[rec.analytic], prim, kNone, probe, unused_rng, cand);
         h.t = probe.t_max, h.a = cand.a, h.b = cand.b, h.c = cand.c, h.inside = cand.inside;
+        if (kLeafCheck && h.hit)
+            h.hit = reference_leaf_box_passes<kAnalytic>(sc, inst, prim, ray, ray.t_max);
     }
     bool take;
     // A sliver's leaf box in the hierarchy is larger than the reference's (commit.cpp), so the walk

@@ -69,6 +69,7 @@ class Emulator:
         return frame, rounds.value
 
     ORDERED = 32      # feature bit of the ordered walk in a forced `variant`
+    WIDE = 256        # ... of the 4-wide quantised hierarchy (with ORDERED)
     REFERENCE = -2    # `variant`: the launcher's pick, but with the reference-order walk
 
     def trace_pixel(self, mcsd_path, x, y, width, ordered=True, capacity=4096):
@@ -91,7 +92,9 @@ class Emulator:
         rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 6)
         out = np.zeros((len(rays), 2), np.float32)
         self.lib.mcpt_emu_closest.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
-        if self.lib.mcpt_emu_closest(str(mcsd_path).encode(), rays.ctypes.data, len(rays), 1 if ordered else 0,
+        # ordered: False / 0 = the reference's trees in the reference's order, True / 1 = the ordered walk of the binary
+        # hierarchy, 2 = the 4-wide quantised hierarchy with the short stack (the production walk of scenes outside LDS)
+        if self.lib.mcpt_emu_closest(str(mcsd_path).encode(), rays.ctypes.data, len(rays), int(ordered),
                                      out.ctypes.data) != 0:
             raise RuntimeError(self.lib.mcpt_emu_last_error().decode())
         return out[:, 0].astype(np.int64), out[:, 1].copy()

@@ -20,6 +20,7 @@
 #include "path_core.h"
 #include "stream_core.h"
 #include "queue_core.h"
+#include "short_stack.h"
 
 namespace
 {
@@ -194,7 +195,10 @@ void RenderAllQueued(DeviceScene sc, float *frame, uint32_t n_slots, uint32_t *r
     sc.prehit = prehit.data(), sc.prehit_step = 1;
     n_slots = std::max(1u, std::min(n_slots ? n_slots : n_items, n_items));
     std::vector<uint32_t> slots(size_t(n_slots) * kQueueSlotWords, 0u);
-    struct Ext { V3 o, d; uint32_t id; };
+    struct Ext { V3 o, d; uint32_t id, miss_group; };
+    // the trace launch's short stack (short_stack.h) with a ring of TWO entries: nearly every walk spills and reloads
+    std::vector<uint32_t> ring(2 * kWalkStackStride), spill(kWalkStackMax);
+    ShortStack<2> short_stack{ring.data(), spill.data(), 1u, 0u};
     struct Shadow { V3 o, d; float t_max; uint32_t id; V3 contribution; };
     struct Entry { uint32_t w[kQueueEntryWords]; };
     std::vector<Ext> ext, ext_next;
@@ -248,7 +252,7 @@ void RenderAllQueued(DeviceScene sc, float *frame, uint32_t n_slots, uint32_t *r
             return;
         queue_save<C>(rec, s);
         if (rays.ext)
-            ext_next.push_back(Ext{s.st.origin, s.st.dir, id});
+            ext_next.push_back(Ext{s.st.origin, s.st.dir, id, rays.miss_group});
         if (rays.shadow)
             shadow_next.push_back(Shadow{s.sh_origin[0], s.sh_dir[0], s.sh_tmax[0], id | rays.shadow_id_bits, rays.contribution});
         if (rays.requeue)
@@ -292,10 +296,11 @@ void RenderAllQueued(DeviceScene sc, float *frame, uint32_t n_slots, uint32_t *r
             Ray ray = make_ray(r.o, r.d);
             HitRaw hit;
             TraceStats ts{0, 0, 0, 0};
-            const bool found = walk_ordered<false, C::kAnalytic, false, C::kSlivers>(sc, stack.data(), ray, hit, ts);
+            (void)ts;
+            const bool found = walk_ordered_short<false, C::kAnalytic, C::kSlivers, 2>(sc, short_stack, ray, hit);
             Entry e{};
             e.w[0] = r.id, e.w[1] = kNone;
-            uint32_t group = 0;
+            uint32_t group = r.miss_group;
             if (found)
             {
                 group = queue_group_of_instance(sc, hit.inst);
@@ -310,7 +315,8 @@ void RenderAllQueued(DeviceScene sc, float *frame, uint32_t n_slots, uint32_t *r
             ray.t_max = r.t_max;
             HitRaw hit;
             TraceStats ts{0, 0, 0, 0};
-            if (!walk_ordered<true, C::kAnalytic, false, C::kSlivers>(sc, stack.data(), ray, hit, ts))
+            (void)ts;
+            if (!walk_ordered_short<true, C::kAnalytic, C::kSlivers, 2>(sc, short_stack, ray, hit))
             {
                 uint32_t *L = slots.data() + size_t(r.id & kQueueSlotMask) * kQueueSlotWords + kQL;
                 L[0] = as_uint(as_float(L[0]) + r.contribution.x), L[1] = as_uint(as_float(L[1]) + r.contribution.y);
@@ -443,7 +449,7 @@ int mcpt_emu_render(const char *mcsd_path, float *frame, int variant, uint32_t *
         if (variant >= 0)
         {
             ordered = (static_cast<uint32_t>(variant) & kFeatOrderedWalk) != 0;
-            pick = static_cast<uint32_t>(variant) & ~kFeatOrderedWalk;
+            pick = static_cast<uint32_t>(variant) & ~(kFeatOrderedWalk | kFeatWideWalk);
         }
         else if (f == 0)
             pick = 0;
@@ -461,7 +467,12 @@ int mcpt_emu_render(const char *mcsd_path, float *frame, int variant, uint32_t *
         // (a no-op on the one-lane "wavefronts" of the host build) in the others
         constexpr uint32_t kO = kFeatOrderedWalk, kV = kFeatOrderedWalk | kFeatVoteWalk;
         constexpr uint32_t kSurfaceF = kFeatEmitters | kFeatTextures | kFeatMicrofacet;
-        if (ordered && flat.integrator.walk_sliver_reach > 0.0f)
+        if (ordered && variant >= 0 && (static_cast<uint32_t>(variant) & kFeatWideWalk))
+        {
+            // the production walk of scenes outside LDS: the 4-wide quantised hierarchy (full-feature instantiation)
+            RenderAll<kAll | kV | kFeatSlivers | kFeatWideWalk>(sc, frame, cnt);
+        }
+        else if (ordered && flat.integrator.walk_sliver_reach > 0.0f)
         {
             // like the launcher: scenes with sliver triangles run the sliver-aware instantiations
             if ((pick & ~kSurfaceF) == 0)
@@ -987,8 +998,9 @@ int mcpt_emu_closest(const char *mcsd_path, const float *rays, uint32_t n, int o
                         HitRaw raw;
                         TraceStats ts{0, 0, 0, 0};
                         uint32_t rng = 1;
-                        const bool hit = ordered ? walk_ordered<false, true, false>(sc, stack.data(), ray, raw, ts)
-                                                 : walk_scene<false, true, true, false>(sc, ray, rng, raw, ts);
+                        const bool hit = ordered == 2   ? walk_wide_vote<false, true, false>(sc, stack.data(), ray, raw, ts) // the 4-wide quantised hierarchy
+                                         : ordered ? walk_ordered<false, true, false>(sc, stack.data(), ray, raw, ts)
+                                                   : walk_scene<false, true, true, false>(sc, ray, rng, raw, ts);
                         out[2 * i] = hit ? static_cast<float>(raw.prim) : -1.0f;
                         out[2 * i + 1] = ray.t_max;
                     }
