@@ -166,11 +166,15 @@ int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint
 /* Which kernel formulation later draws use; the image does not depend on it (tests assert the frames are
  * bit-identical).  Replaces the reference's megakernel dispatch (src/renderer/renderer.cpp:88-95).
  *   mode -1 (default): the lane-owns-a-path kernel for the few-KB scenes whose traversal data sits in LDS
- *          (cornell-box, volumetric-caustic: it is VALU-bound there and faster); for every other scene the
- *          renderer's FIRST draw calibrates — lanes kernel with fixed lists, lanes kernel with the work counter and
- *          stream kernel with the work counter (workgroup rounds, wavefront rounds: modes 1 and 4) render a sample of the frame's tiles at a few spp, the fastest is kept
- *          (they are within +-25 % of each other and the winner depends on the scene: DESIGN.md section 3).
- *          mcpt_renderer_last_kernel reports the choice and the four timings.
+ *          (cornell-box, volumetric-caustic: it is VALU-bound there and faster); for every other scene the stream kernel
+ *          in wavefront rounds with the work counter (mode 4) — the built-in rule, no measurement inside a draw — UNLESS a
+ *          calibrated choice for this scene, film and device is known: mcpt_renderer_calibrate (or MCPT_CALIBRATE=1 in
+ *          the environment, for the first draw) times four configurations — lanes kernel with fixed lists / with the work
+ *          counter, stream kernel in workgroup rounds / in wavefront rounds — on a sample of the frame's tiles at a few
+ *          spp, keeps the fastest (they are within +-25 % of each other: DESIGN.md section 3) and STORES it, in the
+ *          process and in the file MCPT_CALIBRATION_FILE (default $HOME/.cache/mcpt/calibration.txt, "off" = none), so
+ *          that later renderers and later processes start with it.  mcpt_renderer_last_kernel reports the choice and,
+ *          when it was measured, the four timings.
  *   mode 1: the STREAM kernel (csrc/stream_core.h) — a workgroup owns `slots` path slots (0 = built-in
  *          choice, otherwise a multiple of 256) whose rays go through a workgroup-local pool: emitted rays are
  *          compacted by wavefront ballot / prefix count, a lane that finishes a ray fetches the next one
@@ -191,8 +195,21 @@ int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint
  *          other three; its shadow rays fill only its own free lanes.  Faster than mode 1 on matpreview (+10 %) and the
  *          interior scenes (+9 .. +21 %), slower on dragon/scene.xml (-14 %): the fourth candidate of mode -1's
  *          calibration.  Same frame.
- *   mode 0: the lane-owns-a-path state machine (csrc/path_core.h, round 1's kernel). */
+ *   mode 0: the lane-owns-a-path state machine (csrc/path_core.h, round 1's kernel).
+ *   mode 5: the QUEUED renderer (csrc/queue_core.h, csrc/hip/queued_kernels.*): path slots as 96-byte records in a
+ *          pool in HBM (`slots` = pool size in units of 4096 slots, 0 = one per pixel of the draw), a frame = rounds of
+ *          one lean trace launch — it files every answered extension ray, with its hit, under the MATERIAL GROUP it hit
+ *          (wavefront ballot + prefix count, one atomic per wavefront and group); an unoccluded shadow ray adds the
+ *          direct light it carries to its slot — and one shade launch per BSDF kind present in the scene, each compiled
+ *          with that kind's model only (no register spills) and fed 64 slots of that kind per wavefront.  Same frame.
+ *          Surface paths on triangle meshes with one light sample per vertex (otherwise falls back).  Blocking.
+ *          Measured slower than mode 4 on the BASELINE scenes (every round waits for the slowest ray of the whole GPU,
+ *          and the per-pixel random stream makes a frame a chain of rounds: DESIGN.md section 3e), so the library never
+ *          picks it by itself. */
 int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_t refill_at);
+/* Times the kernel configurations on this renderer's scene and film now (blocking, eight sample launches) and stores
+ * the winner for mode -1 — see mcpt_renderer_set_kernel.  No reference counterpart. */
+int mcpt_renderer_calibrate(mcpt_renderer *r);
 /* What the last draw actually ran, as arguments for mcpt_renderer_set_kernel / _set_work_distribution / _set_prepass
  * (so that a second renderer, a profiler run, ... can repeat the calibrated choice without calibrating). */
 int mcpt_renderer_last_choice(const mcpt_renderer *r, int *kernel, int *work_distribution, int *prepass);

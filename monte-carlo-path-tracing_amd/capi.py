@@ -139,7 +139,7 @@ EXPORTED_SYMBOLS = [
     "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_set_walk", "mcpt_renderer_set_walk_schedule",
     "mcpt_renderer_set_kernel", "mcpt_renderer_last_kernel", "mcpt_renderer_check_walks", "mcpt_renderer_set_rng", "mcpt_renderer_set_prepass", "mcpt_renderer_set_lane_spread", "mcpt_renderer_set_pixel_order", "mcpt_renderer_set_work_distribution", "mcpt_renderer_last_choice",
     "mcpt_renderer_destroy",
-    "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_trace_pixel", "mcpt_debug_trace_rate",
+    "mcpt_renderer_calibrate", "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_trace_pixel", "mcpt_debug_trace_rate",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
     "mcpt_config_serialize", "mcpt_tiled_renderer_create", "mcpt_tiled_renderer_draw",
     "mcpt_tiled_renderer_set_kernel", "mcpt_tiled_renderer_destroy", "mcpt_render_tiled", "mcpt_device_count",
@@ -347,6 +347,11 @@ class Renderer:
         """0: the reference's random stream (default; frames comparable per pixel).  1: throughput mode — an
         independent PCG-hashed stream per (pixel, sample), samples of a pixel spread over `sample_split` lanes."""
         _check(lib().mcpt_renderer_set_rng(self._h, mode, seed, sample_split))
+        return self
+
+    def calibrate(self):
+        """mcpt_renderer_calibrate: time the kernel configurations on this scene now and store the winner for mode -1."""
+        _check(lib().mcpt_renderer_calibrate(self._h))
         return self
 
     def last_choice(self):

@@ -9,7 +9,9 @@
 #include <dlfcn.h>
 #include <mutex>
 #include <thread>
+#include <fstream>
 #include <functional>
+#include <map>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +20,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include <sys/stat.h>
 
 #include <hip/hip_runtime_api.h>
 
@@ -122,6 +126,7 @@ struct mcpt_renderer
     // calibrated, 0 = lane-owns-a-path, 1 = stream), and what it measured
     int auto_choice = -1;
     float auto_ms[4] = {0, 0, 0, 0}; // lanes + fixed lists, lanes + work counter, stream + work counter (workgroup rounds, wavefront rounds)
+    int auto_source = 0;             // 0 the built-in rule, 1 calibrated by this renderer, 2 taken from the calibration store
     int last_kernel = 0, last_work = 0, last_prepass = 0; // what the last draw actually ran (mcpt_renderer_last_choice)
     uint32_t stream_slots = 0, stream_refill = 0;
     // slot storage of the stream kernel's workgroups; one draw at a time per renderer (the reference's
@@ -337,20 +342,133 @@ constexpr AutoCandidate kAutoCandidates[kAutoCount] = {{0, 0}, {0, 1}, {1, 1}, {
 
 void Calibrate(mcpt_renderer *r, hipStream_t stream, bool stream_allowed);
 
-// Runs the first-draw calibration now if a draw of `range` would (the library's choices, a scene outside LDS).
-// Returns whether the renderer holds a calibrated choice afterwards.
-bool EnsureCalibrated(mcpt_renderer *r, const mcpt_tile_range &range, hipStream_t stream)
+// ---- calibrated choices, kept across renderers and processes -------------------------------------------------
+// A calibration costs eight blocking sample launches (about half a frame of dragon/scene.xml), so it is NOT part of a
+// draw by default: the library's choice for a scene outside LDS is the built-in rule (stream kernel in wavefront rounds
+// with the work counter: the winner on every mesh scene measured, within 2 % of the best on the rest).  A calibration
+// runs when the caller asks for it — mcpt_renderer_calibrate, or MCPT_CALIBRATE=1 in the environment for the first
+// draw — and its result is STORED under a key of the scene, the film and the device: in this process, and in the text
+// file MCPT_CALIBRATION_FILE (default $HOME/.cache/mcpt/calibration.txt) so that the next process — an `mcpt_cli` run
+// of the same scene — starts with the measured choice and pays nothing.
+struct StoredChoice
 {
-    if (r->auto_choice >= 0)
+    int choice;
+    float ms[4];
+};
+struct CalibrationStore
+{
+    std::mutex mu;
+    std::map<uint64_t, StoredChoice> entries;
+    bool loaded = false;
+    std::string path;
+
+    static CalibrationStore &Get()
+    {
+        static CalibrationStore store;
+        return store;
+    }
+    void LoadLocked()
+    {
+        if (loaded)
+            return;
+        loaded = true;
+        if (const char *p = std::getenv("MCPT_CALIBRATION_FILE"))
+            path = p;
+        else if (const char *home = std::getenv("HOME"))
+            path = std::string(home) + "/.cache/mcpt/calibration.txt";
+        if (path.empty() || path == "off")
+        {
+            path.clear();
+            return;
+        }
+        std::ifstream in(path);
+        uint64_t key;
+        StoredChoice c{};
+        while (in >> key >> c.choice >> c.ms[0] >> c.ms[1] >> c.ms[2] >> c.ms[3])
+            if (c.choice >= 0 && c.choice < 4)
+                entries[key] = c;
+    }
+    bool Find(uint64_t key, StoredChoice *out)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        LoadLocked();
+        const auto it = entries.find(key);
+        if (it == entries.end())
+            return false;
+        *out = it->second;
         return true;
-    if (r->kernel_mode != -1 || mcpt::StreamPrefersLanes(r->dev) || RangeSize(r->Tiles(), range) == 0)
-        return false;
-    mcpt::RenderJob job{};
-    job.n_items = RangeSize(r->Tiles(), range) * 64u;
-    job.reference_walk = r->reference_walk ? 1u : 0u;
-    r->auto_choice = r->work_mode == 0 ? 0 : 1;
-    Calibrate(r, stream, mcpt::StreamSupports(r->dev, job));
-    return true;
+    }
+    void Put(uint64_t key, const StoredChoice &c)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        LoadLocked();
+        entries[key] = c;
+        if (path.empty())
+            return;
+        // (best effort: a read-only home directory must not fail a render)
+        const size_t slash = path.find_last_of('/');
+        if (slash != std::string::npos)
+        {
+            std::string dir;
+            for (size_t k = 1; k <= slash; ++k)
+                if (path[k] == '/')
+                    dir = path.substr(0, k), (void)::mkdir(dir.c_str(), 0755);
+        }
+        std::ofstream out(path, std::ios::app);
+        if (out)
+            out << key << ' ' << c.choice << ' ' << c.ms[0] << ' ' << c.ms[1] << ' ' << c.ms[2] << ' ' << c.ms[3] << '\n';
+    }
+};
+
+// Scene + film + device: what a calibrated choice depends on.
+uint64_t CalibrationKey(const mcpt_renderer *r)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t n)
+    {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        for (size_t k = 0; k < n; ++k)
+            h = (h ^ b[k]) * 1099511628211ull;
+    };
+    const mcpt::FlatScene &f = r->flat;
+    const uint32_t head[] = {f.integrator.n_prims, f.integrator.n_walk_nodes, f.integrator.n_instances, f.features,
+                             static_cast<uint32_t>(f.camera.width), static_cast<uint32_t>(f.camera.height), f.integrator.depth_max,
+                             f.integrator.n_emitters, f.integrator.n_area_lights, static_cast<uint32_t>(f.bsdfs.size()), r->n_cus,
+                             static_cast<uint32_t>(r->work_mode), r->reference_walk ? 1u : 0u};
+    mix(head, sizeof head);
+    mix(&f.camera.eye, 12 * sizeof(float));
+    // a sample of the geometry: three 4 KiB windows of the walk's primitive records
+    const size_t bytes = f.walk_prims.size() * sizeof(float4), window = std::min<size_t>(bytes, 4096);
+    const unsigned char *base = reinterpret_cast<const unsigned char *>(f.walk_prims.data());
+    for (size_t at : {size_t(0), (bytes - window) / 2, bytes - window})
+        mix(base + at, window);
+    return h;
+}
+
+// The library's choice (kernel_mode -1) for a scene outside LDS, decided once per renderer: stored choice, or a
+// calibration when one was asked for, or the built-in rule.
+void ResolveAutoChoice(mcpt_renderer *r, hipStream_t stream, bool stream_allowed, bool may_calibrate)
+{
+    const uint64_t key = CalibrationKey(r);
+    StoredChoice stored{};
+    if (CalibrationStore::Get().Find(key, &stored) && (stream_allowed || kAutoCandidates[stored.choice].kernel == 0))
+    {
+        r->auto_choice = stored.choice, r->auto_source = 2;
+        std::memcpy(r->auto_ms, stored.ms, sizeof r->auto_ms);
+        return;
+    }
+    const char *env = std::getenv("MCPT_CALIBRATE");
+    if (may_calibrate && env && std::atoi(env) != 0)
+    {
+        Calibrate(r, stream, stream_allowed);
+        r->auto_source = 1;
+        StoredChoice c{r->auto_choice, {r->auto_ms[0], r->auto_ms[1], r->auto_ms[2], r->auto_ms[3]}};
+        CalibrationStore::Get().Put(key, c);
+        return;
+    }
+    // built-in rule: the stream kernel in wavefront rounds with the work counter; a fixed work distribution keeps it
+    r->auto_source = 0;
+    r->auto_choice = stream_allowed && r->work_mode != 0 ? kAutoCount - 1 : (r->work_mode == 0 ? 0 : 1);
 }
 
 void Calibrate(mcpt_renderer *r, hipStream_t stream, bool stream_allowed)
@@ -536,7 +654,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     {
         r->auto_choice = r->work_mode == 0 ? 0 : 1; // lanes kernel, fixed lists / work counter
         if (!small_scene && r->kernel_mode == -1 && job.n_items != 0)
-            Calibrate(r, stream, mcpt::StreamSupports(r->dev, job));
+            ResolveAutoChoice(r, stream, mcpt::StreamSupports(r->dev, job), true);
     }
     float *render_target = out_device;
     const uint32_t out_pixels = packed ? job.n_items : static_cast<uint32_t>(r->flat.camera.width) * r->flat.camera.height;
@@ -721,13 +839,13 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         r->variant += " + camera-ray pre-pass";
     if (dynamic_work)
         r->variant += ", work counter";
-    if (r->kernel_mode == -1 && r->work_mode == -1 && r->auto_ms[0] > 0.0f)
+    if (r->kernel_mode == -1 && r->auto_source != 0)
     {
-        char note[256];
+        char note[320];
         std::snprintf(note, sizeof note,
-                      " [calibrated on this scene: lanes fixed lists %.3f ms, lanes work counter %.3f ms, stream %.3f ms, stream "
+                      " [calibrated on this scene%s: lanes fixed lists %.3f ms, lanes work counter %.3f ms, stream %.3f ms, stream "
                       "wavefront rounds %.3f ms]",
-                      r->auto_ms[0], r->auto_ms[1], r->auto_ms[2], r->auto_ms[3]);
+                      r->auto_source == 2 ? " (stored choice)" : "", r->auto_ms[0], r->auto_ms[1], r->auto_ms[2], r->auto_ms[3]);
         r->variant += note;
     }
     if (r->rng_mode == 1)
@@ -1275,7 +1393,7 @@ int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_
     if (slots % 256u != 0 || slots > 4096u || refill_at > 64u)
         return Fail("mcpt_renderer_set_kernel: slots is a multiple of 256 up to 4096, refill_at at most 64");
     r->kernel_mode = mode, r->stream_slots = slots, r->stream_refill = refill_at;
-    r->auto_choice = -1; // (mode -1 calibrates again at the next draw)
+    r->auto_choice = -1, r->auto_source = 0; // (mode -1 decides again at the next draw)
     return 0;
 }
 
@@ -1335,6 +1453,35 @@ int mcpt_renderer_set_rng(mcpt_renderer *r, int mode, uint32_t seed, uint32_t sa
         ; // (fine: the reference-order walk draws from whatever stream the path carries)
     r->rng_mode = mode, r->rng_seed = seed, r->sample_split = sample_split;
     return 0;
+}
+
+int mcpt_renderer_calibrate(mcpt_renderer *r)
+{
+    if (!r)
+        return Fail("null argument");
+    try
+    {
+        Check(hipSetDevice(r->device), "select device");
+        EnsureWalkSpill(r);
+        if (mcpt::StreamPrefersLanes(r->dev) || r->Tiles() == 0)
+            return 0; // (scenes in LDS have one configuration)
+        mcpt::RenderJob job{};
+        job.n_items = r->Tiles() * 64u;
+        job.reference_walk = r->reference_walk ? 1u : 0u;
+        const int saved_mode = r->kernel_mode;
+        r->kernel_mode = -1;
+        r->auto_choice = r->work_mode == 0 ? 0 : 1;
+        Calibrate(r, nullptr, mcpt::StreamSupports(r->dev, job));
+        r->kernel_mode = saved_mode;
+        r->auto_source = 1;
+        const StoredChoice c{r->auto_choice, {r->auto_ms[0], r->auto_ms[1], r->auto_ms[2], r->auto_ms[3]}};
+        CalibrationStore::Get().Put(CalibrationKey(r), c);
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(std::string("error when calibrate.\n\t") + e.what());
+    }
 }
 
 const char *mcpt_renderer_last_kernel(const mcpt_renderer *r) { return r ? r->variant.c_str() : ""; }
@@ -1587,22 +1734,7 @@ int mcpt_tiled_renderer_draw(mcpt_tiled_renderer *t, float *frame, mcpt_stats *s
         mcpt_renderer *r0 = t->ranks[0].get();
         const uint32_t tiles = r0->Tiles(), width = r0->flat.camera.width, height = r0->flat.camera.height;
         const size_t frame_floats = static_cast<size_t>(width) * height * 3;
-        // First draw: ONE rank calibrates its kernel configuration (blocking sample launches) and the others take its
-        // choice — same scene, same interleaved share of the tiles — instead of N calibrations one after the other.
-        for (uint32_t k = 1; k < n; ++k)
-        {
-            mcpt_renderer *r = t->ranks[k].get();
-            if (r0->auto_choice < 0 && k == 1)
-            {
-                Check(hipSetDevice(r0->device), "select device");
-                (void)EnsureCalibrated(r0, mcpt_tile_range{0, n, 0}, t->streams[0]);
-            }
-            if (r->auto_choice < 0 && r0->auto_choice >= 0 && r->kernel_mode == r0->kernel_mode && r->work_mode == r0->work_mode)
-            {
-                r->auto_choice = r0->auto_choice;
-                std::memcpy(r->auto_ms, r0->auto_ms, sizeof r->auto_ms);
-            }
-        }
+        // (a calibrated choice is shared by the ranks through the calibration store: same scene, same film, same device class)
         // every GPU starts on its tiles (asynchronous launches from this thread)
         for (uint32_t k = 0; k < n; ++k)
         {

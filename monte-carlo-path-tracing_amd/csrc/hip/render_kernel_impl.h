@@ -180,7 +180,20 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
 
 constexpr uint32_t kAll = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
 constexpr uint32_t kSurface = kFeatEmitters | kFeatTextures | kFeatMicrofacet;
-constexpr uint32_t kO = kFeatOrderedWalk, kV = kFeatOrderedWalk | kFeatVoteWalk, kS = kFeatSlivers;
+// kV: the walk of scenes outside LDS — vote-scheduled, on the binary hierarchy.  -DMCPT_WIDE_WALK=1 builds these
+// instantiations on the 4-wide quantised hierarchy with the short stack instead (short_stack.h): exact (same goldens),
+// measured, not faster inside the render kernels — dragon 98.1 -> 100.8 ms, matpreview 332 -> 335 and 515 -> 522 ms at
+// a quarter of the spp (profiles/r03_experiments/wide_walk.md): half the node steps at twice the VALU work per step, and
+// the walk is bound by VALU issue on diverged wavefronts, not by records fetched.
+#ifndef MCPT_WIDE_WALK
+#define MCPT_WIDE_WALK 0
+#endif
+constexpr uint32_t kO = kFeatOrderedWalk, kV = kFeatOrderedWalk | kFeatVoteWalk | (MCPT_WIDE_WALK ? kFeatWideWalk : 0u), kS = kFeatSlivers;
+// stack entries per lane in LDS: the ring of the short stack, or one entry per level of the binary hierarchy
+inline size_t WalkStackEntries(const DeviceScene &sc, uint32_t features)
+{
+    return (features & kFeatWideWalk) ? size_t(kWideRing) : size_t(sc.integrator.walk_depth);
+}
 
 inline size_t StagedBytes(const DeviceScene &sc, bool ordered)
 {
@@ -198,7 +211,7 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
 {
     constexpr bool kOrdered = (kFeatures & kFeatOrderedWalk) != 0;
     const size_t lds_bytes = (kLdsGeometry ? StagedBytes(sc, kOrdered) : 0) +
-                             (kOrdered ? size_t(sc.integrator.walk_depth) * kBlockSize * sizeof(uint32_t) : 0);
+                             (kOrdered ? WalkStackEntries(sc, kFeatures) * kBlockSize * sizeof(uint32_t) : 0);
     int per_cu = 0;
     hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &per_cu, render_kernel<kFeatures, kCount, kLdsGeometry>, kBlockSize, lds_bytes);

@@ -237,7 +237,7 @@ MCPT_HD bool walk_wide_vote(const DeviceScene &sc, uint32_t *ring, Ray &ray, Hit
                 continue;
             if (kCount)
             {
-                stats.node_tests += 4;
+                stats.node_tests += 2; // (one 64-byte record = two 32-byte units of SURVEY.md section 8(d), like a binary node with its two boxes)
                 if (is_leading_lane())
                     ++stats.wave_node_steps;
             }

@@ -9,6 +9,13 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# calibrated kernel choices are stored per (scene, film, device) in a file (mcpt.h, mcpt_renderer_calibrate): the suite
+# keeps its own, fresh one, so that a run never starts from what an earlier run measured
+import tempfile
+os.environ["MCPT_CALIBRATION_FILE"] = os.path.join(tempfile.mkdtemp(prefix="mcpt_tests_"), "calibration.txt")
+os.environ.pop("MCPT_CALIBRATE", None)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 

@@ -680,15 +680,32 @@ def test_lane_spread_does_not_change_the_image(name, pkg, scenes):
 
 
 @pytest.mark.gpu
-def test_calibration_reports_its_measurements(pkg):
-    """A scene outside LDS: the first draw times four configurations on a sample of the frame and says so."""
+def test_calibration_is_on_request_and_its_choice_is_stored(pkg):
+    """A scene outside LDS.  A draw does not measure anything by itself: the built-in rule (stream kernel, wavefront
+    rounds, work counter).  mcpt_renderer_calibrate times four configurations on a sample of the frame, says so, and
+    stores the winner — in the process (a second renderer of the same scene starts with it) and in the calibration
+    file.  Same frame all along."""
     scene = pkg.scenes.terrain_scene(64, 160, 120, 8)
-    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
+    cfg = pkg.capi.Config.from_scene(scene)
+    r = pkg.capi.Renderer(cfg, device=0)
     try:
         assert r.info()["primitives"] >= 2048
         a, _ = r.draw()
-        assert "calibrated on this scene" in r.last_kernel() and "stream wavefront rounds" in r.last_kernel()
+        assert "calibrated" not in r.last_kernel() and "wavefront rounds" in r.last_kernel(), r.last_kernel()
+        r.calibrate()
+        c, _ = r.draw()
+        assert "calibrated on this scene:" in r.last_kernel() and "stream wavefront rounds" in r.last_kernel()
         b, _ = r.set_kernel(0).set_work_distribution(0).set_prepass(0).draw()
-        assert np.array_equal(a, b)
+        assert np.array_equal(a, b) and np.array_equal(a, c)
     finally:
         r.close()
+    r2 = pkg.capi.Renderer(cfg, device=0)
+    try:
+        d, _ = r2.draw()
+        assert "calibrated on this scene (stored choice)" in r2.last_kernel(), r2.last_kernel()
+        assert np.array_equal(a, d)
+    finally:
+        r2.close()
+    # ... and in the calibration file (tests/conftest.py points MCPT_CALIBRATION_FILE at a fresh one): key, choice, four timings
+    lines = [l.split() for l in open(os.environ["MCPT_CALIBRATION_FILE"])]
+    assert lines and all(len(l) == 6 and 0 <= int(l[1]) < 4 for l in lines)

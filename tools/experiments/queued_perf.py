@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--workloads", default="dragon,matpreview-rc,matpreview-rd")
     ap.add_argument("--pools", default="0,64,128")
     ap.add_argument("--draws", type=int, default=2)
+    ap.add_argument("--modes", default="", help="also these set_kernel modes (0 lanes, 1 stream, 4 stream in wavefront rounds)")
     a = ap.parse_args()
     from _pkg import load_package
     pkg = load_package()
@@ -31,7 +32,8 @@ def main():
         cfg = pkg.workloads.config(name, w, h, spp)
         r = pkg.capi.Renderer(cfg, device=0)
         ref_hash = None
-        configs = [("auto", -1, 0)] + [(f"queued pool {p}", 5, int(p)) for p in a.pools.split(",")]
+        configs = [("auto", -1, 0)] + [(f"queued pool {p}", 5, int(p)) for p in a.pools.split(",") if p != ""]
+        configs += [({0: "lanes", 1: "stream", 4: "stream, wavefront rounds"}[int(m)], int(m), 0) for m in a.modes.split(",") if m != ""]
         for label, mode, pool in configs:
             r.set_kernel(mode, slots=pool)
             t0 = time.perf_counter()
