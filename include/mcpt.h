@@ -225,6 +225,13 @@ int mcpt_renderer_last_choice(const mcpt_renderer *r, int *kernel, int *work_dis
  * out 64-pixel patches dynamically, renderer.cpp:688-699; its CUDA back end launches one thread per pixel). */
 int mcpt_renderer_set_work_distribution(mcpt_renderer *r, int mode);
 
+/* Order in which the work counter hands out the tiles of a draw; the image does not depend on it.  A pixel is a
+ * sequential chain of rounds (one random stream through all its samples, renderer.cpp:62-81), so a frame ends with the
+ * chains that started last.  1: tiles sorted by an estimate of their cost — what the pre-pass's camera rays hit, weighted
+ * by BSDF kind (csrc/hip/tile_order.hip) — most expensive first, image order within a cost class.  0: image order.
+ * -1 (default): 1 whenever a draw runs the pre-pass and the work counter.  No reference counterpart. */
+int mcpt_renderer_set_tile_order(mcpt_renderer *r, int mode);
+
 /* Primary-visibility pre-pass (csrc/hip/primary_kernel.hip): the camera ray of sample s of pixel p is a function of
  * (p, s) alone — stratified in x, van der Corput in y, no random number (reference src/renderer/renderer.cpp:68-76) —
  * so the closest hits of ALL camera rays of a draw are computed first by a lean kernel (one lane per (pixel, sample),

@@ -543,6 +543,12 @@ MCPT_HD void plastic_eval(const ShadeTables &T, const BsdfRec &b, BsdfQuery &q) 
 // kind (the queued renderer's per-material shade launches, hip/queued_kernels.hip: only that model is compiled in);
 // kBsdfNoCode = the caller never reaches a BSDF (its launch shades misses, emitters and pass-through surfaces).
 constexpr uint32_t kBsdfNoCode = 0xFFu;
+// Developer switch for register-pressure experiments: -DMCPT_BSDF_KINDS=<bit per BsdfKind> compiles the dispatch for
+// those kinds only (the default compiles all of them).
+#ifndef MCPT_BSDF_KINDS
+#define MCPT_BSDF_KINDS 0xFFFFFFFFu
+#endif
+MCPT_HD constexpr bool bsdf_kind_compiled(uint32_t kind) { return ((MCPT_BSDF_KINDS >> kind) & 1u) != 0; }
 
 template <bool kMicrofacet, uint32_t kOnly = 0>
 MCPT_HD void bsdf_sample(const ShadeTables &T, const BsdfRec &b, uint32_t &rng, BsdfQuery &q)
@@ -558,11 +564,11 @@ MCPT_HD void bsdf_sample(const ShadeTables &T, const BsdfRec &b, uint32_t &rng, 
     }
     switch (kind)
     {
-    case kBsdfRoughDiffuse: rough_diffuse_sample(T, b, rng, q); break;
-    case kBsdfConductor: conductor_sample(T, b, rng, q); break;
-    case kBsdfDielectric: dielectric_sample(T, b, rng, q); break;
-    case kBsdfThinDielectric: thin_dielectric_sample(T, b, rng, q); break;
-    case kBsdfPlastic: plastic_sample(T, b, rng, q); break;
+    case kBsdfRoughDiffuse: if (bsdf_kind_compiled(kBsdfRoughDiffuse)) rough_diffuse_sample(T, b, rng, q); break;
+    case kBsdfConductor: if (bsdf_kind_compiled(kBsdfConductor)) conductor_sample(T, b, rng, q); break;
+    case kBsdfDielectric: if (bsdf_kind_compiled(kBsdfDielectric)) dielectric_sample(T, b, rng, q); break;
+    case kBsdfThinDielectric: if (bsdf_kind_compiled(kBsdfThinDielectric)) thin_dielectric_sample(T, b, rng, q); break;
+    case kBsdfPlastic: if (bsdf_kind_compiled(kBsdfPlastic)) plastic_sample(T, b, rng, q); break;
     default: break;
     }
 }
@@ -581,11 +587,11 @@ MCPT_HD void bsdf_eval(const ShadeTables &T, const BsdfRec &b, BsdfQuery &q)
     }
     switch (kind)
     {
-    case kBsdfRoughDiffuse: rough_diffuse_eval(T, b, q); break;
-    case kBsdfConductor: conductor_eval(T, b, q); break;
-    case kBsdfDielectric: dielectric_eval(T, b, q); break;
-    case kBsdfThinDielectric: thin_dielectric_eval(T, b, q); break;
-    case kBsdfPlastic: plastic_eval(T, b, q); break;
+    case kBsdfRoughDiffuse: if (bsdf_kind_compiled(kBsdfRoughDiffuse)) rough_diffuse_eval(T, b, q); break;
+    case kBsdfConductor: if (bsdf_kind_compiled(kBsdfConductor)) conductor_eval(T, b, q); break;
+    case kBsdfDielectric: if (bsdf_kind_compiled(kBsdfDielectric)) dielectric_eval(T, b, q); break;
+    case kBsdfThinDielectric: if (bsdf_kind_compiled(kBsdfThinDielectric)) thin_dielectric_eval(T, b, q); break;
+    case kBsdfPlastic: if (bsdf_kind_compiled(kBsdfPlastic)) plastic_eval(T, b, q); break;
     default: break;
     }
 }

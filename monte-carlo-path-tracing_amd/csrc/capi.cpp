@@ -155,6 +155,13 @@ struct mcpt_renderer
     size_t queued_words = 0;
     uint32_t queued_slots = 0; // mcpt_renderer_set_kernel's `slots` in mode 5 is the pool size in units of 4096 slots (0 = one slot per pixel)
     uint32_t *queued_host = nullptr; // pinned: the counter block read back after every batch of rounds
+    // cost-ordered tile hand-out (mcpt_renderer_set_tile_order; hip/tile_order.hip): keys, sorted keys, sort scratch
+    int tile_order_mode = -1; // -1 the library's choice (on with the pre-pass and the work counter), 0 image order, 1 cost order
+    unsigned long long *tile_keys_dev = nullptr;
+    void *tile_temp_dev = nullptr;
+    uint32_t tile_keys_capacity = 0;
+    size_t tile_temp_bytes = 0;
+    int last_tile_order = 0;
     uint32_t *work_counter_dev = nullptr; // RenderJob::work_counter (dynamic work distribution), zeroed before every launch
     int work_mode = -1;                   // mcpt_renderer_set_work_distribution: -1 library's choice, 0 fixed lists, 1 work counter
 
@@ -176,6 +183,10 @@ struct mcpt_renderer
             (void)hipFree(queued_dev);
         if (walk_spill_dev)
             (void)hipFree(walk_spill_dev);
+        if (tile_keys_dev)
+            (void)hipFree(tile_keys_dev);
+        if (tile_temp_dev)
+            (void)hipFree(tile_temp_dev);
         if (queued_host)
             (void)hipHostFree(queued_host);
         if (frame_dev)
@@ -797,6 +808,27 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             Check(mcpt::LaunchPrimaryPrepass(r->dev, job, r->prehit_dev, counters, stream, r->n_cus), "launch pre-pass kernel");
             r->dev.prehit = r->prehit_dev;
             r->dev.prehit_step = job.sample_split ? job.sample_split : 1u;
+            // tiles most expensive first (by what their camera rays hit), for the work counter to hand out
+            if (dynamic_work && r->tile_order_mode != 0 && job.sample_split <= 1 && n_tiles > 1)
+            {
+                if (n_tiles > r->tile_keys_capacity)
+                {
+                    if (r->tile_keys_dev)
+                    {
+                        Check(hipDeviceSynchronize(), "wait before growing the tile table");
+                        (void)hipFree(r->tile_keys_dev), (void)hipFree(r->tile_temp_dev);
+                        r->tile_keys_dev = nullptr, r->tile_temp_dev = nullptr, r->tile_keys_capacity = 0;
+                    }
+                    r->tile_temp_bytes = mcpt::TileOrderTempBytes(n_tiles);
+                    Check(hipMalloc(reinterpret_cast<void **>(&r->tile_keys_dev), size_t(2) * n_tiles * sizeof(unsigned long long)), "allocate tile table");
+                    Check(hipMalloc(&r->tile_temp_dev, r->tile_temp_bytes), "allocate tile sort scratch");
+                    r->tile_keys_capacity = n_tiles;
+                }
+                Check(mcpt::LaunchTileOrder(r->dev, job, r->prehit_dev, r->tile_keys_dev, r->tile_keys_dev + r->tile_keys_capacity, r->tile_temp_dev,
+                                            r->tile_temp_bytes, stream),
+                      "order the tiles");
+                job.tile_order = r->tile_keys_dev + r->tile_keys_capacity;
+            }
         }
     }
     const bool wavefront = r->kernel_mode == 3 && !counted && r->rng_mode == 0 && mcpt::WavefrontSupports(r->dev, job);
@@ -838,7 +870,8 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     if (r->dev.prehit)
         r->variant += " + camera-ray pre-pass";
     if (dynamic_work)
-        r->variant += ", work counter";
+        r->variant += job.tile_order ? ", work counter (tiles most expensive first)" : ", work counter";
+    r->last_tile_order = job.tile_order ? 1 : 0;
     if (r->kernel_mode == -1 && r->auto_source != 0)
     {
         char note[320];
@@ -1416,6 +1449,16 @@ int mcpt_renderer_set_prepass(mcpt_renderer *r, int mode)
         return Fail("mcpt_renderer_set_prepass: mode is -1 (the library's choice), 0 (off) or 1 (on where the scene allows it)");
     r->prepass_mode = mode;
     r->auto_choice = -1;
+    return 0;
+}
+
+int mcpt_renderer_set_tile_order(mcpt_renderer *r, int mode)
+{
+    if (!r)
+        return Fail("null argument");
+    if (mode < -1 || mode > 1)
+        return Fail("mcpt_renderer_set_tile_order: mode is -1 (the library's choice), 0 (image order) or 1 (most expensive tiles first)");
+    r->tile_order_mode = mode;
     return 0;
 }
 

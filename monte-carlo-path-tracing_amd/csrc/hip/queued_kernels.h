@@ -101,7 +101,7 @@ queued_shade(const DeviceScene sc, const RenderJob job, float *__restrict__ out,
                 s.flags = kSlotExhausted;
                 return;
             }
-            const uint32_t local_tile = item >> 6, r = item & 63u;
+            const uint32_t local_tile = job.tile_order ? static_cast<uint32_t>(job.tile_order[item >> 6]) : item >> 6, r = item & 63u;
             const uint32_t tile = job.tile_first + local_tile * job.tile_stride;
             const uint32_t x = (tile % job.tiles_x) * 8u + (r & 7u), y = (tile / job.tiles_x) * 8u + (r >> 3);
             if (x < width && y < height)

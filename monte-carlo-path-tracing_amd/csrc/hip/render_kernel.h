@@ -63,6 +63,12 @@ struct RenderJob
     // expensive part of the job is.  The stream kernel sizes lane_spread from it (lane_spread 0 only).
     uint32_t *hit_counters;
     uint32_t *work_counter;
+    // Hand-out order of the tiles (null: image order).  The work counter hands out items 0, 1, 2, ...; with a table,
+    // hand-out position p stands for local tile (uint32_t)tile_order[p >> 6] — the tiles sorted MOST EXPENSIVE FIRST
+    // (hip/tile_order.hip: a cost from the pre-pass's camera-ray hits).  The reference's one random stream per pixel makes
+    // a pixel a sequential chain, so a frame ends with the chains that started last: those should be the short ones.
+    // Only with the work counter; packed output keeps the image-order layout.
+    const unsigned long long *tile_order;
 };
 
 // ---- stream kernel (stream_core.h, stream_kernel_impl.h) ------------------------------------------
@@ -103,6 +109,13 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
 bool PrimaryPrepassSupports(const DeviceScene &sc, const RenderJob &job);
 hipError_t LaunchPrimaryPrepass(const DeviceScene &sc, const RenderJob &job, uint32_t *prehit, TraceCounters *counters,
                                 hipStream_t stream, uint32_t n_cus);
+
+// Tile hand-out order from the pre-pass (hip/tile_order.hip).  keys / sorted: n_tiles 64-bit words each; `temp`: scratch of
+// TileOrderTempBytes(n_tiles) bytes.  After the call (asynchronous on `stream`) the low words of `sorted` are the job's
+// local tiles, most expensive first (equal cost: image order).
+size_t TileOrderTempBytes(uint32_t n_tiles);
+hipError_t LaunchTileOrder(const DeviceScene &sc, const RenderJob &job, const uint32_t *prehit, unsigned long long *keys,
+                           unsigned long long *sorted, void *temp, size_t temp_bytes, hipStream_t stream);
 
 // frame[p] = (planes[0][p] + ... + planes[K-1][p]) / spp for p < n_pixels (3 floats each), planes K x plane_stride pixels.
 hipError_t LaunchReduceSamplePlanes(const float *planes, float *frame, uint32_t n_pixels, uint32_t split, uint32_t plane_stride,

@@ -130,8 +130,9 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
                 break;
             // (n_work is a multiple of 64: whole tiles)
             const uint32_t qs = job.scatter ? (q & 63u) * (n_work >> 6) + (q >> 6) : q;
-            const uint32_t k = split == 1 ? 0u : qs / job.n_items, item = qs - k * job.n_items;
-            // item -> tile -> pixel
+            const uint32_t k = split == 1 ? 0u : qs / job.n_items, position = qs - k * job.n_items;
+            // hand-out position -> item (RenderJob::tile_order: most expensive tiles first) -> tile -> pixel
+            const uint32_t item = job.tile_order ? (static_cast<uint32_t>(job.tile_order[position >> 6]) << 6) | (position & 63u) : position;
             const uint32_t local_tile = item >> 6, r = item & 63u;
             const uint32_t tile = job.tile_first + local_tile * job.tile_stride;
             const uint32_t x = (tile % job.tiles_x) * 8u + (r & 7u), y = (tile / job.tiles_x) * 8u + (r >> 3);
@@ -180,6 +181,7 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
 
 constexpr uint32_t kAll = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
 constexpr uint32_t kSurface = kFeatEmitters | kFeatTextures | kFeatMicrofacet;
+constexpr uint32_t kVolumeLean = kFeatVolPath | kFeatAnalytic | kFeatMicrofacet; // volume paths, quadrics, every BSDF; no emitters, constant textures
 // kV: the walk of scenes outside LDS — vote-scheduled, on the binary hierarchy.  -DMCPT_WIDE_WALK=1 builds these
 // instantiations on the 4-wide quantised hierarchy with the short stack instead (short_stack.h): exact (same goldens),
 // measured, not faster inside the render kernels — dragon 98.1 -> 100.8 ms, matpreview 332 -> 335 and 515 -> 522 ms at
@@ -259,6 +261,7 @@ extern template hipError_t Launch<kAll | kV | kS, true, false>(MCPT_LAUNCH_ARGS)
 #endif
 #if !defined(MCPT_UNIT_LDS)
 extern template hipError_t Launch<kAll | kO, false, true>(MCPT_LAUNCH_ARGS);
+extern template hipError_t Launch<kVolumeLean | kO, false, true>(MCPT_LAUNCH_ARGS);
 #endif
 #if !defined(MCPT_UNIT_SURFACE)
 extern template hipError_t Launch<kSurface | kV, false, false>(MCPT_LAUNCH_ARGS);

@@ -165,11 +165,13 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
                 s.flags |= kSlotExhausted;
                 return;
             }
-            const uint32_t k = split == 1 ? 0u : q / job.n_items;
+            const uint32_t k = split == 1 ? 0u : q / job.n_items, position = q - k * job.n_items;
+            // (RenderJob::tile_order, work counter only: hand-out position -> item, most expensive tiles first)
+            const uint32_t item = job.tile_order ? (static_cast<uint32_t>(job.tile_order[position >> 6]) << 6) | (position & 63u) : position;
             uint32_t pixel;
-            if (pixel_of(q - k * job.n_items, pixel))
+            if (pixel_of(item, pixel))
             {
-                s.item = q;
+                s.item = item + k * job.n_items;
                 start_pixel(s.st, pixel);
                 s.st.sample = k;
                 return;

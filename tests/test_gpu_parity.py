@@ -578,6 +578,37 @@ def test_scheduling_choices_do_not_change_the_image(name, pkg, scenes):
         r.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["rough_dielectric_envmap", "terrain_directional", "bumpy_directional"])
+def test_tile_hand_out_order_does_not_change_the_image(name, pkg, scenes):
+    """mcpt_renderer_set_tile_order: tiles handed out most expensive first (cost from the pre-pass's camera-ray hits,
+    hip/tile_order.hip) or in image order — lanes kernel, stream kernel in both round shapes, queued renderer; whole frames
+    and a packed tile share: always the golden."""
+    import torch
+    golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
+    try:
+        seen = set()
+        for kernel in (0, 1, 4, 5):
+            for order in (1, 0, -1):
+                frame, _ = r.set_kernel(kernel).set_work_distribution(1).set_prepass(1).set_tile_order(order).draw()
+                seen.add(("most expensive first" in r.last_kernel(), order))
+                assert np.array_equal(frame, golden), (kernel, order, r.last_kernel())
+        assert (True, 1) in seen and (False, 0) in seen and (True, -1) in seen, seen
+        h, w = golden.shape[:2]
+        composed = np.zeros_like(golden)
+        r.set_kernel(4).set_tile_order(1)
+        for rank in range(2):
+            rng = pkg.capi.TileRange(rank, 2, 0)
+            buf = torch.zeros(r.tiles_in(rng) * 64 * 3, dtype=torch.float32, device="cuda:0")
+            r.draw_device(buf.data_ptr(), rng, packed=True)
+            assert "most expensive first" in r.last_kernel()
+            pkg.capi.unpack_tiles(buf.cpu().numpy(), rng, w, h, composed)
+        assert np.array_equal(composed, golden)
+    finally:
+        r.close()
+
+
 QUEUED_CASES = ["cornell_64_spp8", "cornell_96_spp32", "rough_conductor_envmap", "rough_dielectric_envmap", "plastic_spot",
                 "bumpy_directional", "depth_limited", "terrain_directional"]
 

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--workloads", default="dragon,matpreview-rc,matpreview-rd")
     ap.add_argument("--pools", default="0,64,128")
     ap.add_argument("--draws", type=int, default=2)
+    ap.add_argument("--tile-orders", default="", help="e.g. 0,1: every configuration with image-order and cost-ordered tile hand-out")
     ap.add_argument("--modes", default="", help="also these set_kernel modes (0 lanes, 1 stream, 4 stream in wavefront rounds)")
     a = ap.parse_args()
     from _pkg import load_package
@@ -34,8 +35,13 @@ def main():
         ref_hash = None
         configs = [("auto", -1, 0)] + [(f"queued pool {p}", 5, int(p)) for p in a.pools.split(",") if p != ""]
         configs += [({0: "lanes", 1: "stream", 4: "stream, wavefront rounds"}[int(m)], int(m), 0) for m in a.modes.split(",") if m != ""]
-        for label, mode, pool in configs:
+        if a.tile_orders:
+            configs = [(f"{label}, tile order {o}", mode, pool, int(o)) for (label, mode, pool) in configs for o in a.tile_orders.split(",")]
+        else:
+            configs = [(label, mode, pool, -1) for (label, mode, pool) in configs]
+        for label, mode, pool, order in configs:
             r.set_kernel(mode, slots=pool)
+            r.set_tile_order(order)
             t0 = time.perf_counter()
             frame, st = r.draw()
             first = time.perf_counter() - t0
