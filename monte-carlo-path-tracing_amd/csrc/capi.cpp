@@ -658,6 +658,14 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     job.sample_split = 1;
     job.lane_spread = r->lane_spread;
     job.scatter = r->pixel_order < 0 ? mcpt::kScatterAuto : static_cast<uint32_t>(r->pixel_order);
+    {
+        static const int compact = []
+        {
+            const char *e = std::getenv("MCPT_COMPACT"); // (measurements: 0 switches the compaction of thinning workgroups off)
+            return e ? std::atoi(e) : 1;
+        }();
+        job.compact = compact != 0 ? 1u : 0u;
+    }
     // The library's choices (kernel_mode -1): the first draw of a renderer calibrates — BEFORE this draw sizes any of its
     // own buffers, because the calibration's nested draws re-size the renderer's scratch allocations.
     const bool small_scene = mcpt::StreamPrefersLanes(r->dev);

@@ -69,6 +69,10 @@ struct RenderJob
     // a pixel a sequential chain, so a frame ends with the chains that started last: those should be the short ones.
     // Only with the work counter; packed output keeps the image-order layout.
     const unsigned long long *tile_order;
+    // Lane-owns-a-path kernel on LDS-resident scenes: 1 = once the items are handed out, the paths still in flight are
+    // moved into the first wavefronts of their workgroup whenever another 64 of its lanes have retired
+    // (render_kernel_impl.h, "COMPACTION").  The image does not depend on it.
+    uint32_t compact;
 };
 
 // ---- stream kernel (stream_core.h, stream_kernel_impl.h) ------------------------------------------
