@@ -741,12 +741,12 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     // CALIBRATES on a sample of the frame and keeps the fastest (measure, don't guess).
     // (decided here because the stream kernel's launch shape depends on it: with a pre-pass the kernel sizes its lane
     //  spread from the pre-pass's hit count)
-    const size_t prehit_need = size_t(r->flat.camera.width) * r->flat.camera.height * r->dev.camera.spp * 2;
+    const size_t prehit_need = size_t(job.n_items) * r->dev.camera.spp * 2; // 8 B per sample of THIS draw's tiles
     bool prepass = (r->prepass_mode == 1 || (r->prepass_mode == -1 && !small_scene) || (r->kernel_mode == 5 && r->prepass_mode != 0)) && job.n_items != 0 &&
                    mcpt::PrimaryPrepassSupports(r->dev, job) && prehit_need * sizeof(uint32_t) <= (size_t(32) << 30);
     if (prepass && prehit_need > r->prehit_words)
     {
-        // 8 B per sample of the frame.  A failed allocation is not an error: the draw renders without the pre-pass.
+        // 8 B per sample of the draw.  A failed allocation is not an error: the draw renders without the pre-pass.
         if (r->prehit_dev)
         {
             Check(hipDeviceSynchronize(), "wait before growing the pre-pass buffer");
@@ -816,6 +816,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             Check(mcpt::LaunchPrimaryPrepass(r->dev, job, r->prehit_dev, counters, stream, r->n_cus), "launch pre-pass kernel");
             r->dev.prehit = r->prehit_dev;
             r->dev.prehit_step = job.sample_split ? job.sample_split : 1u;
+            r->dev.prehit_tile_first = job.tile_first, r->dev.prehit_tile_stride = job.tile_stride, r->dev.prehit_tiles_x = job.tiles_x;
             // tiles most expensive first (by what their camera rays hit), for the work counter to hand out
             if (dynamic_work && r->tile_order_mode != 0 && job.sample_split <= 1 && n_tiles > 1)
             {

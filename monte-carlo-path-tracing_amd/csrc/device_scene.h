@@ -284,12 +284,15 @@ struct DeviceScene
     const float *lut_brdf;   // kLutRes * kLutRes
     const float *lut_albedo; // kLutRes
     // Primary-visibility pre-pass (hip/primary_kernel.hip), or null: the closest hit of the CAMERA ray of sample s of
-    // pixel p, two words at 2 (p * spp + s): primitive (kNone: miss) and instance.  The camera ray of a sample is a
+    // pixel p, two words at 2 (item(p) * spp + s): primitive (kNone: miss) and instance.  The camera ray of a sample is a
     // function of (pixel, sample index) only — stratified in x, van der Corput in y, no random number
     // (renderer.cpp:68-76) — so all of a frame's camera rays can be traced ahead of the per-pixel sample chains, by
     // a lean kernel with coherent wavefronts, and the chains start every sample at its first vertex.
     const uint32_t *prehit;
     uint32_t prehit_step; // start_sample's step of the launch that reads prehit (split samples; 1 otherwise)
+    // the tile enumeration of the draw the pre-pass was made for (RenderJob: tile_first, tile_stride, tiles_x): the buffer
+    // holds the draw's OWN items only — record of (pixel, sample) at 2 (item(pixel) * spp + sample), path_core.h::prehit_record
+    uint32_t prehit_tile_first, prehit_tile_stride, prehit_tiles_x;
 };
 
 // Counters of the measurement mode: totals over a launch.

@@ -13,8 +13,10 @@
 // closest rays per sample leaves the sequential chain, and a sample whose camera ray misses costs the chain a few
 // dozen instructions.
 //
-// Output: two words per (pixel, sample) at 2 (pixel * spp + s): primitive (kNone: miss), instance.
-// Memory: 8 B per sample of the frame in HBM (dragon 1280x720 spp 256: 1.9 GB; sized for 288 GB).
+// Output: two words per (pixel, sample) at 2 (item * spp + s), item = the pixel's position in the draw's tile enumeration:
+// primitive (kNone: miss), instance.
+// Memory: 8 B per sample of the DRAW (a rank's tile share of an N-GPU frame: 1 / N of it) in HBM (dragon 1280x720 spp
+// 256, whole frame: 1.9 GB; sized for 288 GB).
 // Replaces nothing in the reference one to one: it is the camera-ray part of ShadePath's first Scene::Intersect
 // (src/renderer/integrators/path.cpp:18-21) hoisted out of the per-pixel loop.
 #include <hip/hip_runtime.h>
@@ -58,7 +60,7 @@ __global__ void __launch_bounds__(kBlockSize) primary_kernel(const DeviceScene s
         HitRaw hit;
         const bool found = kVote ? walk_ordered_vote<false, kAnalytic, kCount, kSlivers>(sc, stack, ray, hit, ts)
                                  : walk_ordered<false, kAnalytic, kCount, kSlivers>(sc, stack, ray, hit, ts);
-        uint32_t *rec = prehit + 2 * (static_cast<size_t>(st.pixel) * spp + s);
+        uint32_t *rec = prehit + 2 * (static_cast<size_t>(item) * spp + s); // (by work item of THIS draw: path_core.h::prehit_record)
         rec[0] = found ? hit.prim : kNone, rec[1] = found ? hit.inst : 0u;
         ++rays;
         hits += found ? 1u : 0u;

@@ -152,7 +152,7 @@ queued_shade(const DeviceScene sc, const RenderJob job, float *__restrict__ out,
             while (!(s.flags & kSlotExhausted) && queue_shade<C, kGroup>(sc, s, budget, rays, nullptr) == kQueuePixelDone)
             {
                 const V3 v = pixel_value(sc, s.st);
-                const size_t at = job.packed ? queue_item_of_pixel(s.st.pixel, width, job.tiles_x, job.tile_first, job.tile_stride) : s.st.pixel;
+                const size_t at = job.packed ? item_of_pixel(s.st.pixel, width, job.tiles_x, job.tile_first, job.tile_stride) : s.st.pixel;
                 float *dst = out + 3 * at;
                 dst[0] = v.x, dst[1] = v.y, dst[2] = v.z;
                 assign(s, n_slots + wave_reserve(job.work_counter, true));

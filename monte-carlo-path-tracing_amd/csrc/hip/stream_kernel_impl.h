@@ -213,7 +213,7 @@ stream_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         // wavefront and kind)
         auto shade_slot = [&](StreamSlot<S> &s, uint32_t i)
         {
-            while (stream_shade<C, S>(sc, s, cnt, job.independent_samples != 0, job.rng_seed, split) == kStreamPixelDone)
+            while (stream_shade<C, S>(sc, s, cnt, job.independent_samples != 0, job.rng_seed, split, job.n_items) == kStreamPixelDone)
             {
                 const uint32_t k = split == 1 ? 0u : s.item / job.n_items;
                 const V3 c = split == 1 ? pixel_value(sc, s.st) : s.st.pixel_sum; // (planes hold unnormalised partial sums)

@@ -58,12 +58,12 @@ __global__ void __launch_bounds__(kBlockSize) tile_cost_kernel(const DeviceScene
     uint32_t cost = 0;
     if (x < width && y < height)
     {
-        const size_t pixel = static_cast<size_t>(y) * width + x;
+        const size_t item = static_cast<size_t>(local_tile) * 64u + r;
         const uint32_t n = spp < kCostSamples ? spp : kCostSamples;
         for (uint32_t s = 0; s < n; ++s)
         {
             // (spread over the pixel's samples: s * spp / n)
-            const uint32_t *rec = prehit + 2 * (pixel * spp + static_cast<size_t>(s) * spp / n);
+            const uint32_t *rec = prehit + 2 * (item * spp + static_cast<size_t>(s) * spp / n);
             cost += rec[0] == kNone ? 1u : kind_weight(sc, rec[1]);
         }
     }

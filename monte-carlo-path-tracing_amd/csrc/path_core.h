@@ -90,6 +90,21 @@ MCPT_HD LightTables light_tables(const DeviceScene &sc)
     return LightTables{sc.textures, sc.texels, sc.env_tables, !C::kTextures};
 }
 
+// Work item (position in a draw's tile enumeration: RenderJob) of a pixel — where a packed tile buffer keeps it.
+MCPT_HD uint32_t item_of_pixel(uint32_t pixel, uint32_t width, uint32_t tiles_x, uint32_t tile_first, uint32_t tile_stride)
+{
+    const uint32_t x = pixel % width, y = pixel / width;
+    const uint32_t tile = (y >> 3) * tiles_x + (x >> 3);
+    return ((tile - tile_first) / tile_stride) * 64u + (y & 7u) * 8u + (x & 7u);
+}
+
+// The pre-pass's record of the camera ray of (pixel, sample): primitive (kNone: miss), instance.
+MCPT_HD const uint32_t *prehit_record(const DeviceScene &sc, uint32_t pixel, uint32_t sample)
+{
+    const uint32_t item = item_of_pixel(pixel, static_cast<uint32_t>(sc.camera.width), sc.prehit_tiles_x, sc.prehit_tile_first, sc.prehit_tile_stride);
+    return sc.prehit + 2 * (static_cast<size_t>(item) * sc.camera.spp + sample);
+}
+
 MCPT_HD void start_pixel(PathState &st, uint32_t pixel)
 {
     st.pixel = pixel;
@@ -367,7 +382,7 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
     const bool known = C::kOrdered && st.primary && sc.prehit != nullptr; // the pre-pass traced this camera ray
     if (known)
     {
-        const uint32_t *rec = sc.prehit + 2 * (static_cast<size_t>(st.pixel) * sc.camera.spp + (st.sample - sc.prehit_step)); // (start_sample advanced it)
+        const uint32_t *rec = prehit_record(sc, st.pixel, st.sample - sc.prehit_step); // (start_sample advanced it)
         const uint32_t prim = rec[0];
         hit_valid = prim != kNone;
         if (hit_valid)

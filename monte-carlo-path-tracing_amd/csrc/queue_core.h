@@ -144,7 +144,7 @@ template <class C>
 MCPT_HD void queue_primary_hit(const DeviceScene &sc, StreamSlot<1> &s)
 {
     PathState &st = s.st;
-    const uint32_t *rec = sc.prehit + 2 * (static_cast<size_t>(st.pixel) * sc.camera.spp + (st.sample - 1u)); // (start_sample advanced it)
+    const uint32_t *rec = prehit_record(sc, st.pixel, st.sample - 1u); // (start_sample advanced it)
     const uint32_t prim = rec[0];
     s.hit_valid = prim != kNone, s.hit_t = kMaxFloat;
     if (s.hit_valid)
@@ -162,7 +162,7 @@ MCPT_HD uint32_t queue_group_after_end(const DeviceScene &sc, const PathState &s
 {
     if (st.sample >= sc.camera.spp)
         return 0u; // the pixel is finished: any launch can store it and take the next one
-    const uint32_t *rec = sc.prehit + 2 * (static_cast<size_t>(st.pixel) * sc.camera.spp + st.sample);
+    const uint32_t *rec = prehit_record(sc, st.pixel, st.sample);
     return rec[0] != kNone ? queue_group_of_instance(sc, rec[1]) : 0u;
 }
 
@@ -259,14 +259,6 @@ MCPT_HD QueueShadeResult queue_shade(const DeviceScene &sc, StreamSlot<1> &s, ui
         out.shadow_id_bits = kQueuePush | (queue_group_after_end<C>(sc, st) << kQueueGroupShift);
     stream_pack(s);
     return kQueueContinue;
-}
-
-// Work item (position in the job's tile enumeration) of a pixel: where a packed tile buffer keeps it.
-MCPT_HD uint32_t queue_item_of_pixel(uint32_t pixel, uint32_t width, uint32_t tiles_x, uint32_t tile_first, uint32_t tile_stride)
-{
-    const uint32_t x = pixel % width, y = pixel / width;
-    const uint32_t tile = (y >> 3) * tiles_x + (x >> 3);
-    return ((tile - tile_first) / tile_stride) * 64u + (y & 7u) * 8u + (x & 7u);
 }
 
 } // namespace mcpt

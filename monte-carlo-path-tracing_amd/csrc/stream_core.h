@@ -417,9 +417,10 @@ enum StreamShadeResult : uint32_t
 // emitter seen directly, ...) the next sample starts in the same call.
 // `independent` / `seed`: the independent-sample RNG mode (mcpt_renderer_set_rng) without split samples — every sample
 // starts its own PCG-hashed stream (path_core.h::start_sample).
+// `plane_items` (split samples, step > 1): the slot's item is k * plane_items + the pixel's work item.
 template <class C, uint32_t S>
 MCPT_HD StreamShadeResult stream_shade(const DeviceScene &sc, StreamSlot<S> &s, LaneCounters *cnt, bool independent = false,
-                                       uint32_t seed = 0, uint32_t step = 1)
+                                       uint32_t seed = 0, uint32_t step = 1, uint32_t plane_items = 0)
 {
     PathState &st = s.st;
     stream_unpack(s);
@@ -454,7 +455,9 @@ MCPT_HD StreamShadeResult stream_shade(const DeviceScene &sc, StreamSlot<S> &s, 
             ++cnt->samples;
         if (sc.prehit == nullptr)
             break;
-        const uint32_t *rec = sc.prehit + 2 * (static_cast<size_t>(st.pixel) * sc.camera.spp + (st.sample - step));
+        // (the slot knows its work item: no pixel -> item arithmetic per sample)
+        const uint32_t item = step == 1 ? s.item : s.item % plane_items;
+        const uint32_t *rec = sc.prehit + 2 * (static_cast<size_t>(item) * sc.camera.spp + (st.sample - step));
         const uint32_t prim = rec[0];
         s.hit_valid = prim != kNone, s.hit_t = kMaxFloat;
         if (s.hit_valid)

@@ -160,7 +160,7 @@ void RenderAllQueued(DeviceScene sc, float *frame, uint32_t n_slots, uint32_t *r
     const uint32_t tiles_x = (w + 7) / 8, tiles_y = (h + 7) / 8, n_items = tiles_x * tiles_y * 64;
     std::vector<uint32_t> stack(kWalkStackMax * kWalkStackStride);
     // pre-pass: the closest hit of every camera ray
-    std::vector<uint32_t> prehit(size_t(2) * w * h * spp);
+    std::vector<uint32_t> prehit(size_t(2) * n_items * spp);
     {
         const unsigned workers = std::max(1u, std::thread::hardware_concurrency());
         std::atomic<uint32_t> next{0};
@@ -181,7 +181,8 @@ void RenderAllQueued(DeviceScene sc, float *frame, uint32_t n_slots, uint32_t *r
                     HitRaw hit;
                     TraceStats ts{0, 0, 0, 0};
                     const bool found = walk_ordered<false, C::kAnalytic, false, C::kSlivers>(sc, st.data(), ray, hit, ts);
-                    prehit[2 * (size_t(p) * spp + k)] = found ? hit.prim : kNone, prehit[2 * (size_t(p) * spp + k) + 1] = found ? hit.inst : 0u;
+                    const size_t at = 2 * (size_t(item_of_pixel(p, w, tiles_x, 0, 1)) * spp + k); // (by work item, like hip/primary_kernel.hip)
+                    prehit[at] = found ? hit.prim : kNone, prehit[at + 1] = found ? hit.inst : 0u;
                 }
             }
         };
@@ -193,6 +194,7 @@ void RenderAllQueued(DeviceScene sc, float *frame, uint32_t n_slots, uint32_t *r
             t.join();
     }
     sc.prehit = prehit.data(), sc.prehit_step = 1;
+    sc.prehit_tile_first = 0, sc.prehit_tile_stride = 1, sc.prehit_tiles_x = tiles_x;
     n_slots = std::max(1u, std::min(n_slots ? n_slots : n_items, n_items));
     std::vector<uint32_t> slots(size_t(n_slots) * kQueueSlotWords, 0u);
     struct Ext { V3 o, d; uint32_t id, miss_group; };

@@ -60,3 +60,42 @@ def test_spread_rule_from_the_hit_count():
     assert rule(lanes, 22_000 * 256, 256, 115_200) == 16        # its 1/8 share
     assert rule(lanes, 700_000 * 512, 512, 1_048_576) == 1      # matpreview, whole frame: dense
     assert rule(lanes, 0, 256, 64) == 16                        # nothing hit: as sparse as allowed
+
+
+def item_of_pixel(pixel, width, tiles_x, tile_first, tile_stride):
+    """path_core.h::item_of_pixel: position of a pixel in a draw's tile enumeration (the pre-pass record, the packed layout)"""
+    x, y = pixel % width, pixel // width
+    tile = (y >> 3) * tiles_x + (x >> 3)
+    return ((tile - tile_first) // tile_stride) * 64 + (y & 7) * 8 + (x & 7)
+
+
+@pytest.mark.parametrize("width,height", [(64, 64), (203, 117), (1280, 720)])
+@pytest.mark.parametrize("rank,world", [(0, 1), (1, 3), (7, 8)])
+def test_item_of_pixel_inverts_the_tile_enumeration(width, height, rank, world):
+    """item q -> tile tile_first + (q >> 6) * tile_stride, pixel q & 63 of it (render kernels) and back (pre-pass records,
+    packed output of the queued renderer): every pixel of a rank's tiles maps to its own item."""
+    tiles_x, tiles_y = (width + 7) // 8, (height + 7) // 8
+    tiles = np.arange(rank, tiles_x * tiles_y, world)
+    q = np.arange(len(tiles) * 64)
+    tile, r = tiles[q >> 6], q & 63
+    x, y = (tile % tiles_x) * 8 + (r & 7), (tile // tiles_x) * 8 + (r >> 3)
+    inside = (x < width) & (y < height)
+    back = item_of_pixel((y * width + x)[inside], width, tiles_x, rank, world)
+    assert np.array_equal(back, q[inside])
+
+
+@pytest.mark.parametrize("n_tiles", [1, 5, 1000])
+def test_tile_order_table_is_a_permutation_and_keeps_image_order_within_a_class(n_tiles):
+    """hip/tile_order.hip: key = (31 - cost class) << 32 | local tile, sorted ascending -> most expensive class first,
+    image order inside a class; hand-out position p renders item (table[p >> 6] << 6) | (p & 63)."""
+    rng = np.random.default_rng(n_tiles)
+    cls = rng.integers(0, 32, n_tiles)
+    keys = ((31 - cls).astype(np.uint64) << np.uint64(32)) | np.arange(n_tiles, dtype=np.uint64)
+    table = (np.sort(keys) & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    assert np.array_equal(np.sort(table), np.arange(n_tiles))
+    assert (np.diff(cls[table]) <= 0).all()                                  # classes descend
+    same = np.diff(cls[table]) == 0
+    assert (np.diff(table)[same] > 0).all()                                  # image order within a class
+    p = np.arange(n_tiles * 64)
+    items = (table[p >> 6] << 6) | (p & 63)
+    assert np.array_equal(np.sort(items), p)
