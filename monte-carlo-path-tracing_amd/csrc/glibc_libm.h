@@ -32,6 +32,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include "glibc_libm_tables.inc"
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define MCPT_GL_HD __host__ __device__ __forceinline__
@@ -402,6 +404,166 @@ MCPT_GL_HD float tanf(float x)
     }
     const float y0 = static_cast<float>(dx), y1 = static_cast<float>(dx - static_cast<double>(y0));
     return kernel_tanf(y0, y1, 1 - ((n & 1) << 1));
+}
+
+// ---- exp, log in double (the medium code) ---------------------------------------------------------
+// The reference's homogeneous medium calls the C library's DOUBLE exp / log on float arguments
+// (src/renderer/medium/homogeneous.cpp:18-24,37,45,58: unqualified `exp(...)` / `log(...)` resolve to
+// ::exp(double) / ::log(double)) and rounds the result to float.  glibc 2.35's exp / log are not
+// correctly rounded (0.51 ulp), so a device library's exp / log can differ in the last bit of the double,
+// which very rarely — about once in 2^29 calls — changes the float.  Restated: sysdeps/ieee754/dbl-64/e_exp.c,
+// e_log.c (the "optimized routines" design: 128-entry tables, see glibc_libm_tables.inc), in the multiarch
+// variants __exp_fma / __log_fma the loader selects on FMA hosts.  Which products are fused was read off
+// that library's machine code (scratch disassembly of libm.so.6; noted per line below) — the C sources
+// leave it to the compiler.  Pinned by tests/test_glibc_libm.py: all 2^32 float arguments (as doubles) and
+// 2^28 random double bit patterns against the host, on the host build and on the device.
+MCPT_GL_HD uint64_t bits64(double x)
+{
+    uint64_t u;
+    __builtin_memcpy(&u, &x, 8);
+    return u;
+}
+MCPT_GL_HD double from_bits64(uint64_t u)
+{
+    double x;
+    __builtin_memcpy(&x, &u, 8);
+    return x;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ const uint64_t kExpTab[256] = {MCPT_GLIBC_EXP_TAB};
+__device__ const double kLogTab[256] = {MCPT_GLIBC_LOG_TAB};
+#else
+static const uint64_t kExpTab[256] = {MCPT_GLIBC_EXP_TAB};
+static const double kLogTab[256] = {MCPT_GLIBC_LOG_TAB};
+#endif
+
+// e_exp.c specialcase(): the scale factor would over- / underflow.
+MCPT_GL_HD double exp_special(double tmp, uint64_t sbits, uint64_t ki)
+{
+    if ((ki & 0x80000000ull) == 0)
+    {
+        // k > 0: the exponent of scale might have overflowed by <= 460
+        sbits -= 1009ull << 52;
+        const double scale = from_bits64(sbits);
+        return 0x1p1009 * fmad(scale, tmp, scale);
+    }
+    // k < 0: careful in the subnormal range
+    sbits += 1022ull << 52;
+    const double scale = from_bits64(sbits);
+    const double st = scale * tmp; // (not fused in __exp_fma: the product is used twice)
+    double y = scale + st;
+    if (y < 1.0)
+    {
+        // round y to the right precision before scaling it into the subnormal range
+        double lo = scale - y + st;
+        const double hi = 1.0 + y;
+        lo = 1.0 - hi + y + lo;
+        y = (hi + lo) - 1.0;
+        if (y == 0.0)
+            y = 0.0; // no -0
+    }
+    return 0x1p-1022 * y;
+}
+
+MCPT_GL_HD double exp(double x)
+{
+    constexpr double kInvLn2N = 0x1.71547652b82fep0 * 128, kShift = 0x1.8p52, kNegLn2hiN = -0x1.62e42fefa0000p-8,
+                     kNegLn2loN = -0x1.cf79abc9e3b3ap-47;
+    constexpr double kC2 = 0x1.ffffffffffdbdp-2, kC3 = 0x1.555555555543cp-3, kC4 = 0x1.55555cf172b91p-5, kC5 = 0x1.1111167a4d017p-7;
+    uint32_t abstop = static_cast<uint32_t>(bits64(x) >> 52) & 0x7ffu;
+    if (abstop - 0x3c9u >= 0x3fu) // |x| < 2^-54 or |x| >= 512
+    {
+        if (abstop - 0x3c9u >= 0x80000000u)
+            return 1.0 + x; // tiny
+        if (abstop >= 0x409u) // |x| >= 1024, inf, nan
+        {
+            if (bits64(x) == bits64(-__builtin_inf()))
+                return 0.0;
+            if (abstop >= 0x7ffu)
+                return 1.0 + x;
+            return (bits64(x) >> 63) ? 0.0 : __builtin_inf(); // __math_uflow(0) / __math_oflow(0)
+        }
+        abstop = 0; // large x is special cased below
+    }
+    // exp(x) = 2^(k/N) * exp(r), r = x - k ln2/N in [-ln2/2N, ln2/2N]
+    double kd = fmad(x, kInvLn2N, kShift); // fused in __exp_fma
+    const uint64_t ki = bits64(kd);
+    kd -= kShift;
+    double r = fmad(kd, kNegLn2hiN, x);
+    r = fmad(kd, kNegLn2loN, r);
+    const uint64_t idx = 2 * (ki % 128);
+    const uint64_t top = ki << 45;
+    const double tail = from_bits64(kExpTab[idx]);
+    const uint64_t sbits = kExpTab[idx + 1] + top;
+    const double r2 = r * r;
+    // tmp = tail + r + r2 (C2 + r C3) + r2 r2 (C4 + r C5), as __exp_fma evaluates it
+    double tmp = fmad(fmad(r, kC3, kC2), r2, tail + r);
+    tmp = fmad(r2 * r2, fmad(r, kC5, kC4), tmp);
+    if (abstop == 0)
+        return exp_special(tmp, sbits, ki);
+    const double scale = from_bits64(sbits);
+    return fmad(scale, tmp, scale);
+}
+
+MCPT_GL_HD double log(double x)
+{
+    constexpr double kLn2hi = 0x1.62e42fefa3800p-1, kLn2lo = 0x1.ef35793c76730p-45;
+    constexpr double kA0 = -0x1.0000000000001p-1, kA1 = 0x1.555555551305bp-2, kA2 = -0x1.fffffffeb459p-3, kA3 = 0x1.999b324f10111p-3,
+                     kA4 = -0x1.55575e506c89fp-3;
+    constexpr double kB0 = -0x1p-1, kB1 = 0x1.5555555555577p-2, kB2 = -0x1.ffffffffffdcbp-3, kB3 = 0x1.999999995dd0cp-3,
+                     kB4 = -0x1.55555556745a7p-3, kB5 = 0x1.24924a344de3p-3, kB6 = -0x1.fffffa4423d65p-4, kB7 = 0x1.c7184282ad6cap-4,
+                     kB8 = -0x1.999eb43b068ffp-4, kB9 = 0x1.78182f7afd085p-4, kB10 = -0x1.5521375d145cdp-4;
+    uint64_t ix = bits64(x);
+    const uint32_t top = static_cast<uint32_t>(ix >> 48);
+    constexpr uint64_t kLo = 0x3fee000000000000ull, kHi = 0x3ff1090000000000ull; // 1 - 2^-4, 1 + 0x1.09p-4
+    if (ix - kLo < kHi - kLo)
+    {
+        // close to 1: a polynomial in r = x - 1 with the leading terms in double-double
+        if (ix == 0x3ff0000000000000ull)
+            return 0.0;
+        const double r = x - 1.0, r2 = r * r, r3 = r * r2;
+        const double q0 = fmad(r2, kB3, fmad(r, kB2, kB1));
+        const double q1 = fmad(r2, kB6, fmad(r, kB5, kB4));
+        double q2 = fmad(r2, kB9, fmad(r, kB8, kB7));
+        q2 = fmad(r3, kB10, q2);
+        const double p = fmad(fmad(q2, r3, q1), r3, q0); // y = r3 * p, folded into the last sum below
+        const double w = r * 0x1p27;
+        const double rhi = r + w - w, rlo = r - rhi;
+        const double ww = rhi * rhi * kB0;
+        const double hi = r + ww;
+        double lo = r - hi + ww;
+        lo = fmad(kB0 * rlo, rhi + r, lo); // fused in __log_fma
+        return hi + fmad(p, r3, lo);       // y = r3 p + lo (fused), + hi
+    }
+    if (top - 0x0010u >= 0x7ff0u - 0x0010u)
+    {
+        // x < 2^-1022, infinite or NaN
+        if (ix * 2 == 0)
+            return -__builtin_inf();
+        if (ix == bits64(__builtin_inf()))
+            return x;
+        if ((top & 0x8000u) || (top & 0x7ff0u) == 0x7ff0u)
+            return __builtin_nan("");
+        ix = bits64(x * 0x1p52); // subnormal: normalise
+        ix -= 52ull << 52;
+    }
+    // x = 2^k z, z in [0.6875, 1.375) cut into 128 subintervals; log x = log1p(z / c - 1) + log c + k ln 2
+    const uint64_t tmp = ix - 0x3fe6000000000000ull;
+    const uint32_t i = static_cast<uint32_t>(tmp >> 45) % 128;
+    const int64_t k = static_cast<int64_t>(tmp) >> 52;
+    const uint64_t iz = ix - (tmp & (0xfffull << 52));
+    const double invc = kLogTab[2 * i], logc = kLogTab[2 * i + 1];
+    const double z = from_bits64(iz);
+    const double r = fmad(z, invc, -1.0); // __FP_FAST_FMA form
+    const double kd = static_cast<double>(static_cast<int32_t>(k));
+    const double w = fmad(kd, kLn2hi, logc);
+    const double hi = w + r;
+    const double lo = fmad(kd, kLn2lo, w - hi + r);
+    const double r2 = r * r;
+    // y = lo + r2 A0 + r r2 (A1 + r A2 + r2 (A3 + r A4)) + hi
+    const double q = fmad(fmad(r, kA4, kA3), r2, fmad(r, kA2, kA1));
+    return fmad(r * r2, q, fmad(r2, kA0, lo)) + hi;
 }
 
 } // namespace gl

@@ -172,8 +172,8 @@ MCPT_HD MediumEvent medium_event_init()
 
 MCPT_HD V3 transmittance3(V3 sigma_t, float d) // exp() is the double one
 {
-    return V3{static_cast<float>(exp(D(-sigma_t.x * d))), static_cast<float>(exp(D(-sigma_t.y * d))),
-              static_cast<float>(exp(D(-sigma_t.z * d)))};
+    return V3{static_cast<float>(gl::exp(D(-sigma_t.x * d))), static_cast<float>(gl::exp(D(-sigma_t.y * d))),
+              static_cast<float>(gl::exp(D(-sigma_t.z * d)))};
 }
 
 MCPT_HD void medium_sample_distance(const MediumRec &m, float max_distance, uint32_t &rng, MediumEvent &r) // :9-53
@@ -184,13 +184,13 @@ MCPT_HD void medium_sample_distance(const MediumRec &m, float max_distance, uint
     {
         xi0 /= m.sampling_weight;
         const int channel = static_cast<int>(lcg_next(rng) * 3);
-        r.distance = static_cast<float>(-log(D(1.0f - xi0)) / D(comp(st, channel)));
+        r.distance = static_cast<float>(-gl::log(D(1.0f - xi0)) / D(comp(st, channel)));
         if (r.distance < max_distance)
         {
             // accumulated on top of the record's initial pdf of 1
-            r.pdf = static_cast<float>(D(r.pdf) + D(st.x) * exp(D(-st.x * r.distance)));
-            r.pdf = static_cast<float>(D(r.pdf) + D(st.y) * exp(D(-st.y * r.distance)));
-            r.pdf = static_cast<float>(D(r.pdf) + D(st.z) * exp(D(-st.z * r.distance)));
+            r.pdf = static_cast<float>(D(r.pdf) + D(st.x) * gl::exp(D(-st.x * r.distance)));
+            r.pdf = static_cast<float>(D(r.pdf) + D(st.y) * gl::exp(D(-st.y * r.distance)));
+            r.pdf = static_cast<float>(D(r.pdf) + D(st.z) * gl::exp(D(-st.z * r.distance)));
             r.pdf *= m.sampling_weight * (1.0f / 3.0f);
             r.scattered = true;
         }
@@ -199,9 +199,9 @@ MCPT_HD void medium_sample_distance(const MediumRec &m, float max_distance, uint
     {
         r.distance = max_distance;
         r.pdf = 0;
-        r.pdf = static_cast<float>(D(r.pdf) + exp(D(-st.x * r.distance)));
-        r.pdf = static_cast<float>(D(r.pdf) + exp(D(-st.y * r.distance)));
-        r.pdf = static_cast<float>(D(r.pdf) + exp(D(-st.z * r.distance)));
+        r.pdf = static_cast<float>(D(r.pdf) + gl::exp(D(-st.x * r.distance)));
+        r.pdf = static_cast<float>(D(r.pdf) + gl::exp(D(-st.y * r.distance)));
+        r.pdf = static_cast<float>(D(r.pdf) + gl::exp(D(-st.z * r.distance)));
         r.pdf = m.sampling_weight * (1.0f / 3.0f) * r.pdf + (1.0f - m.sampling_weight);
     }
     r.attenuation = transmittance3(st, r.distance);

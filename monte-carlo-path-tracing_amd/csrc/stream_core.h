@@ -477,13 +477,19 @@ MCPT_HD StreamShadeResult stream_shade(const DeviceScene &sc, StreamSlot<S> &s, 
 // Primitive test of the pooled walk: test_slot (traversal.h) with the query kind as a run-time value, so
 // that extension and shadow rays can share a wavefront.  The expensive part (the watertight probe) is
 // common to both kinds.
-template <bool kAnalytic, bool kSlivers>
+template <bool kAnalytic, bool kSlivers, bool kLeafCheck = false>
 MCPT_HD bool pool_test_slot(const DeviceScene &sc, uint32_t slot, bool any, Ray &ray, HitRaw &hit, ClosestState &best)
 {
     if (any)
-        return test_slot<true, kAnalytic, kSlivers>(sc, slot, ray, hit, best);
-    return test_slot<false, kAnalytic, kSlivers>(sc, slot, ray, hit, best);
+        return test_slot<true, kAnalytic, kSlivers, kLeafCheck>(sc, slot, ray, hit, best);
+    return test_slot<false, kAnalytic, kSlivers, kLeafCheck>(sc, slot, ray, hit, best);
 }
+
+// Experiment switch (-DMCPT_STREAM_WIDE=1 on a unit whose instantiations all run outside LDS): the trace phase walks the
+// 4-wide quantised hierarchy with the short stack (short_stack.h) instead of the binary one.
+#ifndef MCPT_STREAM_WIDE
+#define MCPT_STREAM_WIDE 0
+#endif
 
 // ---- slot storage -----------------------------------------------------------------------------
 // Structure of arrays over the P slots of a workgroup: field f of slot i at [f * P + i], so that the
@@ -669,6 +675,16 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
     hit.inst = hit.prim = 0, hit.a = hit.b = hit.c = 0.0f, hit.inside = false;
     ClosestState best{false, 0.0f, 0};
     uint32_t depth = 1, cur = kWalkDone;
+    constexpr bool kWideTrace = MCPT_STREAM_WIDE != 0;
+    ShortStack<kWideRing> wstack = wide_stack_of(sc, stack);
+    auto begin_walk = [&]()
+    {
+        if (kWideTrace)
+            wstack.reset(), wstack.store(0, kWalkDone);
+        else
+            stack[0] = kWalkDone;
+        depth = 1, cur = 0;
+    };
     bool pool_empty = total == 0; // wavefront-uniform
     if (own)
     {
@@ -678,8 +694,7 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
             my = kOwnRayId, kind = 0;
             ray = make_ray(own->origin, own->dir);
             best = ClosestState{false, kMaxFloat, 0};
-            stack[0] = kWalkDone;
-            depth = 1, cur = 0;
+            begin_walk();
             if (cnt)
                 ++cnt->closest_rays;
         }
@@ -704,7 +719,17 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
             const uint32_t n_free = lanes_where(cur == kWalkDone), n_holding = n_lanes - n_searching - n_free;
             if (n_holding > n_searching || (!pool_empty && n_free >= fetch_at))
                 break; // (each exit is followed by progress below: a primitive phase or a fetch)
-            if (searching)
+            if (searching && kWideTrace)
+            {
+                if (kCount)
+                {
+                    cnt->node_tests += 2;
+                    if (is_leading_lane())
+                        ++cnt->wave_node_steps;
+                }
+                wide_node_step(sc, wstack, ray, cur, depth);
+            }
+            else if (searching)
             {
                 const float4 *n = sc.walk_nodes + 4 * static_cast<size_t>(cur);
                 const float4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
@@ -735,12 +760,12 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
                     ++cnt->wave_prim_steps;
             }
             const bool any = kind != 0;
-            if (pool_test_slot<C::kAnalytic, C::kSlivers>(sc, cur & ~kWalkLeaf, any, ray, hit, best) && any)
+            if (pool_test_slot<C::kAnalytic, C::kSlivers, kWideTrace>(sc, cur & ~kWalkLeaf, any, ray, hit, best) && any)
                 cur = kWalkDone;
             else
             {
                 --depth;
-                cur = stack[depth * kWalkStackStride];
+                cur = kWideTrace ? wstack.load(depth) : stack[depth * kWalkStackStride];
             }
         }
         // ---- retire finished rays, fetch new ones ----
@@ -793,8 +818,7 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
                 ray = make_ray(o, d);
                 ray.t_max = t_max;
                 best = ClosestState{false, t_max, 0};
-                stack[0] = kWalkDone;
-                depth = 1, cur = 0;
+                begin_walk();
                 if (cnt)
                 {
                     if (kind == 0)

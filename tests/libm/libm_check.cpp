@@ -85,6 +85,37 @@ extern "C" long long mcpt_libm_check(const char *name, unsigned long long stride
                 bad += local;
             });
     }
+    else if (!strcmp(name, "exp") || !strcmp(name, "log"))
+    {
+        // the DOUBLE functions of the medium code: every float bit pattern promoted to double (what the renderer passes:
+        // a float product / a float difference), then per argument two doubles that are not floats — the float's double
+        // with a hashed low mantissa half, and a hashed 64-bit pattern
+        const bool is_exp = name[0] == 'e';
+        double (*mine2)(double) = is_exp ? mcpt::gl::exp : mcpt::gl::log;
+        double (*theirs2)(double) = is_exp ? static_cast<double (*)(double)>(::exp) : static_cast<double (*)(double)>(::log);
+        auto same2 = [](double a, double b) { return mcpt::gl::bits64(a) == mcpt::gl::bits64(b) || (a != a && b != b); };
+        for (unsigned t = 0; t < n_threads; ++t)
+            pool.emplace_back([&, t]() {
+                long long local = 0;
+                for (unsigned long long u = t * stride; u < (1ull << 32); u += n_threads * stride)
+                {
+                    const double x0 = static_cast<double>(from_bits(static_cast<unsigned>(u)));
+                    unsigned long long h = (u + 0x9e3779b97f4a7c15ull) * 0xbf58476d1ce4e5b9ull;
+                    h ^= h >> 31, h *= 0x94d049bb133111ebull, h ^= h >> 29;
+                    const double x1 = mcpt::gl::from_bits64(mcpt::gl::bits64(x0) ^ (h & 0x1fffffffull));
+                    const double x2 = mcpt::gl::from_bits64(h);
+                    for (double x : {x0, x1, x2})
+                        if (!same2(mine2(x), theirs2(x)))
+                        {
+                            ++local;
+                            const int k = stored.fetch_add(2);
+                            if (k + 1 < max_bad)
+                                first_bad[k] = static_cast<unsigned>(mcpt::gl::bits64(x) >> 32), first_bad[k + 1] = static_cast<unsigned>(mcpt::gl::bits64(x));
+                        }
+                }
+                bad += local;
+            });
+    }
     else
         return -1;
     for (auto &th : pool)

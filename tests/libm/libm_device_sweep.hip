@@ -2,7 +2,7 @@
 //
 // tests/libm/libm_check.cpp sweeps the HOST build of the header; "device == host" was inferred from frames.  This
 // program evaluates the same header's functions in a gfx950 kernel for every float bit pattern (sinf cosf tanf acosf
-// atanf) and for 2^26 (y, x) pairs of atan2f, and compares with what the host's libm (::sinf ...) returns for the same
+// atanf; the medium code's DOUBLE exp and log with three double arguments per pattern) and for 2^26 (y, x) pairs of atan2f, and compares with what the host's libm (::sinf ...) returns for the same
 // arguments — not argument by argument over PCIe but chunk by chunk: both sides fold a chunk of 65 536 consecutive
 // arguments into sum_i canon(bits(f(x_i))) * (2 i + 1) mod 2^64 (order independent, position sensitive; every NaN
 // counts as 0x7fc00000).  A differing chunk is then resolved on the host argument by argument (device values of that
@@ -26,7 +26,7 @@
 namespace gl = mcpt::gl;
 
 constexpr unsigned kChunkBits = 16, kChunk = 1u << kChunkBits, kChunks = 1u << (32 - kChunkBits);
-constexpr int kFunctions = 6; // sinf cosf tanf acosf atanf atan2f
+constexpr int kFunctions = 8; // sinf cosf tanf acosf atanf atan2f exp log (the last two in double)
 
 __host__ __device__ inline unsigned canon(float v)
 {
@@ -48,32 +48,67 @@ __host__ __device__ inline unsigned atan2_x(unsigned u)
     }
 }
 
+__host__ __device__ inline unsigned long long canon64(double v)
+{
+    const unsigned long long b = gl::bits64(v);
+    return (b & 0x7fffffffffffffffull) > 0x7ff0000000000000ull ? 0x7ff8000000000000ull : b;
+}
+
+// exp / log (double): per float bit pattern u three arguments — the float promoted to double (what the renderer
+// passes), the same with a hashed low mantissa half, and a hashed 64-bit pattern (tests/libm/libm_check.cpp sweeps
+// the same three on the host build)
+__host__ __device__ inline void double_arguments(unsigned u, double x[3])
+{
+    x[0] = static_cast<double>(gl::from_bits(u));
+    unsigned long long h = (static_cast<unsigned long long>(u) + 0x9e3779b97f4a7c15ull) * 0xbf58476d1ce4e5b9ull;
+    h ^= h >> 31, h *= 0x94d049bb133111ebull, h ^= h >> 29;
+    x[1] = gl::from_bits64(gl::bits64(x[0]) ^ (h & 0x1fffffffull));
+    x[2] = gl::from_bits64(h);
+}
+
+// the word a function contributes for argument index u (float functions: the canonical result bits)
 template <int kF>
-__host__ __device__ inline float device_side(unsigned u)
+__host__ __device__ inline unsigned long long device_side(unsigned u)
 {
     const float x = gl::from_bits(u);
     switch (kF)
     {
-    case 0: return gl::sinf(x);
-    case 1: return gl::cosf(x);
-    case 2: return gl::tanf(x);
-    case 3: return gl::acosf(x);
-    case 4: return gl::atanf(x);
-    default: return gl::atan2f(x, gl::from_bits(atan2_x(u)));
+    case 0: return canon(gl::sinf(x));
+    case 1: return canon(gl::cosf(x));
+    case 2: return canon(gl::tanf(x));
+    case 3: return canon(gl::acosf(x));
+    case 4: return canon(gl::atanf(x));
+    case 5: return canon(gl::atan2f(x, gl::from_bits(atan2_x(u))));
+    default:
+    {
+        double a[3];
+        double_arguments(u, a);
+        if (kF == 6)
+            return canon64(gl::exp(a[0])) + 3ull * canon64(gl::exp(a[1])) + 5ull * canon64(gl::exp(a[2]));
+        return canon64(gl::log(a[0])) + 3ull * canon64(gl::log(a[1])) + 5ull * canon64(gl::log(a[2]));
+    }
     }
 }
 
-static float host_libm(int f, unsigned u)
+static unsigned long long host_libm(int f, unsigned u)
 {
     const float x = gl::from_bits(u);
     switch (f)
     {
-    case 0: return ::sinf(x);
-    case 1: return ::cosf(x);
-    case 2: return ::tanf(x);
-    case 3: return ::acosf(x);
-    case 4: return ::atanf(x);
-    default: return ::atan2f(x, gl::from_bits(atan2_x(u)));
+    case 0: return canon(::sinf(x));
+    case 1: return canon(::cosf(x));
+    case 2: return canon(::tanf(x));
+    case 3: return canon(::acosf(x));
+    case 4: return canon(::atanf(x));
+    case 5: return canon(::atan2f(x, gl::from_bits(atan2_x(u))));
+    default:
+    {
+        double a[3];
+        double_arguments(u, a);
+        if (f == 6)
+            return canon64(::exp(a[0])) + 3ull * canon64(::exp(a[1])) + 5ull * canon64(::exp(a[2]));
+        return canon64(::log(a[0])) + 3ull * canon64(::log(a[1])) + 5ull * canon64(::log(a[2]));
+    }
     }
 }
 
@@ -86,7 +121,7 @@ __global__ void __launch_bounds__(256) sweep(unsigned long long *sums, unsigned 
         return;
     unsigned long long acc = 0;
     for (unsigned i = threadIdx.x; i < kChunk; i += 256)
-        acc += static_cast<unsigned long long>(canon(device_side<kF>(chunk * kChunk + i))) * (2ull * i + 1ull);
+        acc += device_side<kF>(chunk * kChunk + i) * (2ull * i + 1ull);
     for (int off = 32; off > 0; off >>= 1)
         acc += __shfl_xor(acc, off, 64);
     __shared__ unsigned long long part[4];
@@ -98,11 +133,11 @@ __global__ void __launch_bounds__(256) sweep(unsigned long long *sums, unsigned 
 }
 
 template <int kF>
-__global__ void values(unsigned *out, unsigned chunk)
+__global__ void values(unsigned long long *out, unsigned chunk)
 {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < kChunk)
-        out[i] = gl::bits(device_side<kF>(chunk * kChunk + i));
+        out[i] = device_side<kF>(chunk * kChunk + i);
 }
 
 #define CHECK(x)                                                                                  \
@@ -122,11 +157,11 @@ int main(int argc, char **argv)
     // atan2f: 2^26 pairs (every 64th chunk of y) — the pairs libm_check.cpp sweeps on the host are 3 x 2^32 / stride
     const unsigned n_blocks = (kChunks + stride - 1) / stride;
     unsigned long long *d_sums = nullptr;
-    unsigned *d_vals = nullptr;
+    unsigned long long *d_vals = nullptr;
     CHECK(hipMalloc(&d_sums, sizeof(unsigned long long) * n_blocks));
-    CHECK(hipMalloc(&d_vals, sizeof(unsigned) * kChunk));
+    CHECK(hipMalloc(&d_vals, sizeof(unsigned long long) * kChunk));
     std::vector<unsigned long long> dev(n_blocks), host(n_blocks);
-    const char *names[kFunctions] = {"sinf", "cosf", "tanf", "acosf", "atanf", "atan2f"};
+    const char *names[kFunctions] = {"sinf", "cosf", "tanf", "acosf", "atanf", "atan2f", "exp", "log"};
     const unsigned n_threads = std::max(1u, std::thread::hardware_concurrency());
     std::string json = "{";
     long long total_bad = 0;
@@ -145,7 +180,9 @@ int main(int argc, char **argv)
         case 2: hipLaunchKernelGGL(sweep<2>, dim3(blocks), dim3(256), 0, nullptr, d_sums, fstride, kChunks); break;
         case 3: hipLaunchKernelGGL(sweep<3>, dim3(blocks), dim3(256), 0, nullptr, d_sums, fstride, kChunks); break;
         case 4: hipLaunchKernelGGL(sweep<4>, dim3(blocks), dim3(256), 0, nullptr, d_sums, fstride, kChunks); break;
-        default: hipLaunchKernelGGL(sweep<5>, dim3(blocks), dim3(256), 0, nullptr, d_sums, fstride, kChunks); break;
+        case 5: hipLaunchKernelGGL(sweep<5>, dim3(blocks), dim3(256), 0, nullptr, d_sums, fstride, kChunks); break;
+        case 6: hipLaunchKernelGGL(sweep<6>, dim3(blocks), dim3(256), 0, nullptr, d_sums, fstride, kChunks); break;
+        default: hipLaunchKernelGGL(sweep<7>, dim3(blocks), dim3(256), 0, nullptr, d_sums, fstride, kChunks); break;
         }
         CHECK(hipGetLastError());
         CHECK(hipEventRecord(e1, nullptr));
@@ -162,7 +199,7 @@ int main(int argc, char **argv)
                     const unsigned chunk = b * fstride;
                     unsigned long long acc = 0;
                     for (unsigned i = 0; i < kChunk; ++i)
-                        acc += static_cast<unsigned long long>(canon(host_libm(f, chunk * kChunk + i))) * (2ull * i + 1ull);
+                        acc += host_libm(f, chunk * kChunk + i) * (2ull * i + 1ull);
                     host[b] = acc;
                 }
             });
@@ -189,12 +226,14 @@ int main(int argc, char **argv)
                 case 2: hipLaunchKernelGGL(values<2>, dim3(kChunk / 256), dim3(256), 0, nullptr, d_vals, chunk); break;
                 case 3: hipLaunchKernelGGL(values<3>, dim3(kChunk / 256), dim3(256), 0, nullptr, d_vals, chunk); break;
                 case 4: hipLaunchKernelGGL(values<4>, dim3(kChunk / 256), dim3(256), 0, nullptr, d_vals, chunk); break;
-                default: hipLaunchKernelGGL(values<5>, dim3(kChunk / 256), dim3(256), 0, nullptr, d_vals, chunk); break;
+                case 5: hipLaunchKernelGGL(values<5>, dim3(kChunk / 256), dim3(256), 0, nullptr, d_vals, chunk); break;
+                case 6: hipLaunchKernelGGL(values<6>, dim3(kChunk / 256), dim3(256), 0, nullptr, d_vals, chunk); break;
+                default: hipLaunchKernelGGL(values<7>, dim3(kChunk / 256), dim3(256), 0, nullptr, d_vals, chunk); break;
                 }
-                std::vector<unsigned> vals(kChunk);
-                CHECK(hipMemcpy(vals.data(), d_vals, sizeof(unsigned) * kChunk, hipMemcpyDeviceToHost));
+                std::vector<unsigned long long> vals(kChunk);
+                CHECK(hipMemcpy(vals.data(), d_vals, sizeof(unsigned long long) * kChunk, hipMemcpyDeviceToHost));
                 for (unsigned i = 0; i < kChunk; ++i)
-                    if (canon(gl::from_bits(vals[i])) != canon(host_libm(f, chunk * kChunk + i)))
+                    if (vals[i] != host_libm(f, chunk * kChunk + i))
                     {
                         ++bad_args;
                         if (!have_first)

@@ -1,4 +1,4 @@
-"""csrc/glibc_libm.h (the device's sinf / cosf / tanf / acosf / atanf / atan2f) against the host's libm,
+"""csrc/glibc_libm.h (the device's sinf / cosf / tanf / acosf / atanf / atan2f and the medium code's double exp / log) against the host's libm,
 GNU libc 2.35 — the library the reference CPU integrator calls.  Bit for bit, NaN == NaN.
 
 The CPU suite sweeps every 61st float bit pattern (70 M arguments per function, all exponents and both
@@ -34,7 +34,7 @@ def checker():
 
 
 @pytest.mark.skipif(_glibc() != "2.35", reason="the restatement is of GNU libc 2.35")
-@pytest.mark.parametrize("name", ["sinf", "cosf", "tanf", "acosf", "atanf", "atan2f"])
+@pytest.mark.parametrize("name", ["sinf", "cosf", "tanf", "acosf", "atanf", "atan2f", "exp", "log"])
 def test_matches_host_libm(checker, name):
     first = np.zeros(16, np.uint32)
     bad = checker.mcpt_libm_check(name.encode(), 61, first.ctypes.data, 16)
@@ -44,7 +44,8 @@ def test_matches_host_libm(checker, name):
 @pytest.mark.gpu
 def test_device_evaluation_equals_the_host_libm_on_every_argument():
     """The header as the GPU evaluates it: tests/libm/libm_device_sweep runs sinf cosf tanf acosf atanf for ALL 2^32
-    float bit patterns (and atan2f for 2^26 pairs) in a gfx950 kernel and compares, chunk by chunk, with what this
+    float bit patterns (atan2f for 2^26 pairs; double exp / log for three arguments per float bit pattern: the float as a
+    double, a neighbour that is not a float, a hashed 64-bit pattern) in a gfx950 kernel and compares, chunk by chunk, with what this
     host's libm returns.  "device == host" is thereby tested, not inferred from frames.  It FAILS — not skips — on a
     host whose libm is not the restated one (GNU libc 2.35 on an FMA-capable CPU): on such a box "the CPU reference
     image of the same box" is not bit-equal to the GPU frame, and the suite must say so."""
@@ -58,5 +59,5 @@ def test_device_evaluation_equals_the_host_libm_on_every_argument():
     bad = {k: v for k, v in rec.items() if isinstance(v, dict) and v["differing_chunks"]}
     assert not bad, (f"device evaluation of csrc/glibc_libm.h differs from this host's libm ({host}; the restatement is of "
                      f"glibc 2.35, FMA variant): {bad}")
-    for name in ("sinf", "cosf", "tanf", "acosf", "atanf"):
-        assert rec[name]["arguments"] == 2 ** 32
+    for name in ("sinf", "cosf", "tanf", "acosf", "atanf", "exp", "log"):
+        assert rec[name]["arguments"] == 2 ** 32  # (exp / log: three double arguments per float bit pattern)
