@@ -61,7 +61,7 @@ PMC_GROUPS = [
     ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
      "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_SALU", "SQ_INSTS_VMEM"],
 ]
-KERNEL_WORDS = ("render_kernel", "stream_kernel", "primary_kernel", "queued_")
+KERNEL_WORDS = ("render_kernel", "sorted_kernel", "stream_kernel", "primary_kernel", "queued_")
 # Issue cost per wave64 VALU instruction by class, from this repository's microbenchmark on MI355X
 # (tools/microbench/valu_rate.hip, profiles/r02_experiments/valu_issue_rate_microbench.jsonl): plain fp32
 # add / sub / mul, moves and bit operations issue every ~2.7 cycles per SIMD, compares / selects / min / max / fma /

@@ -232,6 +232,16 @@ int mcpt_renderer_set_work_distribution(mcpt_renderer *r, int mode);
  * -1 (default): 1 whenever a draw runs the pre-pass and the work counter.  No reference counterpart. */
 int mcpt_renderer_set_tile_order(mcpt_renderer *r, int mode);
 
+/* Class sort of the lane-owns-a-path kernel (csrc/hip/sorted_kernel.hip); the image does not depend on it.  Scenes whose
+ * traversal data sits in LDS and that need more than the diffuse model (a participating medium, quadrics, microfacet
+ * BSDFs): between the closest-hit query and the shading, the paths of a 256-lane workgroup are counting-sorted by what
+ * their ray found (came from a medium vertex or not x {miss, surface without BSDF, diffuse-like, specular / microfacet,
+ * light}) and their state moves through LDS to its place in that order, so that a wavefront shades one or two kinds of
+ * vertex instead of all of them.  The reference runs whatever each thread's path hit, diverged: the per-hit `switch` of
+ * src/renderer/bsdfs/bsdf.cpp:188-211 inside the megakernel src/renderer/renderer.cpp:88-95.
+ * mode -1 (default): on for those scenes; 0: off (the unsorted kernel); 1: same as -1. */
+int mcpt_renderer_set_class_sort(mcpt_renderer *r, int mode);
+
 /* Primary-visibility pre-pass (csrc/hip/primary_kernel.hip): the camera ray of sample s of pixel p is a function of
  * (p, s) alone — stratified in x, van der Corput in y, no random number (reference src/renderer/renderer.cpp:68-76) —
  * so the closest hits of ALL camera rays of a draw are computed first by a lean kernel (one lane per (pixel, sample),

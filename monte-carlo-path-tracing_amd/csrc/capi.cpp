@@ -156,6 +156,7 @@ struct mcpt_renderer
     uint32_t queued_slots = 0; // mcpt_renderer_set_kernel's `slots` in mode 5 is the pool size in units of 4096 slots (0 = one slot per pixel)
     uint32_t *queued_host = nullptr; // pinned: the counter block read back after every batch of rounds
     // cost-ordered tile hand-out (mcpt_renderer_set_tile_order; hip/tile_order.hip): keys, sorted keys, sort scratch
+    int class_sort_mode = -1; // mcpt_renderer_set_class_sort: -1 / 1 on where the scene is of that class, 0 off
     int tile_order_mode = -1; // -1 the library's choice (on with the pre-pass and the work counter), 0 image order, 1 cost order
     unsigned long long *tile_keys_dev = nullptr;
     void *tile_temp_dev = nullptr;
@@ -665,6 +666,12 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             return e ? std::atoi(e) : 1;
         }();
         job.compact = compact != 0 ? 1u : 0u;
+        static const int sort_classes = []
+        {
+            const char *e = std::getenv("MCPT_SORT"); // (measurements: 0 = render_kernel instead of the class-sorted kernel)
+            return e ? std::atoi(e) : 1;
+        }();
+        job.sort_classes = sort_classes != 0 && r->class_sort_mode != 0 ? 1u : 0u;
     }
     // The library's choices (kernel_mode -1): the first draw of a renderer calibrates — BEFORE this draw sizes any of its
     // own buffers, because the calibration's nested draws re-size the renderer's scratch allocations.
@@ -856,7 +863,15 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     else if (streamed)
         Check(mcpt::LaunchRenderStream(r->dev, job, render_target, counters, stream, r->scratch_dev, plan), "launch stream kernel");
     else
-        Check(mcpt::LaunchRender(r->dev, job, render_target, counters, stream, r->n_cus, &variant), "launch render kernel");
+    {
+        hipError_t sorted = hipErrorNotSupported;
+        if (job.sort_classes && counters == nullptr)
+            sorted = mcpt::LaunchRenderSorted(r->dev, job, render_target, stream, r->n_cus, &variant);
+        if (sorted == hipErrorNotSupported)
+            Check(mcpt::LaunchRender(r->dev, job, render_target, counters, stream, r->n_cus, &variant), "launch render kernel");
+        else
+            Check(sorted, "launch class-sorted render kernel");
+    }
     if (job.sample_split > 1)
         Check(mcpt::LaunchReduceSamplePlanes(r->planes_dev, out_device, out_pixels, job.sample_split, job.plane_stride,
                                              r->flat.camera.spp_inv, stream),
@@ -1468,6 +1483,16 @@ int mcpt_renderer_set_tile_order(mcpt_renderer *r, int mode)
     if (mode < -1 || mode > 1)
         return Fail("mcpt_renderer_set_tile_order: mode is -1 (the library's choice), 0 (image order) or 1 (most expensive tiles first)");
     r->tile_order_mode = mode;
+    return 0;
+}
+
+int mcpt_renderer_set_class_sort(mcpt_renderer *r, int mode)
+{
+    if (!r)
+        return Fail("null argument");
+    if (mode < -1 || mode > 1)
+        return Fail("mcpt_renderer_set_class_sort: mode is -1 (the library's choice), 0 (off) or 1 (on where the scene is of that class)");
+    r->class_sort_mode = mode;
     return 0;
 }
 

@@ -73,6 +73,9 @@ struct RenderJob
     // moved into the first wavefronts of their workgroup whenever another 64 of its lanes have retired
     // (render_kernel_impl.h, "COMPACTION").  The image does not depend on it.
     uint32_t compact;
+    // Full-feature scenes with the traversal data in LDS: 1 = the class-sorted kernel (hip/sorted_kernel.hip: the paths of a
+    // workgroup are regrouped by what their ray found, between the ray query and the shading).  The image does not depend on it.
+    uint32_t sort_classes;
 };
 
 // ---- stream kernel (stream_core.h, stream_kernel_impl.h) ------------------------------------------
@@ -105,6 +108,10 @@ hipError_t LaunchRenderStream(const DeviceScene &sc, const RenderJob &job, float
 
 hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
                         hipStream_t stream, uint32_t n_cus, const char **variant);
+// The class-sorted form of the lane-owns-a-path kernel (hip/sorted_kernel.hip); hipErrorNotSupported when the scene is
+// not one of its classes (the caller takes LaunchRender).
+hipError_t LaunchRenderSorted(const DeviceScene &sc, const RenderJob &job, float *out, hipStream_t stream, uint32_t n_cus,
+                              const char **variant);
 
 // Primary-visibility pre-pass (hip/primary_kernel.hip): the closest hit of every camera ray of the job's pixels into
 // `prehit` (2 words per (pixel, sample) of the WHOLE frame: width * height * spp * 2 words); the render kernels use it

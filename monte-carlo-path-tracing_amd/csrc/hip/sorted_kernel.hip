@@ -1,0 +1,278 @@
+// The lane-owns-a-path kernel with a CLASS SORT between the ray query and the shading (north_star: "a persistent-threads
+// shade stage that sorts hit records by material in LDS"), for the full-feature scenes whose traversal data sits in LDS.
+//
+// What it cures.  render_kernel's step is extend -> resolve -> roulette -> connect -> scatter for 64 lanes in lock
+// step.  On a scene with a participating medium, quadrics and several BSDF models (volumetric-caustic) the walk is
+// only a third of the kernel's VALU instructions; the other two thirds are shading code that runs at a quarter of the
+// lanes (measured: 552 VALU wave-instructions per sample, 187 of them in the walk at 0.63 / 0.43 lane utilisation,
+// 365 in the rest at 0.24), because the lanes of a wavefront sit at different kinds of vertices — medium scattering
+// event, diffuse wall, glass, pass-through boundary, light, miss — and the wavefront executes every kind's code.
+//
+// What it does.  A workgroup of 256 lanes steps in lock step.  A step is cut where the kinds part ways: extend (the
+// closest-hit query), resolve (surface frame, free-flight sampling of the medium the ray crossed, escape / light / back
+// face) and the roulette run first; then every path has a class — medium scattering event, surface vertex by BSDF kind,
+// finished sample (nothing left to do in this step), exhausted lane — and the paths are counting-sorted by class over the
+// workgroup: per wavefront one ballot and population count per class, one LDS word per (wavefront, class), a prefix over
+// those 4 x K words gives every path its destination lane, and its state (RNG, pixel bookkeeping, sums, the vertex and
+// its shading frame: 36 words) moves through LDS to that lane.  Then connect (light sampling, shadow query, BSDF / phase
+// evaluation, MIS) and scatter run on wavefronts that hold one or two classes instead of all of them, and the wavefronts
+// at the end of the order hold only finished samples: they skip that half and start their next camera rays together.
+// Which lane carries a path is irrelevant to its pixel (the state is all there is) — the frame is bit for bit
+// render_kernel's.
+#include "render_kernel_impl.h"
+
+namespace mcpt
+{
+
+#ifndef MCPT_SORT_PASSES
+#define MCPT_SORT_PASSES 2
+#endif
+constexpr uint32_t kSortWords = 36, kSortPasses = MCPT_SORT_PASSES, kSortPassWords = kSortWords / kSortPasses;
+constexpr uint32_t kSortClasses = 10; // medium vertex, surface without BSDF, 6 BSDF kinds, finished sample, exhausted lane
+constexpr uint32_t kClassIdle = 8, kClassExhausted = 9;
+
+#ifndef MCPT_SORTED_WAVES
+#define MCPT_SORTED_WAVES 3
+#endif
+
+// Class of a path after resolve + roulette.  Order = order of the sorted sequence.
+__device__ __forceinline__ uint32_t path_class(const DeviceScene &sc, const PathState &st, const Surface &surf)
+{
+    if (st.in_medium)
+        return 0u;
+    const uint32_t bsdf = sc.instances[surf.inst].bsdf;
+    if (bsdf == kNone)
+        return 1u;
+    const uint32_t k = sc.bsdfs[bsdf].kind; // kBsdfDiffuse = 2 ... kBsdfPlastic = 7 (a light ends the path in resolve)
+    return k >= kBsdfDiffuse && k <= kBsdfPlastic ? k : 2u;
+}
+
+// Measured on volumetric-caustic (1280 x 720 spp 128, one box, unsorted kernel 120.5 ms): 256 lanes 116.7-117.8 ms, 128
+// lanes 115.8-116.6 (a smaller group sorts less purely but waits for fewer wavefronts at its barriers); 1 / 2 / 3 exchange
+// passes: 136.8 (LDS costs a workgroup per CU) / 116.4 / 116.2; 2 / 3 / 4 wavefronts per SIMD: 150.8 / 116.4 / 138.8.
+#ifndef MCPT_SORT_LANES
+#define MCPT_SORT_LANES 128
+#endif
+constexpr uint32_t kSortLanes = MCPT_SORT_LANES; // lanes of a workgroup = paths sorted together
+
+template <uint32_t kFeatures>
+__global__ void __launch_bounds__(kSortLanes, MCPT_SORTED_WAVES)
+sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ out)
+{
+    using C = Config<kFeatures>;
+    constexpr uint32_t kBlockSize = kSortLanes; // (shadows mcpt::kBlockSize: the traversal stacks keep their stride of 256 words)
+    extern __shared__ float4 lds_geometry[];
+    DeviceScene sc = sc_in;
+    uint32_t n_staged = 0;
+    {
+        const uint32_t n_node_vec = 2u * sc_in.integrator.n_nodes, n_tri_vec = 3u * sc_in.integrator.n_prims;
+        const uint32_t n_walk_vec = 4u * sc_in.integrator.n_walk_nodes, n_slot_vec = n_tri_vec;
+        for (uint32_t i = threadIdx.x; i < n_node_vec; i += blockDim.x)
+            lds_geometry[i] = sc_in.nodes[i];
+        for (uint32_t i = threadIdx.x; i < n_tri_vec; i += blockDim.x)
+            lds_geometry[n_node_vec + i] = sc_in.tri_pos[i];
+        for (uint32_t i = threadIdx.x; i < n_walk_vec; i += blockDim.x)
+            lds_geometry[n_node_vec + n_tri_vec + i] = sc_in.walk_nodes[i];
+        for (uint32_t i = threadIdx.x; i < n_slot_vec; i += blockDim.x)
+            lds_geometry[n_node_vec + n_tri_vec + n_walk_vec + i] = sc_in.walk_prims[i];
+        sc.nodes = lds_geometry;
+        sc.tri_pos = lds_geometry + n_node_vec;
+        sc.walk_nodes = lds_geometry + n_node_vec + n_tri_vec;
+        sc.walk_prims = lds_geometry + n_node_vec + n_tri_vec + n_walk_vec;
+        n_staged = n_node_vec + n_tri_vec + n_walk_vec + n_slot_vec;
+    }
+    uint32_t *lds_words = reinterpret_cast<uint32_t *>(lds_geometry + n_staged);
+    uint32_t *stack = lds_words + threadIdx.x;
+    lds_words += static_cast<size_t>(sc_in.integrator.walk_depth) * 256u;
+    uint32_t *exchange = lds_words;                                  // kSortPassWords x 256 words, word-major
+    uint32_t *counts = exchange + kSortPassWords * kBlockSize;       // [parity][wavefront][class]
+    constexpr uint32_t kWaves = kBlockSize / 64u;
+    __syncthreads(); // geometry staged
+
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t width = static_cast<uint32_t>(sc.camera.width), height = static_cast<uint32_t>(sc.camera.height);
+    const uint32_t split = job.sample_split ? job.sample_split : 1u, n_work = job.n_items * split;
+    const bool independent = job.independent_samples != 0;
+    const uint32_t wave = threadIdx.x >> 6;
+
+    PathState st{};
+    st.alive = false;
+    st.stack = stack;
+    bool has_pixel = false;
+    uint32_t slot = 0;
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+
+    for (uint32_t step = 0;; ++step)
+    {
+        // ---- every lane that can still get work holds a live path ----
+        while (!st.alive)
+        {
+            if (!has_pixel)
+            {
+                if (q >= n_work)
+                    break; // exhausted
+                const uint32_t qs = job.scatter ? (q & 63u) * (n_work >> 6) + (q >> 6) : q;
+                const uint32_t k = split == 1 ? 0u : qs / job.n_items, position = qs - k * job.n_items;
+                const uint32_t item = job.tile_order ? (static_cast<uint32_t>(job.tile_order[position >> 6]) << 6) | (position & 63u) : position;
+                const uint32_t local_tile = item >> 6, r = item & 63u;
+                const uint32_t tile = job.tile_first + local_tile * job.tile_stride;
+                const uint32_t x = (tile % job.tiles_x) * 8u + (r & 7u), y = (tile / job.tiles_x) * 8u + (r >> 3);
+                q = job.work_counter ? stride + wave_reserve(job.work_counter, true) : q + stride;
+                if (x >= width || y >= height)
+                    continue; // padding of an edge tile
+                const uint32_t pixel = y * width + x;
+                start_pixel(st, pixel);
+                st.sample = k;
+                slot = (job.packed ? item : pixel) + k * job.plane_stride;
+                has_pixel = true;
+            }
+            if (st.sample >= sc.camera.spp)
+            {
+                const V3 c = split == 1 ? pixel_value(sc, st) : st.pixel_sum;
+                float *dst = out + 3 * static_cast<size_t>(slot);
+                dst[0] = c.x, dst[1] = c.y, dst[2] = c.z;
+                has_pixel = false;
+                continue;
+            }
+            start_sample(sc, st, split, independent, job.rng_seed);
+        }
+
+        // ---- extend, resolve, roulette ----
+        Surface surf;
+        surf.inside = false, surf.inst = 0, surf.uv = V2{0, 0};
+        surf.position = surf.normal = surf.tangent = surf.bitangent = V3{0, 0, 0};
+        if (st.alive)
+        {
+            Ray ray;
+            HitRaw raw;
+            const bool hit_valid = path_extend<C>(sc, st, nullptr, ray, raw);
+            path_resolve<C>(sc, st, nullptr, ray, raw, hit_valid, surf);
+        }
+
+        // ---- class sort over the workgroup ----
+        const uint32_t key = st.alive ? path_class(sc, st, surf) : (has_pixel || q < n_work) ? kClassIdle : kClassExhausted;
+        uint32_t *cnt = counts + (step & 1u) * kWaves * 16u;
+        uint32_t rank = 0, mine = 0; // this lane's rank among its wavefront's lanes of the same class; lane c: that class's count
+#pragma unroll
+        for (uint32_t c = 0; c < kSortClasses; ++c)
+        {
+            const unsigned long long mask = __ballot(key == c);
+            const uint32_t n = static_cast<uint32_t>(__popcll(mask));
+            if (key == c)
+                rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+            if ((threadIdx.x & 63u) == c)
+                mine = n;
+        }
+        if ((threadIdx.x & 63u) < 16u)
+            cnt[wave * 16u + (threadIdx.x & 63u)] = (threadIdx.x & 63u) < kSortClasses ? mine : 0u;
+        __syncthreads();
+        // destination = (paths of smaller classes) + (paths of this class in earlier wavefronts) + rank
+        uint32_t before = 0, exhausted = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kWaves; ++w)
+        {
+            const uint4 *row = reinterpret_cast<const uint4 *>(cnt + w * 16u);
+            const uint4 r0 = row[0], r1 = row[1], r2 = row[2];
+            const uint32_t n[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+            for (uint32_t c = 0; c < kSortClasses; ++c)
+                before += (c < key || (c == key && w < wave)) ? n[c] : 0u;
+            exhausted += n[kClassExhausted];
+        }
+        if (exhausted == kBlockSize)
+            break; // every lane of the workgroup is out of work (uniform)
+        // The order is rotated by whole wavefronts, differently per workgroup and step: the wavefronts of a workgroup sit on
+        // different SIMDs, and the front of the order (medium vertices, the common and expensive class) must not always
+        // land on the same one while the SIMD of the last wavefront (finished samples) idles.
+#ifndef MCPT_SORT_ROTATE
+#define MCPT_SORT_ROTATE 1
+#endif
+        const uint32_t dst = MCPT_SORT_ROTATE ? (before + rank + 64u * ((blockIdx.x + step) & (kWaves - 1u))) & (kBlockSize - 1u) : before + rank;
+
+        const V3 vertex = st.in_medium ? st.origin : surf.position;
+        uint32_t in[kSortWords], got[kSortWords];
+        in[0] = st.rng, in[1] = st.pixel, in[2] = st.sample, in[3] = st.depth;
+        in[4] = (st.alive ? 1u : 0u) | (st.in_medium ? 4u : 0u) | (has_pixel ? 8u : 0u) | (surf.inside ? 32u : 0u);
+        in[5] = st.medium, in[6] = surf.inst;
+        auto put = [&](uint32_t at, V3 v) { in[at] = as_uint(v.x), in[at + 1] = as_uint(v.y), in[at + 2] = as_uint(v.z); };
+        put(7, vertex), put(10, st.wo), put(13, st.throughput), put(16, st.L), put(19, st.pixel_sum);
+        put(22, surf.normal), put(25, surf.tangent), put(28, surf.bitangent);
+        in[31] = as_uint(surf.uv.u), in[32] = as_uint(surf.uv.v), in[33] = slot, in[34] = q, in[35] = 0;
+#pragma unroll
+        for (uint32_t pass = 0; pass < kSortPasses; ++pass)
+        {
+            if (pass != 0)
+                __syncthreads(); // the previous pass's words have been read
+#pragma unroll
+            for (uint32_t k = 0; k < kSortPassWords; ++k)
+                exchange[k * kBlockSize + dst] = in[pass * kSortPassWords + k];
+            __syncthreads();
+#pragma unroll
+            for (uint32_t k = 0; k < kSortPassWords; ++k)
+                got[pass * kSortPassWords + k] = exchange[k * kBlockSize + threadIdx.x];
+        }
+        // (the next step's first exchange write comes after that step's count barrier: every lane has read by then)
+        st.rng = got[0], st.pixel = got[1], st.sample = got[2], st.depth = got[3];
+        st.alive = (got[4] & 1u) != 0, st.primary = false, st.in_medium = (got[4] & 4u) != 0;
+        has_pixel = (got[4] & 8u) != 0, surf.inside = (got[4] & 32u) != 0;
+        st.medium = got[5], surf.inst = got[6];
+        auto get = [&](uint32_t at) { return V3{as_float(got[at]), as_float(got[at + 1]), as_float(got[at + 2])}; };
+        st.origin = surf.position = get(7);
+        st.wo = get(10), st.throughput = get(13), st.L = get(16), st.pixel_sum = get(19);
+        surf.normal = get(22), surf.tangent = get(25), surf.bitangent = get(28);
+        surf.uv = V2{as_float(got[31]), as_float(got[32])};
+        slot = got[33], q = got[34];
+
+        // ---- connect, scatter ----
+        if (st.alive)
+            path_connect_scatter<C>(sc, st, nullptr, surf);
+    }
+}
+
+template <uint32_t kFeatures>
+static hipError_t LaunchSorted(const DeviceScene &sc, const RenderJob &job, float *out, hipStream_t stream, uint32_t max_blocks)
+{
+    constexpr uint32_t kBlockSize = kSortLanes;
+    const size_t lds_bytes = StagedBytes(sc, true) + size_t(sc.integrator.walk_depth) * 256u * sizeof(uint32_t) + // (the stacks' stride is 256 words whatever the workgroup size)
+                             (size_t(kSortPassWords) * kBlockSize + 2u * (kBlockSize / 64u) * 16u) * sizeof(uint32_t);
+    int per_cu = 0;
+    hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sorted_kernel<kFeatures>, kBlockSize, lds_bytes);
+    if (err != hipSuccess)
+        return err;
+    if (per_cu < 1)
+        return hipErrorOutOfMemory;
+    const uint32_t n_work = job.n_items * (job.sample_split ? job.sample_split : 1u);
+    const uint32_t resident = max_blocks * static_cast<uint32_t>(per_cu);
+    RenderJob j = job;
+    j.lane_spread = 1;
+    if (j.scatter == kScatterAuto)
+        j.scatter = 0;
+    NoteTransposed(j.scatter != 0);
+    uint64_t blocks = (uint64_t(n_work) + kBlockSize - 1) / kBlockSize;
+    if (blocks > resident)
+        blocks = resident;
+    if (blocks == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL((sorted_kernel<kFeatures>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlockSize), lds_bytes, stream, sc, j, out);
+    return hipGetLastError();
+}
+
+// The class-sorted kernel for the job's scene, or hipErrorNotSupported when the scene is not one of its classes (the
+// caller then takes render_kernel): full-feature scenes with the traversal data in LDS, ordered walk, no counters.
+hipError_t LaunchRenderSorted(const DeviceScene &sc, const RenderJob &job, float *out, hipStream_t stream, uint32_t n_cus,
+                              const char **variant)
+{
+    const uint32_t f = sc.features;
+    if (job.reference_walk || sc.integrator.has_masks || sc.integrator.walk_sliver_reach > 0.0f ||
+        StagedBytes(sc, true) > kLdsGeometryBytes || (f & (kFeatVolPath | kFeatAnalytic | kFeatMicrofacet)) == 0)
+        return hipErrorNotSupported;
+    if ((f & ~kVolumeLean) == 0)
+    {
+        *variant = "volume-quadrics-microfacet+lds, class-sorted";
+        return LaunchSorted<kVolumeLean | kO>(sc, job, out, stream, n_cus);
+    }
+    *variant = "all+lds, class-sorted";
+    return LaunchSorted<kAll | kO>(sc, job, out, stream, n_cus);
+}
+
+} // namespace mcpt

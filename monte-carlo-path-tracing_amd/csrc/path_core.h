@@ -367,16 +367,13 @@ MCPT_HD V3 connect_lights(const DeviceScene &sc, uint32_t *stack, bool at_medium
 // what it found, run the roulette, connect to the lights, scatter.  On return
 // either st.alive is still true (st.origin/st.dir hold the next ray) or the
 // sample has been finished (st.alive == false).
+// The step in two halves, so that a kernel can regroup paths between the ray query and the shading (the class-sorted
+// kernel, hip/sorted_kernel.hip).  path_extend: the closest-hit query of the ray in flight (ray, raw, return value =
+// hit_valid; ray.t_max = the distance).  path_shade: everything after it.  path_step = one after the other.
 template <class C>
-MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
+MCPT_HD bool path_extend(const DeviceScene &sc, PathState &st, LaneCounters *cnt, Ray &ray, HitRaw &raw)
 {
-    const IntegratorRec &ig = sc.integrator;
-    const bool vol = C::kVolPath && ig.volpath != 0;
-    const LightTables LT = light_tables<C>(sc);
-
-    // ---- extend --------------------------------------------------------------
-    Ray ray = make_ray(st.origin, st.dir);
-    HitRaw raw;
+    ray = make_ray(st.origin, st.dir);
     TraceStats ts{0, 0, 0, 0};
     bool hit_valid;
     const bool known = C::kOrdered && st.primary && sc.prehit != nullptr; // the pre-pass traced this camera ray
@@ -402,7 +399,20 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
         cnt->last_shadow_count = 0;
         cnt->last_hit_prim = hit_valid ? raw.prim : kNone, cnt->last_hit_t = ray.t_max;
     }
-    Surface surf;
+    return hit_valid;
+}
+
+// path_resolve: what the ray found (surface frame, primary miss, free-flight sampling of the medium it crossed, escape,
+// back face, light) and the roulette; afterwards either the sample is finished (st.alive == false) or the path stands at
+// its next vertex — a medium scattering event (st.in_medium, st.origin) or the surface point `surf` — and
+// path_connect_scatter does the rest of the step there.  path_shade = one after the other.
+template <class C>
+MCPT_HD void path_resolve(const DeviceScene &sc, PathState &st, LaneCounters *cnt, const Ray &ray, const HitRaw &raw, bool hit_valid,
+                          Surface &surf)
+{
+    const IntegratorRec &ig = sc.integrator;
+    const bool vol = C::kVolPath && ig.volpath != 0;
+    const LightTables LT = light_tables<C>(sc);
     if (hit_valid)
     {
         surf = make_surface<C::kAnalytic, C::kTextures>(sc, ray, raw);
@@ -517,7 +527,13 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
         finish_sample(st);
         return;
     }
+}
 
+template <class C>
+MCPT_HD void path_connect_scatter(const DeviceScene &sc, PathState &st, LaneCounters *cnt, const Surface &surf)
+{
+    const bool vol = C::kVolPath && sc.integrator.volpath != 0;
+    const uint32_t bsdf = st.in_medium ? kNone : sc.instances[surf.inst].bsdf; // (a surface vertex is a valid hit)
     // ---- connect -------------------------------------------------------------
     const V3 vertex = st.in_medium ? st.origin : surf.position;
     st.L += st.throughput * connect_lights<C>(sc, st.stack, st.in_medium, surf, vertex, st.medium, st.wo, st.rng, cnt);
@@ -565,6 +581,25 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
         return;
     }
     st.dir = -st.wi;
+}
+
+template <class C>
+MCPT_HD void path_shade(const DeviceScene &sc, PathState &st, LaneCounters *cnt, const Ray &ray, const HitRaw &raw, bool hit_valid)
+{
+    Surface surf;
+    path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
+    if (st.alive)
+        path_connect_scatter<C>(sc, st, cnt, surf);
+}
+
+template <class C>
+MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
+{
+    // ---- extend --------------------------------------------------------------
+    Ray ray;
+    HitRaw raw;
+    const bool hit_valid = path_extend<C>(sc, st, cnt, ray, raw);
+    path_shade<C>(sc, st, cnt, ray, raw, hit_valid);
 }
 
 // Convenience for CPU-side emulation and unit tests: a whole pixel.

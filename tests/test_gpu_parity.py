@@ -576,6 +576,43 @@ def test_scheduling_choices_do_not_change_the_image(name, pkg, scenes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["volumetric_96x54_spp16", "volumetric_iso_64x36_spp8", "conductor_aniso_mixed", "dielectric_area_sphere",
+                                  "thin_dielectric_sun", "rough_plastic_constant_cyl", "rough_diffuse_point_disk", "cornell_96_spp32"])
+def test_class_sort_does_not_change_the_image(name, pkg, scenes):
+    """mcpt_renderer_set_class_sort (csrc/hip/sorted_kernel.hip): the paths of a workgroup regrouped by what their ray
+    found, between the ray query and the shading — which lane carries a path is irrelevant to its pixel.  On / off x fixed
+    lists / work counter x pixel order x a packed tile range: the compiled reference's golden, bit for bit; the sorted
+    kernel really runs on the full-feature LDS-resident scenes and only there."""
+    golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
+    try:
+        ran = {}
+        for sort in (1, 0, -1):
+            for work in (0, 1):
+                frame, _ = r.set_kernel(0).set_class_sort(sort).set_work_distribution(work).set_prepass(0).draw()
+                ran[sort] = r.last_kernel()
+                assert np.array_equal(frame, golden), (sort, work, r.last_kernel())
+        assert "class-sorted" not in ran[0]
+        expect_sorted = not name.startswith("cornell")
+        assert ("class-sorted" in ran[1]) == expect_sorted and ("class-sorted" in ran[-1]) == expect_sorted, ran
+        if expect_sorted:
+            # packed tile shares of three ranks (edge tiles included) compose the same frame
+            import torch
+            h, w = golden.shape[:2]
+            frame = np.zeros_like(golden)
+            r.set_class_sort(1).set_work_distribution(1)
+            for rank in range(3):
+                rng = pkg.capi.TileRange(rank, 3, 0)
+                buf = torch.zeros(r.tiles_in(rng) * 64 * 3, dtype=torch.float32, device="cuda:0")
+                r.draw_device(buf.data_ptr(), rng, packed=True)
+                assert "class-sorted" in r.last_kernel()
+                pkg.capi.unpack_tiles(buf.cpu().numpy(), rng, w, h, frame)
+            assert np.array_equal(frame, golden)
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["rough_dielectric_envmap", "terrain_directional", "bumpy_directional"])
 def test_tile_hand_out_order_does_not_change_the_image(name, pkg, scenes):
     """mcpt_renderer_set_tile_order: tiles handed out most expensive first (cost from the pre-pass's camera-ray hits,

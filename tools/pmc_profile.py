@@ -62,7 +62,7 @@ def main():
             # the plain render kernel only: bench.py also launches the counting
             # instantiation (second template argument true) for its bookkeeping
             name = row["Kernel_Name"]
-            if ("render_kernel" not in name and "stream_kernel" not in name) or \
+            if ("render_kernel" not in name and "stream_kernel" not in name and "sorted_kernel" not in name) or \
                     (", true, " in name and "render_kernel" in name) or ("u, true, " in name and "stream_kernel" in name):
                 continue
             kernels.add(row["Kernel_Name"][:120])
