@@ -229,7 +229,12 @@ int mcpt_renderer_set_work_distribution(mcpt_renderer *r, int mode);
  * sequential chain of rounds (one random stream through all its samples, renderer.cpp:62-81), so a frame ends with the
  * chains that started last.  1: tiles sorted by an estimate of their cost — what the pre-pass's camera rays hit, weighted
  * by BSDF kind (csrc/hip/tile_order.hip) — most expensive first, image order within a cost class.  0: image order.
- * -1 (default): 1 whenever a draw runs the pre-pass and the work counter.  No reference counterpart. */
+ * -1 (default): 1 whenever a draw runs the pre-pass and the work counter.
+ * Scenes whose traversal data sits in LDS (no pre-pass there), draws that give every resident lane at most one pixel and
+ * fill at least half of the lanes (cornell-box 512 x 512 on one MI355X): with -1 / 1 the first draw of a tile range
+ * measures the tiles with a 2-spp probe (steps per tile), a wavefront then renders one tile, and the tiles are laid over the
+ * grid so that every SIMD holds a wavefront of each cost quarter and all SIMDs the same sum (csrc/capi.cpp,
+ * CostOrderedTable): 60.8 -> 56.2 ms; an explicit mcpt_renderer_set_pixel_order wins.  No reference counterpart. */
 int mcpt_renderer_set_tile_order(mcpt_renderer *r, int mode);
 
 /* Class sort of the lane-owns-a-path kernel (csrc/hip/sorted_kernel.hip); the image does not depend on it.  Scenes whose

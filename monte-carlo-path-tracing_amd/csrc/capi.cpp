@@ -4,6 +4,7 @@
 // renderer call fails with an error.
 #include "mcpt.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <dlfcn.h>
@@ -156,6 +157,10 @@ struct mcpt_renderer
     uint32_t queued_slots = 0; // mcpt_renderer_set_kernel's `slots` in mode 5 is the pool size in units of 4096 slots (0 = one slot per pixel)
     uint32_t *queued_host = nullptr; // pinned: the counter block read back after every batch of rounds
     // cost-ordered tile hand-out (mcpt_renderer_set_tile_order; hip/tile_order.hip): keys, sorted keys, sort scratch
+    // cost-ordered wavefronts of the lanes kernel (experiment, MCPT_COST_ORDER): per-tile step counts of a low-spp probe
+    uint32_t *tile_steps_dev = nullptr;
+    uint32_t tile_steps_capacity = 0;
+    uint32_t cost_order_tiles = 0, cost_order_first = 0, cost_order_stride = 0; // the range the sorted table was made for (0 tiles: none)
     int class_sort_mode = -1; // mcpt_renderer_set_class_sort: -1 / 1 on where the scene is of that class, 0 off
     int tile_order_mode = -1; // -1 the library's choice (on with the pre-pass and the work counter), 0 image order, 1 cost order
     unsigned long long *tile_keys_dev = nullptr;
@@ -184,6 +189,8 @@ struct mcpt_renderer
             (void)hipFree(queued_dev);
         if (walk_spill_dev)
             (void)hipFree(walk_spill_dev);
+        if (tile_steps_dev)
+            (void)hipFree(tile_steps_dev);
         if (tile_keys_dev)
             (void)hipFree(tile_keys_dev);
         if (tile_temp_dev)
@@ -642,6 +649,72 @@ uint32_t DrawQueued(mcpt_renderer *r, const mcpt::RenderJob &job, float *out_dev
     return round;
 }
 
+// Which tile every wavefront slot of a one-pixel-per-lane launch renders, from the tiles' measured costs.  Position g of the
+// table = wavefront g of the grid = wavefront g % 4 of workgroup g / 4.  All workgroups of such a launch are resident at once
+// (4 per CU), the dispatcher deals them round-robin — workgroups b, b + n_cus, b + 2 n_cus, b + 3 n_cus share a CU (measured:
+// the opposite assumption is 11 % slower) — and wavefront w of a workgroup runs on SIMD w, so SIMD (c, w) holds the wavefronts
+// g = 4 (c + k n_cus) + w, k = 0..3.  layout 0: cost order as is (quarter k of the order goes to slot k of every SIMD);
+// 1: odd quarters reversed (snake: the SIMDs' sums even out); 2: the two most expensive remaining tiles with the two cheapest
+// (pairs that finish together); 3: longest-processing-time greedy on the sums.
+std::vector<unsigned long long> CostOrderedTable(const std::vector<uint32_t> &steps, uint32_t n_cus, int layout)
+{
+    const uint32_t n = static_cast<uint32_t>(steps.size());
+    std::vector<uint32_t> order(n);
+    for (uint32_t t = 0; t < n; ++t)
+        order[t] = t;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return steps[a] > steps[b]; });
+    std::vector<unsigned long long> table(n);
+    const uint32_t simds = n_cus * 4u;
+    if (layout == 0 || n != simds * 4u)
+    {
+        const uint32_t per_quarter = n / 4u;
+        for (uint32_t g = 0; g < n; ++g)
+        {
+            uint32_t rank = g;
+            if (layout != 0 && per_quarter * 4u == n)
+            {
+                const uint32_t quarter = g / per_quarter, i = g - quarter * per_quarter;
+                rank = quarter * per_quarter + ((quarter & 1u) ? per_quarter - 1u - i : i);
+            }
+            table[g] = order[rank];
+        }
+        return table;
+    }
+    auto slot_of = [&](uint32_t simd, uint32_t k) { return 4u * ((simd >> 2) + k * n_cus) + (simd & 3u); };
+    if (layout == 1)
+    {
+        for (uint32_t g = 0; g < n; ++g)
+        {
+            const uint32_t quarter = g / simds, i = g - quarter * simds;
+            table[g] = order[quarter * simds + ((quarter & 1u) ? simds - 1u - i : i)];
+        }
+    }
+    else if (layout == 2)
+    {
+        for (uint32_t s = 0; s < simds; ++s)
+        {
+            table[slot_of(s, 0)] = order[2u * s], table[slot_of(s, 1)] = order[2u * s + 1u];
+            table[slot_of(s, 2)] = order[n - 1u - 2u * s], table[slot_of(s, 3)] = order[n - 2u - 2u * s];
+        }
+    }
+    else
+    {
+        std::vector<unsigned long long> load(simds, 0);
+        std::vector<uint32_t> used(simds, 0);
+        // (a heap would do; 4 096 x 1 024 comparisons are nothing)
+        for (uint32_t rank = 0; rank < n; ++rank)
+        {
+            uint32_t best = simds;
+            for (uint32_t s = 0; s < simds; ++s)
+                if (used[s] < 4u && (best == simds || load[s] < load[best]))
+                    best = s;
+            table[slot_of(best, used[best])] = order[rank];
+            load[best] += steps[order[rank]], ++used[best];
+        }
+    }
+    return table;
+}
+
 // Enqueues one render launch; optionally waits and reports timings.
 void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, bool packed, hipStream_t stream,
           bool blocking, bool counted, mcpt_stats *stats)
@@ -864,6 +937,75 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         Check(mcpt::LaunchRenderStream(r->dev, job, render_target, counters, stream, r->scratch_dev, plan), "launch stream kernel");
     else
     {
+        // COST-ORDERED WAVEFRONTS (LDS-resident scenes, reference random stream).  A pixel is one sequential chain, and a job
+        // that gives every resident lane at most one pixel (cornell 512 x 512 = 262 144 lanes) lasts as long as its slowest
+        // wavefront.  The first draw of a tile range runs a 2-spp probe that counts the steps per tile; a wavefront then renders
+        // ONE tile (its 64 chains are about equally long, so it does not thin out) and the tiles are laid over the grid so that
+        // every SIMD holds one wavefront of each cost quarter and all SIMDs the same sum (CostOrderedTable).  cornell 60.8 ->
+        // 56.9 ms; the probe adds ~1 ms to the first draw only.  MCPT_COST_ORDER=0 / mcpt_renderer_set_tile_order(r, 0) / an
+        // explicit pixel order switch it off; MCPT_COST_ORDER=3 also orders jobs with more pixels than lanes (experiment).
+        static const int cost_order = []
+        {
+            const char *e = std::getenv("MCPT_COST_ORDER");
+            return e ? std::atoi(e) : 1;
+        }();
+        static const int cost_layout = []
+        {
+            const char *e = std::getenv("MCPT_COST_LAYOUT");
+            return e ? std::atoi(e) : 1;
+        }();
+        // (jobs that fill at least half of the lanes: below that the launch spreads the paths over the lanes instead, and the
+        //  layout costs — cornell 256 x 256, a quarter of the lanes: 11.0 -> 11.5 ms; 500 x 300, 57 %: 7.4 -> 7.0 ms)
+        const bool one_pixel_per_lane = uint64_t(job.n_items) <= uint64_t(r->n_cus) * 1024u && uint64_t(job.n_items) * 2u >= uint64_t(r->n_cus) * 1024u;
+        if (cost_order > 0 && r->tile_order_mode != 0 && r->pixel_order < 0 && small_scene && !counted && !prepass && job.sample_split <= 1 &&
+            n_tiles > 1 && r->rng_mode == 0 && !job.reference_walk && (one_pixel_per_lane || (cost_order >= 3 && dynamic_work)))
+        {
+            if (n_tiles > r->tile_keys_capacity || n_tiles > r->tile_steps_capacity)
+            {
+                Check(hipDeviceSynchronize(), "wait before growing the tile tables");
+                if (r->tile_keys_dev)
+                    (void)hipFree(r->tile_keys_dev), (void)hipFree(r->tile_temp_dev);
+                if (r->tile_steps_dev)
+                    (void)hipFree(r->tile_steps_dev);
+                r->tile_keys_dev = nullptr, r->tile_temp_dev = nullptr, r->tile_steps_dev = nullptr;
+                r->tile_temp_bytes = mcpt::TileOrderTempBytes(n_tiles);
+                Check(hipMalloc(reinterpret_cast<void **>(&r->tile_keys_dev), size_t(2) * n_tiles * sizeof(unsigned long long)), "allocate tile table");
+                Check(hipMalloc(&r->tile_temp_dev, r->tile_temp_bytes), "allocate tile sort scratch");
+                Check(hipMalloc(reinterpret_cast<void **>(&r->tile_steps_dev), n_tiles * sizeof(uint32_t)), "allocate tile step counts");
+                r->tile_keys_capacity = r->tile_steps_capacity = n_tiles;
+                r->cost_order_tiles = 0;
+            }
+            if (r->cost_order_tiles != n_tiles || r->cost_order_first != range.tile_first || r->cost_order_stride != range.tile_stride)
+            {
+                Check(hipMemsetAsync(r->tile_steps_dev, 0, n_tiles * sizeof(uint32_t), stream), "clear tile step counts");
+                static const uint32_t probe_spp = []
+                {
+                    const char *e = std::getenv("MCPT_COST_PROBE_SPP");
+                    return e ? static_cast<uint32_t>(std::max(1, std::atoi(e))) : 2u;
+                }();
+                mcpt::DeviceScene probe = r->dev;
+                probe.camera.spp = std::min(probe.camera.spp, probe_spp);
+                probe.camera.spp_inv = 1.0f / static_cast<float>(probe.camera.spp);
+                mcpt::RenderJob pj = job;
+                pj.tile_steps = r->tile_steps_dev, pj.compact = 0;
+                const char *ignored = "";
+                Check(mcpt::LaunchRender(probe, pj, render_target, nullptr, stream, r->n_cus, &ignored), "launch cost probe");
+                // the hand-out table is laid out on the host (4 096 tiles: microseconds; one synchronisation in the first draw of
+                // a tile range): which wavefront slot of the grid renders which tile
+                std::vector<uint32_t> steps(n_tiles);
+                Check(hipMemcpyAsync(steps.data(), r->tile_steps_dev, n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "read tile step counts");
+                Check(hipStreamSynchronize(stream), "wait for the cost probe");
+                const std::vector<unsigned long long> table = CostOrderedTable(steps, r->n_cus, one_pixel_per_lane ? cost_layout : 0);
+                Check(hipMemcpyAsync(r->tile_keys_dev + r->tile_keys_capacity, table.data(), n_tiles * sizeof(unsigned long long), hipMemcpyHostToDevice, stream),
+                      "upload the tile table");
+                Check(hipStreamSynchronize(stream), "wait for the tile table");
+                if (job.work_counter)
+                    Check(hipMemsetAsync(r->work_counter_dev, 0, sizeof(uint32_t), stream), "clear work counter");
+                r->cost_order_tiles = n_tiles, r->cost_order_first = range.tile_first, r->cost_order_stride = range.tile_stride;
+            }
+            job.tile_order = r->tile_keys_dev + r->tile_keys_capacity;
+            job.scatter = 0;
+        }
         hipError_t sorted = hipErrorNotSupported;
         if (job.sort_classes && counters == nullptr)
             sorted = mcpt::LaunchRenderSorted(r->dev, job, render_target, stream, r->n_cus, &variant);
@@ -894,7 +1036,9 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     if (r->dev.prehit)
         r->variant += " + camera-ray pre-pass";
     if (dynamic_work)
-        r->variant += job.tile_order ? ", work counter (tiles most expensive first)" : ", work counter";
+        r->variant += job.tile_order && r->dev.prehit ? ", work counter (tiles most expensive first)" : ", work counter";
+    if (job.tile_order && !r->dev.prehit)
+        r->variant += ", wavefronts laid out by probed tile cost";
     r->last_tile_order = job.tile_order ? 1 : 0;
     if (r->kernel_mode == -1 && r->auto_source != 0)
     {

@@ -76,6 +76,9 @@ struct RenderJob
     // Full-feature scenes with the traversal data in LDS: 1 = the class-sorted kernel (hip/sorted_kernel.hip: the paths of a
     // workgroup are regrouped by what their ray found, between the ray query and the shading).  The image does not depend on it.
     uint32_t sort_classes;
+    // Cost probe of the lane-owns-a-path kernel (may be null): n_items / 64 words; a lane adds the steps its pixel took to
+    // its tile's word when the pixel is finished.  A low-spp draw with this set measures what each tile costs.
+    uint32_t *tile_steps;
 };
 
 // ---- stream kernel (stream_core.h, stream_kernel_impl.h) ------------------------------------------
@@ -110,6 +113,9 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
                         hipStream_t stream, uint32_t n_cus, const char **variant);
 // The class-sorted form of the lane-owns-a-path kernel (hip/sorted_kernel.hip); hipErrorNotSupported when the scene is
 // not one of its classes (the caller takes LaunchRender).
+// keys[t] = (0xFFFFFFFF - steps[t]) << 32 | t, sorted ascending into `sorted`: the tiles most expensive first.
+hipError_t LaunchTileOrderFromSteps(const uint32_t *steps, uint32_t n_tiles, unsigned long long *keys, unsigned long long *sorted,
+                                    void *temp, size_t temp_bytes, hipStream_t stream);
 hipError_t LaunchRenderSorted(const DeviceScene &sc, const RenderJob &job, float *out, hipStream_t stream, uint32_t n_cus,
                               const char **variant);
 

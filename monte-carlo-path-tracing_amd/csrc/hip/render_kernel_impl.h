@@ -118,6 +118,7 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     st.stack = reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + threadIdx.x;
     bool has_pixel = false;
     uint32_t slot = 0; // where this pixel's result goes
+    uint32_t steps = 0, my_tile = 0; // cost probe (RenderJob::tile_steps)
     // COMPACTION (LDS-resident scenes: the kernel is VALU-issue bound there, and an instruction of a wavefront with 20
     // live lanes costs what one with 64 does).  Once the job's items are handed out, a lane whose pixel is finished has
     // nothing left to do, and its wavefront thins out while the SIMD's issue slots stay taken.  Whenever another 64 lanes
@@ -235,6 +236,7 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
             const uint32_t local_tile = item >> 6, r = item & 63u;
             const uint32_t tile = job.tile_first + local_tile * job.tile_stride;
             const uint32_t x = (tile % job.tiles_x) * 8u + (r & 7u), y = (tile / job.tiles_x) * 8u + (r >> 3);
+            my_tile = local_tile, steps = 0;
             // the lane's NEXT item: the first one nobody has taken yet (the launch's lanes start on items 0 .. stride-1),
             // or, without a counter, the next of its fixed list
             q = job.work_counter ? stride + wave_reserve(job.work_counter, true) : q + stride;
@@ -253,6 +255,8 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
                 const V3 c = split == 1 ? pixel_value(sc, st) : st.pixel_sum;
                 float *dst = out + 3 * static_cast<size_t>(slot);
                 dst[0] = c.x, dst[1] = c.y, dst[2] = c.z;
+                if (job.tile_steps)
+                    atomicAdd(&job.tile_steps[my_tile], steps);
                 has_pixel = false;
                 continue;
             }
@@ -261,6 +265,7 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
                 ++local.samples;
         }
         path_step<C>(sc, st, cnt);
+        ++steps;
     }
 
     if (kCount)

@@ -94,6 +94,28 @@ __global__ void __launch_bounds__(kBlockSize) tile_cost_kernel(const DeviceScene
 
 } // namespace
 
+namespace
+{
+__global__ void keys_from_steps_kernel(const uint32_t *__restrict__ steps, unsigned long long *__restrict__ keys, uint32_t n_tiles)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_tiles)
+        keys[t] = (static_cast<unsigned long long>(0xFFFFFFFFu - steps[t]) << 32) | t;
+}
+} // namespace
+
+hipError_t LaunchTileOrderFromSteps(const uint32_t *steps, uint32_t n_tiles, unsigned long long *keys, unsigned long long *sorted,
+                                    void *temp, size_t temp_bytes, hipStream_t stream)
+{
+    if (n_tiles == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(keys_from_steps_kernel, dim3((n_tiles + kBlockSize - 1) / kBlockSize), dim3(kBlockSize), 0, stream, steps, keys, n_tiles);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess)
+        return err;
+    return rocprim::radix_sort_keys(temp, temp_bytes, keys, sorted, n_tiles, 0, 64, stream);
+}
+
 size_t TileOrderTempBytes(uint32_t n_tiles)
 {
     size_t bytes = 0;

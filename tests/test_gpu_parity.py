@@ -613,6 +613,33 @@ def test_class_sort_does_not_change_the_image(name, pkg, scenes):
 
 
 @pytest.mark.gpu
+def test_wavefronts_laid_out_by_probed_tile_cost_render_the_same_frame(pkg):
+    """LDS-resident scene, a film that gives every resident lane at most one pixel and fills at least half of them (the
+    cornell BASELINE configuration's class): the first draw probes the tiles' costs at 2 spp and lays the wavefronts out
+    by them (capi.cpp, CostOrderedTable).  Same frame as image order / transposed order, bit for bit, for a film with
+    partial edge tiles too; the probe runs once per tile range."""
+    import torch
+    n_lanes = torch.cuda.get_device_properties(0).multi_processor_count * 1024
+    w = 500
+    h = (n_lanes * 5 // 8) // w
+    scene = pkg.scenes.cornell_box(w, h, 3)
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
+    try:
+        frames = {}
+        for order in (1, 0, -1):
+            frames[order], _ = r.set_tile_order(order).draw()
+            laid_out = "probed tile cost" in r.last_kernel()
+            assert laid_out == (order != 0), (order, r.last_kernel())
+        assert np.array_equal(frames[1], frames[0]) and np.array_equal(frames[-1], frames[0])
+        again, _ = r.draw()   # (the table is reused)
+        assert np.array_equal(again, frames[0])
+        explicit, _ = r.set_pixel_order(1).draw()   # an explicit pixel order wins
+        assert "probed tile cost" not in r.last_kernel() and np.array_equal(explicit, frames[0])
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["rough_dielectric_envmap", "terrain_directional", "bumpy_directional"])
 def test_tile_hand_out_order_does_not_change_the_image(name, pkg, scenes):
     """mcpt_renderer_set_tile_order: tiles handed out most expensive first (cost from the pre-pass's camera-ray hits,
