@@ -654,8 +654,9 @@ uint32_t DrawQueued(mcpt_renderer *r, const mcpt::RenderJob &job, float *out_dev
 // (4 per CU), the dispatcher deals them round-robin — workgroups b, b + n_cus, b + 2 n_cus, b + 3 n_cus share a CU (measured:
 // the opposite assumption is 11 % slower) — and wavefront w of a workgroup runs on SIMD w, so SIMD (c, w) holds the wavefronts
 // g = 4 (c + k n_cus) + w, k = 0..3.  layout 0: cost order as is (quarter k of the order goes to slot k of every SIMD);
-// 1: odd quarters reversed (snake: the SIMDs' sums even out); 2: the two most expensive remaining tiles with the two cheapest
-// (pairs that finish together); 3: longest-processing-time greedy on the sums.
+// 1 (default): odd quarters reversed (snake: the SIMDs' sums even out); 3: longest-processing-time greedy on the sums.  (Measured and
+// removed: pairs that finish together, 5 ms slower; greedy on a finish-time model of the SIMD, 1 % faster with the right issue-rate
+// constant, 10 % slower with a wrong one: EXPERIMENTS.md R3-12.)
 std::vector<unsigned long long> CostOrderedTable(const std::vector<uint32_t> &steps, uint32_t n_cus, int layout)
 {
     const uint32_t n = static_cast<uint32_t>(steps.size());
@@ -663,6 +664,16 @@ std::vector<unsigned long long> CostOrderedTable(const std::vector<uint32_t> &st
     for (uint32_t t = 0; t < n; ++t)
         order[t] = t;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return steps[a] > steps[b]; });
+    if (std::getenv("MCPT_COST_DEBUG"))
+    {
+        unsigned long long sum = 0;
+        for (uint32_t t = 0; t < n; ++t)
+            sum += steps[t];
+        std::fprintf(stderr, "tile costs (steps, probe): n %u mean %.1f; quantiles of cost / mean:", n, double(sum) / n);
+        for (uint32_t k = 0; k <= 16; ++k)
+            std::fprintf(stderr, " %.2f", steps[order[std::min(n - 1u, k * n / 16u)]] * double(n) / double(sum));
+        std::fprintf(stderr, "\n");
+    }
     std::vector<unsigned long long> table(n);
     const uint32_t simds = n_cus * 4u;
     if (layout == 0 || n != simds * 4u)
@@ -687,14 +698,6 @@ std::vector<unsigned long long> CostOrderedTable(const std::vector<uint32_t> &st
         {
             const uint32_t quarter = g / simds, i = g - quarter * simds;
             table[g] = order[quarter * simds + ((quarter & 1u) ? simds - 1u - i : i)];
-        }
-    }
-    else if (layout == 2)
-    {
-        for (uint32_t s = 0; s < simds; ++s)
-        {
-            table[slot_of(s, 0)] = order[2u * s], table[slot_of(s, 1)] = order[2u * s + 1u];
-            table[slot_of(s, 2)] = order[n - 1u - 2u * s], table[slot_of(s, 3)] = order[n - 2u - 2u * s];
         }
     }
     else

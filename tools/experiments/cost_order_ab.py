@@ -11,7 +11,7 @@ r = pkg.capi.Renderer(pkg.workloads.config(name, w, h, spp), device=0)
 _, first = r.draw()
 ms = sorted(r.draw()[1]["kernel_milliseconds"] for _ in range(5))
 frame, st = r.draw()
-print(json.dumps({"workload": name, "film": [w, h, spp], "cost_order": os.environ.get("MCPT_COST_ORDER", "0") + " " + os.environ.get("MCPT_COMPACT", "") + " " + os.environ.get("MCPT_COST_PROBE_SPP", ""), "kernel": r.last_kernel(), "first_ms": round(first["kernel_milliseconds"], 3),
+print(json.dumps({"workload": name, "film": [w, h, spp], "cost_order": os.environ.get("MCPT_COST_ORDER", "0") + " " + os.environ.get("MCPT_COMPACT", "") + " " + os.environ.get("MCPT_COST_PROBE_SPP", "") + " L" + os.environ.get("MCPT_COST_LAYOUT", "") + " r1=" + os.environ.get("MCPT_COST_R1", ""), "kernel": r.last_kernel(), "first_ms": round(first["kernel_milliseconds"], 3),
                   "ms_best": round(ms[0], 3), "ms_median": round(ms[2], 3), "msamples": round(w * h * spp / ms[0] / 1e3, 1), "sha": hashlib.sha256(frame.tobytes()).hexdigest()[:12]}))
 ''' % ROOT
 jobs = [j.split(":") for j in (sys.argv[1] if len(sys.argv) > 1 else "cornell:512:512:256").split(",")]
