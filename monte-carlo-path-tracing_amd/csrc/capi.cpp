@@ -960,7 +960,9 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         // (jobs that fill at least half of the lanes: below that the launch spreads the paths over the lanes instead, and the
         //  layout costs — cornell 256 x 256, a quarter of the lanes: 11.0 -> 11.5 ms; 500 x 300, 57 %: 7.4 -> 7.0 ms)
         const bool one_pixel_per_lane = uint64_t(job.n_items) <= uint64_t(r->n_cus) * 1024u && uint64_t(job.n_items) * 2u >= uint64_t(r->n_cus) * 1024u;
-        if (cost_order > 0 && r->tile_order_mode != 0 && r->pixel_order < 0 && small_scene && !counted && !prepass && job.sample_split <= 1 &&
+        // (measured on the diffuse instantiations; cost_order >= 3 extends it to every LDS-resident scene)
+        const bool probed_class = (r->dev.features & ~uint32_t(mcpt::kFeatEmitters)) == 0 || cost_order >= 3;
+        if (cost_order > 0 && probed_class && r->tile_order_mode != 0 && r->pixel_order < 0 && small_scene && !counted && !prepass && job.sample_split <= 1 &&
             n_tiles > 1 && r->rng_mode == 0 && !job.reference_walk && (one_pixel_per_lane || (cost_order >= 3 && dynamic_work)))
         {
             if (n_tiles > r->tile_keys_capacity || n_tiles > r->tile_steps_capacity)

@@ -73,8 +73,7 @@ constexpr uint32_t kCompactWords = 8, kCompactPasses = 4; // a path's 30 state w
 // The ordered walk's stacks always live in LDS: lane t of the workgroup owns the
 // words t, t + 256, t + 512, ... of the stack area.
 template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
-__global__ void __launch_bounds__(kBlockSize, (Budget<kFeatures, kLdsGeometry>::kWavesPerSimd))
-render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ out, TraceCounters *__restrict__ counters)
+__device__ __forceinline__ void render_body(const DeviceScene &sc_in, const RenderJob &job, float *__restrict__ out, TraceCounters *__restrict__ counters)
 {
     using C = Config<kFeatures>;
     extern __shared__ float4 lds_geometry[];
@@ -283,6 +282,22 @@ render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     }
 }
 
+template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
+__global__ void __launch_bounds__(kBlockSize, (Budget<kFeatures, kLdsGeometry>::kWavesPerSimd))
+render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ out, TraceCounters *__restrict__ counters)
+{
+    render_body<kFeatures, kCount, kLdsGeometry>(sc_in, job, out, counters);
+}
+
+// The same kernel under its own name for the low-spp COST PROBE (RenderJob::tile_steps; capi.cpp, CostOrderedTable), so that a
+// kernel trace tells the probe launch of a renderer's first draw from the frames (only the diffuse LDS instantiations are probed).
+template <uint32_t kFeatures>
+__global__ void __launch_bounds__(kBlockSize, (Budget<kFeatures, true>::kWavesPerSimd))
+cost_probe_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ out)
+{
+    render_body<kFeatures, false, true>(sc_in, job, out, nullptr);
+}
+
 constexpr uint32_t kAll = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
 constexpr uint32_t kSurface = kFeatEmitters | kFeatTextures | kFeatMicrofacet;
 constexpr uint32_t kVolumeLean = kFeatVolPath | kFeatAnalytic | kFeatMicrofacet; // volume paths, quadrics, every BSDF; no emitters, constant textures
@@ -350,6 +365,14 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
         blocks = resident;
     if (blocks == 0)
         return hipSuccess;
+    if constexpr (kLdsGeometry && !kCount && (kFeatures & kAll & ~kFeatEmitters) == 0)
+    {
+        if (job.tile_steps)
+        {
+            hipLaunchKernelGGL((cost_probe_kernel<kFeatures>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlockSize), lds_bytes, stream, sc, spread_job, out);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((render_kernel<kFeatures, kCount, kLdsGeometry>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlockSize),
                        lds_bytes, stream, sc, spread_job, out, counters);
     return hipGetLastError();
