@@ -227,8 +227,10 @@ int mcpt_renderer_set_work_distribution(mcpt_renderer *r, int mode);
 
 /* Order in which the work counter hands out the tiles of a draw; the image does not depend on it.  A pixel is a
  * sequential chain of rounds (one random stream through all its samples, renderer.cpp:62-81), so a frame ends with the
- * chains that started last.  1: tiles sorted by an estimate of their cost — what the pre-pass's camera rays hit, weighted
- * by BSDF kind (csrc/hip/tile_order.hip) — most expensive first, image order within a cost class.  0: image order.
+ * chains that started last.  1: tiles most expensive first.  Their cost is MEASURED: the first draw of a tile range runs a
+ * 2-spp probe in which the lanes kernel counts the steps of every tile (jobs where at least half of the camera rays hit
+ * something; others keep image order); without the probe (MCPT_COST_ORDER=0) an estimate from what the pre-pass's camera
+ * rays hit, weighted by BSDF kind (csrc/hip/tile_order.hip).  0: image order.
  * -1 (default): 1 whenever a draw runs the pre-pass and the work counter.
  * Scenes whose traversal data sits in LDS (no pre-pass there), draws that give every resident lane at most one pixel and
  * fill at least half of the lanes (cornell-box 512 x 512 on one MI355X): with -1 / 1 the first draw of a tile range

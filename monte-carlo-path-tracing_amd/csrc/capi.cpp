@@ -160,6 +160,9 @@ struct mcpt_renderer
     // cost-ordered wavefronts of the lanes kernel (experiment, MCPT_COST_ORDER): per-tile step counts of a low-spp probe
     uint32_t *tile_steps_dev = nullptr;
     uint32_t tile_steps_capacity = 0;
+    unsigned long long *mesh_table_dev = nullptr; // probed hand-out table of a scene outside LDS (cost_order_* say for which range)
+    uint32_t mesh_table_capacity = 0;
+    bool mesh_table_ready = false;
     uint32_t cost_order_tiles = 0, cost_order_first = 0, cost_order_stride = 0; // the range the sorted table was made for (0 tiles: none)
     int class_sort_mode = -1; // mcpt_renderer_set_class_sort: -1 / 1 on where the scene is of that class, 0 off
     int tile_order_mode = -1; // -1 the library's choice (on with the pre-pass and the work counter), 0 image order, 1 cost order
@@ -191,6 +194,8 @@ struct mcpt_renderer
             (void)hipFree(walk_spill_dev);
         if (tile_steps_dev)
             (void)hipFree(tile_steps_dev);
+        if (mesh_table_dev)
+            (void)hipFree(mesh_table_dev);
         if (tile_keys_dev)
             (void)hipFree(tile_keys_dev);
         if (tile_temp_dev)
@@ -649,6 +654,16 @@ uint32_t DrawQueued(mcpt_renderer *r, const mcpt::RenderJob &job, float *out_dev
     return round;
 }
 
+int CostOrderEnv()
+{
+    static const int v = []
+    {
+        const char *e = std::getenv("MCPT_COST_ORDER");
+        return e ? std::atoi(e) : 1;
+    }();
+    return v;
+}
+
 // Which tile every wavefront slot of a one-pixel-per-lane launch renders, from the tiles' measured costs.  Position g of the
 // table = wavefront g of the grid = wavefront g % 4 of workgroup g / 4.  All workgroups of such a launch are resident at once
 // (4 per CU), the dispatcher deals them round-robin — workgroups b, b + n_cus, b + 2 n_cus, b + 3 n_cus share a CU (measured:
@@ -916,10 +931,68 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                     Check(hipMalloc(&r->tile_temp_dev, r->tile_temp_bytes), "allocate tile sort scratch");
                     r->tile_keys_capacity = n_tiles;
                 }
-                Check(mcpt::LaunchTileOrder(r->dev, job, r->prehit_dev, r->tile_keys_dev, r->tile_keys_dev + r->tile_keys_capacity, r->tile_temp_dev,
-                                            r->tile_temp_bytes, stream),
-                      "order the tiles");
-                job.tile_order = r->tile_keys_dev + r->tile_keys_capacity;
+                // The order comes from MEASURED tile costs where the job is of the class that is ordered at all (at least half of
+                // its camera rays hit something: hip/tile_order.hip): the first draw of a tile range reads the pre-pass's hit count,
+                // runs a 2-spp probe with the lanes kernel counting steps per tile, and keeps the table (most expensive first).
+                // Against the estimate from what the camera rays hit (A/B, one box, spp 64): matpreview rough conductor 130.5 ->
+                // 128.4 / 127.6 ms, rough dielectric 167.4 -> 162.0 / 161.7 ms; the first draw pays ~8 ms.  (dragon/scene.xml is not
+                // of that class: ordered by probed cost it loses 10 %, like with the estimate.)
+                bool probed = false;
+                if (CostOrderEnv() >= 1 && r->rng_mode == 0 && !counted)
+                {
+                    if (n_tiles > r->mesh_table_capacity)
+                    {
+                        Check(hipDeviceSynchronize(), "wait before growing the probed tile table");
+                        if (r->mesh_table_dev)
+                            (void)hipFree(r->mesh_table_dev);
+                        if (r->tile_steps_dev)
+                            (void)hipFree(r->tile_steps_dev);
+                        r->mesh_table_dev = nullptr, r->tile_steps_dev = nullptr;
+                        Check(hipMalloc(reinterpret_cast<void **>(&r->mesh_table_dev), n_tiles * sizeof(unsigned long long)), "allocate probed tile table");
+                        Check(hipMalloc(reinterpret_cast<void **>(&r->tile_steps_dev), n_tiles * sizeof(uint32_t)), "allocate tile step counts");
+                        r->mesh_table_capacity = r->tile_steps_capacity = n_tiles, r->cost_order_tiles = 0;
+                    }
+                    if (r->cost_order_tiles != n_tiles || r->cost_order_first != range.tile_first || r->cost_order_stride != range.tile_stride)
+                    {
+                        uint32_t hit_words[mcpt::kHitCounters];
+                        Check(hipMemcpyAsync(hit_words, r->hit_counters_dev, sizeof hit_words, hipMemcpyDeviceToHost, stream), "read hit counters");
+                        Check(hipStreamSynchronize(stream), "wait for the pre-pass");
+                        unsigned long long hits = 0;
+                        for (uint32_t k = 0; k < mcpt::kHitCounters; ++k)
+                            hits += hit_words[k];
+                        r->mesh_table_ready = 2ull * hits >= static_cast<unsigned long long>(job.n_items) * r->dev.camera.spp;
+                        if (r->mesh_table_ready)
+                        {
+                            Check(hipMemsetAsync(r->tile_steps_dev, 0, n_tiles * sizeof(uint32_t), stream), "clear tile step counts");
+                            mcpt::DeviceScene probe = r->dev;
+                            probe.prehit = nullptr;
+                            probe.camera.spp = std::min(probe.camera.spp, 2u);
+                            probe.camera.spp_inv = 1.0f / static_cast<float>(probe.camera.spp);
+                            mcpt::RenderJob pj = job;
+                            pj.tile_steps = r->tile_steps_dev, pj.compact = 0, pj.tile_order = nullptr, pj.hit_counters = nullptr;
+                            const char *ignored = "";
+                            Check(mcpt::LaunchRender(probe, pj, render_target, nullptr, stream, r->n_cus, &ignored), "launch cost probe");
+                            std::vector<uint32_t> steps(n_tiles);
+                            Check(hipMemcpyAsync(steps.data(), r->tile_steps_dev, n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "read tile step counts");
+                            Check(hipStreamSynchronize(stream), "wait for the cost probe");
+                            const std::vector<unsigned long long> table = CostOrderedTable(steps, r->n_cus, 0);
+                            Check(hipMemcpyAsync(r->mesh_table_dev, table.data(), n_tiles * sizeof(unsigned long long), hipMemcpyHostToDevice, stream), "upload the tile table");
+                            Check(hipStreamSynchronize(stream), "wait for the tile table");
+                            Check(hipMemsetAsync(r->work_counter_dev, 0, sizeof(uint32_t), stream), "clear work counter");
+                        }
+                        r->cost_order_tiles = n_tiles, r->cost_order_first = range.tile_first, r->cost_order_stride = range.tile_stride;
+                    }
+                    probed = r->mesh_table_ready;
+                }
+                if (probed)
+                    job.tile_order = r->mesh_table_dev;
+                else
+                {
+                    Check(mcpt::LaunchTileOrder(r->dev, job, r->prehit_dev, r->tile_keys_dev, r->tile_keys_dev + r->tile_keys_capacity, r->tile_temp_dev,
+                                                r->tile_temp_bytes, stream),
+                          "order the tiles");
+                    job.tile_order = r->tile_keys_dev + r->tile_keys_capacity;
+                }
             }
         }
     }
@@ -947,11 +1020,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         // every SIMD holds one wavefront of each cost quarter and all SIMDs the same sum (CostOrderedTable).  cornell 60.8 ->
         // 56.9 ms; the probe adds ~1 ms to the first draw only.  MCPT_COST_ORDER=0 / mcpt_renderer_set_tile_order(r, 0) / an
         // explicit pixel order switch it off; MCPT_COST_ORDER=3 also orders jobs with more pixels than lanes (experiment).
-        static const int cost_order = []
-        {
-            const char *e = std::getenv("MCPT_COST_ORDER");
-            return e ? std::atoi(e) : 1;
-        }();
+        const int cost_order = CostOrderEnv();
         static const int cost_layout = []
         {
             const char *e = std::getenv("MCPT_COST_LAYOUT");
