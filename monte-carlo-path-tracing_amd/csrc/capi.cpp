@@ -163,6 +163,10 @@ struct mcpt_renderer
     unsigned long long *mesh_table_dev = nullptr; // probed hand-out table of a scene outside LDS (cost_order_* say for which range)
     uint32_t mesh_table_capacity = 0;
     bool mesh_table_ready = false;
+    bool range_fresh = false;             // the range's statistics were just (re)read: tables made from them are stale
+    unsigned long long range_hits = 0;    // camera rays of the range that hit something (pre-pass)
+    int stream_waves_mode = -1;           // mcpt_renderer_set_stream_waves: -1 the library's rule, 2 / 3 / 4
+    uint32_t stream_waves_auto = 0;       // the rule's choice for the current range (0: not known yet)
     uint32_t cost_order_tiles = 0, cost_order_first = 0, cost_order_stride = 0; // the range the sorted table was made for (0 tiles: none)
     int class_sort_mode = -1; // mcpt_renderer_set_class_sort: -1 / 1 on where the scene is of that class, 0 off
     int tile_order_mode = -1; // -1 the library's choice (on with the pre-pass and the work counter), 0 image order, 1 cost order
@@ -654,6 +658,22 @@ uint32_t DrawQueued(mcpt_renderer *r, const mcpt::RenderJob &job, float *out_dev
     return round;
 }
 
+// Wavefronts per SIMD the stream kernel's instantiation is compiled for (StreamLaunch::waves).
+uint32_t StreamWavesFor(const mcpt_renderer *r, bool counted)
+{
+    static const int env = []
+    {
+        const char *e = std::getenv("MCPT_STREAM_WAVES");
+        return e ? std::atoi(e) : -1;
+    }();
+    if (counted || r->rng_mode != 0)
+        return 4u; // (the counting instantiations and the independent-sample mode keep the default budget)
+    const int mode = r->stream_waves_mode >= 0 ? r->stream_waves_mode : env;
+    if (mode >= 2 && mode <= 4)
+        return static_cast<uint32_t>(mode);
+    return r->stream_waves_auto ? r->stream_waves_auto : 3u;
+}
+
 int CostOrderEnv()
 {
     static const int v = []
@@ -827,6 +847,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     mcpt::StreamLaunch plan{};
     plan.slots = r->stream_slots, plan.refill_at = r->stream_refill, plan.slots_in_memory = r->kernel_mode == 2 ? 1u : 0u;
     plan.wave_local = r->kernel_mode == 4 ? 1u : 0u;
+    plan.waves = StreamWavesFor(r, counted);
     bool streamed = false;
     // by scene class: the stream kernel wins where walks are long and uneven (meshes: dragon stand-in 1.4x,
     // matpreview 1.3x) and loses where the whole scene sits in LDS and the lane-owns-a-path kernel is already
@@ -915,6 +936,40 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             r->dev.prehit = r->prehit_dev;
             r->dev.prehit_step = job.sample_split ? job.sample_split : 1u;
             r->dev.prehit_tile_first = job.tile_first, r->dev.prehit_tile_stride = job.tile_stride, r->dev.prehit_tiles_x = job.tiles_x;
+            // statistics of the tile range, read once (first draw of the range, one synchronisation): how many camera rays hit
+            const bool range_stats = r->rng_mode == 0 && !counted;
+            if (range_stats && (r->cost_order_tiles != n_tiles || r->cost_order_first != range.tile_first || r->cost_order_stride != range.tile_stride))
+            {
+                uint32_t hit_words[mcpt::kHitCounters];
+                Check(hipMemcpyAsync(hit_words, r->hit_counters_dev, sizeof hit_words, hipMemcpyDeviceToHost, stream), "read hit counters");
+                Check(hipStreamSynchronize(stream), "wait for the pre-pass");
+                r->range_hits = 0;
+                for (uint32_t k = 0; k < mcpt::kHitCounters; ++k)
+                    r->range_hits += hit_words[k];
+                r->range_fresh = true, r->mesh_table_ready = false;
+                r->cost_order_tiles = n_tiles, r->cost_order_first = range.tile_first, r->cost_order_stride = range.tile_stride;
+                // REGISTER BUDGET of the stream kernel (hip/stream_kernel_impl.h, StreamBudget): a chain-bound job — fewer
+                // expensive pixels than the GPU holds lanes: dragon/scene.xml — runs the instantiation without spills at 2
+                // wavefronts per SIMD (186 -> 170 ms), a throughput-bound one the one at 3 (matpreview rough conductor 990 ->
+                // 848 ms, rough dielectric 1268 -> 1287 ms; 4 wavefronts per SIMD is mcpt_renderer_set_stream_waves(r, 4))
+                const unsigned long long expensive = r->range_hits / std::max(1u, r->dev.camera.spp);
+                r->stream_waves_auto = expensive <= uint64_t(r->n_cus) * 1024u ? 2u : 3u;
+                if (streamed && plan.waves != StreamWavesFor(r, counted))
+                {
+                    plan.waves = StreamWavesFor(r, counted);
+                    Check(mcpt::PlanRenderStream(r->dev, job, counted, r->n_cus, &plan, &variant), "plan the stream kernel");
+                    const size_t words = static_cast<size_t>(plan.blocks) * plan.scratch_words_per_block;
+                    if (words > r->scratch_words)
+                    {
+                        Check(hipDeviceSynchronize(), "wait before growing the slot storage");
+                        if (r->scratch_dev)
+                            Check(hipFree(r->scratch_dev), "free slot storage");
+                        r->scratch_dev = nullptr, r->scratch_words = 0;
+                        Check(hipMalloc(reinterpret_cast<void **>(&r->scratch_dev), words * sizeof(uint32_t)), "allocate slot storage");
+                        r->scratch_words = words;
+                    }
+                }
+            }
             // tiles most expensive first (by what their camera rays hit), for the work counter to hand out
             if (dynamic_work && r->tile_order_mode != 0 && job.sample_split <= 1 && n_tiles > 1)
             {
@@ -938,7 +993,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                 // 128.4 / 127.6 ms, rough dielectric 167.4 -> 162.0 / 161.7 ms; the first draw pays ~8 ms.  (dragon/scene.xml is not
                 // of that class: ordered by probed cost it loses 10 %, like with the estimate.)
                 bool probed = false;
-                if (CostOrderEnv() >= 1 && r->rng_mode == 0 && !counted)
+                if (CostOrderEnv() >= 1 && range_stats)
                 {
                     if (n_tiles > r->mesh_table_capacity)
                     {
@@ -950,17 +1005,12 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                         r->mesh_table_dev = nullptr, r->tile_steps_dev = nullptr;
                         Check(hipMalloc(reinterpret_cast<void **>(&r->mesh_table_dev), n_tiles * sizeof(unsigned long long)), "allocate probed tile table");
                         Check(hipMalloc(reinterpret_cast<void **>(&r->tile_steps_dev), n_tiles * sizeof(uint32_t)), "allocate tile step counts");
-                        r->mesh_table_capacity = r->tile_steps_capacity = n_tiles, r->cost_order_tiles = 0;
+                        r->mesh_table_capacity = r->tile_steps_capacity = n_tiles, r->range_fresh = true;
                     }
-                    if (r->cost_order_tiles != n_tiles || r->cost_order_first != range.tile_first || r->cost_order_stride != range.tile_stride)
+                    if (r->range_fresh)
                     {
-                        uint32_t hit_words[mcpt::kHitCounters];
-                        Check(hipMemcpyAsync(hit_words, r->hit_counters_dev, sizeof hit_words, hipMemcpyDeviceToHost, stream), "read hit counters");
-                        Check(hipStreamSynchronize(stream), "wait for the pre-pass");
-                        unsigned long long hits = 0;
-                        for (uint32_t k = 0; k < mcpt::kHitCounters; ++k)
-                            hits += hit_words[k];
-                        r->mesh_table_ready = 2ull * hits >= static_cast<unsigned long long>(job.n_items) * r->dev.camera.spp;
+                        r->range_fresh = false;
+                        r->mesh_table_ready = 2ull * r->range_hits >= static_cast<unsigned long long>(job.n_items) * r->dev.camera.spp;
                         if (r->mesh_table_ready)
                         {
                             Check(hipMemsetAsync(r->tile_steps_dev, 0, n_tiles * sizeof(uint32_t), stream), "clear tile step counts");
@@ -980,7 +1030,6 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                             Check(hipStreamSynchronize(stream), "wait for the tile table");
                             Check(hipMemsetAsync(r->work_counter_dev, 0, sizeof(uint32_t), stream), "clear work counter");
                         }
-                        r->cost_order_tiles = n_tiles, r->cost_order_first = range.tile_first, r->cost_order_stride = range.tile_stride;
                     }
                     probed = r->mesh_table_ready;
                 }
@@ -1701,6 +1750,16 @@ int mcpt_renderer_set_tile_order(mcpt_renderer *r, int mode)
     if (mode < -1 || mode > 1)
         return Fail("mcpt_renderer_set_tile_order: mode is -1 (the library's choice), 0 (image order) or 1 (most expensive tiles first)");
     r->tile_order_mode = mode;
+    return 0;
+}
+
+int mcpt_renderer_set_stream_waves(mcpt_renderer *r, int waves)
+{
+    if (!r)
+        return Fail("null argument");
+    if (waves != -1 && (waves < 2 || waves > 4))
+        return Fail("mcpt_renderer_set_stream_waves: -1 (the library's rule), 2, 3 or 4 wavefronts per SIMD");
+    r->stream_waves_mode = waves;
     return 0;
 }
 

@@ -252,6 +252,10 @@ enum SceneFeature : uint32_t
     kFeatSlivers = 1u << 7,
     // the ordered walk runs on the 4-wide quantised hierarchy (wide_nodes) with a short stack (short_stack.h)
     kFeatWideWalk = 1u << 8,
+    // stream kernel only: the register budget of the instantiation — 3 / 2 wavefronts per SIMD instead of 4 (168 / 256 VGPRs:
+    // 210 / 4 spilled registers instead of 288); which one is faster depends on the scene (stream_kernel_impl.h, StreamBudget)
+    kFeatWaves3 = 1u << 9,
+    kFeatWaves2 = 1u << 10,
 };
 
 // Device view: raw pointers into HBM + the scalar records.

@@ -88,6 +88,7 @@ struct StreamLaunch
 {
     uint32_t slots_in_memory; // input: 0 = one slot per lane, path state in registers; 1 = `slots` slots per workgroup in memory
     uint32_t lane_spread; // output: RenderJob::lane_spread as resolved by the plan (one slot per lane only)
+    uint32_t waves;      // input: wavefronts per SIMD the instantiation is compiled for (2, 3; 0 / 4: the default budget)
     uint32_t wave_local; // input (one slot per lane only): 1 = every wavefront runs its rounds alone, no workgroup barrier
     uint32_t slots;      // path slots per workgroup (a multiple of 256)
     uint32_t refill_at;  // a wavefront fetches new rays when this many of its lanes are free

@@ -48,8 +48,11 @@ hipError_t PlanRenderStream(const DeviceScene &sc, const RenderJob &job, bool co
     const bool slivers = sc.integrator.walk_sliver_reach > 0.0f;
     const uint32_t f = sc.features & (kAll);
     const bool small = StagedBytes(sc, true) <= kLdsGeometryBytes;
-    // the leanest instantiation that covers the scene: fewest feature bits, then fewest shadow records
+    // the leanest instantiation that covers the scene: fewest feature bits, then fewest shadow records — at the register
+    // budget asked for (StreamLaunch::waves; only the surface-materials mesh instantiations exist at 3 and 2: otherwise 4)
     int pick = -1;
+    for (uint32_t want_waves = (cfg->waves == 2 || cfg->waves == 3) ? cfg->waves : 4u; pick < 0; want_waves = 4u)
+    {
     for (uint32_t v = 0; v < kVariantCount; ++v)
     {
         const StreamVariant &k = kVariants[v];
@@ -58,16 +61,21 @@ hipError_t PlanRenderStream(const DeviceScene &sc, const RenderJob &job, bool co
             continue;
         if (slivers && !(k.features & kFeatSlivers))
             continue;
+        if (((k.features & kFeatWaves2) ? 2u : (k.features & kFeatWaves3) ? 3u : 4u) != want_waves)
+            continue;
         if (pick < 0)
         {
             pick = static_cast<int>(v);
             continue;
         }
         const StreamVariant &b = kVariants[pick];
-        const int cost_k = __builtin_popcount(k.features) * 4 + static_cast<int>(k.shadow);
-        const int cost_b = __builtin_popcount(b.features) * 4 + static_cast<int>(b.shadow);
+        const int cost_k = __builtin_popcount(k.features & ~(kFeatWaves2 | kFeatWaves3)) * 4 + static_cast<int>(k.shadow);
+        const int cost_b = __builtin_popcount(b.features & ~(kFeatWaves2 | kFeatWaves3)) * 4 + static_cast<int>(b.shadow);
         if (cost_k < cost_b)
             pick = static_cast<int>(v);
+    }
+    if (want_waves == 4u)
+        break;
     }
     if (pick < 0)
         return hipErrorNotSupported;

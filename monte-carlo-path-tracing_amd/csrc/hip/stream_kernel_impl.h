@@ -55,7 +55,13 @@ constexpr uint32_t kStreamWaves = kBlockSize / 64u;
 template <uint32_t kFeatures, bool kLdsGeometry, bool kRegs>
 struct StreamBudget
 {
+    // Mesh instantiations exist at 4, 3 and 2 wavefronts per SIMD (kFeatWaves3 / kFeatWaves2).  Round 3, with wavefront rounds,
+    // pre-pass and work counter in place, full configurations on one box: matpreview rough conductor 990 / 848 / 895 ms at
+    // 4 / 3 / 2, rough dielectric 1268 / 1287 / 1530, dragon/scene.xml 186 / 176 / 170 — a throughput-bound frame wants the
+    // wavefronts, a chain-bound one (fewer expensive pixels than lanes: dragon) wants its rounds free of spill traffic.
     static constexpr int kWavesPerSimd = !kRegs ? MCPT_STREAM_WAVES_MEMORY
+                                         : (kFeatures & kFeatWaves2) ? 2
+                                         : (kFeatures & kFeatWaves3) ? 3
                                          : !kLdsGeometry ? MCPT_STREAM_WAVES_MESH
                                          : (kFeatures & (kFeatVolPath | kFeatAnalytic | kFeatMicrofacet)) ? MCPT_STREAM_WAVES_SMALL_FULL
                                                                                                         : 4;

@@ -1,5 +1,5 @@
 // Which translation unit instantiates which stream-kernel variant (stream_variants.inc): a unit defines
-// MCPT_STREAM_UNIT (0..3) before including this header and gets explicit instantiations of its own variants;
+// MCPT_STREAM_UNIT (0..5) before including this header and gets explicit instantiations of its own variants;
 // every other unit's variants are declared `extern template`, so that `make -j` compiles the units side by side.
 #ifndef MCPT_STREAM_UNITS_H
 #define MCPT_STREAM_UNITS_H
@@ -39,6 +39,17 @@ namespace mcpt
 #define MCPT_STREAM_DECL_3 MCPT_STREAM_DEFINE
 #else
 #define MCPT_STREAM_DECL_3 MCPT_STREAM_EXTERN
+#endif
+
+#if MCPT_STREAM_UNIT == 4
+#define MCPT_STREAM_DECL_4 MCPT_STREAM_DEFINE
+#else
+#define MCPT_STREAM_DECL_4 MCPT_STREAM_EXTERN
+#endif
+#if MCPT_STREAM_UNIT == 5
+#define MCPT_STREAM_DECL_5 MCPT_STREAM_DEFINE
+#else
+#define MCPT_STREAM_DECL_5 MCPT_STREAM_EXTERN
 #endif
 
 #define X(index, features, S, counted, small, hot, regs, unit, name) MCPT_STREAM_DECL_##unit(features, S, counted, small, hot, regs)
