@@ -666,11 +666,13 @@ uint32_t StreamWavesFor(const mcpt_renderer *r, bool counted)
         const char *e = std::getenv("MCPT_STREAM_WAVES");
         return e ? std::atoi(e) : -1;
     }();
-    if (counted || r->rng_mode != 0)
-        return 4u; // (the counting instantiations and the independent-sample mode keep the default budget)
+    if (counted)
+        return 4u; // (the counting instantiations exist at the default budget only)
     const int mode = r->stream_waves_mode >= 0 ? r->stream_waves_mode : env;
     if (mode >= 2 && mode <= 4)
         return static_cast<uint32_t>(mode);
+    if (r->rng_mode != 0)
+        return 4u; // (the rule below is for the reference stream's chains)
     return r->stream_waves_auto ? r->stream_waves_auto : 3u;
 }
 
