@@ -550,7 +550,9 @@ constexpr uint32_t kBsdfNoCode = 0xFFu;
 #endif
 MCPT_HD constexpr bool bsdf_kind_compiled(uint32_t kind) { return ((MCPT_BSDF_KINDS >> kind) & 1u) != 0; }
 
-template <bool kMicrofacet, uint32_t kOnly = 0>
+// kTransmission == false: the caller guarantees a scene without dielectric / thin dielectric BSDFs (device_scene.h,
+// kFeatNoTransmission); their code is left out.
+template <bool kMicrofacet, uint32_t kOnly = 0, bool kTransmission = true>
 MCPT_HD void bsdf_sample(const ShadeTables &T, const BsdfRec &b, uint32_t &rng, BsdfQuery &q)
 {
     if (kOnly == kBsdfNoCode)
@@ -566,14 +568,14 @@ MCPT_HD void bsdf_sample(const ShadeTables &T, const BsdfRec &b, uint32_t &rng, 
     {
     case kBsdfRoughDiffuse: if (bsdf_kind_compiled(kBsdfRoughDiffuse)) rough_diffuse_sample(T, b, rng, q); break;
     case kBsdfConductor: if (bsdf_kind_compiled(kBsdfConductor)) conductor_sample(T, b, rng, q); break;
-    case kBsdfDielectric: if (bsdf_kind_compiled(kBsdfDielectric)) dielectric_sample(T, b, rng, q); break;
-    case kBsdfThinDielectric: if (bsdf_kind_compiled(kBsdfThinDielectric)) thin_dielectric_sample(T, b, rng, q); break;
+    case kBsdfDielectric: if (kTransmission && bsdf_kind_compiled(kBsdfDielectric)) dielectric_sample(T, b, rng, q); break;
+    case kBsdfThinDielectric: if (kTransmission && bsdf_kind_compiled(kBsdfThinDielectric)) thin_dielectric_sample(T, b, rng, q); break;
     case kBsdfPlastic: if (bsdf_kind_compiled(kBsdfPlastic)) plastic_sample(T, b, rng, q); break;
     default: break;
     }
 }
 
-template <bool kMicrofacet, uint32_t kOnly = 0>
+template <bool kMicrofacet, uint32_t kOnly = 0, bool kTransmission = true>
 MCPT_HD void bsdf_eval(const ShadeTables &T, const BsdfRec &b, BsdfQuery &q)
 {
     if (kOnly == kBsdfNoCode)
@@ -589,8 +591,8 @@ MCPT_HD void bsdf_eval(const ShadeTables &T, const BsdfRec &b, BsdfQuery &q)
     {
     case kBsdfRoughDiffuse: if (bsdf_kind_compiled(kBsdfRoughDiffuse)) rough_diffuse_eval(T, b, q); break;
     case kBsdfConductor: if (bsdf_kind_compiled(kBsdfConductor)) conductor_eval(T, b, q); break;
-    case kBsdfDielectric: if (bsdf_kind_compiled(kBsdfDielectric)) dielectric_eval(T, b, q); break;
-    case kBsdfThinDielectric: if (bsdf_kind_compiled(kBsdfThinDielectric)) thin_dielectric_eval(T, b, q); break;
+    case kBsdfDielectric: if (kTransmission && bsdf_kind_compiled(kBsdfDielectric)) dielectric_eval(T, b, q); break;
+    case kBsdfThinDielectric: if (kTransmission && bsdf_kind_compiled(kBsdfThinDielectric)) thin_dielectric_eval(T, b, q); break;
     case kBsdfPlastic: if (bsdf_kind_compiled(kBsdfPlastic)) plastic_eval(T, b, q); break;
     default: break;
     }

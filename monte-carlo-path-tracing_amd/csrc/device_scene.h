@@ -225,6 +225,7 @@ struct IntegratorRec // reference integrator.hpp:31-69 (the scalar part)
     uint32_t wide_stack;   // stack entries a walk of the wide form can need (sentinel included)
     uint32_t walk_depth;   // stack entries a lane needs: the tree's depth + 1 (sentinel)
     uint32_t has_masks;    // some BSDF carries an opacity map: the walk must keep the reference's order
+    uint32_t has_transmission; // some BSDF is a dielectric or a thin dielectric
     uint32_t walk_hold;    // ... or when at least this many lanes hold a primitive (0 = never for that reason)
     uint32_t walk_break;   // wavefront scheduling of the ordered walk (traversal.h, walk_ordered_vote): leave
                            // the node phase when fewer lanes than this are searching; 0 = wait for all
@@ -256,6 +257,9 @@ enum SceneFeature : uint32_t
     // 210 / 4 spilled registers instead of 288); which one is faster depends on the scene (stream_kernel_impl.h, StreamBudget)
     kFeatWaves3 = 1u << 9,
     kFeatWaves2 = 1u << 10,
+    // stream kernel only: the instantiation leaves the transmissive BSDFs (dielectric, thin dielectric) out — for scenes
+    // without one (IntegratorRec::has_transmission == 0): 210 -> 53 spilled VGPRs at the 3-wavefront budget
+    kFeatNoTransmission = 1u << 11,
 };
 
 // Device view: raw pointers into HBM + the scalar records.

@@ -2,6 +2,8 @@
 #define MCPT_STREAM_UNIT 0
 #include "stream_units.h"
 
+#include <cstdlib>
+
 namespace mcpt
 {
 
@@ -50,6 +52,7 @@ hipError_t PlanRenderStream(const DeviceScene &sc, const RenderJob &job, bool co
     const bool small = StagedBytes(sc, true) <= kLdsGeometryBytes;
     // the leanest instantiation that covers the scene: fewest feature bits, then fewest shadow records — at the register
     // budget asked for (StreamLaunch::waves; only the surface-materials mesh instantiations exist at 3 and 2: otherwise 4)
+    static const bool full_bsdf_set = std::getenv("MCPT_STREAM_FULL_BSDF_SET") != nullptr; // (measurements: never the instantiations without transmissive BSDFs)
     int pick = -1;
     for (uint32_t want_waves = (cfg->waves == 2 || cfg->waves == 3) ? cfg->waves : 4u; pick < 0; want_waves = 4u)
     {
@@ -61,6 +64,8 @@ hipError_t PlanRenderStream(const DeviceScene &sc, const RenderJob &job, bool co
             continue;
         if (slivers && !(k.features & kFeatSlivers))
             continue;
+        if ((k.features & kFeatNoTransmission) && (sc.integrator.has_transmission || full_bsdf_set))
+            continue;
         if (((k.features & kFeatWaves2) ? 2u : (k.features & kFeatWaves3) ? 3u : 4u) != want_waves)
             continue;
         if (pick < 0)
@@ -69,8 +74,8 @@ hipError_t PlanRenderStream(const DeviceScene &sc, const RenderJob &job, bool co
             continue;
         }
         const StreamVariant &b = kVariants[pick];
-        const int cost_k = __builtin_popcount(k.features & ~(kFeatWaves2 | kFeatWaves3)) * 4 + static_cast<int>(k.shadow);
-        const int cost_b = __builtin_popcount(b.features & ~(kFeatWaves2 | kFeatWaves3)) * 4 + static_cast<int>(b.shadow);
+        const int cost_k = __builtin_popcount(k.features & ~(kFeatWaves2 | kFeatWaves3 | kFeatNoTransmission)) * 4 + static_cast<int>(k.shadow) - ((k.features & kFeatNoTransmission) ? 1 : 0);
+        const int cost_b = __builtin_popcount(b.features & ~(kFeatWaves2 | kFeatWaves3 | kFeatNoTransmission)) * 4 + static_cast<int>(b.shadow) - ((b.features & kFeatNoTransmission) ? 1 : 0);
         if (cost_k < cost_b)
             pick = static_cast<int>(v);
     }

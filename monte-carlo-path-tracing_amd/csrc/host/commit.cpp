@@ -1327,6 +1327,7 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
         case MCSD_BSDF_DIELECTRIC:
         case MCSD_BSDF_THIN_DIELECTRIC:
             o.kind = b.type == MCSD_BSDF_DIELECTRIC ? kBsdfDielectric : kBsdfThinDielectric;
+            fs.integrator.has_transmission = 1;
             if (b.type == MCSD_BSDF_DIELECTRIC)
             {
                 o.f_avg = AverageFresnelDielectric(b.eta);
