@@ -112,7 +112,10 @@ int mcpt_renderer_draw(mcpt_renderer *r, float *frame, mcpt_stats *stats);
  *   packed == 0: out is a full frame (width*height*3 floats), only this
  *                range's pixels are written;
  *   packed != 0: out holds the range's tiles back to back, 64 pixels * 3
- *                floats per tile (pixels outside the image are left untouched). */
+ *                floats per tile (pixels outside the image are left untouched).
+ * The FIRST draw of a tile range waits on `stream` once or twice even with blocking == 0: it reads the range's statistics
+ * (camera-ray hits of the pre-pass, the 2-spp cost probe: mcpt_renderer_set_tile_order, _set_stream_waves) to the host, lays
+ * the tiles out and keeps the result; later draws of the same range only enqueue. */
 int mcpt_renderer_draw_device(mcpt_renderer *r, float *out_device, const mcpt_tile_range *range,
                               int packed, void *stream, int blocking, mcpt_stats *stats);
 
