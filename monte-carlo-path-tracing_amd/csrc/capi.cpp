@@ -673,7 +673,7 @@ uint32_t StreamWavesFor(const mcpt_renderer *r, bool counted)
         return static_cast<uint32_t>(mode);
     if (r->rng_mode != 0)
         return 4u; // (the rule below is for the reference stream's chains)
-    return r->stream_waves_auto ? r->stream_waves_auto : 3u;
+    return r->stream_waves_auto ? r->stream_waves_auto : (r->flat.integrator.has_transmission ? 4u : 3u);
 }
 
 int CostOrderEnv()
@@ -955,7 +955,9 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                 // wavefronts per SIMD (186 -> 170 ms), a throughput-bound one the one at 3 (matpreview rough conductor 990 ->
                 // 848 ms, rough dielectric 1268 -> 1287 ms; 4 wavefronts per SIMD is mcpt_renderer_set_stream_waves(r, 4))
                 const unsigned long long expensive = r->range_hits / std::max(1u, r->dev.camera.spp);
-                r->stream_waves_auto = expensive <= uint64_t(r->n_cus) * 1024u ? 2u : 3u;
+                // (throughput-bound with a transmissive BSDF — long chains of bounces inside the object, the walk dominates: the
+                //  default budget, rough dielectric 1268 against 1287 ms at 3)
+                r->stream_waves_auto = expensive <= uint64_t(r->n_cus) * 1024u ? 2u : r->flat.integrator.has_transmission ? 4u : 3u;
                 if (streamed && plan.waves != StreamWavesFor(r, counted))
                 {
                     plan.waves = StreamWavesFor(r, counted);
