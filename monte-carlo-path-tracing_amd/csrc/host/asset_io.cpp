@@ -13,12 +13,24 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
 
 #include <zlib.h>
+
+// MCPT_MESH_TANGENTS=uv: OBJ / PLY meshes are handed over WITHOUT per-vertex tangents and bitangents, which selects the
+// reference's own per-triangle UV-derived frame in the commit (scene.cpp:63-80) — the pinned alternative to the restatement
+// of the importer's CalcTangentSpace (mesh_postprocess.cpp: unpinned, there is no assimp here to compare with; SURVEY.md
+// section 8c names this pin).  A maintainer who binds the library behind the reference's own assimp loader passes assimp's
+// tangents and needs neither.
+static bool UvDerivedTangentsOnly()
+{
+    const char *e = std::getenv("MCPT_MESH_TANGENTS");
+    return e && e[0] == 'u';
+}
 
 namespace mcpt
 {
@@ -263,7 +275,7 @@ MeshData LoadPly(const std::string &path, bool face_normals)
                 m.normals[3 * v + j] = len > 0 ? static_cast<float>(sum[3 * v + j] / len) : (j == 1 ? 1.0f : 0.0f);
         }
     }
-    if (!face_normals)
+    if (!face_normals && !UvDerivedTangentsOnly())
         CalcTangentSpace(m); // (with face_normals a PLY without stored normals has none to build the frame on)
     return m;
 }
@@ -373,7 +385,8 @@ MeshData LoadObj(const std::string &path, bool flip_texcoords, bool face_normals
     // the importer steps the reference asks for (model_loader.cpp:512-517), in assimp's order
     if (m.normals.empty() && !face_normals)
         GenerateSmoothNormals(m);
-    CalcTangentSpace(m); // from the file's or the generated normals; nothing without normals or texcoords
+    if (!UvDerivedTangentsOnly())
+        CalcTangentSpace(m); // from the file's or the generated normals; nothing without normals or texcoords
     if (face_normals)
         m.normals.clear(); // not handed over (model_loader.cpp:362); flat normals come from the commit (scene.cpp:51-56)
     return m;

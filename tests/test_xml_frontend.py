@@ -484,6 +484,21 @@ f -4/1/1 -3/2/1 -2/3/1
         translate(pkg, tmp_path, scene_xml('<shape type="obj"><string name="filename" value="missing.obj"/></shape>'))
 
 
+def test_uv_derived_tangents_switch(pkg, tmp_path, monkeypatch):
+    """MCPT_MESH_TANGENTS=uv (SURVEY.md section 8c's pin): an OBJ mesh is handed over without per-vertex tangents, so the
+    commit builds the reference's own per-triangle UV-derived frame (scene.cpp:63-80) instead of the restated importer's."""
+    obj = b"v 0 0 0\nv 1 0 0\nv 1 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvn 0 0 1\nf 1/1/1 2/2/1 3/3/1\n"
+    body = '<shape type="obj"><string name="filename" value="models/t.obj"/></shape>'
+    with_importer = translate(pkg, tmp_path, scene_xml(body), files={"models/t.obj": obj}).instances[0]
+    assert with_importer.tangents.shape == (3, 3) and with_importer.bitangents.shape == (3, 3)
+    monkeypatch.setenv("MCPT_MESH_TANGENTS", "uv")
+    pinned = translate(pkg, tmp_path, scene_xml(body), name="scene2.xml", files={"models/t.obj": obj}).instances[0]
+    assert pinned.tangents.size == 0 and pinned.bitangents.size == 0
+    np.testing.assert_array_equal(pinned.positions, with_importer.positions)
+    np.testing.assert_array_equal(pinned.normals, with_importer.normals)
+    np.testing.assert_array_equal(pinned.texcoords, with_importer.texcoords)
+
+
 def pfm_bytes(img):
     h, w, c = img.shape
     return f"{'PF' if c == 3 else 'Pf'}\n{w} {h}\n-1.0\n".encode() + img[::-1].astype("<f4").tobytes()
