@@ -3,7 +3,8 @@ Random scenes (test_random_combinations' generator with more
 seeds, plus mesh resolutions on both sides of the 2048-primitive switch to the vote walk, supplied
 tangents, object transforms), both walks, plain and counting kernels, against the oracle.  Round-1 result: profiles/r01_gpu_campaign.json.
 Round 2: every frame must EQUAL the oracle's (bit-exact device libm), and so must the frames of the other scheduling
-choices: stream kernel, work counter, camera-ray pre-pass (profiles/r02_gpu_campaign.json)."""
+choices: stream kernel, work counter, camera-ray pre-pass (profiles/r02_gpu_campaign.json).
+Round 3 adds: class sort off, image-order tiles, the stream kernel at 2 / 3 / 4 wavefronts per SIMD (profiles/r03_gpu_campaign.json)."""
 import sys, time, importlib, tempfile, os, json, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -50,6 +51,14 @@ for seed in seeds:
             f, _ = r.set_kernel(kernel).set_work_distribution(work).set_prepass(prepass).draw()
             others.append(bool(np.array_equal(f, a)))
         r.set_kernel(-1).set_work_distribution(-1).set_prepass(-1)
+        # round 3: class sort off, image-order tiles (no cost probe), the stream kernel's three register budgets
+        f, _ = r.set_class_sort(0).set_tile_order(0).draw()
+        others.append(bool(np.array_equal(f, a)))
+        r.set_class_sort(-1).set_tile_order(-1)
+        for waves in (2, 3, 4):
+            f, _ = r.set_kernel(4).set_work_distribution(1).set_prepass(1).set_stream_waves(waves).draw()
+            others.append(bool(np.array_equal(f, a)))
+        r.set_kernel(-1).set_work_distribution(-1).set_prepass(-1).set_stream_waves(-1)
         r.set_walk(True); b, _ = r.draw(); r.close()
         n += 1
         d = np.abs(a.astype(np.float64) - want)
