@@ -231,6 +231,7 @@ struct IntegratorRec // reference integrator.hpp:31-69 (the scalar part)
                            // the node phase when fewer lanes than this are searching; 0 = wait for all
     float walk_tie;        // distance below which two hits of the ordered walk count as tied (traversal.h,
                            // test_slot): ~40 float roundings at the scene's largest coordinate
+    float walk_extent;     // largest |coordinate| of any box plane of the ordered-walk hierarchy (fused slab test: traversal.h)
     float walk_sliver_reach; // culling slack while the best hit is a sliver (kWalkSliver): the largest amount a
                              // sliver's leaf box was grown by (commit.cpp), never below walk_tie; 0 = the scene has none
 };

@@ -1209,6 +1209,7 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
         // are "tied": the walk must visit both and decide like the reference (traversal.h, test_slot).
         // Offsets are at most (largest |coordinate| of the geometry or the eye) * 2.
         ig.walk_tie = 5e-6f * coordinate;
+        ig.walk_extent = coordinate + largest_grow; // (every box plane lies within the geometry's coordinates, grown sliver boxes included)
         ig.walk_sliver_reach = largest_grow > 0.0f ? std::max(ig.walk_tie, largest_grow) : 0.0f; // 0: no slivers
         fs.walk_prims.reserve(3 * slot_prim.size());
         for (const uint32_t prim : slot_prim)

@@ -605,6 +605,9 @@ MCPT_HD bool is_leading_lane()
 #endif
 }
 
+#ifndef MCPT_FUSED_SLAB
+#define MCPT_FUSED_SLAB 0 // (experiment switch: the slab test of the LDS-resident walk as one fma per plane, see walk_ordered)
+#endif
 #ifndef MCPT_SIGN_ADDRESSED_NODES
 #define MCPT_SIGN_ADDRESSED_NODES 1 // measured: cornell 992 -> 1007 Msamples/s, frame unchanged (profiles/r02_experiments)
 #endif
@@ -628,6 +631,23 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
     uint32_t cur = 0;   // the top node
 #if MCPT_SIGN_ADDRESSED_NODES && defined(__HIP_DEVICE_COMPILE__)
     const uint32_t near_x = ray.dir_rcp.x > 0 ? 0u : 4u, near_y = ray.dir_rcp.y > 0 ? 0u : 4u, near_z = ray.dir_rcp.z > 0 ? 0u : 4u;
+#if MCPT_FUSED_SLAB
+    // FUSED SLAB TEST (culling only).  The reference's plane distance is fl(fl(p - o) r): a subtraction and a product per
+    // plane.  Here it is fma(p, r, c) with c = -(o r) -/+ s fixed per ray: one operation.  The two differ by roundings —
+    // |fma(p, r, -fl(o r)) - fl(fl(p - o) r)| <= 3.01 eps |T| + 1.01 eps |o r| with T = (p - o) r the real value, |T| <= (M + |o|) |r|,
+    // M = the largest |coordinate| of any box plane (IntegratorRec::walk_extent), eps = 2^-24 — so the slack
+    // s = 2^-21 (M + 2 |o|) |r| (twice what the bound asks for, rounding of c and s included) makes every entry distance at most
+    // and every exit distance at least the reference's: a box the reference's test lets the ray into is entered here too.  What
+    // the looser test lets through in addition is stopped at the primitive by the exact leaf-box test (test_slot, kLeafCheck:
+    // the reference reaches a primitive exactly when its own leaf box passes — interior boxes are supersets and the test is
+    // monotone), so the answers are the reference's.
+    const float slab = 0x1p-21f;
+    const float qx = ray.origin.x * ray.dir_rcp.x, qy = ray.origin.y * ray.dir_rcp.y, qz = ray.origin.z * ray.dir_rcp.z;
+    const float sx = slab * ((sc.integrator.walk_extent + 2.0f * fabsf(ray.origin.x)) * fabsf(ray.dir_rcp.x));
+    const float sy = slab * ((sc.integrator.walk_extent + 2.0f * fabsf(ray.origin.y)) * fabsf(ray.dir_rcp.y));
+    const float sz = slab * ((sc.integrator.walk_extent + 2.0f * fabsf(ray.origin.z)) * fabsf(ray.dir_rcp.z));
+    const float cnx = -qx - sx, cfx = -qx + sx, cny = -qy - sy, cfy = -qy + sy, cnz = -qz - sz, cfz = -qz + sz;
+#endif
 #endif
     for (;;)
     {
@@ -654,12 +674,21 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
                 const float *w = reinterpret_cast<const float *>(sc.walk_nodes) + 16 * static_cast<size_t>(cur);
                 const float *wnx = w + near_x, *wfx = w + (4u - near_x), *wny = w + near_y + 1, *wfy = w + (5u - near_y),
                             *wnz = w + near_z + 2, *wfz = w + (6u - near_z);
+#if MCPT_FUSED_SLAB
+                const float nx0 = __builtin_fmaf(wnx[0], ray.dir_rcp.x, cnx), fx0 = __builtin_fmaf(wfx[0], ray.dir_rcp.x, cfx);
+                const float ny0 = __builtin_fmaf(wny[0], ray.dir_rcp.y, cny), fy0 = __builtin_fmaf(wfy[0], ray.dir_rcp.y, cfy);
+                const float nz0 = __builtin_fmaf(wnz[0], ray.dir_rcp.z, cnz), fz0 = __builtin_fmaf(wfz[0], ray.dir_rcp.z, cfz);
+                const float nx1 = __builtin_fmaf(wnx[8], ray.dir_rcp.x, cnx), fx1 = __builtin_fmaf(wfx[8], ray.dir_rcp.x, cfx);
+                const float ny1 = __builtin_fmaf(wny[8], ray.dir_rcp.y, cny), fy1 = __builtin_fmaf(wfy[8], ray.dir_rcp.y, cfy);
+                const float nz1 = __builtin_fmaf(wnz[8], ray.dir_rcp.z, cnz), fz1 = __builtin_fmaf(wfz[8], ray.dir_rcp.z, cfz);
+#else
                 const float nx0 = (wnx[0] - ray.origin.x) * ray.dir_rcp.x, fx0 = (wfx[0] - ray.origin.x) * ray.dir_rcp.x;
                 const float ny0 = (wny[0] - ray.origin.y) * ray.dir_rcp.y, fy0 = (wfy[0] - ray.origin.y) * ray.dir_rcp.y;
                 const float nz0 = (wnz[0] - ray.origin.z) * ray.dir_rcp.z, fz0 = (wfz[0] - ray.origin.z) * ray.dir_rcp.z;
                 const float nx1 = (wnx[8] - ray.origin.x) * ray.dir_rcp.x, fx1 = (wfx[8] - ray.origin.x) * ray.dir_rcp.x;
                 const float ny1 = (wny[8] - ray.origin.y) * ray.dir_rcp.y, fy1 = (wfy[8] - ray.origin.y) * ray.dir_rcp.y;
                 const float nz1 = (wnz[8] - ray.origin.z) * ray.dir_rcp.z, fz1 = (wfz[8] - ray.origin.z) * ray.dir_rcp.z;
+#endif
                 enter0 = fmaxf(fmaxf(fmaxf(kEpsDistance, nx0), ny0), nz0);
                 enter1 = fmaxf(fmaxf(fmaxf(kEpsDistance, nx1), ny1), nz1);
                 hit0 = enter0 <= fminf(fminf(fminf(ray.t_max, fx0), fy0), fz0);
@@ -697,7 +726,12 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
             if (is_leading_lane())
                 ++stats.wave_prim_steps;
         }
-        if (test_slot<kAny, kAnalytic, kSlivers>(sc, cur & ~kWalkLeaf, ray, hit, best) && kAny)
+#if MCPT_SIGN_ADDRESSED_NODES && defined(__HIP_DEVICE_COMPILE__) && MCPT_FUSED_SLAB
+        constexpr bool kLeafCheck = true; // the boxes on the way here were tested loosely: the primitive's own box decides
+#else
+        constexpr bool kLeafCheck = false;
+#endif
+        if (test_slot<kAny, kAnalytic, kSlivers, kLeafCheck>(sc, cur & ~kWalkLeaf, ray, hit, best) && kAny)
             return true;
         --depth;
         cur = stack[depth * kWalkStackStride];
