@@ -342,6 +342,11 @@ int mcpt_device_count(int *n_devices);
  * or 0xFFFFFFFF), geom[7k] = area, geom[7k+1..3] = lo, geom[7k+4..6] = hi.
  * seconds (may be NULL): build time; for the device builder it includes the copies
  * to and from the GPU. */
+/* Diagnostics / tests: the hand-out table the renderer lays out from probed tile costs (csrc/capi.cpp, CostOrderedTable):
+ * table[g] = the tile wavefront slot g of a one-pixel-per-lane launch renders.  steps: n_tiles words; layout 0 = cost order
+ * (most expensive first), 1 = the production layout (odd quarters reversed), 3 = greedy on the SIMDs' sums.  Host only. */
+int mcpt_debug_cost_table(const uint32_t *steps, uint32_t n_tiles, uint32_t n_cus, int layout, uint32_t *table);
+
 int mcpt_debug_lbvh_build(uint32_t n, const float *boxes, const float *areas, int on_device, uint32_t *links,
                           float *geom, double *seconds);
 

@@ -107,6 +107,7 @@ def lib():
     L.mcpt_renderer_last_choice.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(i32)]
     L.mcpt_renderer_last_kernel.argtypes = [vp]
     L.mcpt_renderer_last_kernel.restype = cp
+    L.mcpt_debug_cost_table.argtypes = [vp, u32, u32, i32, vp]
     L.mcpt_debug_lbvh_build.argtypes = [u32, vp, vp, i32, vp, vp, ctypes.POINTER(ctypes.c_double)]
     L.mcpt_debug_intersect.argtypes = [vp, u32, vp, vp, vp, vp]
     L.mcpt_debug_bsdf.argtypes = [vp, u32, i32, u32, vp, vp, vp, vp]
@@ -141,11 +142,19 @@ EXPORTED_SYMBOLS = [
     "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_set_walk", "mcpt_renderer_set_walk_schedule",
     "mcpt_renderer_set_kernel", "mcpt_renderer_last_kernel", "mcpt_renderer_check_walks", "mcpt_renderer_set_rng", "mcpt_renderer_set_prepass", "mcpt_renderer_set_lane_spread", "mcpt_renderer_set_pixel_order", "mcpt_renderer_set_work_distribution", "mcpt_renderer_last_choice",
     "mcpt_renderer_destroy",
-    "mcpt_renderer_calibrate", "mcpt_renderer_set_tile_order", "mcpt_renderer_set_class_sort", "mcpt_renderer_set_stream_waves", "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_trace_pixel", "mcpt_debug_trace_rate",
+    "mcpt_renderer_calibrate", "mcpt_renderer_set_tile_order", "mcpt_renderer_set_class_sort", "mcpt_renderer_set_stream_waves", "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_cost_table", "mcpt_debug_trace_pixel", "mcpt_debug_trace_rate",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
     "mcpt_config_serialize", "mcpt_tiled_renderer_create", "mcpt_tiled_renderer_draw",
     "mcpt_tiled_renderer_set_kernel", "mcpt_tiled_renderer_destroy", "mcpt_render_tiled", "mcpt_device_count",
 ]
+
+
+def debug_cost_table(steps, n_cus: int, layout: int = 1):
+    """The wavefront-slot -> tile table laid out from probed tile costs (csrc/capi.cpp, CostOrderedTable)."""
+    steps = np.ascontiguousarray(steps, np.uint32)
+    table = np.zeros(len(steps), np.uint32)
+    _check(lib().mcpt_debug_cost_table(steps.ctypes.data, len(steps), n_cus, layout, table.ctypes.data))
+    return table
 
 
 def lbvh_build(boxes, areas, on_device=False):

@@ -1609,6 +1609,23 @@ int mcpt_renderer_table(const mcpt_renderer *r, const char *what, const void **d
     return Fail("unknown table '" + w + "'");
 }
 
+int mcpt_debug_cost_table(const uint32_t *steps, uint32_t n_tiles, uint32_t n_cus, int layout, uint32_t *table)
+{
+    if (!steps || !table || n_tiles == 0 || n_cus == 0)
+        return Fail("mcpt_debug_cost_table: null argument or empty input");
+    try
+    {
+        const std::vector<unsigned long long> t = CostOrderedTable(std::vector<uint32_t>(steps, steps + n_tiles), n_cus, layout);
+        for (uint32_t g = 0; g < n_tiles; ++g)
+            table[g] = static_cast<uint32_t>(t[g]);
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        return Fail(e.what());
+    }
+}
+
 int mcpt_debug_lbvh_build(uint32_t n, const float *boxes, const float *areas, int on_device, uint32_t *links,
                           float *geom, double *seconds)
 {

@@ -126,6 +126,31 @@ def test_image_writers(pkg, lib, tmp_path):
         pkg.capi.write_image(tmp_path / "a.bmp", frame)
 
 
+@pytest.mark.parametrize("n_cus, n_tiles", [(256, 4096), (8, 128), (256, 2400), (4, 7)])
+def test_cost_ordered_table_layout(n_cus, n_tiles, pkg, lib):
+    """capi.cpp::CostOrderedTable (wavefronts laid out by probed tile cost): every layout is a permutation of the tiles;
+    layout 0 is the cost order; the production layout (1) gives every SIMD of a fully resident one-pixel-per-lane launch —
+    wavefront g = 4 (cu + k n_cus) + w, k = 0..3, sits on SIMD (cu, w) — one tile of each quarter of the cost order, and the
+    SIMDs' sums differ far less than in plain cost order."""
+    rng = np.random.default_rng(n_tiles)
+    steps = (rng.gamma(4.0, 150.0, n_tiles)).astype(np.uint32) + 1
+    order = np.argsort(-steps.astype(np.int64), kind="stable")
+    tables = {layout: pkg.capi.debug_cost_table(steps, n_cus, layout) for layout in (0, 1, 3)}
+    for layout, t in tables.items():
+        assert sorted(t.tolist()) == list(range(n_tiles)), layout
+    np.testing.assert_array_equal(tables[0], order)
+    if n_tiles == 16 * n_cus:
+        g = np.arange(n_tiles)
+        simd = ((g // 4) % n_cus) * 4 + (g % 4)
+        rank = np.empty(n_tiles, np.int64)
+        rank[order] = np.arange(n_tiles)
+        quarter = rank[tables[1]] // (n_tiles // 4)
+        for s_id in range(0, 4 * n_cus, max(1, n_cus // 4)):
+            assert sorted(quarter[simd == s_id].tolist()) == [0, 1, 2, 3]
+        spread = {layout: np.ptp(np.bincount(simd, weights=steps[t].astype(np.float64))) for layout, t in tables.items()}
+        assert spread[3] < spread[1] < spread[0], spread
+
+
 def test_tile_unpack(pkg, lib):
     w, h = 21, 13
     frame = np.zeros((h, w, 3), dtype=np.float32)
