@@ -254,10 +254,12 @@ int mcpt_renderer_set_class_sort(mcpt_renderer *r, int mode);
 
 /* Register budget of the stream kernel's instantiation on scenes outside LDS (surface materials): compiled for 4, 3 or 2
  * wavefronts per SIMD (128 / 168 / 256 VGPRs: 288 / 210 / 4 spilled registers).  The image does not depend on it.
- * -1 (default): the library's rule — a chain-bound job (fewer pixels whose camera ray hits something than the GPU holds
- * lanes: dragon/scene.xml 1280 x 720) runs at 2 (186 -> 170 ms), a throughput-bound one at 3 (matpreview rough conductor 990 ->
- * 848 ms) unless the scene has a transmissive BSDF (rough dielectric: 1268 ms at 4, 1287 at 3); the first draw of a tile range starts at 3 and switches when the pre-pass's hit count
- * is known.  No reference counterpart (its CUDA back end compiles one megakernel at whatever the compiler allots). */
+ * -1 (default): the library's rule — scenes without a dielectric or thin dielectric run the instantiations compiled
+ * without those models at 3 (matpreview rough conductor 990 -> 831 ms, dragon/scene.xml 185 -> 172 ms against the full set
+ * at 4); scenes with one keep the full set, at 4 when throughput-bound (rough dielectric: 1268 ms at 4, 1287 at 3) and at
+ * 2 when chain-bound (fewer pixels whose camera ray hits something than the GPU holds lanes; decided in the first draw of
+ * a tile range, when the pre-pass's hit count is known).  No reference counterpart (its CUDA back end compiles one
+ * megakernel at whatever the compiler allots). */
 int mcpt_renderer_set_stream_waves(mcpt_renderer *r, int waves);
 
 /* Primary-visibility pre-pass (csrc/hip/primary_kernel.hip): the camera ray of sample s of pixel p is a function of

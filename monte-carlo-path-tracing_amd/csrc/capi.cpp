@@ -950,14 +950,14 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                     r->range_hits += hit_words[k];
                 r->range_fresh = true, r->mesh_table_ready = false;
                 r->cost_order_tiles = n_tiles, r->cost_order_first = range.tile_first, r->cost_order_stride = range.tile_stride;
-                // REGISTER BUDGET of the stream kernel (hip/stream_kernel_impl.h, StreamBudget): a chain-bound job — fewer
-                // expensive pixels than the GPU holds lanes: dragon/scene.xml — runs the instantiation without spills at 2
-                // wavefronts per SIMD (186 -> 170 ms), a throughput-bound one the one at 3 (matpreview rough conductor 990 ->
-                // 848 ms, rough dielectric 1268 -> 1287 ms; 4 wavefronts per SIMD is mcpt_renderer_set_stream_waves(r, 4))
+                // REGISTER BUDGET of the stream kernel (hip/stream_kernel_impl.h, StreamBudget).  Scenes without a transmissive BSDF
+                // run the instantiations that leave those models out, at 3 wavefronts per SIMD (79-86 spilled VGPRs): matpreview
+                // rough conductor 990 -> 831 ms against the full set at 4, dragon/scene.xml (medians of 7, one box) 185 -> 172 ms —
+                // and 184 at 2 wavefronts without any spill: its 175 000 chains all fit the lanes at 3.  Scenes WITH one keep the full
+                // set: at 4 when throughput-bound (rough dielectric 1268 ms, 1287 at 3), at 2 — no spills — when chain-bound
+                // (fewer pixels whose camera ray hits something than the GPU holds lanes).
                 const unsigned long long expensive = r->range_hits / std::max(1u, r->dev.camera.spp);
-                // (throughput-bound with a transmissive BSDF — long chains of bounces inside the object, the walk dominates: the
-                //  default budget, rough dielectric 1268 against 1287 ms at 3)
-                r->stream_waves_auto = expensive <= uint64_t(r->n_cus) * 1024u ? 2u : r->flat.integrator.has_transmission ? 4u : 3u;
+                r->stream_waves_auto = !r->flat.integrator.has_transmission ? 3u : expensive <= uint64_t(r->n_cus) * 1024u ? 2u : 4u;
                 if (streamed && plan.waves != StreamWavesFor(r, counted))
                 {
                     plan.waves = StreamWavesFor(r, counted);
