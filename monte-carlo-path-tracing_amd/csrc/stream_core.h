@@ -490,6 +490,14 @@ MCPT_HD bool pool_test_slot(const DeviceScene &sc, uint32_t slot, bool any, Ray 
 #ifndef MCPT_STREAM_WIDE
 #define MCPT_STREAM_WIDE 0
 #endif
+// SPECULATIVE SEARCH (-DMCPT_STREAM_SPECULATE=1): a lane whose walk arrives at a primitive does not wait for the wavefront's
+// primitive phase — it sets the primitive aside (one per lane) and goes on searching from its stack with the bound it has; the
+// primitive is tested in the next primitive phase.  The answers do not change: a later test can only have left the bound
+// larger than it would have been (more nodes visited, never fewer), and the primitive test decides ties by replaying the
+// reference on the pair, whatever the order (traversal.h, test_slot).
+#ifndef MCPT_STREAM_SPECULATE
+#define MCPT_STREAM_SPECULATE 0
+#endif
 
 // ---- slot storage -----------------------------------------------------------------------------
 // Structure of arrays over the P slots of a workgroup: field f of slot i at [f * P + i], so that the
@@ -676,9 +684,12 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
     ClosestState best{false, 0.0f, 0};
     uint32_t depth = 1, cur = kWalkDone;
     constexpr bool kWideTrace = MCPT_STREAM_WIDE != 0;
+    constexpr bool kSpeculate = MCPT_STREAM_SPECULATE != 0 && !kWideTrace;
+    uint32_t held = kWalkDone; // kSpeculate: the primitive set aside (kWalkDone: none)
     ShortStack<kWideRing> wstack = wide_stack_of(sc, stack);
     auto begin_walk = [&]()
     {
+        held = kWalkDone;
         if (kWideTrace)
             wstack.reset(), wstack.store(0, kWalkDone);
         else
@@ -716,7 +727,7 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
             const uint32_t n_searching = lanes_where(searching);
             if (n_searching == 0)
                 break;
-            const uint32_t n_free = lanes_where(cur == kWalkDone), n_holding = n_lanes - n_searching - n_free;
+            const uint32_t n_free = lanes_where(cur == kWalkDone && (!kSpeculate || held == kWalkDone)), n_holding = n_lanes - n_searching - n_free;
             if (n_holding > n_searching || (!pool_empty && n_free >= fetch_at))
                 break; // (each exit is followed by progress below: a primitive phase or a fetch)
             if (searching && kWideTrace)
@@ -748,10 +759,24 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
                 stack[depth * kWalkStackStride] = first0 ? ref1 : ref0;
                 depth = depth + (both ? 1u : 0u) - (none ? 1u : 0u);
                 cur = none ? postponed : toward;
+                if (kSpeculate)
+                {
+                    // arrived at a primitive with nothing set aside yet: set it aside and take the next postponed reference
+                    // (depth >= 1 here: entry 0 is the sentinel)
+                    const bool aside = (cur & kWalkLeaf) != 0 && cur != kWalkDone && held == kWalkDone;
+                    const uint32_t below = stack[(depth ? depth - 1u : 0u) * kWalkStackStride];
+                    held = aside ? cur : held;
+                    depth -= aside ? 1u : 0u;
+                    cur = aside ? below : cur;
+                }
             }
         }
         // ---- primitive phase: every lane that holds a primitive tests it ----
-        if ((cur & kWalkLeaf) != 0 && cur != kWalkDone)
+        // (kSpeculate: the primitive set aside comes first and the lane's cursor stays where it is; a lane that is still
+        //  searching tests its set-aside primitive too — the wavefront is in its primitive phase anyway, and the bound shrinks
+        //  earlier)
+        const bool from_aside = kSpeculate && held != kWalkDone;
+        if (from_aside || ((cur & kWalkLeaf) != 0 && cur != kWalkDone))
         {
             if (kCount)
             {
@@ -760,20 +785,23 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
                     ++cnt->wave_prim_steps;
             }
             const bool any = kind != 0;
-            if (pool_test_slot<C::kAnalytic, C::kSlivers, kWideTrace>(sc, cur & ~kWalkLeaf, any, ray, hit, best) && any)
+            const uint32_t p = from_aside ? held : cur;
+            held = kWalkDone;
+            if (pool_test_slot<C::kAnalytic, C::kSlivers, kWideTrace>(sc, p & ~kWalkLeaf, any, ray, hit, best) && any)
                 cur = kWalkDone;
-            else
+            else if (!from_aside)
             {
                 --depth;
                 cur = kWideTrace ? wstack.load(depth) : stack[depth * kWalkStackStride];
             }
         }
         // ---- retire finished rays, fetch new ones ----
-        const uint32_t n_free = lanes_where(cur == kWalkDone);
+        const bool lane_free = cur == kWalkDone && (!kSpeculate || held == kWalkDone);
+        const uint32_t n_free = lanes_where(lane_free);
         if (n_free == n_lanes || (n_free >= fetch_at && !pool_empty))
         {
             fetch_at = refill_at;
-            if (my != kNone && cur == kWalkDone)
+            if (my != kNone && lane_free)
             {
                 if (my == kOwnRayId)
                 {
