@@ -1,6 +1,6 @@
-"""GPU box: BASELINE configs at their full film sizes, HIP frame vs the oracle's frame
-(about 11 minutes of box time, most of it the CPU oracle).  The matpreview / volumetric
-configurations come from scratch/real/*.mcsd (tools/convert_reference_scenes.py)."""
+"""GPU box: every BASELINE configuration at its FULL film and spp (monte-carlo-path-tracing_amd/workloads.py: the
+reference's own scene files through the product's front end), HIP frame vs the oracle's frame, pixel by pixel
+(about 12 minutes of box time, most of it the CPU oracle).  Not collected by pytest: python tests/full_size_parity.py"""
 import sys, os, time, json, tempfile
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,19 +10,19 @@ pkg = load_package()
 import checkers
 from mcpt_amd import capi
 orc = checkers.Oracle()
-os.makedirs('/tmp/standin', exist_ok=True)
-pkg.mcsd.dump(pkg.scenes.blob_field_scene(), '/tmp/standin/blob.mcsd')
-CASES = [('config 2: cornell-box 512x512 spp 256', 'builtin:cornell-box', (512, 512, 256)),
-         ('config 3 stand-in: blob field 0.8M triangles 1280x720 spp 256', '/tmp/standin/blob.mcsd', (1280, 720, 256)),
-         ('config 4: matpreview rough_conductor 1024x1024 spp 512', 'scratch/real/matpreview_rough_conductor.mcsd', (1024, 1024, 512)),
-         ('config 4: matpreview rough_dielectric 1024x1024 spp 512', 'scratch/real/matpreview_rough_dielectric.mcsd', (1024, 1024, 512)),
-         ('config 5: volumetric-caustic 1280x720 spp 1024', 'scratch/real/volumetric_caustic.mcsd', (1280, 720, 1024))]
+CASES = [('config 2: cornell-box 512x512 spp 256', 'cornell'),
+         ('config 3: dragon/scene.xml 1280x720 spp 256 (12 shipped meshes + stand-ins, 831 580 triangles)', 'dragon'),
+         ('config 4: matpreview rough_conductor 1024x1024 spp 512', 'matpreview-rc'),
+         ('config 4: matpreview rough_dielectric 1024x1024 spp 512', 'matpreview-rd'),
+         ('config 5: volumetric-caustic 1280x720 spp 1024', 'volumetric')]
 out = []
-for name, src, film in CASES:
-    cfg = (capi.Config.builtin(src[8:]) if src.startswith('builtin:') else capi.Config.load_mcsd(src)).set_film(*film)
+for name, workload in CASES:
+    film = pkg.workloads.WORKLOADS[workload][1]
+    cfg = pkg.workloads.config(workload)
     p = tempfile.mktemp(suffix='.mcsd'); cfg.save_mcsd(p)
     r = capi.Renderer(cfg)
     r.draw(); frame, st = r.draw()
+    r_name = r.last_kernel()
     r.close()
     t = time.time(); want, info = orc.render(p); t_cpu = time.time() - t
     d = frame.astype(np.float64) - want
@@ -31,7 +31,7 @@ for name, src, film in CASES:
     rec = {'config': name, 'film': film, 'rmse': float(np.sqrt((d ** 2).mean())), 'mean_l2': float(l2.mean()),
            'median_l2': float(np.median(l2)), 'max_l2': float(l2.max()), 'frac_l2_over_1e-3': float((l2 > 1e-3).mean()),
            'frac_bit_exact': float((l2 == 0).mean()), 'hip_kernel_ms': st['kernel_milliseconds'],
-           'hip_msamples_per_s': n / st['kernel_milliseconds'] / 1e3, 'oracle_seconds': info['seconds'],
+           'hip_kernel': r_name, 'hip_msamples_per_s': n / st['kernel_milliseconds'] / 1e3, 'oracle_seconds': info['seconds'],
            'oracle_msamples_per_s': n / info['seconds'] / 1e6, 'oracle_threads': os.cpu_count()}
     print(json.dumps(rec), flush=True)
     out.append(rec)
