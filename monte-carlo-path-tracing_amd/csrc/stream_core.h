@@ -495,6 +495,14 @@ MCPT_HD bool pool_test_slot(const DeviceScene &sc, uint32_t slot, bool any, Ray 
 // primitive is tested in the next primitive phase.  The answers do not change: a later test can only have left the bound
 // larger than it would have been (more nodes visited, never fewer), and the primitive test decides ties by replaying the
 // reference on the pair, whatever the order (traversal.h, test_slot).
+// When the wavefront leaves its node phase for a primitive phase: holding lanes x NUM > searching lanes x DEN.  Round 3, one box,
+// 1:1 / 2:1 / 1:2: matpreview rough conductor 209.5 / 209.9 / 216.1 ms, rough dielectric 317.2 / 316.3 / 328.2, dragon 160.8 / 162.6 / 169.6.
+#ifndef MCPT_STREAM_HOLD_NUM
+#define MCPT_STREAM_HOLD_NUM 1u
+#endif
+#ifndef MCPT_STREAM_HOLD_DEN
+#define MCPT_STREAM_HOLD_DEN 1u
+#endif
 #ifndef MCPT_STREAM_SPECULATE
 #define MCPT_STREAM_SPECULATE 0
 #endif
@@ -728,7 +736,7 @@ MCPT_HD void stream_trace(const DeviceScene &sc, const StreamStore &m, const Str
             if (n_searching == 0)
                 break;
             const uint32_t n_free = lanes_where(cur == kWalkDone && (!kSpeculate || held == kWalkDone)), n_holding = n_lanes - n_searching - n_free;
-            if (n_holding > n_searching || (!pool_empty && n_free >= fetch_at))
+            if (MCPT_STREAM_HOLD_NUM * n_holding > MCPT_STREAM_HOLD_DEN * n_searching || (!pool_empty && n_free >= fetch_at))
                 break; // (each exit is followed by progress below: a primitive phase or a fetch)
             if (searching && kWideTrace)
             {
