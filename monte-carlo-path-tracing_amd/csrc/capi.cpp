@@ -1039,6 +1039,8 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                 }
                 if (probed)
                     job.tile_order = r->mesh_table_dev;
+                else if (CostOrderEnv() >= 1 && range_stats)
+                    job.tile_order = nullptr; // (not of the ordered class — the host knows the hit count: image order, no table)
                 else
                 {
                     Check(mcpt::LaunchTileOrder(r->dev, job, r->prehit_dev, r->tile_keys_dev, r->tile_keys_dev + r->tile_keys_capacity, r->tile_temp_dev,
