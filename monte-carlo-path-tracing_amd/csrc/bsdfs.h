@@ -552,7 +552,8 @@ MCPT_HD constexpr bool bsdf_kind_compiled(uint32_t kind) { return ((MCPT_BSDF_KI
 
 // kTransmission == false: the caller guarantees a scene without dielectric / thin dielectric BSDFs (device_scene.h,
 // kFeatNoTransmission); their code is left out.
-template <bool kMicrofacet, uint32_t kOnly = 0, bool kTransmission = true>
+// kReflectors == false: likewise without rough diffuse / conductor / thin dielectric / plastic (kFeatDielectricOnly).
+template <bool kMicrofacet, uint32_t kOnly = 0, bool kTransmission = true, bool kReflectors = true>
 MCPT_HD void bsdf_sample(const ShadeTables &T, const BsdfRec &b, uint32_t &rng, BsdfQuery &q)
 {
     if (kOnly == kBsdfNoCode)
@@ -566,16 +567,16 @@ MCPT_HD void bsdf_sample(const ShadeTables &T, const BsdfRec &b, uint32_t &rng, 
     }
     switch (kind)
     {
-    case kBsdfRoughDiffuse: if (bsdf_kind_compiled(kBsdfRoughDiffuse)) rough_diffuse_sample(T, b, rng, q); break;
-    case kBsdfConductor: if (bsdf_kind_compiled(kBsdfConductor)) conductor_sample(T, b, rng, q); break;
+    case kBsdfRoughDiffuse: if (kReflectors && bsdf_kind_compiled(kBsdfRoughDiffuse)) rough_diffuse_sample(T, b, rng, q); break;
+    case kBsdfConductor: if (kReflectors && bsdf_kind_compiled(kBsdfConductor)) conductor_sample(T, b, rng, q); break;
     case kBsdfDielectric: if (kTransmission && bsdf_kind_compiled(kBsdfDielectric)) dielectric_sample(T, b, rng, q); break;
-    case kBsdfThinDielectric: if (kTransmission && bsdf_kind_compiled(kBsdfThinDielectric)) thin_dielectric_sample(T, b, rng, q); break;
-    case kBsdfPlastic: if (bsdf_kind_compiled(kBsdfPlastic)) plastic_sample(T, b, rng, q); break;
+    case kBsdfThinDielectric: if (kTransmission && kReflectors && bsdf_kind_compiled(kBsdfThinDielectric)) thin_dielectric_sample(T, b, rng, q); break;
+    case kBsdfPlastic: if (kReflectors && bsdf_kind_compiled(kBsdfPlastic)) plastic_sample(T, b, rng, q); break;
     default: break;
     }
 }
 
-template <bool kMicrofacet, uint32_t kOnly = 0, bool kTransmission = true>
+template <bool kMicrofacet, uint32_t kOnly = 0, bool kTransmission = true, bool kReflectors = true>
 MCPT_HD void bsdf_eval(const ShadeTables &T, const BsdfRec &b, BsdfQuery &q)
 {
     if (kOnly == kBsdfNoCode)
@@ -589,11 +590,11 @@ MCPT_HD void bsdf_eval(const ShadeTables &T, const BsdfRec &b, BsdfQuery &q)
     }
     switch (kind)
     {
-    case kBsdfRoughDiffuse: if (bsdf_kind_compiled(kBsdfRoughDiffuse)) rough_diffuse_eval(T, b, q); break;
-    case kBsdfConductor: if (bsdf_kind_compiled(kBsdfConductor)) conductor_eval(T, b, q); break;
+    case kBsdfRoughDiffuse: if (kReflectors && bsdf_kind_compiled(kBsdfRoughDiffuse)) rough_diffuse_eval(T, b, q); break;
+    case kBsdfConductor: if (kReflectors && bsdf_kind_compiled(kBsdfConductor)) conductor_eval(T, b, q); break;
     case kBsdfDielectric: if (kTransmission && bsdf_kind_compiled(kBsdfDielectric)) dielectric_eval(T, b, q); break;
-    case kBsdfThinDielectric: if (kTransmission && bsdf_kind_compiled(kBsdfThinDielectric)) thin_dielectric_eval(T, b, q); break;
-    case kBsdfPlastic: if (bsdf_kind_compiled(kBsdfPlastic)) plastic_eval(T, b, q); break;
+    case kBsdfThinDielectric: if (kTransmission && kReflectors && bsdf_kind_compiled(kBsdfThinDielectric)) thin_dielectric_eval(T, b, q); break;
+    case kBsdfPlastic: if (kReflectors && bsdf_kind_compiled(kBsdfPlastic)) plastic_eval(T, b, q); break;
     default: break;
     }
 }

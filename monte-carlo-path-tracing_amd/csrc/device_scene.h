@@ -226,6 +226,7 @@ struct IntegratorRec // reference integrator.hpp:31-69 (the scalar part)
     uint32_t walk_depth;   // stack entries a lane needs: the tree's depth + 1 (sentinel)
     uint32_t has_masks;    // some BSDF carries an opacity map: the walk must keep the reference's order
     uint32_t has_transmission; // some BSDF is a dielectric or a thin dielectric
+    uint32_t has_reflectors;   // some BSDF is a rough diffuse, conductor, thin dielectric or plastic model
     uint32_t walk_hold;    // ... or when at least this many lanes hold a primitive (0 = never for that reason)
     uint32_t walk_break;   // wavefront scheduling of the ordered walk (traversal.h, walk_ordered_vote): leave
                            // the node phase when fewer lanes than this are searching; 0 = wait for all
@@ -261,6 +262,9 @@ enum SceneFeature : uint32_t
     // stream kernel only: the instantiation leaves the transmissive BSDFs (dielectric, thin dielectric) out — for scenes
     // without one (IntegratorRec::has_transmission == 0): 210 -> 53 spilled VGPRs at the 3-wavefront budget
     kFeatNoTransmission = 1u << 11,
+    // stream kernel only: of the models beyond diffuse only the dielectric is compiled in — for scenes whose other BSDFs are all
+    // diffuse (IntegratorRec::has_reflectors == 0: matpreview rough dielectric): 288 -> 214 spilled VGPRs at the default budget
+    kFeatDielectricOnly = 1u << 12,
 };
 
 // Device view: raw pointers into HBM + the scalar records.

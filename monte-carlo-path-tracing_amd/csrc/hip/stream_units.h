@@ -1,5 +1,5 @@
 // Which translation unit instantiates which stream-kernel variant (stream_variants.inc): a unit defines
-// MCPT_STREAM_UNIT (0..7) before including this header and gets explicit instantiations of its own variants;
+// MCPT_STREAM_UNIT (0..8) before including this header and gets explicit instantiations of its own variants;
 // every other unit's variants are declared `extern template`, so that `make -j` compiles the units side by side.
 #ifndef MCPT_STREAM_UNITS_H
 #define MCPT_STREAM_UNITS_H
@@ -61,6 +61,12 @@ namespace mcpt
 #define MCPT_STREAM_DECL_7 MCPT_STREAM_DEFINE
 #else
 #define MCPT_STREAM_DECL_7 MCPT_STREAM_EXTERN
+#endif
+
+#if MCPT_STREAM_UNIT == 8
+#define MCPT_STREAM_DECL_8 MCPT_STREAM_DEFINE
+#else
+#define MCPT_STREAM_DECL_8 MCPT_STREAM_EXTERN
 #endif
 
 #define X(index, features, S, counted, small, hot, regs, unit, name) MCPT_STREAM_DECL_##unit(features, S, counted, small, hot, regs)

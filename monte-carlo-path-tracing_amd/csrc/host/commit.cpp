@@ -1312,12 +1312,14 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
             // use_fast_approx is parsed but never reaches the committed BSDF in
             // the reference (bsdf.cpp:139-144): the full Oren-Nayar model runs.
             o.kind = kBsdfRoughDiffuse;
+            fs.integrator.has_reflectors = 1;
             o.tex0 = b.id_diffuse_reflectance, o.tex1 = b.id_roughness;
             check(o.tex0, false), check(o.tex1, false);
             fs.features |= kFeatMicrofacet;
             break;
         case MCSD_BSDF_CONDUCTOR:
             o.kind = kBsdfConductor;
+            fs.integrator.has_reflectors = 1;
             o.tex0 = b.id_roughness_u, o.tex1 = b.id_roughness_v, o.tex2 = b.id_specular_reflectance;
             check(o.tex0, false), check(o.tex1, false), check(o.tex2, false);
             o.reflectivity3 = Vec3f{b.reflectivity[0], b.reflectivity[1], b.reflectivity[2]};
@@ -1329,6 +1331,8 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
         case MCSD_BSDF_THIN_DIELECTRIC:
             o.kind = b.type == MCSD_BSDF_DIELECTRIC ? kBsdfDielectric : kBsdfThinDielectric;
             fs.integrator.has_transmission = 1;
+            if (b.type == MCSD_BSDF_THIN_DIELECTRIC)
+                fs.integrator.has_reflectors = 1;
             if (b.type == MCSD_BSDF_DIELECTRIC)
             {
                 o.f_avg = AverageFresnelDielectric(b.eta);
@@ -1345,6 +1349,7 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
             break;
         case MCSD_BSDF_PLASTIC:
             o.kind = kBsdfPlastic;
+            fs.integrator.has_reflectors = 1;
             o.tex0 = b.id_roughness, o.tex1 = b.id_diffuse_reflectance, o.tex2 = b.id_specular_reflectance;
             check(o.tex0, false), check(o.tex1, false), check(o.tex2, false);
             o.reflectivity = sqr(b.eta - 1.0f) / sqr(b.eta + 1.0f);

@@ -43,6 +43,7 @@ struct Config
     static constexpr bool kVote = (kFeatures & kFeatVoteWalk) != 0;       // ... scheduled by wavefront vote
     static constexpr bool kSlivers = (kFeatures & kFeatSlivers) != 0;     // ... with the sliver handling of test_slot
     static constexpr bool kTransmission = (kFeatures & kFeatNoTransmission) == 0; // dielectric / thin dielectric compiled in
+    static constexpr bool kReflectors = (kFeatures & kFeatDielectricOnly) == 0;   // rough diffuse / conductor / thin dielectric / plastic compiled in
     static constexpr bool kWide = (kFeatures & kFeatWideWalk) != 0;       // ... on the 4-wide quantised hierarchy
 };
 
@@ -220,7 +221,7 @@ MCPT_HD BsdfQuery eval_at(const DeviceScene &sc, const Surface &s, uint32_t bsdf
     BsdfQuery q = query_at(s, wo, -wi);
     q.wi = wi;
     if (bsdf != kNone)
-        bsdf_eval<C::kMicrofacet, kOnly, C::kTransmission>(shade_tables<C>(sc), sc.bsdfs[bsdf], q);
+        bsdf_eval<C::kMicrofacet, kOnly, C::kTransmission, C::kReflectors>(shade_tables<C>(sc), sc.bsdfs[bsdf], q);
     else
         q.pdf = 1, q.attenuation = V3{1, 1, 1}, q.valid = true;
     return q;
@@ -559,7 +560,7 @@ MCPT_HD void path_connect_scatter(const DeviceScene &sc, PathState &st, LaneCoun
         BsdfQuery q = query_at(surf, st.wo, st.wo); // path.cpp:268-296
         if (bsdf != kNone)
         {
-            bsdf_sample<C::kMicrofacet, 0, C::kTransmission>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
+            bsdf_sample<C::kMicrofacet, 0, C::kTransmission, C::kReflectors>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
         }
         else
         {
