@@ -550,10 +550,9 @@ constexpr uint32_t kBsdfNoCode = 0xFFu;
 #endif
 MCPT_HD constexpr bool bsdf_kind_compiled(uint32_t kind) { return ((MCPT_BSDF_KINDS >> kind) & 1u) != 0; }
 
-// kTransmission == false: the caller guarantees a scene without dielectric / thin dielectric BSDFs (device_scene.h,
-// kFeatNoTransmission); their code is left out.
-// kReflectors == false: likewise without rough diffuse / conductor / thin dielectric / plastic (kFeatDielectricOnly).
-template <bool kMicrofacet, uint32_t kOnly = 0, bool kTransmission = true, bool kReflectors = true>
+// kKinds: bit per BsdfKind the instantiation compiles — the caller guarantees that the scene has no other (device_scene.h:
+// kFeatNoTransmission, kFeatDielectricOnly, kFeatConductorOnly; path_core.h, Config::kKinds).
+template <bool kMicrofacet, uint32_t kOnly = 0, uint32_t kKinds = 0xFFFFFFFFu>
 MCPT_HD void bsdf_sample(const ShadeTables &T, const BsdfRec &b, uint32_t &rng, BsdfQuery &q)
 {
     if (kOnly == kBsdfNoCode)
@@ -567,16 +566,16 @@ MCPT_HD void bsdf_sample(const ShadeTables &T, const BsdfRec &b, uint32_t &rng, 
     }
     switch (kind)
     {
-    case kBsdfRoughDiffuse: if (kReflectors && bsdf_kind_compiled(kBsdfRoughDiffuse)) rough_diffuse_sample(T, b, rng, q); break;
-    case kBsdfConductor: if (kReflectors && bsdf_kind_compiled(kBsdfConductor)) conductor_sample(T, b, rng, q); break;
-    case kBsdfDielectric: if (kTransmission && bsdf_kind_compiled(kBsdfDielectric)) dielectric_sample(T, b, rng, q); break;
-    case kBsdfThinDielectric: if (kTransmission && kReflectors && bsdf_kind_compiled(kBsdfThinDielectric)) thin_dielectric_sample(T, b, rng, q); break;
-    case kBsdfPlastic: if (kReflectors && bsdf_kind_compiled(kBsdfPlastic)) plastic_sample(T, b, rng, q); break;
+    case kBsdfRoughDiffuse: if (((kKinds >> kBsdfRoughDiffuse) & 1u) && bsdf_kind_compiled(kBsdfRoughDiffuse)) rough_diffuse_sample(T, b, rng, q); break;
+    case kBsdfConductor: if (((kKinds >> kBsdfConductor) & 1u) && bsdf_kind_compiled(kBsdfConductor)) conductor_sample(T, b, rng, q); break;
+    case kBsdfDielectric: if (((kKinds >> kBsdfDielectric) & 1u) && bsdf_kind_compiled(kBsdfDielectric)) dielectric_sample(T, b, rng, q); break;
+    case kBsdfThinDielectric: if (((kKinds >> kBsdfThinDielectric) & 1u) && bsdf_kind_compiled(kBsdfThinDielectric)) thin_dielectric_sample(T, b, rng, q); break;
+    case kBsdfPlastic: if (((kKinds >> kBsdfPlastic) & 1u) && bsdf_kind_compiled(kBsdfPlastic)) plastic_sample(T, b, rng, q); break;
     default: break;
     }
 }
 
-template <bool kMicrofacet, uint32_t kOnly = 0, bool kTransmission = true, bool kReflectors = true>
+template <bool kMicrofacet, uint32_t kOnly = 0, uint32_t kKinds = 0xFFFFFFFFu>
 MCPT_HD void bsdf_eval(const ShadeTables &T, const BsdfRec &b, BsdfQuery &q)
 {
     if (kOnly == kBsdfNoCode)
@@ -590,11 +589,11 @@ MCPT_HD void bsdf_eval(const ShadeTables &T, const BsdfRec &b, BsdfQuery &q)
     }
     switch (kind)
     {
-    case kBsdfRoughDiffuse: if (kReflectors && bsdf_kind_compiled(kBsdfRoughDiffuse)) rough_diffuse_eval(T, b, q); break;
-    case kBsdfConductor: if (kReflectors && bsdf_kind_compiled(kBsdfConductor)) conductor_eval(T, b, q); break;
-    case kBsdfDielectric: if (kTransmission && bsdf_kind_compiled(kBsdfDielectric)) dielectric_eval(T, b, q); break;
-    case kBsdfThinDielectric: if (kTransmission && kReflectors && bsdf_kind_compiled(kBsdfThinDielectric)) thin_dielectric_eval(T, b, q); break;
-    case kBsdfPlastic: if (kReflectors && bsdf_kind_compiled(kBsdfPlastic)) plastic_eval(T, b, q); break;
+    case kBsdfRoughDiffuse: if (((kKinds >> kBsdfRoughDiffuse) & 1u) && bsdf_kind_compiled(kBsdfRoughDiffuse)) rough_diffuse_eval(T, b, q); break;
+    case kBsdfConductor: if (((kKinds >> kBsdfConductor) & 1u) && bsdf_kind_compiled(kBsdfConductor)) conductor_eval(T, b, q); break;
+    case kBsdfDielectric: if (((kKinds >> kBsdfDielectric) & 1u) && bsdf_kind_compiled(kBsdfDielectric)) dielectric_eval(T, b, q); break;
+    case kBsdfThinDielectric: if (((kKinds >> kBsdfThinDielectric) & 1u) && bsdf_kind_compiled(kBsdfThinDielectric)) thin_dielectric_eval(T, b, q); break;
+    case kBsdfPlastic: if (((kKinds >> kBsdfPlastic) & 1u) && bsdf_kind_compiled(kBsdfPlastic)) plastic_eval(T, b, q); break;
     default: break;
     }
 }

@@ -226,6 +226,7 @@ struct IntegratorRec // reference integrator.hpp:31-69 (the scalar part)
     uint32_t walk_depth;   // stack entries a lane needs: the tree's depth + 1 (sentinel)
     uint32_t has_masks;    // some BSDF carries an opacity map: the walk must keep the reference's order
     uint32_t has_transmission; // some BSDF is a dielectric or a thin dielectric
+    uint32_t has_non_conductor; // some BSDF is a rough diffuse, dielectric, thin dielectric or plastic model
     uint32_t has_reflectors;   // some BSDF is a rough diffuse, conductor, thin dielectric or plastic model
     uint32_t walk_hold;    // ... or when at least this many lanes hold a primitive (0 = never for that reason)
     uint32_t walk_break;   // wavefront scheduling of the ordered walk (traversal.h, walk_ordered_vote): leave
@@ -265,6 +266,8 @@ enum SceneFeature : uint32_t
     // stream kernel only: of the models beyond diffuse only the dielectric is compiled in — for scenes whose other BSDFs are all
     // diffuse (IntegratorRec::has_reflectors == 0: matpreview rough dielectric): 288 -> 214 spilled VGPRs at the default budget
     kFeatDielectricOnly = 1u << 12,
+    // ... or only the conductor (IntegratorRec::has_non_conductor == 0: matpreview rough conductor): 79 -> 53 spilled VGPRs at 3
+    kFeatConductorOnly = 1u << 13,
 };
 
 // Device view: raw pointers into HBM + the scalar records.

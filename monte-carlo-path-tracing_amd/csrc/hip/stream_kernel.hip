@@ -68,6 +68,8 @@ hipError_t PlanRenderStream(const DeviceScene &sc, const RenderJob &job, bool co
             continue;
         if ((k.features & kFeatDielectricOnly) && (sc.integrator.has_reflectors || full_bsdf_set))
             continue;
+        if ((k.features & kFeatConductorOnly) && (sc.integrator.has_non_conductor || full_bsdf_set))
+            continue;
         if (((k.features & kFeatWaves2) ? 2u : (k.features & kFeatWaves3) ? 3u : 4u) != want_waves)
             continue;
         if (pick < 0)
@@ -76,8 +78,8 @@ hipError_t PlanRenderStream(const DeviceScene &sc, const RenderJob &job, bool co
             continue;
         }
         const StreamVariant &b = kVariants[pick];
-        const int cost_k = __builtin_popcount(k.features & ~(kFeatWaves2 | kFeatWaves3 | kFeatNoTransmission | kFeatDielectricOnly)) * 4 + static_cast<int>(k.shadow) - ((k.features & (kFeatNoTransmission | kFeatDielectricOnly)) ? 1 : 0);
-        const int cost_b = __builtin_popcount(b.features & ~(kFeatWaves2 | kFeatWaves3 | kFeatNoTransmission | kFeatDielectricOnly)) * 4 + static_cast<int>(b.shadow) - ((b.features & (kFeatNoTransmission | kFeatDielectricOnly)) ? 1 : 0);
+        const int cost_k = __builtin_popcount(k.features & ~(kFeatWaves2 | kFeatWaves3 | kFeatNoTransmission | kFeatDielectricOnly | kFeatConductorOnly)) * 4 + static_cast<int>(k.shadow) - ((k.features & kFeatNoTransmission) ? 1 : 0) - ((k.features & (kFeatDielectricOnly | kFeatConductorOnly)) ? 2 : 0);
+        const int cost_b = __builtin_popcount(b.features & ~(kFeatWaves2 | kFeatWaves3 | kFeatNoTransmission | kFeatDielectricOnly | kFeatConductorOnly)) * 4 + static_cast<int>(b.shadow) - ((b.features & kFeatNoTransmission) ? 1 : 0) - ((b.features & (kFeatDielectricOnly | kFeatConductorOnly)) ? 2 : 0);
         if (cost_k < cost_b)
             pick = static_cast<int>(v);
     }

@@ -1312,7 +1312,7 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
             // use_fast_approx is parsed but never reaches the committed BSDF in
             // the reference (bsdf.cpp:139-144): the full Oren-Nayar model runs.
             o.kind = kBsdfRoughDiffuse;
-            fs.integrator.has_reflectors = 1;
+            fs.integrator.has_reflectors = 1, fs.integrator.has_non_conductor = 1;
             o.tex0 = b.id_diffuse_reflectance, o.tex1 = b.id_roughness;
             check(o.tex0, false), check(o.tex1, false);
             fs.features |= kFeatMicrofacet;
@@ -1330,7 +1330,7 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
         case MCSD_BSDF_DIELECTRIC:
         case MCSD_BSDF_THIN_DIELECTRIC:
             o.kind = b.type == MCSD_BSDF_DIELECTRIC ? kBsdfDielectric : kBsdfThinDielectric;
-            fs.integrator.has_transmission = 1;
+            fs.integrator.has_transmission = 1, fs.integrator.has_non_conductor = 1;
             if (b.type == MCSD_BSDF_THIN_DIELECTRIC)
                 fs.integrator.has_reflectors = 1;
             if (b.type == MCSD_BSDF_DIELECTRIC)
@@ -1349,7 +1349,7 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
             break;
         case MCSD_BSDF_PLASTIC:
             o.kind = kBsdfPlastic;
-            fs.integrator.has_reflectors = 1;
+            fs.integrator.has_reflectors = 1, fs.integrator.has_non_conductor = 1;
             o.tex0 = b.id_roughness, o.tex1 = b.id_diffuse_reflectance, o.tex2 = b.id_specular_reflectance;
             check(o.tex0, false), check(o.tex1, false), check(o.tex2, false);
             o.reflectivity = sqr(b.eta - 1.0f) / sqr(b.eta + 1.0f);

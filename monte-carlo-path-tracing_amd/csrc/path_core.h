@@ -42,8 +42,12 @@ struct Config
     static constexpr bool kOrdered = (kFeatures & kFeatOrderedWalk) != 0; // which ray query runs (traversal.h)
     static constexpr bool kVote = (kFeatures & kFeatVoteWalk) != 0;       // ... scheduled by wavefront vote
     static constexpr bool kSlivers = (kFeatures & kFeatSlivers) != 0;     // ... with the sliver handling of test_slot
-    static constexpr bool kTransmission = (kFeatures & kFeatNoTransmission) == 0; // dielectric / thin dielectric compiled in
-    static constexpr bool kReflectors = (kFeatures & kFeatDielectricOnly) == 0;   // rough diffuse / conductor / thin dielectric / plastic compiled in
+    // which BSDF models beyond diffuse the instantiation compiles (bsdfs.h, bsdf_sample / bsdf_eval)
+    static constexpr uint32_t kAllKinds = (1u << kBsdfRoughDiffuse) | (1u << kBsdfConductor) | (1u << kBsdfDielectric) | (1u << kBsdfThinDielectric) | (1u << kBsdfPlastic);
+    static constexpr uint32_t kKinds = (kFeatures & kFeatDielectricOnly) ? (1u << kBsdfDielectric)
+                                       : (kFeatures & kFeatConductorOnly) ? (1u << kBsdfConductor)
+                                       : (kFeatures & kFeatNoTransmission) ? kAllKinds & ~((1u << kBsdfDielectric) | (1u << kBsdfThinDielectric))
+                                                                           : kAllKinds;
     static constexpr bool kWide = (kFeatures & kFeatWideWalk) != 0;       // ... on the 4-wide quantised hierarchy
 };
 
@@ -221,7 +225,7 @@ MCPT_HD BsdfQuery eval_at(const DeviceScene &sc, const Surface &s, uint32_t bsdf
     BsdfQuery q = query_at(s, wo, -wi);
     q.wi = wi;
     if (bsdf != kNone)
-        bsdf_eval<C::kMicrofacet, kOnly, C::kTransmission, C::kReflectors>(shade_tables<C>(sc), sc.bsdfs[bsdf], q);
+        bsdf_eval<C::kMicrofacet, kOnly, C::kKinds>(shade_tables<C>(sc), sc.bsdfs[bsdf], q);
     else
         q.pdf = 1, q.attenuation = V3{1, 1, 1}, q.valid = true;
     return q;
@@ -560,7 +564,7 @@ MCPT_HD void path_connect_scatter(const DeviceScene &sc, PathState &st, LaneCoun
         BsdfQuery q = query_at(surf, st.wo, st.wo); // path.cpp:268-296
         if (bsdf != kNone)
         {
-            bsdf_sample<C::kMicrofacet, 0, C::kTransmission, C::kReflectors>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
+            bsdf_sample<C::kMicrofacet, 0, C::kKinds>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
         }
         else
         {

@@ -378,7 +378,7 @@ MCPT_HD void stream_vertex(const DeviceScene &sc, StreamSlot<S> &s, LaneCounters
     {
         BsdfQuery q = query_at(surf, st.wo, st.wo);
         if (bsdf != kNone)
-            bsdf_sample<C::kMicrofacet, kOnly, C::kTransmission, C::kReflectors>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
+            bsdf_sample<C::kMicrofacet, kOnly, C::kKinds>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
         else
             q.wi = st.wo, q.pdf = 1.0f, q.attenuation = V3{1.0f, 1.0f, 1.0f}, q.valid = true;
         if (!q.valid)
