@@ -239,7 +239,8 @@ int mcpt_renderer_set_work_distribution(mcpt_renderer *r, int mode);
  * fill at least half of the lanes (cornell-box 512 x 512 on one MI355X): with -1 / 1 the first draw of a tile range
  * measures the tiles with a 2-spp probe (steps per tile), a wavefront then renders one tile, and the tiles are laid over the
  * grid so that every SIMD holds a wavefront of each cost quarter and all SIMDs the same sum (csrc/capi.cpp,
- * CostOrderedTable): 60.8 -> 56.2 ms; an explicit mcpt_renderer_set_pixel_order wins.  No reference counterpart. */
+ * CostOrderedTable): 60.8 -> 56.2 ms; an explicit mcpt_renderer_set_pixel_order wins.  With more pixels than lanes
+ * (volumetric-caustic) the same probe orders the work counter's hand-out, most expensive first (+1 %).  No reference counterpart. */
 int mcpt_renderer_set_tile_order(mcpt_renderer *r, int mode);
 
 /* Class sort of the lane-owns-a-path kernel (csrc/hip/sorted_kernel.hip); the image does not depend on it.  Scenes whose

@@ -1086,8 +1086,12 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         const bool one_pixel_per_lane = uint64_t(job.n_items) <= uint64_t(r->n_cus) * 1024u && uint64_t(job.n_items) * 2u >= uint64_t(r->n_cus) * 1024u;
         // (measured on the diffuse instantiations; cost_order >= 3 extends it to every LDS-resident scene)
         const bool probed_class = (r->dev.features & ~uint32_t(mcpt::kFeatEmitters)) == 0 || cost_order >= 3;
-        if (cost_order > 0 && probed_class && r->tile_order_mode != 0 && r->pixel_order < 0 && small_scene && !counted && !prepass && job.sample_split <= 1 &&
-            n_tiles > 1 && r->rng_mode == 0 && !job.reference_walk && (one_pixel_per_lane || (cost_order >= 3 && dynamic_work)))
+        // Jobs with MORE pixels than lanes (volumetric-caustic: 3.5 per lane): the work counter hands the tiles out most expensive
+        // first by the same probe (longest-processing-time order): 1280 x 720 spp 1024, one box, 922 / 929 -> 914 / 911 ms, first
+        // draw unchanged.
+        const bool many_pixels = uint64_t(job.n_items) > uint64_t(r->n_cus) * 1024u && dynamic_work;
+        if (cost_order > 0 && r->tile_order_mode != 0 && r->pixel_order < 0 && small_scene && !counted && !prepass && job.sample_split <= 1 &&
+            n_tiles > 1 && r->rng_mode == 0 && !job.reference_walk && ((one_pixel_per_lane && probed_class) || many_pixels))
         {
             if (n_tiles > r->tile_keys_capacity || n_tiles > r->tile_steps_capacity)
             {
@@ -1167,7 +1171,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     if (dynamic_work)
         r->variant += job.tile_order && r->dev.prehit ? ", work counter (tiles most expensive first)" : ", work counter";
     if (job.tile_order && !r->dev.prehit)
-        r->variant += ", wavefronts laid out by probed tile cost";
+        r->variant += uint64_t(job.n_items) > uint64_t(r->n_cus) * 1024u ? ", tiles handed out by probed cost" : ", wavefronts laid out by probed tile cost";
     r->last_tile_order = job.tile_order ? 1 : 0;
     if (r->kernel_mode == -1 && r->auto_source != 0)
     {

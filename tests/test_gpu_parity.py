@@ -663,6 +663,29 @@ def test_wavefronts_laid_out_by_probed_tile_cost_render_the_same_frame(pkg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("builder", ["cornell_box", "volumetric_caustic"])
+def test_tiles_handed_out_by_probed_cost_render_the_same_frame(builder, pkg):
+    """LDS-resident scene with MORE pixels than the GPU holds lanes: the work counter hands the tiles out most expensive first
+    by the first draw's 2-spp probe (capi.cpp).  Same frame as image order, with the class-sorted kernel too."""
+    import torch
+    n_lanes = torch.cuda.get_device_properties(0).multi_processor_count * 1024
+    w = 640
+    h = (n_lanes * 5 // 4) // w
+    scene = getattr(pkg.scenes, builder)(w, h, 2)
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
+    try:
+        frames = {}
+        for order in (1, 0, -1):
+            frames[order], _ = r.set_work_distribution(1).set_tile_order(order).draw()
+            assert ("handed out by probed cost" in r.last_kernel()) == (order != 0), (order, r.last_kernel())
+        assert np.array_equal(frames[1], frames[0]) and np.array_equal(frames[-1], frames[0])
+        if builder == "volumetric_caustic":
+            assert "class-sorted" in r.last_kernel()
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["rough_dielectric_envmap", "terrain_directional", "bumpy_directional"])
 def test_tile_hand_out_order_does_not_change_the_image(name, pkg, scenes):
     """mcpt_renderer_set_tile_order: tiles handed out most expensive first (cost from the pre-pass's camera-ray hits,
