@@ -49,7 +49,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_SPEC_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E, 8 TB/s
-VALU_LANES_PER_SIMD = 16  # a 64-lane fp32 VALU instruction occupies its SIMD for 4 cycles
+# VALU roof, the guide's reading (MI355X_MICROARCH.md:52-54): a wave64 VALU instruction issues over 2 cycles = 32 lanes
+# per clock and SIMD; 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T fp32 lane-operations / s.  `roofline.frac` is quoted
+# against THAT.  SQ's own accounting (4 issue cycles per wave64 instruction = 16 lanes per clock) and the reading by this
+# repository's measured per-class issue costs stay in the line as extra keys.
+VALU_LANES_PER_SIMD_GUIDE = 32
+VALU_LANES_PER_SIMD_SQ = 16
+GUIDE_CLOCK_GHZ = 2.4
 N_XCD = 8
 
 PMC_GROUPS = [
@@ -350,6 +356,9 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
         rays = counts["closest_rays"] + counts["shadow_rays"]
         per_sample = {k: counts[k] / counts["samples"] for k in
                       ("closest_rays", "shadow_rays", "node_tests", "prim_tests", "shaded_hits")}
+        # rays per second next to samples per second: a film whose camera rays mostly miss cannot flatter this one
+        out["grays_per_s"] = rays / counts["samples"] * samples * args.steps / elapsed / 1e9
+        out["rays_per_sample"] = rays / counts["samples"]
         walk = {"rays_per_s": rays / counts["samples"] * rank_samples / (kernel_ms * 1e-3),
                 "node_phase_lane_util": (counts["node_tests"] / 2) / (64.0 * max(counts["wave_node_steps"], 1)),
                 "prim_phase_lane_util": counts["prim_tests"] / (64.0 * max(counts["wave_prim_steps"], 1))}
@@ -369,8 +378,12 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
             cycles = c["GRBM_GUI_ACTIVE"] / N_XCD if c.get("GRBM_GUI_ACTIVE") else pmc_ms * 1e-3 * clock_ghz * 1e9
             issue = c["SQ_INSTS_VALU"] * 4.0 / (n_simd * cycles)
             lanes = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
-            valu_peak = n_simd * VALU_LANES_PER_SIMD * cycles / (pmc_ms * 1e-3) / 1e12   # T lane-ops/s at the measured clock
+            valu_peak = n_simd * VALU_LANES_PER_SIMD_GUIDE * GUIDE_CLOCK_GHZ * 1e9 / 1e12   # the guide's peak: 78.6 T lane-ops/s
+            peak_16_measured_clock = n_simd * VALU_LANES_PER_SIMD_SQ * cycles / (pmc_ms * 1e-3) / 1e12
+            achieved_tlaneops = c["SQ_INSTS_VALU"] * 64.0 * lanes / (pmc_ms * 1e-3) / 1e12   # useful fp32 lane-operations / s
             valu = {"issue_frac": issue, "lane_util": lanes, "useful_frac": issue * lanes,
+                    "frac_of_guide_peak": achieved_tlaneops / valu_peak,
+                    "measured_clock_ghz": cycles / (pmc_ms * 1e-3) / 1e9,
                     # the two readings of the VALU roof: SQ accounts a wave64 instruction at 4 issue cycles (16 lanes / clk /
                     # SIMD); the CDNA4 guide gives 2 cycles (32 lanes / clk / SIMD).  The truth depends on the instruction
                     # mix (this repository's microbenchmark: plain add / mul / mov 2.7, fma / cmp / cndmask / cvt 4.5 cycles).
@@ -378,7 +391,8 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
                     "issue_frac_at_2_cycles": 0.5 * issue,
                     "valu_insts_per_sample": c["SQ_INSTS_VALU"] / samples,
                     "wait_any_per_wave_cycle": c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0),
-                    "peak_tlaneops": valu_peak, "achieved_tlaneops": valu_peak * issue * lanes,
+                    "peak_tlaneops": valu_peak, "peak_tlaneops_at_16_lanes_measured_clock": peak_16_measured_clock,
+                    "achieved_tlaneops": achieved_tlaneops,
                     "pmc_kernel_ms": pmc_ms, "cycles": cycles}
             mix = {k: c[k] for k in CLASS_CYCLES if k in c}
             if mix:
@@ -405,14 +419,16 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
                            fetch_bytes=2.0 * c["FETCH_SIZE"] * 1024.0, write_bytes=c["WRITE_SIZE"] * 1024.0)
             # the roof the kernel is closest to: VALU issue slots or HBM bytes actually moved
             if issue >= hbm.get("measured_frac_of_stream_peak", 0.0):
-                roof.update(bound="valu", achieved=valu["achieved_tlaneops"], peak=valu_peak, unit="Tlane-op/s",
-                            frac=issue * lanes)
-                roof["note"] = ("VALU-issue bound: %.0f %% of the issue slots of the %d SIMDs are taken (SQ's 4-cycle accounting; "
-                                "%.0f %% at the guide's 2 cycles per instruction), %.0f %% of the lanes of those instructions do "
-                                "work -> frac = useful fp32 lane-operations / peak, between %.2f (32 lanes / clk / SIMD) and %.2f "
-                                "(16; reported as `frac`); no FMA: the arithmetic contract forbids contraction.  HBM moves %s per "
-                                "launch against %s of algorithmic bytes: the walk's data comes from LDS / cache."
-                                % (100 * issue, n_simd, 50 * issue, 100 * lanes, 0.5 * issue * lanes, issue * lanes,
+                roof.update(bound="valu", achieved=achieved_tlaneops, peak=valu_peak, unit="Tlane-op/s",
+                            frac=achieved_tlaneops / valu_peak)
+                roof["note"] = ("VALU bound: frac = useful fp32 lane-operations per second (VALU wave-instructions x 64 x lane "
+                                "utilisation / kernel time) / the guide's peak (%d SIMDs x 32 lanes / clk x 2.4 GHz).  %.0f %% of the "
+                                "issue slots are taken by SQ's 4-cycle accounting (%.0f %% at the guide's 2 cycles per instruction), "
+                                "%.0f %% of the lanes of those instructions do work; the same quantity at 16 lanes / clk and the "
+                                "measured clock is %.2f (`valu.frac_at_16_lanes_per_clk`); no FMA: the arithmetic contract forbids "
+                                "contraction.  HBM moves %s per launch against %s of algorithmic bytes: the walk's data comes from "
+                                "LDS / cache."
+                                % (n_simd, 100 * issue, 50 * issue, 100 * lanes, issue * lanes,
                                    "%.3g MB" % (roof["traffic"] / 1e6) if roof["traffic"] else "?",
                                    "%.3g GB" % (algorithmic_bytes / 1e9)))
             else:
@@ -464,6 +480,62 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
     return out
 
 
+def compact(full, detail_path):
+    """The ONE line rank 0 prints: the contract's keys, the roofline / cpu_baseline / parity objects reduced to their
+    numbers, `also.dragon` the same way — under 2000 bytes, so that a driver that keeps the tail of stdout keeps all of
+    it.  Everything measured (per-sample counts, counter readings, notes) goes to `detail_path`."""
+    def roof(r):
+        v, h = r.get("valu", {}), r.get("hbm", {})
+        o = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic") if k in r}
+        if o.get("traffic") is not None:
+            o["traffic"] = int(o["traffic"])
+        o.update(kernel=r["kernel"][:40], kernel_ms=round(r["kernel_ms"], 3),
+                 algorithmic_bytes=round(h["bytes_per_sample"], 1), algorithmic_gbs=round(h["algorithmic_gbs"], 1))
+        if v:
+            o.update(lane_util=round(v["lane_util"], 3), issue_frac_sq=round(v["issue_frac"], 3),
+                     frac_at_16_lanes=round(v["frac_at_16_lanes_per_clk"], 3))
+        for k in ("achieved", "peak", "frac"):
+            o[k] = float("%.4g" % o[k])
+        return o
+
+    def one(m):
+        o = {k: m[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                               "scaling", "vs_baseline", "dtype", "data", "grays_per_s", "rays_per_sample",
+                               "first_draw_ms", "gather_ms", "per_rank_kernel_ms") if k in m}
+        for k in ("value", "ms_per_step", "grays_per_s", "rays_per_sample", "first_draw_ms"):
+            if k in o:
+                o[k] = round(o[k], 3)
+        c = m["config"]
+        o["config"] = {"workload": c["workload"], "baseline_config_index": c["baseline_config_index"],
+                       "rng": c["rng"].split(" (")[0]}
+        if "roofline" in m:
+            o["roofline"] = roof(m["roofline"])
+        if "cpu_baseline" in m:
+            b = m["cpu_baseline"]
+            o["cpu_baseline"] = {"value": round(b["value"], 3), "unit": b["unit"], "cores": b["cores"], "kind": b["kind"],
+                                 "sample": b["sample"]}
+        if "parity" in m:
+            q = m["parity"]
+            o["parity"] = {"film": q["film"], "rmse": q["rmse"], "max_l2": q["max_l2"], "frac_exact": q["frac_exact"]}
+        if "throughput_mode" in m:
+            o["throughput_mode"] = {"value": round(m["throughput_mode"]["value"], 1), "rng": "pcg, not per-pixel comparable"}
+        return o
+
+    line = one(full)
+    if "also" in full:
+        a = one(full["also"]["dragon"])
+        for k in ("metric", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+            a.pop(k, None)
+        a["config"] = {"workload": a["config"]["workload"].split(" (")[0] + " (stand-ins for the 4 unshipped OBJ files)"}
+        a.pop("throughput_mode", None)
+        if "cpu_baseline" in a:
+            a["cpu_baseline"].pop("unit")
+            a["cpu_baseline"]["sample"] = a["cpu_baseline"]["sample"].split(" (")[0]
+        line["also"] = {"dragon": a}
+    line["detail"] = detail_path
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -492,6 +564,9 @@ def main():
     ap.add_argument("--no-also", action="store_true",
                     help="N = 1, default workload: skip the `also` block (dragon/scene.xml 1280x720 spp 256, north_star's "
                          "second target, measured in the same process)")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the full record (every counter, note and per-sample count) on stdout instead of the compact "
+                         "line; the full record always goes to gpurun_out/bench_detail_<workload>_n<N>.json and stderr")
     ap.add_argument("--force-gather", action="store_true",
                     help="take the multi-GPU code path (RCCL process group, packed tiles, gather, scatter) "
                          "even with one rank: lets a 1-GPU box exercise it")
@@ -535,7 +610,22 @@ def main():
                        primary=False)
         out["also"] = {"dragon": also}
     if rank == 0:
-        print(json.dumps(out))
+        # everything measured -> a side file (and stderr); the compact line -> stdout
+        detail_dir = os.path.join(ROOT, "gpurun_out")
+        detail_path = None
+        try:
+            os.makedirs(detail_dir, exist_ok=True)
+            detail_path = os.path.join(detail_dir, f"bench_detail_{name}_n{world}.json")
+            with open(detail_path, "w") as f:
+                json.dump(out, f, indent=1)
+            detail_path = os.path.relpath(detail_path, ROOT)
+        except OSError:
+            pass
+        if args.full_line:
+            print(json.dumps(out))
+        else:
+            print(json.dumps(out), file=sys.stderr)
+            print(json.dumps(compact(out, detail_path), separators=(",", ":")))
     if use_gather:
         dist.destroy_process_group()
 

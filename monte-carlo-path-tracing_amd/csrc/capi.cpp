@@ -167,7 +167,11 @@ struct mcpt_renderer
     unsigned long long range_hits = 0;    // camera rays of the range that hit something (pre-pass)
     int stream_waves_mode = -1;           // mcpt_renderer_set_stream_waves: -1 the library's rule, 2 / 3 / 4
     uint32_t stream_waves_auto = 0;       // the rule's choice for the current range (0: not known yet)
-    uint32_t cost_order_tiles = 0, cost_order_first = 0, cost_order_stride = 0; // the range the sorted table was made for (0 tiles: none)
+    // Two caches keyed by tile range, each with its OWN key (0 tiles: none): the pre-pass's range statistics (range_hits,
+    // stream_waves_auto, mesh_table_dev) and the LDS-path probed table kept at tile_keys_dev + tile_keys_capacity.  Every setter
+    // that changes which path a draw takes drops both (InvalidateRangeCaches).
+    uint32_t cost_order_tiles = 0, cost_order_first = 0, cost_order_stride = 0; // range statistics of the pre-pass
+    uint32_t lds_table_tiles = 0, lds_table_first = 0, lds_table_stride = 0;    // probed wavefront layout / hand-out table, LDS path
     int class_sort_mode = -1; // mcpt_renderer_set_class_sort: -1 / 1 on where the scene is of that class, 0 off
     int tile_order_mode = -1; // -1 the library's choice (on with the pre-pass and the work counter), 0 image order, 1 cost order
     unsigned long long *tile_keys_dev = nullptr;
@@ -219,6 +223,11 @@ struct mcpt_renderer
     uint32_t TilesX() const { return (static_cast<uint32_t>(flat.camera.width) + 7u) / 8u; }
     uint32_t TilesY() const { return (static_cast<uint32_t>(flat.camera.height) + 7u) / 8u; }
     uint32_t Tiles() const { return TilesX() * TilesY(); }
+    void InvalidateRangeCaches()
+    {
+        cost_order_tiles = 0, lds_table_tiles = 0;
+        mesh_table_ready = false, range_fresh = false, stream_waves_auto = 0;
+    }
 };
 
 namespace
@@ -985,6 +994,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                         (void)hipFree(r->tile_keys_dev), (void)hipFree(r->tile_temp_dev);
                         r->tile_keys_dev = nullptr, r->tile_temp_dev = nullptr, r->tile_keys_capacity = 0;
                     }
+                    r->lds_table_tiles = 0; // (the LDS path's table lived behind the keys)
                     r->tile_temp_bytes = mcpt::TileOrderTempBytes(n_tiles);
                     Check(hipMalloc(reinterpret_cast<void **>(&r->tile_keys_dev), size_t(2) * n_tiles * sizeof(unsigned long long)), "allocate tile table");
                     Check(hipMalloc(&r->tile_temp_dev, r->tile_temp_bytes), "allocate tile sort scratch");
@@ -1106,9 +1116,9 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                 Check(hipMalloc(&r->tile_temp_dev, r->tile_temp_bytes), "allocate tile sort scratch");
                 Check(hipMalloc(reinterpret_cast<void **>(&r->tile_steps_dev), n_tiles * sizeof(uint32_t)), "allocate tile step counts");
                 r->tile_keys_capacity = r->tile_steps_capacity = n_tiles;
-                r->cost_order_tiles = 0;
+                r->lds_table_tiles = 0;
             }
-            if (r->cost_order_tiles != n_tiles || r->cost_order_first != range.tile_first || r->cost_order_stride != range.tile_stride)
+            if (r->lds_table_tiles != n_tiles || r->lds_table_first != range.tile_first || r->lds_table_stride != range.tile_stride)
             {
                 Check(hipMemsetAsync(r->tile_steps_dev, 0, n_tiles * sizeof(uint32_t), stream), "clear tile step counts");
                 static const uint32_t probe_spp = []
@@ -1134,7 +1144,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                 Check(hipStreamSynchronize(stream), "wait for the tile table");
                 if (job.work_counter)
                     Check(hipMemsetAsync(r->work_counter_dev, 0, sizeof(uint32_t), stream), "clear work counter");
-                r->cost_order_tiles = n_tiles, r->cost_order_first = range.tile_first, r->cost_order_stride = range.tile_stride;
+                r->lds_table_tiles = n_tiles, r->lds_table_first = range.tile_first, r->lds_table_stride = range.tile_stride;
             }
             job.tile_order = r->tile_keys_dev + r->tile_keys_capacity;
             job.scatter = 0;
@@ -1680,6 +1690,7 @@ int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order)
     if (!r)
         return Fail("null argument");
     r->reference_walk = reference_order != 0;
+    r->InvalidateRangeCaches();
     return 0;
 }
 
@@ -1738,13 +1749,15 @@ int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_
     {
         // `slots`: size of the slot pool in units of 4096 slots (0 = one slot per pixel of the draw)
         r->kernel_mode = mode, r->queued_slots = slots;
-        r->auto_choice = -1;
+        r->auto_choice = -1, r->auto_source = 0;
+        r->InvalidateRangeCaches();
         return 0;
     }
     if (slots % 256u != 0 || slots > 4096u || refill_at > 64u)
         return Fail("mcpt_renderer_set_kernel: slots is a multiple of 256 up to 4096, refill_at at most 64");
     r->kernel_mode = mode, r->stream_slots = slots, r->stream_refill = refill_at;
     r->auto_choice = -1, r->auto_source = 0; // (mode -1 decides again at the next draw)
+    r->InvalidateRangeCaches();
     return 0;
 }
 
@@ -1756,6 +1769,7 @@ int mcpt_renderer_set_work_distribution(mcpt_renderer *r, int mode)
         return Fail("mcpt_renderer_set_work_distribution: mode is -1 (the library's choice), 0 (fixed per-lane pixel lists) or 1 (work counter)");
     r->work_mode = mode;
     r->auto_choice = -1;
+    r->InvalidateRangeCaches();
     return 0;
 }
 
@@ -1767,6 +1781,7 @@ int mcpt_renderer_set_prepass(mcpt_renderer *r, int mode)
         return Fail("mcpt_renderer_set_prepass: mode is -1 (the library's choice), 0 (off) or 1 (on where the scene allows it)");
     r->prepass_mode = mode;
     r->auto_choice = -1;
+    r->InvalidateRangeCaches();
     return 0;
 }
 
@@ -1777,6 +1792,7 @@ int mcpt_renderer_set_tile_order(mcpt_renderer *r, int mode)
     if (mode < -1 || mode > 1)
         return Fail("mcpt_renderer_set_tile_order: mode is -1 (the library's choice), 0 (image order) or 1 (most expensive tiles first)");
     r->tile_order_mode = mode;
+    r->InvalidateRangeCaches();
     return 0;
 }
 
@@ -1787,6 +1803,7 @@ int mcpt_renderer_set_stream_waves(mcpt_renderer *r, int waves)
     if (waves != -1 && (waves < 2 || waves > 4))
         return Fail("mcpt_renderer_set_stream_waves: -1 (the library's rule), 2, 3 or 4 wavefronts per SIMD");
     r->stream_waves_mode = waves;
+    r->InvalidateRangeCaches();
     return 0;
 }
 
@@ -1807,6 +1824,7 @@ int mcpt_renderer_set_pixel_order(mcpt_renderer *r, int mode)
     if (mode < -1 || mode > 1)
         return Fail("mcpt_renderer_set_pixel_order: mode is -1 (the library's choice), 0 (a wavefront renders a tile) or 1 (transposed)");
     r->pixel_order = mode;
+    r->InvalidateRangeCaches();
     return 0;
 }
 
@@ -1833,6 +1851,7 @@ int mcpt_renderer_set_rng(mcpt_renderer *r, int mode, uint32_t seed, uint32_t sa
     if (mode == 1 && r->flat.integrator.has_masks)
         ; // (fine: the reference-order walk draws from whatever stream the path carries)
     r->rng_mode = mode, r->rng_seed = seed, r->sample_split = sample_split;
+    r->InvalidateRangeCaches();
     return 0;
 }
 
@@ -1852,8 +1871,18 @@ int mcpt_renderer_calibrate(mcpt_renderer *r)
         const int saved_mode = r->kernel_mode;
         r->kernel_mode = -1;
         r->auto_choice = r->work_mode == 0 ? 0 : 1;
-        Calibrate(r, nullptr, mcpt::StreamSupports(r->dev, job));
+        r->InvalidateRangeCaches();
+        try
+        {
+            Calibrate(r, nullptr, mcpt::StreamSupports(r->dev, job));
+        }
+        catch (...)
+        {
+            r->kernel_mode = saved_mode; // (a failed calibration must not lose the caller's mcpt_renderer_set_kernel choice)
+            throw;
+        }
         r->kernel_mode = saved_mode;
+        r->InvalidateRangeCaches();
         r->auto_source = 1;
         const StoredChoice c{r->auto_choice, {r->auto_ms[0], r->auto_ms[1], r->auto_ms[2], r->auto_ms[3]}};
         CalibrationStore::Get().Put(CalibrationKey(r), c);

@@ -13,6 +13,9 @@
 //     <file name as written in the XML>  blob   cx cy cz  rx ry rz  rings segments  seed amplitude
 //     <file name as written in the XML>  sheet  x0 z0 x1 z1  y  nx nz  seed amplitude
 //     <file name as written in the XML>  disc   cx cz  r0 r1  y  rings segments  seed amplitude
+//     <file name as written in the XML>  limb   x0 y0 z0  x1 y1 z1  r0 r1  roundness  rings segments  seed amplitude
+//     <file name as written in the XML>  membrane  ax ay az  bx by bz  cx cy cz  nu nv  seed amplitude
+// Several lines with the same file name are the parts of ONE mesh (concatenated in table order).
 // blob:  a sphere of radii (rx, ry, rz) around (cx, cy, cz) in a rings x segments latitude / longitude
 //        grid (2 * segments * (rings - 1) triangles), displaced along its radius by a smooth pseudo-random
 //        function of the direction, relative size `amplitude`;
@@ -21,8 +24,14 @@
 // disc:  the annulus r0 <= r <= r1 around (cx, y, cz) in a rings x segments polar grid (2 rings segments
 //        triangles; r0 = 0 gives a full disc whose innermost ring of triangles is degenerate-free because
 //        the centre ring has radius r1 / (4 rings)), displaced in y like a sheet.
-// Vertices carry uv coordinates; normals and tangent frames come from the same post-processing an
-// OBJ file without normals gets (mesh_postprocess.cpp).  Everything is computed with + - * / sqrt and the
+// limb:  a spindle around the segment p0 -> p1: circular cross-sections whose radius goes from r0 to r1
+//        (linear) times sin(pi t)^(1/2) (roundness 1) or ^(1/4) (roundness 2: blunter ends), poles at both
+//        ends, 2 * segments * (rings - 1) triangles, radius displaced by `amplitude` (relative);
+// membrane: the triangle A B C as a fan of nu x nv quads from the apex A (rows start at 1 / (4 nu) of the
+//        way, so that no triangle is degenerate), 2 nu nv triangles, displaced along the triangle's normal
+//        by `amplitude` (absolute) times the smooth pseudo-random function.
+// Vertices carry uv coordinates; normals come from the same post-processing an OBJ file without normals
+// gets (mesh_postprocess.cpp); tangent frames are left to the commit (see Finish).  Everything is computed with + - * / sqrt and the
 // restated sinf / cosf of glibc_libm.h: the same mesh on every host.
 #include <cmath>
 #include <sstream>
@@ -75,10 +84,12 @@ struct Bumps
     }
 };
 
+// Smooth normals like an OBJ file without normals gets; NO per-vertex tangents: a stand-in is not an importer's
+// output, so the commit gives it the reference's own per-triangle UV-derived frame (scene.cpp:63-80) — the pinned rule
+// (SURVEY.md section 8c), the same one MCPT_MESH_TANGENTS=uv selects for files.
 MeshData Finish(MeshData m)
 {
     GenerateSmoothNormals(m);
-    CalcTangentSpace(m);
     return m;
 }
 
@@ -123,7 +134,7 @@ MeshData Blob(std::istringstream &in, const std::string &line)
         }
     for (int j = 0; j < segments; ++j)
         m.indices.insert(m.indices.end(), {south, at(rings - 1, j), at(rings - 1, j + 1)});
-    return Finish(std::move(m));
+    return m;
 }
 
 MeshData Sheet(std::istringstream &in, const std::string &line)
@@ -150,7 +161,7 @@ MeshData Sheet(std::istringstream &in, const std::string &line)
             m.indices.insert(m.indices.end(), {at(i, j), at(i + 1, j), at(i + 1, j + 1)}); // facing +y
             m.indices.insert(m.indices.end(), {at(i, j), at(i + 1, j + 1), at(i, j + 1)});
         }
-    return Finish(std::move(m));
+    return m;
 }
 
 MeshData Disc(std::istringstream &in, const std::string &line)
@@ -181,7 +192,118 @@ MeshData Disc(std::istringstream &in, const std::string &line)
             m.indices.insert(m.indices.end(), {at(i, j), at(i + 1, j + 1), at(i + 1, j)}); // facing +y
             m.indices.insert(m.indices.end(), {at(i, j), at(i, j + 1), at(i + 1, j + 1)});
         }
-    return Finish(std::move(m));
+    return m;
+}
+
+MeshData Limb(std::istringstream &in, const std::string &line)
+{
+    float p0[3], p1[3], r0, r1, amplitude;
+    int roundness, rings, segments;
+    uint32_t seed;
+    if (!(in >> p0[0] >> p0[1] >> p0[2] >> p1[0] >> p1[1] >> p1[2] >> r0 >> r1 >> roundness >> rings >> segments >> seed >>
+          amplitude) ||
+        rings < 2 || segments < 3 || rings > 8192 || segments > 8192 || roundness < 1 || roundness > 2)
+        throw std::runtime_error("bad stand-in line '" + line + "'.");
+    float a[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    const float length = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+    if (!(length > 0))
+        throw std::runtime_error("bad stand-in line '" + line + "'.");
+    for (float &v : a)
+        v /= length;
+    // frame around the axis: u = a x h (h = +y, or +x for a vertical axis), v = a x u
+    const bool steep = std::fabs(a[1]) >= 0.9f;
+    const float h[3] = {steep ? 1.0f : 0.0f, steep ? 0.0f : 1.0f, 0.0f};
+    float u[3] = {a[1] * h[2] - a[2] * h[1], a[2] * h[0] - a[0] * h[2], a[0] * h[1] - a[1] * h[0]};
+    const float ul = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    for (float &v : u)
+        v /= ul;
+    const float w[3] = {a[1] * u[2] - a[2] * u[1], a[2] * u[0] - a[0] * u[2], a[0] * u[1] - a[1] * u[0]};
+    const Bumps bumps(seed);
+    MeshData m;
+    auto put = [&](float t, float radius, float c, float s)
+    {
+        const float k = radius * (1.0f + amplitude * bumps(3.0f * t, c, s));
+        for (int d = 0; d < 3; ++d)
+            m.positions.push_back(p0[d] + a[d] * (length * t) + k * (c * u[d] + s * w[d]));
+    };
+    put(0.0f, 0.0f, 1.0f, 0.0f);
+    m.texcoords.insert(m.texcoords.end(), {0.5f, 0.0f});
+    for (int i = 1; i < rings; ++i)
+    {
+        const float t = static_cast<float>(i) / static_cast<float>(rings);
+        float profile = std::sqrt(gl::sinf(3.14159265f * t));
+        if (roundness == 2)
+            profile = std::sqrt(profile);
+        const float radius = (r0 + (r1 - r0) * t) * profile;
+        for (int j = 0; j < segments; ++j)
+        {
+            const float phi = 6.2831853f * static_cast<float>(j) / static_cast<float>(segments);
+            put(t, radius, gl::cosf(phi), gl::sinf(phi));
+            m.texcoords.insert(m.texcoords.end(), {static_cast<float>(j) / segments, t});
+        }
+    }
+    put(1.0f, 0.0f, 1.0f, 0.0f);
+    m.texcoords.insert(m.texcoords.end(), {0.5f, 1.0f});
+    const uint32_t last = static_cast<uint32_t>(m.positions.size() / 3 - 1);
+    auto at = [&](int i, int j) { return 1u + static_cast<uint32_t>(i - 1) * segments + static_cast<uint32_t>(j % segments); };
+    for (int j = 0; j < segments; ++j)
+        m.indices.insert(m.indices.end(), {0u, at(1, j), at(1, j + 1)});
+    for (int i = 1; i + 1 < rings; ++i)
+        for (int j = 0; j < segments; ++j)
+        {
+            m.indices.insert(m.indices.end(), {at(i, j), at(i + 1, j + 1), at(i, j + 1)});
+            m.indices.insert(m.indices.end(), {at(i, j), at(i + 1, j), at(i + 1, j + 1)});
+        }
+    for (int j = 0; j < segments; ++j)
+        m.indices.insert(m.indices.end(), {last, at(rings - 1, j + 1), at(rings - 1, j)});
+    return m;
+}
+
+MeshData Membrane(std::istringstream &in, const std::string &line)
+{
+    float A[3], B[3], C[3], amplitude;
+    int nu, nv;
+    uint32_t seed;
+    if (!(in >> A[0] >> A[1] >> A[2] >> B[0] >> B[1] >> B[2] >> C[0] >> C[1] >> C[2] >> nu >> nv >> seed >> amplitude) || nu < 1 ||
+        nv < 1 || nu > 8192 || nv > 8192)
+        throw std::runtime_error("bad stand-in line '" + line + "'.");
+    const float e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]};
+    float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const float nl = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (!(nl > 0))
+        throw std::runtime_error("bad stand-in line '" + line + "'.");
+    for (float &v : n)
+        v /= nl;
+    const Bumps bumps(seed);
+    MeshData m;
+    const float u0 = 1.0f / (4.0f * nu);
+    for (int i = 0; i <= nu; ++i)
+        for (int j = 0; j <= nv; ++j)
+        {
+            const float u = u0 + (1.0f - u0) * static_cast<float>(i) / nu, v = static_cast<float>(j) / nv;
+            const float lift = amplitude * bumps(u, 0.0f, v);
+            for (int d = 0; d < 3; ++d)
+                m.positions.push_back(A[d] + u * ((1.0f - v) * e1[d] + v * e2[d]) + lift * n[d]);
+            m.texcoords.insert(m.texcoords.end(), {u, v});
+        }
+    auto at = [&](int i, int j) { return static_cast<uint32_t>(i * (nv + 1) + j); };
+    for (int i = 0; i < nu; ++i)
+        for (int j = 0; j < nv; ++j)
+        {
+            m.indices.insert(m.indices.end(), {at(i, j), at(i + 1, j), at(i + 1, j + 1)});
+            m.indices.insert(m.indices.end(), {at(i, j), at(i + 1, j + 1), at(i, j + 1)});
+        }
+    return m;
+}
+
+// Parts of one mesh: indices shifted, attribute arrays concatenated (before normals / tangents are made).
+void Append(MeshData &to, MeshData &&part)
+{
+    const uint32_t base = static_cast<uint32_t>(to.positions.size() / 3);
+    to.positions.insert(to.positions.end(), part.positions.begin(), part.positions.end());
+    to.texcoords.insert(to.texcoords.end(), part.texcoords.begin(), part.texcoords.end());
+    for (uint32_t i : part.indices)
+        to.indices.push_back(base + i);
 }
 
 } // namespace
@@ -196,9 +318,9 @@ StandinTable::StandinTable(const std::string &text)
         std::string name, kind;
         if (!(in >> name) || name[0] == '#')
             continue;
-        if (!(in >> kind) || (kind != "blob" && kind != "sheet" && kind != "disc"))
+        if (!(in >> kind) || (kind != "blob" && kind != "sheet" && kind != "disc" && kind != "limb" && kind != "membrane"))
             throw std::runtime_error("bad stand-in line '" + line + "'.");
-        lines_[name] = line;
+        lines_[name].push_back(line);
     }
 }
 
@@ -206,11 +328,23 @@ bool StandinTable::Has(const std::string &name) const { return lines_.count(name
 
 MeshData StandinTable::Build(const std::string &name) const
 {
-    const std::string &line = lines_.at(name);
-    std::istringstream in(line);
-    std::string skip, kind;
-    in >> skip >> kind;
-    return kind == "blob" ? Blob(in, line) : (kind == "sheet" ? Sheet(in, line) : Disc(in, line));
+    MeshData mesh;
+    for (const std::string &line : lines_.at(name))
+    {
+        std::istringstream in(line);
+        std::string skip, kind;
+        in >> skip >> kind;
+        MeshData part = kind == "blob"    ? Blob(in, line)
+                        : kind == "sheet" ? Sheet(in, line)
+                        : kind == "disc"  ? Disc(in, line)
+                        : kind == "limb"  ? Limb(in, line)
+                                          : Membrane(in, line);
+        if (mesh.positions.empty())
+            mesh = std::move(part);
+        else
+            Append(mesh, std::move(part));
+    }
+    return Finish(std::move(mesh));
 }
 
 } // namespace mcpt

@@ -4,6 +4,7 @@
 
 #include <map>
 #include <string>
+#include <vector>
 
 #include "asset_io.hpp"
 
@@ -20,7 +21,7 @@ public:
     bool empty() const { return lines_.empty(); }
 
 private:
-    std::map<std::string, std::string> lines_;
+    std::map<std::string, std::vector<std::string>> lines_; // the parts of a file's mesh, in table order
 };
 
 } // namespace mcpt

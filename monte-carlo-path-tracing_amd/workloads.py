@@ -2,8 +2,12 @@
 
     cornell         configs[0/1]  cornell-box 512x512 spp 256 (spp 16 for the CPU plumbing case)
     dragon          configs[2]    dragon/scene.xml 1280x720 spp 256 — STAND-IN geometry for the four OBJ files the
-                                  reference repository does not ship (standins/dragon.txt): 51 140 real +
-                                  780 440 procedural triangles
+                                  reference repository does not ship (standins/dragon.txt: a body and two wings
+                                  fitted to the silhouette of the reference's own render, 22 % of the film hit):
+                                  51 140 real + 794 668 procedural triangles.  Mesh tangents: none per vertex —
+                                  the fixture was made with MCPT_MESH_TANGENTS=uv and stand-ins never carry any, so
+                                  every triangle gets the reference's own UV-derived frame (scene.cpp:63-80),
+                                  SURVEY.md section 8c's pin
     matpreview-rc   configs[3]    matpreview/rough_conductor.xml 1024x1024 spp 512
     matpreview-rd   configs[3]    matpreview/rough_dielectric.xml 1024x1024 spp 512
     volumetric      configs[4]    volumetric-caustic/scene_v0.6.xml 1280x720 spp 1024
@@ -28,7 +32,7 @@ WORKLOADS = {"cornell":       (None,                          (512, 512, 256),  
              "volumetric":    ("volumetric_caustic",          (1280, 720, 1024),  4)}
 
 DESCRIPTION = {"cornell": "cornell-box.xml 512x512 spp=256",
-               "dragon": "dragon/scene.xml 1280x720 spp=256 (12 real meshes + stand-ins for the 4 unshipped OBJ files, 831580 triangles)",
+               "dragon": "dragon/scene.xml 1280x720 spp=256 (12 real meshes + stand-ins for the 4 unshipped OBJ files, 845808 triangles)",
                "matpreview-rc": "matpreview/rough_conductor.xml 1024x1024 spp=512",
                "matpreview-rd": "matpreview/rough_dielectric.xml 1024x1024 spp=512",
                "volumetric": "volumetric-caustic/scene_v0.6.xml 1280x720 spp=1024"}
@@ -40,12 +44,12 @@ def _fixture(name):
 
 
 def standin_lines(table_path=DRAGON_STANDINS):
-    """file name -> table line"""
+    """file name -> its table lines (several lines with one name = the parts of one mesh), newline-joined"""
     lines = {}
     for line in open(table_path):
         tok = line.split()
         if tok and not tok[0].startswith("#"):
-            lines[tok[0]] = line.strip()
+            lines[tok[0]] = (lines[tok[0]] + "\n" if tok[0] in lines else "") + line.strip()
     return lines
 
 

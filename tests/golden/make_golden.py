@@ -88,5 +88,18 @@ def main():
         json.dump({"frames": manifest, "kat": kat}, f, indent=1, sort_keys=True)
 
 
+def dragon_reference_silhouette():
+    """tests/golden/dragon_reference_silhouette.npz: which 4x4 cells of the reference's own render of
+    dragon/scene.xml (resources/results/dragon.png, 1280x720) are not black — the silhouette the stand-in
+    table (monte-carlo-path-tracing_amd/standins/dragon.txt) is fitted to (tests/test_baseline_configs.py)."""
+    from PIL import Image
+    im = np.array(Image.open("/root/reference/resources/results/dragon.png").convert("RGB")).astype(np.float32)
+    m = im.sum(2) > 0
+    cells = m.reshape(180, 4, 320, 4).sum((1, 3)) >= 8
+    np.savez_compressed(os.path.join(HERE, "dragon_reference_silhouette.npz"), mask_bits=np.packbits(cells),
+                        shape=np.array([180, 320]), full_res_fraction=np.float64(m.mean()))
+
+
 if __name__ == "__main__":
     main()
+    dragon_reference_silhouette()

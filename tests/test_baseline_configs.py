@@ -34,17 +34,53 @@ def test_dragon_has_its_real_meshes_and_the_standins(pkg, tmp_path):
     cfg = pkg.workloads.config("dragon", 64, 36, 1)
     scene = pkg.mcsd.loads(_bytes(cfg, tmp_path, "dragon"))
     tris = [np.asarray(i.indices).size // 3 for i in scene.instances]
-    assert len(tris) == 16 and sum(tris) == 831580
+    assert len(tris) == 16 and sum(tris) == 845808
     assert sum(t for k, t in enumerate(tris) if k not in (4, 5, 6, 7)) == 51140  # the twelve real OBJ files
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_SCENES), reason="needs the reference's scene files")
 @pytest.mark.parametrize("name", ["dragon", "matpreview-rc", "matpreview-rd", "volumetric"])
-def test_fixture_is_what_the_xml_front_end_produces(pkg, tmp_path, name):
+def test_fixture_is_what_the_xml_front_end_produces(pkg, tmp_path, name, monkeypatch):
+    if name == "dragon":  # its fixture is pinned to the reference's own UV-derived tangent frames
+        monkeypatch.setenv("MCPT_MESH_TANGENTS", "uv")
     film = pkg.workloads.WORKLOADS[name][1]
     standins = open(pkg.workloads.DRAGON_STANDINS).read() if name == "dragon" else None
     direct = pkg.capi.Config.load_xml(REF_SCENES + XML[name], standins).set_film(*film)
     assert _bytes(direct, tmp_path, "a") == _bytes(pkg.workloads.config(name), tmp_path, "b")
+
+
+def test_dragon_standins_cover_the_film_like_the_reference_render(pkg, oracle, tmp_path):
+    """The four OBJ files of dragon/scene.xml that the reference repository does not ship are replaced by stand-ins;
+    Msamples/s on that scene only mean something if the stand-ins fill the film like the real dragon does.  The
+    reference's own render of the scene (resources/results/dragon.png -> tests/golden/dragon_reference_silhouette.npz)
+    has 21.3 % of its pixels not black.  Here: camera rays through the centres of a 320x180 film, answered by the
+    oracle's closest-hit query; the hit mask must cover 21 +- 2 % of the film and overlap that silhouette."""
+    want = np.load(os.path.join(os.path.dirname(__file__), "golden", "dragon_reference_silhouette.npz"))
+    h, w = (int(v) for v in want["shape"])
+    silhouette = np.unpackbits(want["mask_bits"])[:h * w].reshape(h, w).astype(bool)
+    assert abs(float(want["full_res_fraction"]) - 0.213) < 0.001
+    cfg = pkg.workloads.config("dragon", w, h, 1)
+    path = str(tmp_path / "dragon.mcsd")
+    cfg.save_mcsd(path)
+    cam = pkg.mcsd.loads(open(path, "rb").read()).camera
+    eye, up = np.array(cam.eye, np.float64), np.array(cam.up, np.float64)
+    front = np.array(cam.look_at, np.float64) - eye
+    front /= np.linalg.norm(front)
+    right = np.cross(front, up)
+    right /= np.linalg.norm(right)
+    up = np.cross(right, front)
+    tan_x = np.tan(np.radians(0.5 * cam.fov_x))                       # camera.cpp:28-40: fov_y = fov_x * height / width
+    tan_y = np.tan(np.radians(0.5 * cam.fov_x * h / w))
+    hit = np.zeros((h, w), bool)
+    with oracle.open(path) as session:
+        for j in range(h):
+            for i in range(w):
+                d = front + (2 * (i + 0.5) / w - 1) * tan_x * right + (1 - 2 * (j + 0.5) / h) * tan_y * up
+                hit[j, i] = session.intersect(eye, d / np.linalg.norm(d))[0][0] != 0
+    cover = hit.mean()
+    print(f"dragon stand-ins: hit mask covers {cover:.4f} of the film, IoU with the reference silhouette {(hit & silhouette).sum() / (hit | silhouette).sum():.3f}")
+    assert 0.19 <= cover <= 0.23, cover
+    assert (hit & silhouette).sum() / (hit | silhouette).sum() >= 0.75
 
 
 def test_missing_mesh_without_a_standin_is_the_reference_error(pkg):

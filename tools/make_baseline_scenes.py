@@ -44,7 +44,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     for name, xml in JOBS:
         store(pkg.capi.Config.load_xml(SCENES + xml), name)
-    # dragon: which <shape> (= instance, in file order) names which missing file
+    # dragon: its OBJ meshes are read with MCPT_MESH_TANGENTS=uv — no per-vertex tangents, so the commit builds the
+    # reference's own UV-derived frame (scene.cpp:63-80): SURVEY.md section 8c's pin, instead of the unpinned restatement
+    # of assimp's CalcTangentSpace.  Which <shape> (= instance, in file order) names which missing file:
+    os.environ["MCPT_MESH_TANGENTS"] = "uv"
     xml = open(SCENES + "dragon/scene.xml").read()
     files = re.findall(r'<shape type="obj".*?name="filename" value="([^"]+)"', xml, flags=re.S)
     missing = {i: f for i, f in enumerate(files) if not os.path.exists(SCENES + "dragon/" + f)}
