@@ -253,6 +253,15 @@ int mcpt_renderer_set_tile_order(mcpt_renderer *r, int mode);
  * mode -1 (default): on for those scenes; 0: off (the unsorted kernel); 1: same as -1. */
 int mcpt_renderer_set_class_sort(mcpt_renderer *r, int mode);
 
+/* Ray queries of the lane-owns-a-path kernel on LDS-resident scenes (csrc/pool_walk.h); the image does not depend on it.
+ * 0: one walk per lane (walk_ordered) — a wavefront's query lasts as long as its slowest lane's walk, the shape of the
+ * reference's per-thread nested stack walk (src/rtcore/accel/tlas.cpp:13-76, blas.cpp:18-77).  1: the wavefront-cooperative
+ * pool walk — the rays of a wavefront's query are records in LDS and every lane takes the next (ray, node) or (ray,
+ * primitive) item of a shared list, whichever ray it belongs to; closest hits are decided at the end among the candidates
+ * within the tie radius of the nearest, in the reference's visiting order.  Scenes without slivers / opacity masks whose
+ * hierarchy has at most 1024 nodes.  -1 (default): the library's choice (environment MCPT_POOL_WALK overrides). */
+int mcpt_renderer_set_pool_walk(mcpt_renderer *r, int mode);
+
 /* Register budget of the stream kernel's instantiation on scenes outside LDS (surface materials): compiled for 4, 3 or 2
  * wavefronts per SIMD (128 / 168 / 256 VGPRs: 288 / 210 / 4 spilled registers).  The image does not depend on it.
  * -1 (default): the library's rule — scenes without a dielectric or thin dielectric run the instantiations compiled

@@ -31,6 +31,10 @@
 #include "host/commit.hpp"
 #include "host/frontend.hpp"
 #include "host/standin_mesh.hpp"
+
+#ifndef MCPT_POOL_WALK_DEFAULT
+#define MCPT_POOL_WALK_DEFAULT 0 // (what mcpt_renderer_set_pool_walk(r, -1) means)
+#endif
 #include "mcsd_scene.hpp"
 
 struct mcpt_config
@@ -173,6 +177,7 @@ struct mcpt_renderer
     uint32_t cost_order_tiles = 0, cost_order_first = 0, cost_order_stride = 0; // range statistics of the pre-pass
     uint32_t lds_table_tiles = 0, lds_table_first = 0, lds_table_stride = 0;    // probed wavefront layout / hand-out table, LDS path
     int class_sort_mode = -1; // mcpt_renderer_set_class_sort: -1 / 1 on where the scene is of that class, 0 off
+    int pool_walk_mode = -1;  // mcpt_renderer_set_pool_walk: -1 the library's choice (MCPT_POOL_WALK), 0 one walk per lane, 1 the cooperative pool walk
     int tile_order_mode = -1; // -1 the library's choice (on with the pre-pass and the work counter), 0 image order, 1 cost order
     unsigned long long *tile_keys_dev = nullptr;
     void *tile_temp_dev = nullptr;
@@ -794,6 +799,12 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             return e ? std::atoi(e) : 1;
         }();
         job.sort_classes = sort_classes != 0 && r->class_sort_mode != 0 ? 1u : 0u;
+        static const int pool_walk = []
+        {
+            const char *e = std::getenv("MCPT_POOL_WALK"); // (measurements: the library's choice when mcpt_renderer_set_pool_walk left it open)
+            return e ? std::atoi(e) : MCPT_POOL_WALK_DEFAULT;
+        }();
+        job.pool_walk = (r->pool_walk_mode < 0 ? pool_walk != 0 : r->pool_walk_mode != 0) ? 1u : 0u;
     }
     // The library's choices (kernel_mode -1): the first draw of a renderer calibrates — BEFORE this draw sizes any of its
     // own buffers, because the calibration's nested draws re-size the renderer's scratch allocations.
@@ -1814,6 +1825,17 @@ int mcpt_renderer_set_class_sort(mcpt_renderer *r, int mode)
     if (mode < -1 || mode > 1)
         return Fail("mcpt_renderer_set_class_sort: mode is -1 (the library's choice), 0 (off) or 1 (on where the scene is of that class)");
     r->class_sort_mode = mode;
+    return 0;
+}
+
+int mcpt_renderer_set_pool_walk(mcpt_renderer *r, int mode)
+{
+    if (!r)
+        return Fail("null argument");
+    if (mode < -1 || mode > 1)
+        return Fail("mcpt_renderer_set_pool_walk: mode is -1 (the library's choice), 0 (one walk per lane) or 1 (wavefront-cooperative pool walk where the scene allows it)");
+    r->pool_walk_mode = mode;
+    r->InvalidateRangeCaches();
     return 0;
 }
 

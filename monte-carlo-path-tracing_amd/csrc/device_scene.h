@@ -268,6 +268,9 @@ enum SceneFeature : uint32_t
     kFeatDielectricOnly = 1u << 12,
     // ... or only the conductor (IntegratorRec::has_non_conductor == 0: matpreview rough conductor): 79 -> 53 spilled VGPRs at 3
     kFeatConductorOnly = 1u << 13,
+    // LDS-resident lane kernels only: the ray queries are the wavefront-cooperative pool walk (pool_walk.h) instead of one
+    // walk per lane (scenes without slivers whose node and slot indices fit 10 bits)
+    kFeatPoolWalk = 1u << 14,
 };
 
 // Device view: raw pointers into HBM + the scalar records.

@@ -155,7 +155,7 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     *variant = "diffuse-area+lds (experiment build)";
     if (counters != nullptr || !ordered || f != 0 || StagedBytes(sc, true) > kLdsGeometryBytes)
         return hipErrorNotSupported;
-    return Launch<kO, false, true>(sc, job, out, nullptr, stream, n_cus);
+    return job.pool_walk ? Launch<kP, false, true>(sc, job, out, nullptr, stream, n_cus) : Launch<kO, false, true>(sc, job, out, nullptr, stream, n_cus);
 #endif
     const bool slivers = sc.integrator.walk_sliver_reach > 0.0f;
     if (counters != nullptr)
@@ -181,17 +181,21 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
         return Launch<kAll | kV | kS, false>(sc, job, out, nullptr, stream, n_cus);
     }
     const bool lds = StagedBytes(sc, true) <= kLdsGeometryBytes;
+    // the wavefront-cooperative pool walk (pool_walk.h): its items hold node and slot indices in 10 bits
+    const bool pool = lds && job.pool_walk != 0 && sc.integrator.n_walk_nodes <= kPoolMaxRef + 1u && sc.integrator.n_prims <= kPoolMaxRef + 1u;
     if (f == 0)
     {
-        *variant = lds ? "diffuse-area+lds" : "diffuse-area";
-        return lds ? Launch<kO, false, true>(sc, job, out, nullptr, stream, n_cus)
-                   : Launch<kV, false>(sc, job, out, nullptr, stream, n_cus);
+        *variant = pool ? "diffuse-area+lds+pool-walk" : lds ? "diffuse-area+lds" : "diffuse-area";
+        return pool  ? Launch<kP, false, true>(sc, job, out, nullptr, stream, n_cus)
+               : lds ? Launch<kO, false, true>(sc, job, out, nullptr, stream, n_cus)
+                     : Launch<kV, false>(sc, job, out, nullptr, stream, n_cus);
     }
     if ((f & ~kFeatEmitters) == 0)
     {
-        *variant = lds ? "diffuse-emitters+lds" : "diffuse-emitters";
-        return lds ? Launch<kFeatEmitters | kO, false, true>(sc, job, out, nullptr, stream, n_cus)
-                   : Launch<kFeatEmitters | kV, false>(sc, job, out, nullptr, stream, n_cus);
+        *variant = pool ? "diffuse-emitters+lds+pool-walk" : lds ? "diffuse-emitters+lds" : "diffuse-emitters";
+        return pool  ? Launch<kFeatEmitters | kP, false, true>(sc, job, out, nullptr, stream, n_cus)
+               : lds ? Launch<kFeatEmitters | kO, false, true>(sc, job, out, nullptr, stream, n_cus)
+                     : Launch<kFeatEmitters | kV, false>(sc, job, out, nullptr, stream, n_cus);
     }
     if ((f & ~kSurface) == 0)
     {

@@ -114,7 +114,9 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
 
     PathState st{}; // (every field defined: a lane that has not started a pixel yet can be moved by a compaction)
     st.alive = false;
-    st.stack = reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + threadIdx.x;
+    // (pool walk: the wavefront's pool area instead of the lane's stack column)
+    st.stack = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + (threadIdx.x >> 6) * pool_wave_words(C::kAnalytic)
+                        : reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + threadIdx.x;
     bool has_pixel = false;
     uint32_t slot = 0; // where this pixel's result goes
     uint32_t steps = 0, my_tile = 0; // cost probe (RenderJob::tile_steps)
@@ -128,8 +130,12 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     // (measured: cornell 1074 -> 1098 Msamples/s; the full-feature instantiation — volumetric-caustic, 3 wavefronts per
     //  SIMD, 3.5 pixels per lane from the work counter — 1012 -> 1007, so not there)
     constexpr bool kCompact = kLdsGeometry && !kCount && C::kOrdered && !(C::kVolPath || C::kAnalytic);
-    uint32_t *compact_words = reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + static_cast<size_t>(sc_in.integrator.walk_depth) * kBlockSize;
-    uint32_t *compact_count = compact_words + kCompactWords * kBlockSize; // [0..3]: live lanes per wavefront, [4]: retired lanes of the workgroup
+    // (pool walk: the words travel through the pool areas — no wavefront is inside a query during an event — and the
+    //  counters, which are read at every step, have their own words behind them)
+    uint32_t *compact_words = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged)
+                                       : reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + static_cast<size_t>(sc_in.integrator.walk_depth) * kBlockSize;
+    uint32_t *compact_count = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + (kBlockSize / 64u) * pool_wave_words(C::kAnalytic)
+                                       : compact_words + kCompactWords * kBlockSize; // [0..3]: live lanes per wavefront, [4]: retired lanes of the workgroup
     bool retired = false;
     uint32_t compact_events = 0; // events this wavefront has taken part in (event k: 64 (k + 1) lanes retired)
     if (kCompact)
@@ -309,6 +315,7 @@ constexpr uint32_t kVolumeLean = kFeatVolPath | kFeatAnalytic | kFeatMicrofacet;
 #ifndef MCPT_WIDE_WALK
 #define MCPT_WIDE_WALK 0
 #endif
+constexpr uint32_t kP = kFeatOrderedWalk | kFeatPoolWalk; // the wavefront-cooperative pool walk (LDS-resident scenes)
 constexpr uint32_t kO = kFeatOrderedWalk, kV = kFeatOrderedWalk | kFeatVoteWalk | (MCPT_WIDE_WALK ? kFeatWideWalk : 0u), kS = kFeatSlivers;
 // stack entries per lane in LDS: the ring of the short stack, or one entry per level of the binary hierarchy
 inline size_t WalkStackEntries(const DeviceScene &sc, uint32_t features)
@@ -331,9 +338,14 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
                   uint32_t max_blocks)
 {
     constexpr bool kOrdered = (kFeatures & kFeatOrderedWalk) != 0;
+    constexpr bool kPool = (kFeatures & kFeatPoolWalk) != 0;
+    static_assert(!kPool || (kLdsGeometry && kOrdered), "the pool walk runs on hierarchies staged in LDS");
+    static_assert((kBlockSize / 64u) * pool_wave_words(false) >= kCompactWords * kBlockSize, "the compaction's words travel through the pool areas");
     const size_t lds_bytes = (kLdsGeometry ? StagedBytes(sc, kOrdered) : 0) +
-                             (kOrdered ? WalkStackEntries(sc, kFeatures) * kBlockSize * sizeof(uint32_t) : 0) +
-                             (kLdsGeometry && !kCount && kOrdered && !(kFeatures & (kFeatVolPath | kFeatAnalytic))
+                             (kPool      ? size_t(kBlockSize / 64u) * pool_wave_words((kFeatures & kFeatAnalytic) != 0) * sizeof(uint32_t) + 8 * sizeof(uint32_t)
+                              : kOrdered ? WalkStackEntries(sc, kFeatures) * kBlockSize * sizeof(uint32_t)
+                                         : 0) +
+                             (!kPool && kLdsGeometry && !kCount && kOrdered && !(kFeatures & (kFeatVolPath | kFeatAnalytic))
                                   ? (size_t(kCompactWords) * kBlockSize + 8) * sizeof(uint32_t)
                                   : 0);
     int per_cu = 0;

@@ -27,6 +27,7 @@
 #include "lights_media.h"
 #include "short_stack.h"
 #include "traversal.h"
+#include "pool_walk.h"
 
 namespace mcpt
 {
@@ -49,6 +50,7 @@ struct Config
                                        : (kFeatures & kFeatNoTransmission) ? kAllKinds & ~((1u << kBsdfDielectric) | (1u << kBsdfThinDielectric))
                                                                            : kAllKinds;
     static constexpr bool kWide = (kFeatures & kFeatWideWalk) != 0;       // ... on the 4-wide quantised hierarchy
+    static constexpr bool kPool = (kFeatures & kFeatPoolWalk) != 0;       // ... as the wavefront-cooperative pool walk (pool_walk.h; device only)
 };
 
 struct LaneCounters
@@ -164,6 +166,10 @@ MCPT_HD bool trace(const DeviceScene &sc, uint32_t *stack, Ray &r, uint32_t &rng
 {
     if (C::kOrdered)
     {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (C::kPool) // (`stack` = the wavefront's pool area)
+            return count ? walk_pool<kAny, C::kAnalytic, true>(sc, stack, r, hit, ts) : walk_pool<kAny, C::kAnalytic, false>(sc, stack, r, hit, ts);
+#endif
         if (C::kWide)
             return count ? walk_wide_vote<kAny, C::kAnalytic, true, C::kSlivers>(sc, stack, r, hit, ts)
                          : walk_wide_vote<kAny, C::kAnalytic, false, C::kSlivers>(sc, stack, r, hit, ts);

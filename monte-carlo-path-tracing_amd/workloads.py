@@ -4,10 +4,11 @@
     dragon          configs[2]    dragon/scene.xml 1280x720 spp 256 — STAND-IN geometry for the four OBJ files the
                                   reference repository does not ship (standins/dragon.txt: a body and two wings
                                   fitted to the silhouette of the reference's own render, 22 % of the film hit):
-                                  51 140 real + 794 668 procedural triangles.  Mesh tangents: none per vertex —
-                                  the fixture was made with MCPT_MESH_TANGENTS=uv and stand-ins never carry any, so
-                                  every triangle gets the reference's own UV-derived frame (scene.cpp:63-80),
-                                  SURVEY.md section 8c's pin
+                                  51 140 real + 794 668 procedural triangles.  Tangent frames: the stand-ins carry
+                                  none and get the reference's own UV-derived frame (scene.cpp:63-80, SURVEY.md
+                                  section 8c's pin); the twelve real OBJ files have `vt 0 0` on every vertex, for
+                                  which that rule gives NaN frames (tools/make_baseline_scenes.py), so they keep the
+                                  restated importer's tangents (mesh_postprocess.cpp)
     matpreview-rc   configs[3]    matpreview/rough_conductor.xml 1024x1024 spp 512
     matpreview-rd   configs[3]    matpreview/rough_dielectric.xml 1024x1024 spp 512
     volumetric      configs[4]    volumetric-caustic/scene_v0.6.xml 1280x720 spp 1024

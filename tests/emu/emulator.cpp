@@ -828,6 +828,246 @@ void RunSpeculative(const DeviceScene &sc, const std::vector<std::array<float, 7
     }
 }
 
+// Pool model, second edition (round 4): closest and shadow rays of a round in ONE pool (`merged`), the primitive phase
+// runs when `prim_at` leaves wait (or no node item is left), the culling bound of a closest ray is its best distance + the
+// tie radius and is read at the START of a step (all lanes of a step see the same value, like 64 lanes reading LDS before
+// any of them writes).  Records what a kernel has to be sized for: the longest item lists and the most hits one ray accepts.
+struct Pool2Model
+{
+    double node_steps = 0, node_visits = 0, prim_steps = 0, prim_tests = 0, rounds = 0;
+    double max_nodes = 0, max_leaves = 0, accepted = 0, rays = 0, accepted_hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double node_lanes_hist[4] = {0, 0, 0, 0}; // node steps with 1-16, 17-32, 33-48, 49-64 lanes busy
+};
+
+void RunPool2(const DeviceScene &sc, const std::vector<std::array<float, 7>> &closest, const std::vector<std::array<float, 7>> &shadow,
+              uint32_t prim_at, Pool2Model &m, bool wide = false)
+{
+    struct Item
+    {
+        uint32_t ray, ref;
+    };
+    const size_t nc = closest.size(), n = nc + shadow.size();
+    if (n == 0 || sc.integrator.n_walk_nodes == 0)
+        return;
+    m.rounds += 1;
+    const float tie = sc.integrator.walk_tie;
+    std::vector<Ray> r(n);
+    std::vector<float> bound(n);  // culling bound the NEXT step reads
+    std::vector<uint32_t> accepted(n, 0);
+    std::vector<char> done(n, 0);
+    for (size_t i = 0; i < n; ++i)
+    {
+        const std::array<float, 7> &q = i < nc ? closest[i] : shadow[i - nc];
+        r[i] = make_ray(V3{q[0], q[1], q[2]}, V3{q[3], q[4], q[5]});
+        r[i].t_max = q[6], bound[i] = q[6];
+    }
+    std::vector<Item> nodes, leaves;
+    for (size_t i = 0; i < n; ++i)
+        nodes.push_back(Item{static_cast<uint32_t>(i), 0u});
+    while (!nodes.empty() || !leaves.empty())
+    {
+        m.max_nodes = std::max<double>(m.max_nodes, nodes.size()), m.max_leaves = std::max<double>(m.max_leaves, leaves.size());
+        if (leaves.size() >= prim_at || nodes.empty())
+        {
+            const size_t take = std::min<size_t>(64, leaves.size());
+            std::vector<Item> batch(leaves.end() - take, leaves.end());
+            leaves.resize(leaves.size() - take);
+            m.prim_steps += 1;
+            std::vector<float> next = bound;
+            for (const Item &it : batch)
+            {
+                m.prim_tests += 1;
+                const bool any = it.ray >= nc;
+                if (any && done[it.ray])
+                    continue;
+                const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(it.ref & ~kWalkLeaf);
+                const SlotHit sh = triangle_probe(p, r[it.ray]);
+                if (sh.hit && !(sh.t > bound[it.ray]))
+                {
+                    ++accepted[it.ray];
+                    if (any)
+                        done[it.ray] = 1, next[it.ray] = -1.0f;
+                    else
+                        next[it.ray] = std::min(next[it.ray], sh.t + tie);
+                }
+            }
+            bound = next;
+            continue;
+        }
+        const size_t take = std::min<size_t>(64, nodes.size());
+        std::vector<Item> batch(nodes.end() - take, nodes.end());
+        nodes.resize(nodes.size() - take);
+        m.node_steps += 1;
+        m.node_lanes_hist[(take - 1) / 16] += 1;
+        std::vector<Item> far_nodes, near_nodes, far_leaves, near_leaves;
+        for (size_t l = 0; l < take; ++l)
+        {
+            const Item it = batch[take - 1 - l];
+            m.node_visits += 1;
+            Ray ray = r[it.ray];
+            ray.t_max = bound[it.ray];
+            const float4 *q = sc.walk_nodes + 4 * static_cast<size_t>(it.ref);
+            float e0, e1;
+            const bool h0 = box_enter(q[0], q[1], ray, e0), h1 = box_enter(q[2], q[3], ray, e1);
+            const uint32_t r0 = as_uint(q[0].w), r1 = as_uint(q[1].w);
+            const bool first0 = e0 <= e1, both = h0 && h1;
+            if (!(h0 || h1))
+                continue;
+            const uint32_t toward = (h0 && (first0 || !h1)) ? r0 : r1, other = first0 ? r1 : r0;
+            if (wide)
+            {
+                // a step tests two levels: a hit inner child is opened at once and ITS hit children are what is pushed (the
+                // work of a 4-wide node: up to four boxes beyond the first two, up to four pushes)
+                const uint32_t kids[2] = {other, toward};
+                const bool hit[2] = {both, true};
+                for (int c = 0; c < 2; ++c)
+                {
+                    if (!hit[c])
+                        continue;
+                    if (kids[c] & kWalkLeaf)
+                    {
+                        (c ? near_leaves : far_leaves).push_back(Item{it.ray, kids[c]});
+                        continue;
+                    }
+                    m.node_visits += 1;
+                    const float4 *g = sc.walk_nodes + 4 * static_cast<size_t>(kids[c]);
+                    float f0, f1;
+                    const bool g0 = box_enter(g[0], g[1], ray, f0), g1 = box_enter(g[2], g[3], ray, f1);
+                    const uint32_t s0 = as_uint(g[0].w), s1 = as_uint(g[1].w);
+                    const bool gf0 = f0 <= f1;
+                    const uint32_t order[2] = {gf0 ? s1 : s0, gf0 ? s0 : s1};
+                    const bool oh[2] = {gf0 ? g1 : g0, gf0 ? g0 : g1};
+                    for (int q = 0; q < 2; ++q)
+                        if (oh[q])
+                            ((order[q] & kWalkLeaf) ? (c ? near_leaves : far_leaves) : (c ? near_nodes : far_nodes)).push_back(Item{it.ray, order[q]});
+                }
+                continue;
+            }
+            ((toward & kWalkLeaf) ? near_leaves : near_nodes).push_back(Item{it.ray, toward});
+            if (both)
+                ((other & kWalkLeaf) ? far_leaves : far_nodes).push_back(Item{it.ray, other});
+        }
+        // far children below near children: the next step takes the near ones first
+        nodes.insert(nodes.end(), far_nodes.begin(), far_nodes.end()), nodes.insert(nodes.end(), near_nodes.begin(), near_nodes.end());
+        leaves.insert(leaves.end(), far_leaves.begin(), far_leaves.end()), leaves.insert(leaves.end(), near_leaves.begin(), near_leaves.end());
+    }
+    for (size_t i = 0; i < nc; ++i)
+        m.accepted += accepted[i], m.rays += 1, m.accepted_hist[std::min<uint32_t>(accepted[i], 7)] += 1;
+}
+
+// params: {merged (0 / 1), prim_at, wide (0 / 1: two levels per step)};  out: Pool2Model's fields in order (23 doubles) preceded by the per-lane model's
+// {wave node steps, lane node visits, wave prim phases, lane prim tests}.
+int mcpt_emu_pool_model2(const char *mcsd_path, const uint32_t *params, double *out)
+{
+    try
+    {
+        const FlatScene flat = CommitScene(mcsd::Load(mcsd_path));
+        const DeviceScene sc = flat.HostView();
+        if (flat.integrator.has_masks || (flat.features & kFeatAnalytic))
+            throw std::runtime_error("triangle-only scenes without masks");
+        using C = Config<kFeatVolPath | kFeatEmitters | kFeatTextures | kFeatMicrofacet | kFeatOrderedWalk>;
+        const uint32_t w = sc.camera.width, h = sc.camera.height;
+        const uint32_t tx = (w + 7) / 8, ty = (h + 7) / 8;
+        const bool merged = params[0] != 0, wide = params[2] != 0;
+        const uint32_t prim_at = params[1];
+        std::vector<double> acc(27, 0.0);
+        std::mutex mu;
+        std::atomic<uint32_t> next{0};
+        auto work = [&]()
+        {
+            double a[4] = {0, 0, 0, 0};
+            Pool2Model pm;
+            for (;;)
+            {
+                const uint32_t tile = next.fetch_add(1);
+                if (tile >= tx * ty)
+                    break;
+                PathState st[64];
+                std::vector<LaneCounters> cnt(64);
+                std::vector<uint32_t> stacks(64 * kWalkStackMax);
+                bool has[64];
+                for (uint32_t l = 0; l < 64; ++l)
+                {
+                    const uint32_t x = (tile % tx) * 8 + (l & 7), y = (tile / tx) * 8 + (l >> 3);
+                    has[l] = x < w && y < h;
+                    cnt[l] = LaneCounters{};
+                    st[l].stack = &stacks[l * kWalkStackMax];
+                    if (has[l])
+                        start_pixel(st[l], y * w + x);
+                }
+                for (;;)
+                {
+                    bool any = false;
+                    std::vector<std::array<float, 7>> closest, shadow;
+                    uint32_t mcn = 0, mcp = 0, msn = 0, msp = 0;
+                    for (uint32_t l = 0; l < 64; ++l)
+                    {
+                        if (!has[l])
+                            continue;
+                        if (!st[l].alive)
+                        {
+                            if (st[l].sample >= sc.camera.spp)
+                            {
+                                has[l] = false;
+                                continue;
+                            }
+                            start_sample(sc, st[l]);
+                        }
+                        any = true;
+                        path_step<C>(sc, st[l], &cnt[l]);
+                        std::array<float, 7> rec;
+                        std::copy(cnt[l].last_closest_ray, cnt[l].last_closest_ray + 7, rec.begin());
+                        closest.push_back(rec);
+                        if (cnt[l].last_shadow_count)
+                        {
+                            std::copy(cnt[l].last_shadow_ray, cnt[l].last_shadow_ray + 7, rec.begin());
+                            shadow.push_back(rec);
+                        }
+                        const uint32_t cn = cnt[l].last_closest_nodes / 2, cp = cnt[l].last_closest_prims;
+                        const uint32_t sn = cnt[l].last_shadow_nodes / 2, sp = cnt[l].last_shadow_prims;
+                        a[1] += cn + sn, a[3] += cp + sp;
+                        mcn = std::max(mcn, cn), mcp = std::max(mcp, cp), msn = std::max(msn, sn), msp = std::max(msp, sp);
+                    }
+                    if (!any)
+                        break;
+                    a[0] += mcn + msn, a[2] += mcp + msp;
+                    if (merged)
+                        RunPool2(sc, closest, shadow, prim_at, pm, wide);
+                    else
+                    {
+                        RunPool2(sc, closest, {}, prim_at, pm, wide);
+                        RunPool2(sc, {}, shadow, prim_at, pm, wide);
+                    }
+                }
+            }
+            std::lock_guard<std::mutex> lock(mu);
+            for (int i = 0; i < 4; ++i)
+                acc[i] += a[i];
+            const double f[23] = {pm.node_steps, pm.node_visits, pm.prim_steps, pm.prim_tests, pm.rounds, 0, 0, pm.accepted, pm.rays,
+                                  pm.accepted_hist[0], pm.accepted_hist[1], pm.accepted_hist[2], pm.accepted_hist[3], pm.accepted_hist[4],
+                                  pm.accepted_hist[5], pm.accepted_hist[6], pm.accepted_hist[7], pm.node_lanes_hist[0], pm.node_lanes_hist[1],
+                                  pm.node_lanes_hist[2], pm.node_lanes_hist[3], 0, 0};
+            for (int i = 0; i < 23; ++i)
+                acc[4 + i] += f[i];
+            acc[4 + 5] = std::max(acc[4 + 5], pm.max_nodes), acc[4 + 6] = std::max(acc[4 + 6], pm.max_leaves);
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < std::max(1u, std::thread::hardware_concurrency()); ++t)
+            pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool)
+            t.join();
+        for (int i = 0; i < 27; ++i)
+            out[i] = acc[i];
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return 1;
+    }
+}
+
 // out: per-lane model {node steps (wave), node visits (lane), prim phases, prim tests} followed by the
 // pooled model's {node steps, node visits, prim steps, prim tests}; triangle-only scenes.
 int mcpt_emu_pool_model(const char *mcsd_path, double *out)

@@ -40,13 +40,29 @@ def test_dragon_has_its_real_meshes_and_the_standins(pkg, tmp_path):
 
 @pytest.mark.skipif(not os.path.isdir(REF_SCENES), reason="needs the reference's scene files")
 @pytest.mark.parametrize("name", ["dragon", "matpreview-rc", "matpreview-rd", "volumetric"])
-def test_fixture_is_what_the_xml_front_end_produces(pkg, tmp_path, name, monkeypatch):
-    if name == "dragon":  # its fixture is pinned to the reference's own UV-derived tangent frames
-        monkeypatch.setenv("MCPT_MESH_TANGENTS", "uv")
+def test_fixture_is_what_the_xml_front_end_produces(pkg, tmp_path, name):
     film = pkg.workloads.WORKLOADS[name][1]
     standins = open(pkg.workloads.DRAGON_STANDINS).read() if name == "dragon" else None
     direct = pkg.capi.Config.load_xml(REF_SCENES + XML[name], standins).set_film(*film)
     assert _bytes(direct, tmp_path, "a") == _bytes(pkg.workloads.config(name), tmp_path, "b")
+
+
+def test_dragon_real_meshes_have_no_usable_uvs(pkg, tmp_path):
+    """Why SURVEY.md section 8c's tangent pin (MCPT_MESH_TANGENTS=uv, the reference's own UV-derived frame, scene.cpp:63-80)
+    is not this fixture's setting: all twelve shipped OBJ files of dragon/scene.xml carry `vt 0 0` on every vertex, so every
+    real triangle has zero UV area and that rule's 1 / (uv area) is a division by zero (NaN frames, NaN rays that walk the
+    whole hierarchy).  The stand-ins have proper UVs and no per-vertex tangents: they do get the UV-derived frame."""
+    cfg = pkg.workloads.config("dragon", 64, 36, 1)
+    scene = pkg.mcsd.loads(_bytes(cfg, tmp_path, "dragon"))
+    for k, inst in enumerate(scene.instances):
+        uv = np.asarray(inst.texcoords, np.float64).reshape(-1, 2)
+        idx = np.asarray(inst.indices).reshape(-1, 3)
+        d1, d2 = uv[idx[:, 1]] - uv[idx[:, 0]], uv[idx[:, 2]] - uv[idx[:, 0]]
+        flat = (d1[:, 1] * d2[:, 0] - d1[:, 0] * d2[:, 1]) == 0
+        if k in (4, 5, 6, 7):   # stand-ins
+            assert not flat.any() and np.asarray(inst.tangents).size == 0
+        else:
+            assert flat.all() and np.asarray(inst.tangents).size == np.asarray(inst.positions).size
 
 
 def test_dragon_standins_cover_the_film_like_the_reference_render(pkg, oracle, tmp_path):

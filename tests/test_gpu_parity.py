@@ -613,6 +613,58 @@ def test_class_sort_does_not_change_the_image(name, pkg, scenes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell_64_spp8", "cornell_96_spp32"])
+def test_pool_walk_does_not_change_the_image(name, pkg, scenes):
+    """mcpt_renderer_set_pool_walk (csrc/pool_walk.h): the ray queries of a wavefront as a shared list of (ray, node) /
+    (ray, primitive) items that all lanes work off, closest hits decided at the end among the candidates within the tie
+    radius — order independent, so the frame is the per-lane walk's: the compiled reference's golden, bit for bit, with
+    fixed lists and the work counter, both pixel orders, a packed tile range of three ranks, and 5 repeated draws."""
+    golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
+    try:
+        for pool in (1, 0):
+            for work in (0, 1):
+                for order in (0, 1):
+                    frame, _ = r.set_kernel(0).set_pool_walk(pool).set_work_distribution(work).set_pixel_order(order).set_prepass(0).draw()
+                    assert ("pool-walk" in r.last_kernel()) == (pool == 1), r.last_kernel()
+                    assert np.array_equal(frame, golden), (pool, work, order, r.last_kernel())
+        r.set_pool_walk(1).set_work_distribution(-1).set_pixel_order(-1)
+        for _ in range(5):
+            frame, _ = r.draw()
+            assert np.array_equal(frame, golden)
+        import torch
+        h, w = golden.shape[:2]
+        frame = np.zeros_like(golden)
+        for rank in range(3):
+            rng = pkg.capi.TileRange(rank, 3, 0)
+            buf = torch.zeros(r.tiles_in(rng) * 64 * 3, dtype=torch.float32, device="cuda:0")
+            r.draw_device(buf.data_ptr(), rng, packed=True)
+            assert "pool-walk" in r.last_kernel()
+            pkg.capi.unpack_tiles(buf.cpu().numpy(), rng, w, h, frame)
+        assert np.array_equal(frame, golden)
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
+def test_pool_walk_full_film_hash_equals_the_per_lane_walk(pkg):
+    """cornell-box 512 x 512 (BASELINE config 2's film) at spp 64: the pool walk's frame == the per-lane walk's, 20 repeated
+    draws hash-identical (the candidate set of a closest query does not depend on the order its items were processed in)."""
+    import hashlib
+    r = pkg.capi.Renderer(pkg.workloads.config("cornell", 512, 512, 64), device=0)
+    try:
+        want, _ = r.set_pool_walk(0).draw()
+        digests = set()
+        for _ in range(20):
+            frame, _ = r.set_pool_walk(1).draw()
+            digests.add(hashlib.sha256(frame.tobytes()).hexdigest())
+        assert "pool-walk" in r.last_kernel()
+        assert digests == {hashlib.sha256(want.tobytes()).hexdigest()}
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["rough_dielectric_envmap", "terrain_directional", "plastic_spot"])
 def test_stream_kernel_register_budgets_render_the_same_frame(name, pkg, scenes):
     """mcpt_renderer_set_stream_waves: the surface-materials mesh instantiations of the stream kernel compiled for 4, 3 and 2

@@ -44,10 +44,15 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     for name, xml in JOBS:
         store(pkg.capi.Config.load_xml(SCENES + xml), name)
-    # dragon: its OBJ meshes are read with MCPT_MESH_TANGENTS=uv — no per-vertex tangents, so the commit builds the
-    # reference's own UV-derived frame (scene.cpp:63-80): SURVEY.md section 8c's pin, instead of the unpinned restatement
-    # of assimp's CalcTangentSpace.  Which <shape> (= instance, in file order) names which missing file:
-    os.environ["MCPT_MESH_TANGENTS"] = "uv"
+    # dragon: SURVEY.md section 8c's tangent pin (MCPT_MESH_TANGENTS=uv: no per-vertex tangents, the commit builds the
+    # reference's own UV-derived frame, scene.cpp:63-80) CANNOT be this fixture's setting: every one of the twelve shipped OBJ
+    # files has `vt 0.000000 0.000000` on all vertices, so that rule divides by a zero UV area and every real triangle gets a
+    # NaN frame — NaN scattered directions, rays that pass every box test and walk the whole hierarchy (measured on an MI355X
+    # with such a fixture: 53 s for a 320 x 180 x 16 film).  The reference binary itself reads these files through assimp,
+    # whose CalcTangentSpace substitutes default axes for a degenerate UV triangle; the fixture keeps the restatement of that
+    # (mesh_postprocess.cpp, unpinned).  tests/test_baseline_configs.py::test_dragon_real_meshes_have_no_usable_uvs pins the
+    # fact.  The stand-ins (valid UVs) carry no tangents and do get the UV-derived frame.
+    # Which <shape> (= instance, in file order) names which missing file:
     xml = open(SCENES + "dragon/scene.xml").read()
     files = re.findall(r'<shape type="obj".*?name="filename" value="([^"]+)"', xml, flags=re.S)
     missing = {i: f for i, f in enumerate(files) if not os.path.exists(SCENES + "dragon/" + f)}
