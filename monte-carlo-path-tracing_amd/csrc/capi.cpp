@@ -33,7 +33,7 @@
 #include "host/standin_mesh.hpp"
 
 #ifndef MCPT_POOL_WALK_DEFAULT
-#define MCPT_POOL_WALK_DEFAULT 0 // (what mcpt_renderer_set_pool_walk(r, -1) means)
+#define MCPT_POOL_WALK_DEFAULT 1 // (what mcpt_renderer_set_pool_walk(r, -1) means: on where an instantiation exists)
 #endif
 #include "mcsd_scene.hpp"
 

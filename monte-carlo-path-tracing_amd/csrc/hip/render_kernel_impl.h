@@ -62,6 +62,10 @@ struct Budget
                                                                                       : 6;
 };
 
+#ifndef MCPT_POOL_MAX_SPREAD
+#define MCPT_POOL_MAX_SPREAD 16
+#endif
+constexpr uint32_t kPoolMaxSpread = MCPT_POOL_MAX_SPREAD; // lanes per path at most, when a launch has fewer pixels than lanes (pool walk)
 constexpr uint32_t kCompactWords = 8, kCompactPasses = 4; // a path's 30 state words travel through LDS in four passes of eight
 
 // kLdsGeometry: the arrays the ray queries and the light sampler read (both
@@ -152,6 +156,8 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
         q = n_work;
     for (;;)
     {
+        // (pool walk: a lane without work of its own stays in the loop as a HELPER of its wavefront's ray queries)
+        bool helper = false;
         if (kCompact && job.compact)
         {
             if (!has_pixel && !retired && q >= n_work)
@@ -227,12 +233,22 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
                 continue;
             }
             if (retired)
-                continue;
+            {
+                if (!C::kPool)
+                    continue;
+                helper = true;
+            }
         }
-        if (!has_pixel)
+        if (!helper && !has_pixel && q >= n_work)
         {
-            if (q >= n_work)
+            if (!C::kPool)
                 break;
+            helper = true;
+        }
+        if (C::kPool && !(kCompact && job.compact) && __ballot(!helper) == 0)
+            break; // every lane of the wavefront that is here is out of work
+        if (!helper && !has_pixel)
+        {
             // (n_work is a multiple of 64: whole tiles)
             const uint32_t qs = job.scatter ? (q & 63u) * (n_work >> 6) + (q >> 6) : q;
             const uint32_t k = split == 1 ? 0u : qs / job.n_items, position = qs - k * job.n_items;
@@ -253,7 +269,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
             slot = (job.packed ? item : pixel) + k * job.plane_stride;
             has_pixel = true;
         }
-        if (!st.alive)
+        if (!helper && !st.alive)
         {
             if (st.sample >= sc.camera.spp)
             {
@@ -269,8 +285,11 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
             if (kCount)
                 ++local.samples;
         }
-        path_step<C>(sc, st, cnt);
-        ++steps;
+        if constexpr (C::kPool)
+            path_step_uniform<C>(sc, st, cnt, !helper);
+        else
+            path_step<C>(sc, st, cnt);
+        steps += helper ? 0u : 1u;
     }
 
     if (kCount)
@@ -363,8 +382,28 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
     //  — except the diffuse LDS instantiations on a quarter of the lanes or less: 1 path per 2 lanes, cornell's 1/4 and
     //  1/8 shares 43.6 -> 38.8 and 41.2 -> 38.8 ms; its 1/2 share 42.8 -> 53.0 ms, so not there)
     if (spread_job.lane_spread == 0)
+    {
         spread_job.lane_spread =
             kLdsGeometry && (kFeatures & kAll & ~kFeatEmitters) == 0 && uint64_t(n_work) * 4u <= uint64_t(resident) * kBlockSize ? 2u : 1u;
+        if (kPool)
+        {
+            // pool walk: the lanes between the paths are helpers of their wavefront's ray queries, which shortens a pixel's chain
+            // of samples — as long as the SIMDs are not full: the helpers' instructions cost issue slots like anybody's.  Measured
+            // on rank shares of cornell 512 x 512 spp 256 (profiles/r04_experiments/pool_walk_rank_shares.jsonl), lanes used =
+            // pixels x spread: a 1/4 share 43.7 / 35.9 / 43.6 ms at a quarter / half / all of the GPU's lanes, a 1/8 share
+            // 35.4 / 32.7 / 40.3 ms; a 1/2 share 46.4 ms dense on half of the lanes, 40.9 ms spread over all of them.  Rule: half
+            // of the lanes — all of them when that leaves the paths dense.
+            const uint64_t lanes = uint64_t(resident) * kBlockSize;
+            uint32_t spread = 1;
+            while (spread < kPoolMaxSpread && uint64_t(n_work) * (spread * 2u) * 2u <= lanes)
+                spread *= 2u;
+            if (spread == 1 && uint64_t(n_work) * 2u <= lanes)
+                spread = 2;
+            spread_job.lane_spread = spread;
+        }
+    }
+    if (kPool && spread_job.lane_spread > 1)
+        spread_job.compact = 0; // (the compaction would gather the paths into the first wavefronts again)
     if (spread_job.scatter == kScatterAuto)
         // (measured on the diffuse instantiations; volumetric-caustic lost 6 % with it at 3.5 pixels per lane)
         spread_job.scatter = kLdsGeometry && (kFeatures & kAll & ~kFeatEmitters) == 0 &&

@@ -168,7 +168,7 @@ MCPT_HD bool trace(const DeviceScene &sc, uint32_t *stack, Ray &r, uint32_t &rng
     {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (C::kPool) // (`stack` = the wavefront's pool area)
-            return count ? walk_pool<kAny, C::kAnalytic, true>(sc, stack, r, hit, ts) : walk_pool<kAny, C::kAnalytic, false>(sc, stack, r, hit, ts);
+            return count ? walk_pool<kAny, C::kAnalytic, true>(sc, stack, true, r, hit, ts) : walk_pool<kAny, C::kAnalytic, false>(sc, stack, true, r, hit, ts);
 #endif
         if (C::kWide)
             return count ? walk_wide_vote<kAny, C::kAnalytic, true, C::kSlivers>(sc, stack, r, hit, ts)
@@ -613,6 +613,179 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
     const bool hit_valid = path_extend<C>(sc, st, cnt, ray, raw);
     path_shade<C>(sc, st, cnt, ray, raw, hit_valid);
 }
+
+#if defined(__HIPCC__)
+// ---- the step with UNIFORM ray queries (pool walk, pool_walk.h) -----------------------------------------------
+// path_step for the kernels whose ray queries are the wavefront-cooperative pool walk: every lane of the wavefront makes
+// every query call of the step, with a flag saying whether it brings a ray — a lane without a path (`has_path` false), or
+// whose sample ended before the query, works on the other lanes' rays.  Statement for statement path_extend /
+// path_resolve / connect_lights / the scatter of path_connect_scatter: the random numbers of a vertex are drawn in the
+// reference's order (every draw of a light precedes its shadow query, nothing after a query draws: path.cpp:144-205).
+template <class C, bool kAny>
+__device__ __forceinline__ bool trace_uniform(const DeviceScene &sc, uint32_t *pool, bool has_ray, Ray &r, HitRaw &hit, TraceStats &ts, bool count)
+{
+    return count ? walk_pool<kAny, C::kAnalytic, true>(sc, pool, has_ray, r, hit, ts) : walk_pool<kAny, C::kAnalytic, false>(sc, pool, has_ray, r, hit, ts);
+}
+
+template <class C>
+__device__ __forceinline__ bool shadow_walk_uniform(const DeviceScene &sc, uint32_t *pool, bool has_ray, V3 origin, V3 dir, float t_max, LaneCounters *cnt)
+{
+    Ray r = make_ray(origin, dir);
+    r.t_max = t_max;
+    HitRaw dummy;
+    TraceStats ts{0, 0, 0, 0};
+    const bool hit = trace_uniform<C, true>(sc, pool, has_ray, r, dummy, ts, cnt != nullptr);
+    if (cnt)
+    {
+        cnt->shadow_rays += has_ray ? 1u : 0u, cnt->node_tests += ts.node_tests, cnt->prim_tests += ts.prim_tests;
+        cnt->wave_node_steps += ts.wave_node_steps, cnt->wave_prim_steps += ts.wave_prim_steps;
+    }
+    return hit;
+}
+
+// connect_lights with the shadow queries made by every lane; `active`: this lane stands at a vertex.
+template <class C>
+__device__ __forceinline__ V3 connect_lights_uniform(const DeviceScene &sc, uint32_t *pool, bool active, const Surface &s, V3 position, V3 wo,
+                                                     uint32_t &rng, LaneCounters *cnt)
+{
+    static_assert(!C::kVolPath, "surface vertices only");
+    V3 L = V3{0, 0, 0};
+    const LightTables LT = light_tables<C>(sc);
+    const uint32_t bsdf = active ? sc.instances[s.inst].bsdf : kNone;
+    auto weigh = [&](V3 wi, V3 &att, float &pdf) -> bool
+    {
+        if (dot(-wi, s.normal) < kEpsFloat)
+            return false;
+        const BsdfQuery q = eval_at<C>(sc, s, bsdf, wi, wo);
+        if (!q.valid)
+            return false;
+        att = q.attenuation, pdf = q.pdf;
+        return true;
+    };
+    if (C::kEmitters)
+    {
+        for (uint32_t k = 0; k < sc.integrator.n_emitters; ++k)
+        {
+            const EmitterRec &e = sc.emitters[k];
+            LightSample ls{};
+            if (active)
+            {
+                const float xi0 = lcg_next(rng), xi1 = lcg_next(rng);
+                ls = emitter_sample(LT, e, position, xi0, xi1);
+            }
+            const bool occluded = shadow_walk_uniform<C>(sc, pool, active, position, -ls.wi, ls.distance - kEpsDistance, cnt);
+            V3 att;
+            float pdf;
+            if (!active || occluded || !weigh(ls.wi, att, pdf))
+                continue;
+            const V3 radiance = emitter_eval_sample(LT, e, ls);
+            if (ls.harsh)
+                L += radiance * att; // path.cpp:170
+            else
+            {
+                const float pdf_direct = emitter_pdf(LT, e, -ls.wi);
+                if (pdf_direct > kEpsFloat)
+                    L += power_heuristic(pdf_direct, pdf) * radiance * (att / pdf_direct); // path.cpp:178
+            }
+        }
+    }
+    if (sc.integrator.n_area_lights != 0)
+    {
+        uint32_t light = 0, inst = 0;
+        LightPoint lp{};
+        V3 d = V3{0, 0, 1};
+        float distance = 0.0f;
+        if (active)
+        {
+            const float xi_pick = lcg_next(rng);
+            light = cdf_search(sc.integrator.n_area_lights + 1, sc.light_cdf, xi_pick) - 1;
+            inst = sc.light_inst[light];
+            const float xi0 = lcg_next(rng), xi1 = lcg_next(rng), xi2 = lcg_next(rng);
+            lp = sample_instance<C::kAnalytic>(sc, inst, xi0, xi1, xi2);
+            d = position - lp.position;
+            distance = length(d);
+        }
+        // the shadow ray starts ON THE LIGHT and travels to the shading point
+        const bool occluded = shadow_walk_uniform<C>(sc, pool, active, lp.position, normalize(d), distance - kEpsDistance, cnt);
+        if (active && !occluded)
+        {
+            const V3 wi = normalize(d);
+            const float cos_light = dot(wi, lp.normal);
+            V3 att;
+            float pdf;
+            if (!(cos_light < kEpsFloat) && weigh(wi, att, pdf))
+            {
+                const float pdf_direct = area_light_pdf(sc, light, inst, distance, cos_light), w = power_heuristic(pdf_direct, pdf);
+                const V3 radiance = texture_color(sc.textures, sc.texels, sc.bsdfs[sc.instances[inst].bsdf].tex0, lp.uv, !C::kTextures);
+                L += w * radiance * (att / pdf_direct); // path.cpp:232
+            }
+        }
+    }
+    return L;
+}
+
+// One step of every lane of the wavefront; `has_path`: the lane's path is alive (st.alive) — the others only help.
+template <class C>
+__device__ __forceinline__ void path_step_uniform(const DeviceScene &sc, PathState &st, LaneCounters *cnt, bool has_path)
+{
+    static_assert(!C::kVolPath && C::kOrdered, "the lean instantiations");
+    // ---- extend ----
+    Ray ray = make_ray(has_path ? st.origin : V3{0, 0, 0}, has_path ? st.dir : V3{0, 0, 1});
+    HitRaw raw;
+    raw.inst = raw.prim = 0, raw.a = raw.b = raw.c = 0.0f, raw.inside = false;
+    TraceStats ts{0, 0, 0, 0};
+    const bool known = has_path && st.primary && sc.prehit != nullptr; // the pre-pass traced this camera ray
+    bool hit_valid = false;
+    if (known)
+    {
+        const uint32_t *rec = prehit_record(sc, st.pixel, st.sample - sc.prehit_step);
+        hit_valid = rec[0] != kNone;
+        if (hit_valid)
+            hit_from_record<C::kAnalytic>(sc, rec[1], rec[0], ray, raw);
+    }
+    const bool traced = trace_uniform<C, false>(sc, st.stack, has_path && !known, ray, raw, ts, cnt != nullptr);
+    hit_valid = known ? hit_valid : traced;
+    if (cnt)
+    {
+        cnt->closest_rays += has_path && !known ? 1u : 0u, cnt->node_tests += ts.node_tests, cnt->prim_tests += ts.prim_tests;
+        cnt->wave_node_steps += ts.wave_node_steps, cnt->wave_prim_steps += ts.wave_prim_steps;
+    }
+    // ---- resolve, roulette ----
+    Surface surf;
+    surf.inside = false, surf.inst = 0, surf.uv = V2{0, 0};
+    surf.position = surf.normal = surf.tangent = surf.bitangent = V3{0, 0, 0};
+    if (has_path)
+        path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
+    const bool at_vertex = has_path && st.alive;
+    // ---- connect ----
+    const V3 direct = connect_lights_uniform<C>(sc, st.stack, at_vertex, surf, surf.position, st.wo, st.rng, cnt);
+    if (!at_vertex)
+        return;
+    st.L += st.throughput * direct;
+    // ---- scatter (path_connect_scatter) ----
+    const uint32_t bsdf = sc.instances[surf.inst].bsdf;
+    BsdfQuery q = query_at(surf, st.wo, st.wo); // path.cpp:268-296
+    if (bsdf != kNone)
+        bsdf_sample<C::kMicrofacet, 0, C::kKinds>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
+    else
+        q.wi = st.wo, q.pdf = 1.0f, q.attenuation = V3{1.0f, 1.0f, 1.0f}, q.valid = true;
+    if (!q.valid)
+    {
+        finish_sample(st);
+        return;
+    }
+    st.wi = q.wi;
+    st.pdf_sample = q.pdf;
+    st.throughput *= q.attenuation / q.pdf;
+    st.origin = surf.position;
+    if (max_component(st.throughput) < kEps)
+    {
+        finish_sample(st);
+        return;
+    }
+    st.dir = -st.wi;
+}
+#endif // __HIPCC__
 
 // Convenience for CPU-side emulation and unit tests: a whole pixel.
 template <class C>

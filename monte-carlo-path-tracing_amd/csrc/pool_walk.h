@@ -81,7 +81,7 @@ MCPT_HD SlotHit probe_slot(const DeviceScene &sc, const float4 *p, const Ray &ra
     return h;
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIPCC__)
 
 __device__ __forceinline__ void pool_sync()
 {
@@ -97,11 +97,12 @@ __device__ __forceinline__ uint32_t pool_rank(unsigned long long mask, uint32_t 
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), base));
 }
 
-// `pool`: the calling wavefront's kPoolWaveWords words of LDS.  Called by the lanes of a wavefront that have a ray (the
-// active ones: they are also the workers).  Returns whether the lane's ray hit anything; closest queries: `hit` and
-// ray.t_max describe it.
+// `pool`: the calling wavefront's kPoolWaveWords words of LDS.  Every lane that calls is a WORKER; the ones with
+// `has_ray` also bring a ray — a lane without a path of its own (its pixel is finished, its sample ended at this vertex,
+// the launch gave it none: RenderJob::lane_spread) helps the others' rays along, which is what shortens a pixel's chain
+// when lanes are idle.  Returns whether the lane's ray hit anything; closest queries: `hit` and ray.t_max describe it.
 template <bool kAny, bool kAnalytic, bool kCount>
-__device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool, Ray &ray, HitRaw &hit, TraceStats &stats)
+__device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool, bool has_ray, Ray &ray, HitRaw &hit, TraceStats &stats)
 {
     if (sc.integrator.n_walk_nodes == 0)
         return false;
@@ -116,6 +117,10 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
     const float tie = sc.integrator.walk_tie;
 
     // ---- the lane's ray becomes a record ----
+    const unsigned long long m_rays = __ballot(has_ray);
+    if (m_rays == 0)
+        return false;
+    if (has_ray)
     {
         // byte offsets, inside a node's 64-byte record {lo0 ref0 | hi0 ref1 | lo1 - | hi1 -}, of the planes the ray
         // enters through (walk_ordered's sign-addressed reads): x: 0 or 16, y: 4 or 20, z: 8 or 24
@@ -128,11 +133,11 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
         if (kAnalytic)
             rays[kRayVecs * lane + 3] = float4{ray.dir.x, ray.dir.y, ray.dir.z, 0.0f};
         counts[lane] = 0;
-        node_items[rank] = static_cast<uint16_t>(lane << 10); // (ray, top node)
+        node_items[pool_rank(m_rays)] = static_cast<uint16_t>(lane << 10); // (ray, top node)
     }
     // (wavefront-uniform values, kept in scalar registers: `uni` tells the compiler so where it cannot see it)
     auto uni = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
-    uint32_t n_nodes = uni(n_workers), n_prims = 0;
+    uint32_t n_nodes = uni(static_cast<uint32_t>(__popcll(m_rays))), n_prims = 0;
     for (uint32_t pass = 0;; ++pass)
     {
         pool_sync();
@@ -253,7 +258,7 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
         if (kAny)
             break;
         // a ray whose candidate list overflowed walks again, its final bound as the initial one
-        const bool again = pass == 0 && counts[lane] > kPoolCands;
+        const bool again = pass == 0 && has_ray && counts[lane] > kPoolCands;
         const unsigned long long m_again = __ballot(again);
         if (m_again == 0)
             break;
@@ -264,6 +269,8 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
         }
         n_nodes = uni(static_cast<uint32_t>(__popcll(m_again)));
     }
+    if (!has_ray)
+        return false;
     if (kAny)
         return counts[lane] != 0;
 
@@ -316,7 +323,7 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
     return true;
 }
 
-#endif // __HIP_DEVICE_COMPILE__
+#endif // __HIPCC__
 
 } // namespace mcpt
 
