@@ -117,7 +117,7 @@ struct mcpt_renderer
     uint32_t n_cus = 0;
     mcpt::FlatScene flat;
     mcpt::DeviceScene dev{};
-    DeviceArray arrays[20];
+    DeviceArray arrays[24];
     uint32_t *walk_spill_dev = nullptr; // DeviceScene::walk_spill (allocated when a launch may use the wide walk)
     bool reference_walk = false;           // mcpt_renderer_set_walk
     float *frame_dev = nullptr;            // scratch frame for mcpt_renderer_draw
@@ -267,6 +267,7 @@ std::unique_ptr<mcpt_renderer> MakeRenderer(mcpt::FlatScene flat, int device)
     d.walk_nodes = r->arrays[k++].Upload(f.walk_nodes, "upload walk hierarchy");
     d.walk_prims = r->arrays[k++].Upload(f.walk_prims, "upload walk primitives");
     d.wide_nodes = r->arrays[k++].Upload(f.wide_nodes, "upload wide walk hierarchy");
+    d.pool_nodes = r->arrays[k++].Upload(f.pool_nodes, "upload pool walk hierarchy");
     d.tri_pos = r->arrays[k++].Upload(f.tri_pos, "upload triangle positions");
     d.tri_attr = r->arrays[k++].Upload(f.tri_attr, "upload triangle attributes");
     d.instances = r->arrays[k++].Upload(f.instances, "upload instances");

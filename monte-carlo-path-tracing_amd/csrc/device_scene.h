@@ -38,6 +38,8 @@
 //              plane = origin + 2^(e - 127) * q: decoded boxes contain the exact ones (verified with these very
 //              operations by the quantiser), so the walk reaches every primitive the exact hierarchy reaches; the exact
 //              leaf-box test at the primitive (test_slot, kLeafCheck) stops what the larger boxes let through.
+//   pool_nodes 8 x float4 per node (128 B) of the SAME hierarchy with four children per node and exact boxes (small scenes only;
+//              the layout is at DeviceScene::pool_nodes)
 //   walk_prims 3 x float4 per slot: p0 | bits(global primitive), p1 | bits(instance),
 //              p2 | bits(rank of the primitive in the reference's visiting order)
 //   tri_pos    3 x float4 per triangle: p0, p1, p2 (w unused)  -> 36 B useful
@@ -236,6 +238,8 @@ struct IntegratorRec // reference integrator.hpp:31-69 (the scalar part)
     float walk_extent;     // largest |coordinate| of any box plane of the ordered-walk hierarchy (fused slab test: traversal.h)
     float walk_sliver_reach; // culling slack while the best hit is a sliver (kWalkSliver): the largest amount a
                              // sliver's leaf box was grown by (commit.cpp), never below walk_tie; 0 = the scene has none
+    uint32_t n_pool_nodes;   // 4-wide exact form of the ordered-walk hierarchy (pool_nodes); 0 = not built (large scenes)
+    uint32_t pool_depth;     // ... its depth
 };
 
 // Feature bits: which parts of the hot path a scene actually exercises.  The
@@ -312,6 +316,12 @@ struct DeviceScene
     // the tile enumeration of the draw the pre-pass was made for (RenderJob: tile_first, tile_stride, tiles_x): the buffer
     // holds the draw's OWN items only — record of (pixel, sample) at 2 (item(pixel) * spp + sample), path_core.h::prehit_record
     uint32_t prehit_tile_first, prehit_tile_stride, prehit_tiles_x;
+    // The ordered-walk hierarchy collapsed to FOUR children per node with their exact boxes, for the wavefront-cooperative
+    // pool walk of small scenes (pool_walk.h; commit.cpp, BuildPoolNodes): 8 x float4 = 128 B per node, plane-major so that
+    // the walk READS the planes a ray enters / leaves through instead of selecting them:
+    //   [0] lo.x of children 0..3   [1] lo.y   [2] lo.z   [3] hi.x   [4] hi.y   [5] hi.z   [6] the four references   [7] -
+    // reference = node index or kWalkLeaf | slot; an unused child has an inverted box (never entered) and names slot 0.
+    const float4 *pool_nodes;
 };
 
 // Counters of the measurement mode: totals over a launch.

@@ -182,7 +182,9 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     }
     const bool lds = StagedBytes(sc, true) <= kLdsGeometryBytes;
     // the wavefront-cooperative pool walk (pool_walk.h): its items hold node and slot indices in 10 bits
-    const bool pool = lds && job.pool_walk != 0 && sc.integrator.n_walk_nodes <= kPoolMaxRef + 1u && sc.integrator.n_prims <= kPoolMaxRef + 1u;
+    const bool pool = lds && job.pool_walk != 0 && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kPoolMaxRef + 1u &&
+                      sc.integrator.n_prims <= kPoolMaxRef + 1u && sc.integrator.pool_depth <= kPoolMaxDepth &&
+                      StagedBytes(sc, true, true) <= kLdsGeometryBytes;
     if (f == 0)
     {
         *variant = pool ? "diffuse-area+lds+pool-walk" : lds ? "diffuse-area+lds" : "diffuse-area";

@@ -86,14 +86,15 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     if (kLdsGeometry)
     {
         const uint32_t n_node_vec = 2u * sc_in.integrator.n_nodes, n_tri_vec = 3u * sc_in.integrator.n_prims;
-        const uint32_t n_walk_vec = C::kOrdered ? 4u * sc_in.integrator.n_walk_nodes : 0u;
+        // (pool walk: the 4-wide exact form of the hierarchy instead of the binary one)
+        const uint32_t n_walk_vec = C::kPool ? 8u * sc_in.integrator.n_pool_nodes : C::kOrdered ? 4u * sc_in.integrator.n_walk_nodes : 0u;
         const uint32_t n_slot_vec = C::kOrdered ? n_tri_vec : 0u;
         for (uint32_t i = threadIdx.x; i < n_node_vec; i += blockDim.x)
             lds_geometry[i] = sc_in.nodes[i];
         for (uint32_t i = threadIdx.x; i < n_tri_vec; i += blockDim.x)
             lds_geometry[n_node_vec + i] = sc_in.tri_pos[i];
         for (uint32_t i = threadIdx.x; i < n_walk_vec; i += blockDim.x)
-            lds_geometry[n_node_vec + n_tri_vec + i] = sc_in.walk_nodes[i];
+            lds_geometry[n_node_vec + n_tri_vec + i] = C::kPool ? sc_in.pool_nodes[i] : sc_in.walk_nodes[i];
         for (uint32_t i = threadIdx.x; i < n_slot_vec; i += blockDim.x)
             lds_geometry[n_node_vec + n_tri_vec + n_walk_vec + i] = sc_in.walk_prims[i];
         __syncthreads();
@@ -102,6 +103,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
         if (C::kOrdered)
         {
             sc.walk_nodes = lds_geometry + n_node_vec + n_tri_vec;
+            sc.pool_nodes = lds_geometry + n_node_vec + n_tri_vec; // (whichever form was staged)
             sc.walk_prims = lds_geometry + n_node_vec + n_tri_vec + n_walk_vec;
         }
         n_staged = n_node_vec + n_tri_vec + n_walk_vec + n_slot_vec;
@@ -342,11 +344,11 @@ inline size_t WalkStackEntries(const DeviceScene &sc, uint32_t features)
     return (features & kFeatWideWalk) ? size_t(kWideRing) : size_t(sc.integrator.walk_depth);
 }
 
-inline size_t StagedBytes(const DeviceScene &sc, bool ordered)
+inline size_t StagedBytes(const DeviceScene &sc, bool ordered, bool pool = false)
 {
     size_t vecs = 2ull * sc.integrator.n_nodes + 3ull * sc.integrator.n_prims;
     if (ordered)
-        vecs += 4ull * sc.integrator.n_walk_nodes + 3ull * sc.integrator.n_prims;
+        vecs += (pool ? 8ull * sc.integrator.n_pool_nodes : 4ull * sc.integrator.n_walk_nodes) + 3ull * sc.integrator.n_prims;
     return vecs * sizeof(float4);
 }
 
@@ -360,7 +362,7 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
     constexpr bool kPool = (kFeatures & kFeatPoolWalk) != 0;
     static_assert(!kPool || (kLdsGeometry && kOrdered), "the pool walk runs on hierarchies staged in LDS");
     static_assert((kBlockSize / 64u) * pool_wave_words(false) >= kCompactWords * kBlockSize, "the compaction's words travel through the pool areas");
-    const size_t lds_bytes = (kLdsGeometry ? StagedBytes(sc, kOrdered) : 0) +
+    const size_t lds_bytes = (kLdsGeometry ? StagedBytes(sc, kOrdered, kPool) : 0) +
                              (kPool      ? size_t(kBlockSize / 64u) * pool_wave_words((kFeatures & kFeatAnalytic) != 0) * sizeof(uint32_t) + 8 * sizeof(uint32_t)
                               : kOrdered ? WalkStackEntries(sc, kFeatures) * kBlockSize * sizeof(uint32_t)
                                          : 0) +

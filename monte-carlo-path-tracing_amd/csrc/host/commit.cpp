@@ -202,6 +202,105 @@ private:
 // traversal stack.
 int g_walk_tree_strategy = 0; // SetWalkTreeStrategyForTesting
 
+// ---- 4-wide, exact form of the ordered-walk hierarchy (device_scene.h: pool_nodes) --------------
+// For the wavefront-cooperative pool walk of small scenes (pool_walk.h): a (ray, node) item of that walk costs a fixed
+// amount of bookkeeping whatever the node holds, and a walk lasts at least as many steps as the tree is deep — four
+// children per item halve both.  The children's boxes are the binary hierarchy's own (a child here is a child or
+// grandchild there): a primitive is reachable under exactly the same conditions, interior boxes that disappear were
+// supersets of what they held (the slab test is monotone in the box).
+constexpr uint32_t kPoolTreeMaxNodes = 1024;
+
+void BuildPoolNodes(FlatScene &fs)
+{
+    IntegratorRec &ig = fs.integrator;
+    fs.pool_nodes.clear();
+    ig.n_pool_nodes = 0, ig.pool_depth = 0;
+    const uint32_t n_binary = ig.n_walk_nodes;
+    if (n_binary == 0 || n_binary > kPoolTreeMaxNodes)
+    {
+        fs.pool_nodes.assign(8, float4{0, 0, 0, 0});
+        return;
+    }
+    struct Child
+    {
+        uint32_t ref; // binary node index, or kWalkLeaf | slot
+        Bounds box;
+    };
+    auto children_of = [&](uint32_t node, Child out[2]) -> int
+    {
+        const float4 *n = &fs.walk_nodes[4 * size_t(node)];
+        int k = 0;
+        uint32_t ref0, ref1;
+        std::memcpy(&ref0, &n[0].w, 4), std::memcpy(&ref1, &n[1].w, 4);
+        Bounds b0, b1;
+        b0.lo = V3{n[0].x, n[0].y, n[0].z}, b0.hi = V3{n[1].x, n[1].y, n[1].z};
+        b1.lo = V3{n[2].x, n[2].y, n[2].z}, b1.hi = V3{n[3].x, n[3].y, n[3].z};
+        if (!(b0.lo.x > b0.hi.x)) // (not the "never entered" box of the top node's second child)
+            out[k++] = Child{ref0, b0};
+        if (!(b1.lo.x > b1.hi.x))
+            out[k++] = Child{ref1, b1};
+        return k;
+    };
+    auto area = [](const Bounds &b)
+    {
+        const double dx = double(b.hi.x) - b.lo.x, dy = double(b.hi.y) - b.lo.y, dz = double(b.hi.z) - b.lo.z;
+        return dx * dy + dy * dz + dz * dx;
+    };
+    struct Todo
+    {
+        uint32_t binary, depth;
+    };
+    std::vector<Todo> todo{{0u, 1u}};
+    for (size_t k = 0; k < todo.size(); ++k)
+    {
+        Child kids[4];
+        int n = children_of(todo[k].binary, kids);
+        for (;;) // open the inner child of largest surface while the result still fits four
+        {
+            int pick = -1;
+            double best = -1.0;
+            for (int i = 0; i < n; ++i)
+                if (!(kids[i].ref & kWalkLeaf) && area(kids[i].box) > best)
+                    best = area(kids[i].box), pick = i;
+            if (pick < 0 || n >= 4)
+                break;
+            Child grand[2];
+            const int g = children_of(kids[pick].ref, grand);
+            if (n - 1 + g > 4)
+                break;
+            kids[pick] = kids[n - 1], --n;
+            for (int i = 0; i < g; ++i)
+                kids[n++] = grand[i];
+        }
+        float plane[6][4];
+        // (an unused child's reference names a real slot: a ray with NaN components passes every box test, this one's too)
+        uint32_t refs[4] = {kWalkLeaf, kWalkLeaf, kWalkLeaf, kWalkLeaf};
+        for (int i = 0; i < 4; ++i)
+        {
+            // unused child: the inverted box that no ray enters
+            const V3 lo = i < n ? kids[i].box.lo : V3{kMaxFloat, kMaxFloat, kMaxFloat}, hi = i < n ? kids[i].box.hi : V3{-kMaxFloat, -kMaxFloat, -kMaxFloat};
+            plane[0][i] = lo.x, plane[1][i] = lo.y, plane[2][i] = lo.z, plane[3][i] = hi.x, plane[4][i] = hi.y, plane[5][i] = hi.z;
+            if (i >= n)
+                continue;
+            if (kids[i].ref & kWalkLeaf)
+                refs[i] = kids[i].ref;
+            else
+            {
+                refs[i] = static_cast<uint32_t>(todo.size());
+                todo.push_back(Todo{kids[i].ref, todo[k].depth + 1u});
+            }
+        }
+        ig.pool_depth = std::max(ig.pool_depth, todo[k].depth);
+        for (int a = 0; a < 6; ++a)
+            fs.pool_nodes.push_back(float4{plane[a][0], plane[a][1], plane[a][2], plane[a][3]});
+        float4 r;
+        std::memcpy(&r, refs, sizeof r);
+        fs.pool_nodes.push_back(r);
+        fs.pool_nodes.push_back(float4{0, 0, 0, 0});
+    }
+    ig.n_pool_nodes = static_cast<uint32_t>(todo.size());
+}
+
 // ---- 4-wide, quantised form of the ordered-walk hierarchy (device_scene.h: wide_nodes) ----------
 // The mesh walk is bound by the number of 64-byte node records it pulls through L2 / Infinity Cache (a lean trace kernel
 // moves ~150 G records/s = 9.4 TB/s whatever its occupancy: DESIGN.md section 6), so the lever is records per ray: a
@@ -881,6 +980,7 @@ DeviceScene FlatScene::HostView() const
     d.nodes = nodes.data(), d.node_area = node_area.data();
     d.walk_nodes = walk_nodes.data(), d.walk_prims = walk_prims.data();
     d.wide_nodes = wide_nodes.data();
+    d.pool_nodes = pool_nodes.data();
     d.tri_pos = tri_pos.data(), d.tri_attr = tri_attr.data();
     d.instances = instances.data(), d.analytic = analytic.data();
     d.light_inst = light_inst.data(), d.light_cdf = light_cdf.data();
@@ -1220,6 +1320,7 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
             fs.walk_prims.push_back(float4{p[2].x, p[2].y, p[2].z, Bits(rank[prim] | (sliver[prim] ? kWalkSliver : 0u))});
         }
         BuildWideNodes(fs);
+        BuildPoolNodes(fs);
         fs.seconds_walk = seconds_since(t_walk);
     }
 
@@ -1547,6 +1648,8 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
         fs.walk_prims.assign(3, float4{0, 0, 0, 0});
     if (fs.wide_nodes.empty())
         fs.wide_nodes.assign(4, uint4{0, 0, 0, 0});
+    if (fs.pool_nodes.empty())
+        fs.pool_nodes.assign(8, float4{0, 0, 0, 0});
     fs.seconds_total = seconds_since(t_begin);
     return fs;
 }

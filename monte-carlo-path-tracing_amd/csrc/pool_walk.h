@@ -5,12 +5,14 @@
 // 29 % / 24 % of the lanes do useful work) — the reference's per-thread nested stack walk has the same shape
 // (tlas.cpp:13-76, blas.cpp:18-77 inside the megakernel, renderer.cpp:88-95).  Here the rays of a wavefront's query
 // (one per active lane) are RECORDS in LDS and the work is a shared LIFO of (ray, node) items and a second one of
-// (ray, primitive slot) items: every step, every lane takes the next item, whichever ray it belongs to — a box test
-// step pushes the children it hits (far children below near ones), a primitive step tests one slot.  All lanes stay
-// busy until the lists run dry; a primitive phase runs when a wavefront's worth of slots waits (or nothing else is left),
-// so both phases run full.  tests/emu's model of exactly this schedule (Pool2Model): 33.6 -> 22.9 node steps and
-// 9.7 -> 3.9 primitive phases per round on cornell, node visits x 1.05 (a far child is sometimes tested with a bound that
-// the near child's hit would have shrunk), primitive tests x 1.28.
+// (ray, primitive slot) items: every step, every lane takes the next item, whichever ray it belongs to — a node step
+// tests the FOUR children of a node of the 4-wide exact hierarchy (DeviceScene::pool_nodes) and pushes the ones the ray
+// enters, a primitive step tests one slot.  All lanes stay busy until the lists run dry; a primitive phase runs when a
+// wavefront's worth of slots waits (or nothing else is left), so both phases run full.  tests/emu's model of this
+// schedule (Pool2Model) on cornell, per round (closest + shadow query): binary nodes 33.6 -> 22.9 node steps, two
+// levels per step (what a 4-wide node is) 11.9; 9.7 -> 3.9 primitive phases; node visits x 1.06 (a child is sometimes
+// tested with a bound that a sibling's hit would have shrunk), primitive tests x 1.3.  Measured instruction counts and
+// frame times: EXPERIMENTS.md R4-1.
 //
 // Same answers as walk_ordered, whatever the order the items are processed in:
 //   * shadow queries: the bound is fixed; a ray is occluded iff some reachable primitive accepts — a boolean OR.  An
@@ -32,7 +34,7 @@
 //
 // LDS per wavefront (kPoolWaveWords): 64 ray records of 12 words (16 with quadrics: the direction) — origin + bound |
 // reciprocal direction + byte offsets of the near planes | shear + axis permutation —, 64 candidate counters, 64 x
-// kPoolCands (distance, slot) pairs, 448 + 192 item slots of 16 bits (ray << 10 | node or slot).  The item counts
+// kPoolCands (distance, slot) pairs, 448 + 320 item slots of 16 bits (ray << 10 | node or slot).  The item counts
 // live in scalar registers: the lists belong to ONE wavefront, no atomics on them.
 #ifndef MCPT_POOL_WALK_H
 #define MCPT_POOL_WALK_H
@@ -45,7 +47,8 @@ namespace mcpt
 constexpr uint32_t kPoolCands = 6;       // candidate hits a closest ray can hold
 constexpr uint32_t kPoolNodeItems = 448; // (ray, node) item slots: 384 in normal operation + 64 of head room (see below)
 constexpr uint32_t kPoolNodeFull = 384;
-constexpr uint32_t kPoolPrimItems = 192; // (ray, slot) item slots: < kPoolPrimAt waiting + 2 x 64 pushed by one node step
+constexpr uint32_t kPoolMaxDepth = 20;   // of the 4-wide hierarchy: 3 x depth <= the head room
+constexpr uint32_t kPoolPrimItems = 320; // (ray, slot) item slots: < kPoolPrimAt waiting + 4 x 64 pushed by one node step
 constexpr uint32_t kPoolPrimAt = 64;     // a primitive phase runs when this many slots wait
 constexpr uint32_t kPoolMaxRef = 1023;   // node and slot indices must fit 10 bits
 
@@ -122,9 +125,9 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
         return false;
     if (has_ray)
     {
-        // byte offsets, inside a node's 64-byte record {lo0 ref0 | hi0 ref1 | lo1 - | hi1 -}, of the planes the ray
-        // enters through (walk_ordered's sign-addressed reads): x: 0 or 16, y: 4 or 20, z: 8 or 24
-        const uint32_t nx = ray.dir_rcp.x > 0 ? 0u : 16u, ny = ray.dir_rcp.y > 0 ? 4u : 20u, nz = ray.dir_rcp.z > 0 ? 8u : 24u;
+        // byte offsets, inside a node's 128-byte record {lo.x lo.y lo.z hi.x hi.y hi.z of the four children | references}, of
+        // the planes the ray enters through (walk_ordered's sign-addressed reads): x: 0 or 48, y: 16 or 64, z: 32 or 80
+        const uint32_t nx = ray.dir_rcp.x > 0 ? 0u : 48u, ny = ray.dir_rcp.y > 0 ? 16u : 64u, nz = ray.dir_rcp.z > 0 ? 32u : 80u;
         const uint32_t pack = nx | (ny << 8) | (nz << 16);
         const uint32_t axes = static_cast<uint32_t>(ray.kx) | (static_cast<uint32_t>(ray.ky) << 2) | (static_cast<uint32_t>(ray.kz) << 4);
         rays[kRayVecs * lane + 0] = float4{ray.origin.x, ray.origin.y, ray.origin.z, ray.t_max};
@@ -194,11 +197,13 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
                 pool_sync();
                 continue;
             }
-            // ---- node phase: the top items, one per lane; both children of a node tested, the hit ones pushed ----
-            // (head room: a step with k lanes grows the list by at most k.  Below kPoolNodeFull every worker takes an item;
-            //  above, fewer do, down to ONE — a depth-first walk, which adds at most the tree's depth (<= 56) to the list)
+            // ---- node phase: the top items, one per lane; the FOUR children of a node (DeviceScene::pool_nodes) tested, the
+            //      hit ones pushed (in the order the node stores them: a model of this schedule with near children on top of far
+            //      ones gave 11.9 instead of 12.4 steps per round on cornell — not worth a sort per item) ----
+            // (head room: a step with k lanes grows the list by at most 3 k.  Below kPoolNodeFull every worker takes an item
+            //  if that fits; above, ONE does — a depth-first walk, which adds at most 3 x the tree's depth to the list)
             uint32_t k = uni(n_nodes < n_workers ? n_nodes : n_workers);
-            const uint32_t room = uni(n_nodes < kPoolNodeFull ? kPoolNodeFull - n_nodes : 1u);
+            const uint32_t room = uni(n_nodes < kPoolNodeFull ? (kPoolNodeFull - n_nodes + 2u) / 3u : 1u);
             k = uni(k < room ? k : room);
             if (kCount && rank == 0)
                 ++stats.wave_node_steps;
@@ -208,49 +213,40 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
             if (rank < k)
             {
                 if (kCount)
-                    stats.node_tests += 2;
+                    stats.node_tests += 4;
                 const uint32_t item = node_items[n_nodes - 1u - rank];
                 const uint32_t ray_bits = item & ~kPoolMaxRef, r = item >> 10, node = item & kPoolMaxRef;
                 const float4 a = rays[kRayVecs * r], b = rays[kRayVecs * r + 1];
                 const uint32_t pack = __float_as_uint(b.w);
-                const char *w = reinterpret_cast<const char *>(sc.walk_nodes) + 64u * node;
+                const char *w = reinterpret_cast<const char *>(sc.pool_nodes) + 128u * node;
                 const uint32_t ox = pack & 0xffu, oy = (pack >> 8) & 0xffu, oz = (pack >> 16) & 0xffu;
-                const float *wnx = reinterpret_cast<const float *>(w + ox), *wfx = reinterpret_cast<const float *>(w + (16u - ox));
-                const float *wny = reinterpret_cast<const float *>(w + oy), *wfy = reinterpret_cast<const float *>(w + (24u - oy));
-                const float *wnz = reinterpret_cast<const float *>(w + oz), *wfz = reinterpret_cast<const float *>(w + (32u - oz));
-                const float nx0 = (wnx[0] - a.x) * b.x, fx0 = (wfx[0] - a.x) * b.x;
-                const float ny0 = (wny[0] - a.y) * b.y, fy0 = (wfy[0] - a.y) * b.y;
-                const float nz0 = (wnz[0] - a.z) * b.z, fz0 = (wfz[0] - a.z) * b.z;
-                const float nx1 = (wnx[8] - a.x) * b.x, fx1 = (wfx[8] - a.x) * b.x;
-                const float ny1 = (wny[8] - a.y) * b.y, fy1 = (wfy[8] - a.y) * b.y;
-                const float nz1 = (wnz[8] - a.z) * b.z, fz1 = (wfz[8] - a.z) * b.z;
-                const float enter0 = fmaxf(fmaxf(fmaxf(kEpsDistance, nx0), ny0), nz0);
-                const float enter1 = fmaxf(fmaxf(fmaxf(kEpsDistance, nx1), ny1), nz1);
-                const bool hit0 = enter0 <= fminf(fminf(fminf(a.w, fx0), fy0), fz0);
-                const bool hit1 = enter1 <= fminf(fminf(fminf(a.w, fx1), fy1), fz1);
-                const uint32_t *refs = reinterpret_cast<const uint32_t *>(w);
-                const uint32_t ref0 = refs[3], ref1 = refs[7];
-                const bool first0 = enter0 <= enter1;
-                const bool both = hit0 && hit1, some = hit0 || hit1;
-                const uint32_t toward = (hit0 && (first0 || !hit1)) ? ref0 : ref1, other = first0 ? ref1 : ref0;
-                const bool toward_leaf = static_cast<int32_t>(toward) < 0, other_leaf = static_cast<int32_t>(other) < 0; // kWalkLeaf = the sign bit
-                // (ballots of plain comparisons, combined as 64-bit masks: a ballot of a combined predicate goes through a
-                //  vector register as a 0 / 1 word)
-                const unsigned long long b0 = __ballot(hit0), b1 = __ballot(hit1), b_tl = __ballot(toward_leaf), b_ol = __ballot(other_leaf);
-                const unsigned long long b_some = b0 | b1, b_both = b0 & b1;
-                const unsigned long long m_nl = b_some & b_tl, m_nn = b_some & ~b_tl, m_fl = b_both & b_ol, m_fn = b_both & ~b_ol;
-                const uint32_t base_n = n_nodes - k, c_fn = static_cast<uint32_t>(__popcll(m_fn)), c_fl = static_cast<uint32_t>(__popcll(m_fl));
-                // far children below near ones: the next step takes the near ones first
-                if (both && !other_leaf)
-                    (node_items + base_n)[pool_rank(m_fn)] = static_cast<uint16_t>(ray_bits | other);
-                if (some && !toward_leaf)
-                    (node_items + (base_n + c_fn))[pool_rank(m_nn)] = static_cast<uint16_t>(ray_bits | toward);
-                if (both && other_leaf)
-                    (prim_items + n_prims)[pool_rank(m_fl)] = static_cast<uint16_t>(ray_bits | (other & kPoolMaxRef));
-                if (some && toward_leaf)
-                    (prim_items + (n_prims + c_fl))[pool_rank(m_nl)] = static_cast<uint16_t>(ray_bits | (toward & kPoolMaxRef));
-                next_nodes = base_n + c_fn + static_cast<uint32_t>(__popcll(m_nn));
-                next_prims = n_prims + c_fl + static_cast<uint32_t>(__popcll(m_nl));
+                // the planes the ray enters / leaves through, of all four children: lo.x at 0, lo.y 16, lo.z 32, hi.x 48, hi.y 64, hi.z 80
+                const float4 nx4 = *reinterpret_cast<const float4 *>(w + ox), fx4 = *reinterpret_cast<const float4 *>(w + (48u - ox));
+                const float4 ny4 = *reinterpret_cast<const float4 *>(w + oy), fy4 = *reinterpret_cast<const float4 *>(w + (80u - oy));
+                const float4 nz4 = *reinterpret_cast<const float4 *>(w + oz), fz4 = *reinterpret_cast<const float4 *>(w + (112u - oz));
+                const uint4 refs = *reinterpret_cast<const uint4 *>(w + 96u);
+                const float nxs[4] = {nx4.x, nx4.y, nx4.z, nx4.w}, fxs[4] = {fx4.x, fx4.y, fx4.z, fx4.w};
+                const float nys[4] = {ny4.x, ny4.y, ny4.z, ny4.w}, fys[4] = {fy4.x, fy4.y, fy4.z, fy4.w};
+                const float nzs[4] = {nz4.x, nz4.y, nz4.z, nz4.w}, fzs[4] = {fz4.x, fz4.y, fz4.z, fz4.w};
+                const uint32_t ref[4] = {refs.x, refs.y, refs.z, refs.w};
+                uint32_t at_nodes = n_nodes - k, at_prims = n_prims;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                {
+                    const float enter = fmaxf(fmaxf(fmaxf(kEpsDistance, (nxs[c] - a.x) * b.x), (nys[c] - a.y) * b.y), (nzs[c] - a.z) * b.z);
+                    const float leave = fminf(fminf(fminf(a.w, (fxs[c] - a.x) * b.x), (fys[c] - a.y) * b.y), (fzs[c] - a.z) * b.z);
+                    const bool hit_c = enter <= leave, leaf_c = static_cast<int32_t>(ref[c]) < 0; // kWalkLeaf = the sign bit
+                    // (ballots of plain comparisons, combined as 64-bit masks: a ballot of a combined predicate goes through a
+                    //  vector register as a 0 / 1 word)
+                    const unsigned long long b_hit = __ballot(hit_c), b_leaf = __ballot(leaf_c);
+                    const unsigned long long m_node = b_hit & ~b_leaf, m_leaf = b_hit & b_leaf;
+                    if (hit_c && !leaf_c)
+                        (node_items + at_nodes)[pool_rank(m_node)] = static_cast<uint16_t>(ray_bits | ref[c]);
+                    if (hit_c && leaf_c)
+                        (prim_items + at_prims)[pool_rank(m_leaf)] = static_cast<uint16_t>(ray_bits | (ref[c] & kPoolMaxRef));
+                    at_nodes += static_cast<uint32_t>(__popcll(m_node)), at_prims += static_cast<uint32_t>(__popcll(m_leaf));
+                }
+                next_nodes = at_nodes, next_prims = at_prims;
             }
             n_nodes = uni(next_nodes), n_prims = uni(next_prims); // (the first active lane has rank 0 < k: it took part)
             pool_sync();

@@ -840,7 +840,7 @@ struct Pool2Model
 };
 
 void RunPool2(const DeviceScene &sc, const std::vector<std::array<float, 7>> &closest, const std::vector<std::array<float, 7>> &shadow,
-              uint32_t prim_at, Pool2Model &m, bool wide = false)
+              uint32_t prim_at, Pool2Model &m, bool wide = false, bool unordered = false)
 {
     struct Item
     {
@@ -918,8 +918,8 @@ void RunPool2(const DeviceScene &sc, const std::vector<std::array<float, 7>> &cl
             {
                 // a step tests two levels: a hit inner child is opened at once and ITS hit children are what is pushed (the
                 // work of a 4-wide node: up to four boxes beyond the first two, up to four pushes)
-                const uint32_t kids[2] = {other, toward};
-                const bool hit[2] = {both, true};
+                const uint32_t kids[2] = {unordered ? r0 : other, unordered ? r1 : toward};
+                const bool hit[2] = {unordered ? h0 : both, unordered ? h1 : true};
                 for (int c = 0; c < 2; ++c)
                 {
                     if (!hit[c])
@@ -937,6 +937,16 @@ void RunPool2(const DeviceScene &sc, const std::vector<std::array<float, 7>> &cl
                     const bool gf0 = f0 <= f1;
                     const uint32_t order[2] = {gf0 ? s1 : s0, gf0 ? s0 : s1};
                     const bool oh[2] = {gf0 ? g1 : g0, gf0 ? g0 : g1};
+                    if (unordered)
+                    {
+                        // children in the order the node stores them, whatever the ray's direction
+                        const uint32_t ks[2] = {kids[c] == r0 ? s0 : s0, s1};
+                        const bool kh[2] = {g0, g1};
+                        for (int q = 0; q < 2; ++q)
+                            if (kh[q])
+                                ((ks[q] & kWalkLeaf) ? near_leaves : near_nodes).push_back(Item{it.ray, ks[q]});
+                        continue;
+                    }
                     for (int q = 0; q < 2; ++q)
                         if (oh[q])
                             ((order[q] & kWalkLeaf) ? (c ? near_leaves : far_leaves) : (c ? near_nodes : far_nodes)).push_back(Item{it.ray, order[q]});
@@ -968,7 +978,7 @@ int mcpt_emu_pool_model2(const char *mcsd_path, const uint32_t *params, double *
         using C = Config<kFeatVolPath | kFeatEmitters | kFeatTextures | kFeatMicrofacet | kFeatOrderedWalk>;
         const uint32_t w = sc.camera.width, h = sc.camera.height;
         const uint32_t tx = (w + 7) / 8, ty = (h + 7) / 8;
-        const bool merged = params[0] != 0, wide = params[2] != 0;
+        const bool merged = params[0] != 0, wide = params[2] != 0, unordered = params[3] != 0;
         const uint32_t prim_at = params[1];
         std::vector<double> acc(27, 0.0);
         std::mutex mu;
@@ -1032,11 +1042,11 @@ int mcpt_emu_pool_model2(const char *mcsd_path, const uint32_t *params, double *
                         break;
                     a[0] += mcn + msn, a[2] += mcp + msp;
                     if (merged)
-                        RunPool2(sc, closest, shadow, prim_at, pm, wide);
+                        RunPool2(sc, closest, shadow, prim_at, pm, wide, unordered);
                     else
                     {
-                        RunPool2(sc, closest, {}, prim_at, pm, wide);
-                        RunPool2(sc, {}, shadow, prim_at, pm, wide);
+                        RunPool2(sc, closest, {}, prim_at, pm, wide, unordered);
+                        RunPool2(sc, {}, shadow, prim_at, pm, wide, unordered);
                     }
                 }
             }
