@@ -259,7 +259,10 @@ int mcpt_renderer_set_class_sort(mcpt_renderer *r, int mode);
  * pool walk — the rays of a wavefront's query are records in LDS and every lane takes the next (ray, node) or (ray,
  * primitive) item of a shared list, whichever ray it belongs to; closest hits are decided at the end among the candidates
  * within the tie radius of the nearest, in the reference's visiting order.  Scenes without slivers / opacity masks whose
- * hierarchy has at most 1024 nodes.  -1 (default): the library's choice (environment MCPT_POOL_WALK overrides). */
+ * hierarchy has at most 1024 nodes, on a 4-wide exact form of that hierarchy (DeviceScene::pool_nodes).  -1 (default): the
+ * library's choice — on in the lean instantiations (cornell-box 512 x 512 spp 256: 55.2 -> 41.6 ms; a rank's 1/8 share of it
+ * 42.0 -> 27.2 ms: lanes without a path of their own work on their wavefront's rays), off in the class-sorted full-feature
+ * ones (volumetric-caustic: 231 -> 241 ms); environment MCPT_POOL_WALK = 0 / 1 / 2 overrides the default. */
 int mcpt_renderer_set_pool_walk(mcpt_renderer *r, int mode);
 
 /* Register budget of the stream kernel's instantiation on scenes outside LDS (surface materials): compiled for 4, 3 or 2

@@ -805,7 +805,9 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             const char *e = std::getenv("MCPT_POOL_WALK"); // (measurements: the library's choice when mcpt_renderer_set_pool_walk left it open)
             return e ? std::atoi(e) : MCPT_POOL_WALK_DEFAULT;
         }();
-        job.pool_walk = (r->pool_walk_mode < 0 ? pool_walk != 0 : r->pool_walk_mode != 0) ? 1u : 0u;
+        // 1: where it is the measured choice (the lean LDS instantiations); 2: wherever an instantiation exists (also the
+        // class-sorted full-feature kernels: volumetric-caustic 231.0 -> 241.3 ms with it, so not by default)
+        job.pool_walk = r->pool_walk_mode < 0 ? (pool_walk != 0 ? static_cast<uint32_t>(pool_walk) : 0u) : r->pool_walk_mode != 0 ? 2u : 0u;
     }
     // The library's choices (kernel_mode -1): the first draw of a renderer calibrates — BEFORE this draw sizes any of its
     // own buffers, because the calibration's nested draws re-size the renderer's scratch allocations.

@@ -79,8 +79,9 @@ struct RenderJob
     // Cost probe of the lane-owns-a-path kernel (may be null): n_items / 64 words; a lane adds the steps its pixel took to
     // its tile's word when the pixel is finished.  A low-spp draw with this set measures what each tile costs.
     uint32_t *tile_steps;
-    // LDS-resident scenes without slivers: 1 = the ray queries are the wavefront-cooperative pool walk (pool_walk.h) where an
-    // instantiation with it exists.  The image does not depend on it.
+    // LDS-resident scenes without slivers: the ray queries as the wavefront-cooperative pool walk (pool_walk.h).  1 = in the
+    // lean instantiations (where it is the measured choice), 2 = wherever an instantiation with it exists (also the class-sorted
+    // full-feature kernels).  The image does not depend on it.
     uint32_t pool_walk;
 };
 

@@ -66,27 +66,34 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     uint32_t n_staged = 0;
     {
         const uint32_t n_node_vec = 2u * sc_in.integrator.n_nodes, n_tri_vec = 3u * sc_in.integrator.n_prims;
-        const uint32_t n_walk_vec = 4u * sc_in.integrator.n_walk_nodes, n_slot_vec = n_tri_vec;
+        // (pool walk, pool_walk.h: the 4-wide exact form of the hierarchy instead of the binary one)
+        const uint32_t n_walk_vec = C::kPool ? 8u * sc_in.integrator.n_pool_nodes : 4u * sc_in.integrator.n_walk_nodes, n_slot_vec = n_tri_vec;
         for (uint32_t i = threadIdx.x; i < n_node_vec; i += blockDim.x)
             lds_geometry[i] = sc_in.nodes[i];
         for (uint32_t i = threadIdx.x; i < n_tri_vec; i += blockDim.x)
             lds_geometry[n_node_vec + i] = sc_in.tri_pos[i];
         for (uint32_t i = threadIdx.x; i < n_walk_vec; i += blockDim.x)
-            lds_geometry[n_node_vec + n_tri_vec + i] = sc_in.walk_nodes[i];
+            lds_geometry[n_node_vec + n_tri_vec + i] = C::kPool ? sc_in.pool_nodes[i] : sc_in.walk_nodes[i];
         for (uint32_t i = threadIdx.x; i < n_slot_vec; i += blockDim.x)
             lds_geometry[n_node_vec + n_tri_vec + n_walk_vec + i] = sc_in.walk_prims[i];
         sc.nodes = lds_geometry;
         sc.tri_pos = lds_geometry + n_node_vec;
         sc.walk_nodes = lds_geometry + n_node_vec + n_tri_vec;
+        sc.pool_nodes = lds_geometry + n_node_vec + n_tri_vec; // (whichever form was staged)
         sc.walk_prims = lds_geometry + n_node_vec + n_tri_vec + n_walk_vec;
         n_staged = n_node_vec + n_tri_vec + n_walk_vec + n_slot_vec;
     }
-    uint32_t *lds_words = reinterpret_cast<uint32_t *>(lds_geometry + n_staged);
-    uint32_t *stack = lds_words + threadIdx.x;
-    lds_words += static_cast<size_t>(sc_in.integrator.walk_depth) * 256u;
-    uint32_t *exchange = lds_words;                                  // kSortPassWords x 256 words, word-major
-    uint32_t *counts = exchange + kSortPassWords * kBlockSize;       // [parity][wavefront][class]
     constexpr uint32_t kWaves = kBlockSize / 64u;
+    uint32_t *lds_words = reinterpret_cast<uint32_t *>(lds_geometry + n_staged);
+    // one walk per lane: the lanes' stack columns, then the exchange words.  Pool walk: one pool area per wavefront, and the
+    // exchange words travel THROUGH the pool areas (no wavefront is inside a query between the count barrier and the barrier
+    // behind the last exchange read), the counters behind them.
+    static_assert(!C::kPool || kWaves * pool_wave_words(C::kAnalytic) >= kSortPassWords * kBlockSize, "the exchange fits the pool areas");
+    uint32_t *stack = C::kPool ? lds_words + (threadIdx.x >> 6) * pool_wave_words(C::kAnalytic) : lds_words + threadIdx.x;
+    if (!C::kPool)
+        lds_words += static_cast<size_t>(sc_in.integrator.walk_depth) * 256u;
+    uint32_t *exchange = lds_words;                                  // kSortPassWords x 256 words, word-major
+    uint32_t *counts = C::kPool ? lds_words + kWaves * pool_wave_words(C::kAnalytic) : exchange + kSortPassWords * kBlockSize; // [parity][wavefront][class]
     __syncthreads(); // geometry staged
 
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -141,7 +148,16 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         Surface surf;
         surf.inside = false, surf.inst = 0, surf.uv = V2{0, 0};
         surf.position = surf.normal = surf.tangent = surf.bitangent = V3{0, 0, 0};
-        if (st.alive)
+        if constexpr (C::kPool)
+        {
+            // (every lane makes the query call; the ones without a path work on the others' rays)
+            Ray ray;
+            HitRaw raw;
+            const bool hit_valid = path_extend_uniform<C>(sc, st, nullptr, st.alive, ray, raw);
+            if (st.alive)
+                path_resolve<C>(sc, st, nullptr, ray, raw, hit_valid, surf);
+        }
+        else if (st.alive)
         {
             Ray ray;
             HitRaw raw;
@@ -224,7 +240,12 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         slot = got[33], q = got[34];
 
         // ---- connect, scatter ----
-        if (st.alive)
+        if constexpr (C::kPool)
+        {
+            __syncthreads(); // every lane has read its words: the pool areas are the queries' again
+            path_connect_scatter_uniform<C>(sc, st, nullptr, surf, st.alive);
+        }
+        else if (st.alive)
             path_connect_scatter<C>(sc, st, nullptr, surf);
     }
 }
@@ -233,8 +254,10 @@ template <uint32_t kFeatures>
 static hipError_t LaunchSorted(const DeviceScene &sc, const RenderJob &job, float *out, hipStream_t stream, uint32_t max_blocks)
 {
     constexpr uint32_t kBlockSize = kSortLanes;
-    const size_t lds_bytes = StagedBytes(sc, true) + size_t(sc.integrator.walk_depth) * 256u * sizeof(uint32_t) + // (the stacks' stride is 256 words whatever the workgroup size)
-                             (size_t(kSortPassWords) * kBlockSize + 2u * (kBlockSize / 64u) * 16u) * sizeof(uint32_t);
+    constexpr bool kPool = (kFeatures & kFeatPoolWalk) != 0;
+    const size_t lds_bytes = kPool ? StagedBytes(sc, true, true) + (size_t(kBlockSize / 64u) * pool_wave_words((kFeatures & kFeatAnalytic) != 0) + 2u * (kBlockSize / 64u) * 16u) * sizeof(uint32_t)
+                                   : StagedBytes(sc, true) + size_t(sc.integrator.walk_depth) * 256u * sizeof(uint32_t) + // (the stacks' stride is 256 words whatever the workgroup size)
+                                         (size_t(kSortPassWords) * kBlockSize + 2u * (kBlockSize / 64u) * 16u) * sizeof(uint32_t);
     int per_cu = 0;
     hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sorted_kernel<kFeatures>, kBlockSize, lds_bytes);
     if (err != hipSuccess)
@@ -266,13 +289,16 @@ hipError_t LaunchRenderSorted(const DeviceScene &sc, const RenderJob &job, float
     if (job.reference_walk || sc.integrator.has_masks || sc.integrator.walk_sliver_reach > 0.0f ||
         StagedBytes(sc, true) > kLdsGeometryBytes || (f & (kFeatVolPath | kFeatAnalytic | kFeatMicrofacet)) == 0)
         return hipErrorNotSupported;
+    // the wavefront-cooperative pool walk (pool_walk.h): its items hold node and slot indices in 10 bits
+    const bool pool = job.pool_walk >= 2 && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kPoolMaxRef + 1u &&
+                      sc.integrator.n_prims <= kPoolMaxRef + 1u && sc.integrator.pool_depth <= kPoolMaxDepth && StagedBytes(sc, true, true) <= kLdsGeometryBytes;
     if ((f & ~kVolumeLean) == 0)
     {
-        *variant = "volume-quadrics-microfacet+lds, class-sorted";
-        return LaunchSorted<kVolumeLean | kO>(sc, job, out, stream, n_cus);
+        *variant = pool ? "volume-quadrics-microfacet+lds+pool-walk, class-sorted" : "volume-quadrics-microfacet+lds, class-sorted";
+        return pool ? LaunchSorted<kVolumeLean | kP>(sc, job, out, stream, n_cus) : LaunchSorted<kVolumeLean | kO>(sc, job, out, stream, n_cus);
     }
-    *variant = "all+lds, class-sorted";
-    return LaunchSorted<kAll | kO>(sc, job, out, stream, n_cus);
+    *variant = pool ? "all+lds+pool-walk, class-sorted" : "all+lds, class-sorted";
+    return pool ? LaunchSorted<kAll | kP>(sc, job, out, stream, n_cus) : LaunchSorted<kAll | kO>(sc, job, out, stream, n_cus);
 }
 
 } // namespace mcpt

@@ -643,19 +643,49 @@ __device__ __forceinline__ bool shadow_walk_uniform(const DeviceScene &sc, uint3
     return hit;
 }
 
-// connect_lights with the shadow queries made by every lane; `active`: this lane stands at a vertex.
+// connect_lights with the shadow queries made by every lane; `active`: this lane stands at a vertex (the other arguments
+// mean something only then).
 template <class C>
-__device__ __forceinline__ V3 connect_lights_uniform(const DeviceScene &sc, uint32_t *pool, bool active, const Surface &s, V3 position, V3 wo,
-                                                     uint32_t &rng, LaneCounters *cnt)
+__device__ __forceinline__ V3 connect_lights_uniform(const DeviceScene &sc, uint32_t *pool, bool active, bool at_medium, const Surface &s, V3 position,
+                                                     uint32_t medium_id, V3 wo, uint32_t &rng, LaneCounters *cnt)
 {
-    static_assert(!C::kVolPath, "surface vertices only");
     V3 L = V3{0, 0, 0};
     const LightTables LT = light_tables<C>(sc);
-    const uint32_t bsdf = active ? sc.instances[s.inst].bsdf : kNone;
-    auto weigh = [&](V3 wi, V3 &att, float &pdf) -> bool
+    const uint32_t bsdf = (!active || at_medium) ? kNone : sc.instances[s.inst].bsdf;
+    uint32_t conn_medium = kNone; // medium the connection travels through
+    if (C::kVolPath && active)
+        conn_medium = at_medium ? medium_id : (sc.integrator.volpath ? medium_on_side(sc, s, true, wo) : kNone);
+    const bool vol = C::kVolPath && sc.integrator.volpath != 0;
+    auto weigh = [&](V3 wi, float distance, V3 &tr, V3 &att, float &pdf) -> bool
     {
+        tr = V3{1.0f, 1.0f, 1.0f};
+        if (C::kVolPath && at_medium)
+        {
+            MediumEvent m = medium_event_init();
+            m.distance = distance;
+            medium_transmittance(sc.media[medium_id], m);
+            if (!m.valid)
+                return false;
+            tr = m.attenuation / m.pdf;
+            PhaseQuery p;
+            p.wi = wi, p.wo = wo;
+            phase_eval(sc.media[medium_id], p);
+            if (!p.valid)
+                return false;
+            att = p.attenuation, pdf = p.pdf;
+            return true;
+        }
         if (dot(-wi, s.normal) < kEpsFloat)
             return false;
+        if (C::kVolPath && conn_medium != kNone)
+        {
+            MediumEvent m = medium_event_init();
+            m.distance = distance;
+            medium_transmittance(sc.media[conn_medium], m);
+            if (!m.valid)
+                return false;
+            tr = m.attenuation / m.pdf;
+        }
         const BsdfQuery q = eval_at<C>(sc, s, bsdf, wi, wo);
         if (!q.valid)
             return false;
@@ -674,18 +704,24 @@ __device__ __forceinline__ V3 connect_lights_uniform(const DeviceScene &sc, uint
                 ls = emitter_sample(LT, e, position, xi0, xi1);
             }
             const bool occluded = shadow_walk_uniform<C>(sc, pool, active, position, -ls.wi, ls.distance - kEpsDistance, cnt);
-            V3 att;
+            V3 tr, att;
             float pdf;
-            if (!active || occluded || !weigh(ls.wi, att, pdf))
+            if (!active || occluded || !weigh(ls.wi, ls.distance, tr, att, pdf))
                 continue;
             const V3 radiance = emitter_eval_sample(LT, e, ls);
             if (ls.harsh)
-                L += radiance * att; // path.cpp:170
+                L += vol ? radiance * tr * att : radiance * att; // path.cpp:170 / volpath.cpp:297,413
             else
             {
                 const float pdf_direct = emitter_pdf(LT, e, -ls.wi);
                 if (pdf_direct > kEpsFloat)
-                    L += power_heuristic(pdf_direct, pdf) * radiance * (att / pdf_direct); // path.cpp:178
+                {
+                    const float w = power_heuristic(pdf_direct, pdf);
+                    if (vol) // volpath.cpp:305-306, 421-422
+                        L += w * radiance * tr * att / pdf_direct;
+                    else // path.cpp:178
+                        L += w * radiance * (att / pdf_direct);
+                }
             }
         }
     }
@@ -711,27 +747,27 @@ __device__ __forceinline__ V3 connect_lights_uniform(const DeviceScene &sc, uint
         {
             const V3 wi = normalize(d);
             const float cos_light = dot(wi, lp.normal);
-            V3 att;
+            V3 tr, att;
             float pdf;
-            if (!(cos_light < kEpsFloat) && weigh(wi, att, pdf))
+            if (!(cos_light < kEpsFloat) && weigh(wi, distance, tr, att, pdf))
             {
                 const float pdf_direct = area_light_pdf(sc, light, inst, distance, cos_light), w = power_heuristic(pdf_direct, pdf);
                 const V3 radiance = texture_color(sc.textures, sc.texels, sc.bsdfs[sc.instances[inst].bsdf].tex0, lp.uv, !C::kTextures);
-                L += w * radiance * (att / pdf_direct); // path.cpp:232
+                if (vol) // volpath.cpp:371-372, 481-482
+                    L += w * (radiance * tr * att / pdf_direct);
+                else // path.cpp:232
+                    L += w * radiance * (att / pdf_direct);
             }
         }
     }
     return L;
 }
 
-// One step of every lane of the wavefront; `has_path`: the lane's path is alive (st.alive) — the others only help.
+// path_extend / path_connect_scatter with every lane making the query calls (the class-sorted kernel's two halves).
 template <class C>
-__device__ __forceinline__ void path_step_uniform(const DeviceScene &sc, PathState &st, LaneCounters *cnt, bool has_path)
+__device__ __forceinline__ bool path_extend_uniform(const DeviceScene &sc, PathState &st, LaneCounters *cnt, bool has_path, Ray &ray, HitRaw &raw)
 {
-    static_assert(!C::kVolPath && C::kOrdered, "the lean instantiations");
-    // ---- extend ----
-    Ray ray = make_ray(has_path ? st.origin : V3{0, 0, 0}, has_path ? st.dir : V3{0, 0, 1});
-    HitRaw raw;
+    ray = make_ray(has_path ? st.origin : V3{0, 0, 0}, has_path ? st.dir : V3{0, 0, 1});
     raw.inst = raw.prim = 0, raw.a = raw.b = raw.c = 0.0f, raw.inside = false;
     TraceStats ts{0, 0, 0, 0};
     const bool known = has_path && st.primary && sc.prehit != nullptr; // the pre-pass traced this camera ray
@@ -744,46 +780,80 @@ __device__ __forceinline__ void path_step_uniform(const DeviceScene &sc, PathSta
             hit_from_record<C::kAnalytic>(sc, rec[1], rec[0], ray, raw);
     }
     const bool traced = trace_uniform<C, false>(sc, st.stack, has_path && !known, ray, raw, ts, cnt != nullptr);
-    hit_valid = known ? hit_valid : traced;
     if (cnt)
     {
         cnt->closest_rays += has_path && !known ? 1u : 0u, cnt->node_tests += ts.node_tests, cnt->prim_tests += ts.prim_tests;
         cnt->wave_node_steps += ts.wave_node_steps, cnt->wave_prim_steps += ts.wave_prim_steps;
     }
-    // ---- resolve, roulette ----
-    Surface surf;
-    surf.inside = false, surf.inst = 0, surf.uv = V2{0, 0};
-    surf.position = surf.normal = surf.tangent = surf.bitangent = V3{0, 0, 0};
-    if (has_path)
-        path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
-    const bool at_vertex = has_path && st.alive;
+    return known ? hit_valid : traced;
+}
+
+template <class C>
+__device__ __forceinline__ void path_connect_scatter_uniform(const DeviceScene &sc, PathState &st, LaneCounters *cnt, const Surface &surf, bool active)
+{
+    const bool vol = C::kVolPath && sc.integrator.volpath != 0;
+    const bool at_medium = active && st.in_medium;
     // ---- connect ----
-    const V3 direct = connect_lights_uniform<C>(sc, st.stack, at_vertex, surf, surf.position, st.wo, st.rng, cnt);
-    if (!at_vertex)
+    const V3 vertex = at_medium ? st.origin : surf.position;
+    const V3 direct = connect_lights_uniform<C>(sc, st.stack, active, at_medium, surf, vertex, st.medium, st.wo, st.rng, cnt);
+    if (!active)
         return;
     st.L += st.throughput * direct;
     // ---- scatter (path_connect_scatter) ----
-    const uint32_t bsdf = sc.instances[surf.inst].bsdf;
-    BsdfQuery q = query_at(surf, st.wo, st.wo); // path.cpp:268-296
-    if (bsdf != kNone)
-        bsdf_sample<C::kMicrofacet, 0, C::kKinds>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
-    else
-        q.wi = st.wo, q.pdf = 1.0f, q.attenuation = V3{1.0f, 1.0f, 1.0f}, q.valid = true;
-    if (!q.valid)
+    const uint32_t bsdf = st.in_medium ? kNone : sc.instances[surf.inst].bsdf;
+    if (vol && st.in_medium)
     {
-        finish_sample(st);
-        return;
+        PhaseQuery p; // volpath.cpp:96-110
+        p.wo = st.wo;
+        phase_sample(sc.media[st.medium], st.rng, p);
+        if (!p.valid)
+        {
+            finish_sample(st);
+            return;
+        }
+        st.wi = p.wi;
+        st.throughput *= p.attenuation / p.pdf;
+        st.pdf_sample = p.pdf;
     }
-    st.wi = q.wi;
-    st.pdf_sample = q.pdf;
-    st.throughput *= q.attenuation / q.pdf;
-    st.origin = surf.position;
+    else
+    {
+        BsdfQuery q = query_at(surf, st.wo, st.wo); // path.cpp:268-296
+        if (bsdf != kNone)
+            bsdf_sample<C::kMicrofacet, 0, C::kKinds>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
+        else
+            q.wi = st.wo, q.pdf = 1.0f, q.attenuation = V3{1.0f, 1.0f, 1.0f}, q.valid = true; // pass-through surface (quirk Q8)
+        if (!q.valid)
+        {
+            finish_sample(st);
+            return;
+        }
+        st.wi = q.wi;
+        st.pdf_sample = q.pdf;
+        st.throughput *= q.attenuation / q.pdf;
+        st.origin = surf.position;
+    }
     if (max_component(st.throughput) < kEps)
     {
         finish_sample(st);
         return;
     }
     st.dir = -st.wi;
+}
+
+// One step of every lane of the wavefront; `has_path`: the lane's path is alive (st.alive) — the others only help.
+template <class C>
+__device__ __forceinline__ void path_step_uniform(const DeviceScene &sc, PathState &st, LaneCounters *cnt, bool has_path)
+{
+    static_assert(C::kOrdered, "ordered walk");
+    Ray ray;
+    HitRaw raw;
+    const bool hit_valid = path_extend_uniform<C>(sc, st, cnt, has_path, ray, raw);
+    Surface surf;
+    surf.inside = false, surf.inst = 0, surf.uv = V2{0, 0};
+    surf.position = surf.normal = surf.tangent = surf.bitangent = V3{0, 0, 0};
+    if (has_path)
+        path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
+    path_connect_scatter_uniform<C>(sc, st, cnt, surf, has_path && st.alive);
 }
 #endif // __HIPCC__
 

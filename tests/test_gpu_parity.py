@@ -613,12 +613,14 @@ def test_class_sort_does_not_change_the_image(name, pkg, scenes):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["cornell_64_spp8", "cornell_96_spp32"])
+@pytest.mark.parametrize("name", ["cornell_64_spp8", "cornell_96_spp32", "volumetric_96x54_spp16", "volumetric_iso_64x36_spp8", "conductor_aniso_mixed",
+                                  "dielectric_area_sphere", "thin_dielectric_sun", "rough_plastic_constant_cyl", "rough_diffuse_point_disk"])
 def test_pool_walk_does_not_change_the_image(name, pkg, scenes):
     """mcpt_renderer_set_pool_walk (csrc/pool_walk.h): the ray queries of a wavefront as a shared list of (ray, node) /
     (ray, primitive) items that all lanes work off, closest hits decided at the end among the candidates within the tie
     radius — order independent, so the frame is the per-lane walk's: the compiled reference's golden, bit for bit, with
-    fixed lists and the work counter, both pixel orders, a packed tile range of three ranks, and 5 repeated draws."""
+    fixed lists and the work counter, both pixel orders, a packed tile range of three ranks, and 5 repeated draws.  The
+    lean instantiations (cornell) and the class-sorted full-feature ones (media, quadrics, every BSDF model, emitters)."""
     golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
     r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
     try:
