@@ -150,6 +150,12 @@ int mcpt_renderer_info(const mcpt_renderer *r, uint64_t info[9]);
  * always used when a BSDF has an opacity map, whose test draws random numbers
  * during the walk). */
 int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order);
+/* Which one later draws use — 1 also when mcpt_renderer_create's self-check found a pixel on which the two walks differ and
+ * fell back to the reference's order (a line on stderr says so): the production walk returns the reference's answers as long
+ * as near-coincident hits lie within its tie radius, an engineering bound; every new renderer renders a sample of its film
+ * (every k-th 8 x 8 tile, at most 65 536 pixels, 1 spp) with both walks and compares.  Environment MCPT_CHECK_WALKS: 0 = no
+ * check, N > 0 = the whole film at N spp instead of the sample. */
+int mcpt_renderer_get_walk(const mcpt_renderer *r, int *reference_order);
 
 /* Self-check of the production ray query on THIS scene and film: renders the frame twice — ordered walk of the
  * SAH hierarchy (what draws use) and the reference's trees in the reference's order — and compares them bit for

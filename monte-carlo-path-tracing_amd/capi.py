@@ -101,6 +101,7 @@ def lib():
     L.mcpt_renderer_set_prepass.argtypes = [vp, i32]
     L.mcpt_renderer_set_class_sort.argtypes = [vp, i32]
     L.mcpt_renderer_set_pool_walk.argtypes = [vp, i32]
+    L.mcpt_renderer_get_walk.argtypes = [vp, ctypes.POINTER(i32)]
     L.mcpt_renderer_set_stream_waves.argtypes = [vp, i32]
     L.mcpt_renderer_set_lane_spread.argtypes = [vp, u32]
     L.mcpt_renderer_set_pixel_order.argtypes = [vp, i32]
@@ -143,7 +144,7 @@ EXPORTED_SYMBOLS = [
     "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_set_walk", "mcpt_renderer_set_walk_schedule",
     "mcpt_renderer_set_kernel", "mcpt_renderer_last_kernel", "mcpt_renderer_check_walks", "mcpt_renderer_set_rng", "mcpt_renderer_set_prepass", "mcpt_renderer_set_lane_spread", "mcpt_renderer_set_pixel_order", "mcpt_renderer_set_work_distribution", "mcpt_renderer_last_choice",
     "mcpt_renderer_destroy",
-    "mcpt_renderer_calibrate", "mcpt_renderer_set_tile_order", "mcpt_renderer_set_class_sort", "mcpt_renderer_set_pool_walk", "mcpt_renderer_set_stream_waves", "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_cost_table", "mcpt_debug_trace_pixel", "mcpt_debug_trace_rate",
+    "mcpt_renderer_calibrate", "mcpt_renderer_set_tile_order", "mcpt_renderer_set_class_sort", "mcpt_renderer_set_pool_walk", "mcpt_renderer_get_walk", "mcpt_renderer_set_stream_waves", "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_cost_table", "mcpt_debug_trace_pixel", "mcpt_debug_trace_rate",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
     "mcpt_config_serialize", "mcpt_tiled_renderer_create", "mcpt_tiled_renderer_draw",
     "mcpt_tiled_renderer_set_kernel", "mcpt_tiled_renderer_destroy", "mcpt_render_tiled", "mcpt_device_count",
@@ -387,6 +388,12 @@ class Renderer:
         """Class-sorted form of the lanes kernel (full-feature scenes in LDS): -1 library's choice (on), 0 off, 1 on.  Same frame."""
         _check(lib().mcpt_renderer_set_class_sort(self._h, mode))
         return self
+
+    def walk(self) -> int:
+        """1: draws use the reference-order walk (set_walk(1), or the self-check of the creation fell back to it); 0: the ordered walk."""
+        v = ctypes.c_int()
+        _check(lib().mcpt_renderer_get_walk(self._h, ctypes.byref(v)))
+        return int(v.value)
 
     def set_pool_walk(self, mode: int):
         """Ray queries of the lanes kernel on LDS-resident scenes: -1 library's choice, 0 one walk per lane, 1 the

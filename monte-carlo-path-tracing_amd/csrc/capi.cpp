@@ -19,6 +19,7 @@
 #include <memory>
 #include <sstream>
 #include <stdexcept>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -1506,33 +1507,90 @@ int mcpt_renderer_create(const mcpt_config *cfg, int device, mcpt_renderer **out
         Check(hipSetDevice(device), "select device");
         DeviceLbvh device_lbvh; // large meshes: reference-topology LBVH on the GPU (bit-identical)
         std::unique_ptr<mcpt_renderer> r = MakeRenderer(mcpt::CommitScene(cfg->scene, &device_lbvh), device);
-        // MCPT_CHECK_WALKS=<spp> (opt-in): right after the commit, render the user's film at that many samples per pixel
-        // with the production ordered walk AND the reference-order walk and warn on stderr if a pixel differs — the tie
-        // radius and the sliver reach of the ordered walk are engineering bounds, this is the
-        // run-time check that a scene lies inside them.  The renderer is created either way.
-        if (const char *check = std::getenv("MCPT_CHECK_WALKS"))
+        // SELF-GUARD of the production ray query.  The ordered walk (and the pool walk) return the reference's answers for any
+        // hierarchy as long as near-coincident hits lie inside the tie radius / sliver reach — engineering bounds with a
+        // derivation of what they bound, not a proof for every scene.  So every renderer is checked when
+        // it is made: a sample of its film — every k-th 8 x 8 tile, at most 1024 of them = 65 536 pixels, 1 sample per pixel —
+        // is rendered with the production configuration AND with the reference-order walk (the reference's trees in the
+        // reference's visiting order: tlas.cpp:13-76, blas.cpp:18-77; triangle.cpp:82 accepts t == t_max, the later visited
+        // primitive wins); if one pixel differs, the renderer falls back to the reference-order walk (mcpt_renderer_set_walk(r, 1))
+        // and says so on stderr.  Cost: two launches of ~1/256 of a frame (cornell 0.2 ms, dragon/scene.xml ~3 ms) plus their
+        // buffers.  MCPT_CHECK_WALKS=0 switches it off, MCPT_CHECK_WALKS=<spp> checks the WHOLE film at that many samples.
+        // A scene that passed is remembered for the process (same geometry, camera and film: CalibrationKey).
+        const char *check = std::getenv("MCPT_CHECK_WALKS");
+        const long want = check ? std::strtol(check, nullptr, 10) : -1; // -1: the default sample
+        static std::mutex guard_mutex;
+        static std::set<uint64_t> guard_passed;
+        bool known_good = false;
+        uint32_t radii[2];
+        std::memcpy(radii, &r->flat.integrator.walk_tie, 4), std::memcpy(radii + 1, &r->flat.integrator.walk_sliver_reach, 4);
+        const uint64_t guard_key = CalibrationKey(r.get()) ^ (uint64_t(radii[0]) << 32 | radii[1]);
+        if (want < 0)
         {
-            const long want = std::strtol(check, nullptr, 10);
-            if (want > 0 && !r->flat.integrator.has_masks)
+            std::lock_guard<std::mutex> lock(guard_mutex);
+            known_good = guard_passed.count(guard_key) != 0;
+        }
+        if (want != 0 && !known_good && !r->flat.integrator.has_masks && r->Tiles() != 0 && r->flat.integrator.n_walk_nodes != 0)
+        {
+            const uint32_t spp = r->dev.camera.spp, few = want > 0 ? std::min<uint32_t>(spp, static_cast<uint32_t>(want)) : 1u;
+            const float spp_inv = r->dev.camera.spp_inv;
+            r->dev.camera.spp = r->flat.camera.spp = few, r->dev.camera.spp_inv = r->flat.camera.spp_inv = 1.0f / static_cast<float>(few);
+            uint64_t differing = 0;
+            uint32_t first = 0;
+            float worst = 0;
+            int rc = 0;
+            if (want > 0)
+                rc = mcpt_renderer_check_walks(r.get(), &differing, &first, &worst);
+            else
             {
-                const uint32_t spp = r->dev.camera.spp, few = std::min<uint32_t>(spp, static_cast<uint32_t>(want));
-                const float spp_inv = r->dev.camera.spp_inv;
-                r->dev.camera.spp = r->flat.camera.spp = few, r->dev.camera.spp_inv = r->flat.camera.spp_inv = 1.0f / static_cast<float>(few);
-                uint64_t differing = 0;
-                uint32_t first = 0;
-                float worst = 0;
-                const int rc = mcpt_renderer_check_walks(r.get(), &differing, &first, &worst);
-                r->dev.camera.spp = r->flat.camera.spp = spp, r->dev.camera.spp_inv = r->flat.camera.spp_inv = spp_inv;
-                r->auto_choice = -1; // (the check's draws calibrated at the reduced spp: calibrate the real film again)
-                if (rc != 0)
-                    std::fprintf(stderr, "mcpt: MCPT_CHECK_WALKS could not run: %s\n", g_error.c_str());
-                else if (differing)
-                    std::fprintf(stderr,
-                                 "mcpt: WARNING: the ordered walk and the reference-order walk differ on %llu pixel(s) of this scene at %u spp "
-                                 "(first pixel %u, largest difference %g); use mcpt_renderer_set_walk(r, 1) for the reference's order.\n",
-                                 static_cast<unsigned long long>(differing), few, first, worst);
-                else
+                const uint32_t tiles = r->Tiles(), stride = (tiles + 1023u) / 1024u;
+                const mcpt_tile_range sample{0u, stride, 0u};
+                const size_t n = size_t(RangeSize(tiles, sample)) * 64u * 3u;
+                float *dev = nullptr;
+                std::vector<float> ordered(n), reference(n);
+                try
+                {
+                    Check(hipMalloc(reinterpret_cast<void **>(&dev), 2 * n * sizeof(float)), "allocate the walk check's tiles");
+                    Check(hipMemset(dev, 0, 2 * n * sizeof(float)), "clear the walk check's tiles");
+                    Draw(r.get(), dev, sample, true, nullptr, true, false, nullptr);
+                    r->reference_walk = true;
+                    r->InvalidateRangeCaches();
+                    Draw(r.get(), dev + n, sample, true, nullptr, true, false, nullptr);
+                    r->reference_walk = false;
+                    Check(hipMemcpy(ordered.data(), dev, n * sizeof(float), hipMemcpyDeviceToHost), "read the walk check's tiles");
+                    Check(hipMemcpy(reference.data(), dev + n, n * sizeof(float), hipMemcpyDeviceToHost), "read the walk check's tiles");
+                    for (size_t p = 0; p < n / 3; ++p)
+                        if (std::memcmp(&ordered[3 * p], &reference[3 * p], 3 * sizeof(float)) != 0 && differing++ == 0)
+                            first = static_cast<uint32_t>(p);
+                }
+                catch (const std::exception &e)
+                {
+                    g_error = e.what(), rc = 1;
+                }
+                r->reference_walk = false;
+                if (dev)
+                    (void)hipFree(dev);
+            }
+            r->dev.camera.spp = r->flat.camera.spp = spp, r->dev.camera.spp_inv = r->flat.camera.spp_inv = spp_inv;
+            r->auto_choice = -1; // (the check's draws chose / calibrated at the reduced film: decide again for the real one)
+            r->InvalidateRangeCaches();
+            if (rc != 0)
+                std::fprintf(stderr, "mcpt: the walk self-check could not run: %s\n", g_error.c_str());
+            else if (differing)
+            {
+                r->reference_walk = true;
+                std::fprintf(stderr,
+                             "mcpt: WARNING: the ordered walk and the reference-order walk differ on %llu of the checked pixel(s) of this scene at %u spp "
+                             "(first: %u%s): this renderer uses the reference's visiting order (slower, the reference's image); "
+                             "mcpt_renderer_set_walk(r, 0) overrides, MCPT_CHECK_WALKS=0 skips the check.\n",
+                             static_cast<unsigned long long>(differing), few, first, want > 0 ? "" : " in the sample's packed tiles");
+            }
+            else
+            {
+                if (want > 0)
                     std::fprintf(stderr, "mcpt: MCPT_CHECK_WALKS: both walks agree on every pixel at %u spp.\n", few);
+                std::lock_guard<std::mutex> lock(guard_mutex);
+                guard_passed.insert(guard_key);
             }
         }
         *out = r.release();
@@ -1705,6 +1763,14 @@ int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order)
         return Fail("null argument");
     r->reference_walk = reference_order != 0;
     r->InvalidateRangeCaches();
+    return 0;
+}
+
+int mcpt_renderer_get_walk(const mcpt_renderer *r, int *reference_order)
+{
+    if (!r || !reference_order)
+        return Fail("null argument");
+    *reference_order = r->reference_walk ? 1 : 0;
     return 0;
 }
 

@@ -32,11 +32,14 @@ void Usage()
                  "  mcpt_cli [-g|--gpu] -i|--input <scene.xml | scene.mcsd | builtin:cornell-box>\n"
                  "           [-o|--output <result.png|.exr|.pfm|.f32>] [-w|--width N] [-h|--height N]\n"
                  "           [-s|--spp N] [-d|--device N] [--gpus N] [-c|--cpu] [--threads N]\n"
-                 "           [--save-config <file.mcsd>] [--standins <table.txt>]\n\n"
+                 "           [--save-config <file.mcsd>] [--standins <table.txt>] [--rng reference|pcg] [--seed N]\n\n"
                  "  --standins   procedural stand-ins for mesh files the scene names but that are not on disk\n"
                  "  --gpu        render with HIP on the selected device (the default)\n"
                  "  --gpus N     cut the frame over HIP devices 0 .. N-1 (one RCCL gather to device 0)\n"
-                 "  --cpu        render on host threads (needs libmcpt_host.so next to this program)\n",
+                 "  --cpu        render on host threads (needs libmcpt_host.so next to this program)\n"
+                 "  --rng        reference (default): the reference's random stream, one per pixel through all its samples\n"
+                 "               (include/csrt/utils/math.hpp:43-63, renderer.cpp:62-81): frames comparable per pixel;\n"
+                 "               pcg: throughput mode, an independent PCG-hashed stream per (pixel, sample) from --seed\n",
                  mcpt_version());
 }
 
@@ -59,6 +62,8 @@ int main(int argc, char **argv)
     std::string input, output = "result.png", save_config, standins_file;
     int width = 0, height = 0, spp = 0, device = 0, gpus = 1, threads = 0;
     bool on_cpu = false;
+    int rng_mode = 0; // --rng reference | pcg | sobol (mcpt_renderer_set_rng)
+    unsigned rng_seed = 1;
     for (int i = 1; i < argc; ++i)
     {
         const std::string a = argv[i];
@@ -92,6 +97,22 @@ int main(int argc, char **argv)
             save_config = argv[++i];
         else if (a == "--standins" && has_value)
             standins_file = argv[++i];
+        else if (a == "--rng" && has_value)
+        {
+            const std::string v = argv[++i];
+            if (v == "reference")
+                rng_mode = 0;
+            else if (v == "pcg")
+                rng_mode = 1;
+            else
+            {
+                std::fprintf(stderr, "[error] --rng: reference (the reference's per-pixel stream: frames comparable per pixel) or pcg "
+                                     "(throughput mode: an independent PCG-hashed stream per sample).\n");
+                return 2;
+            }
+        }
+        else if (a == "--seed" && has_value)
+            rng_seed = static_cast<unsigned>(std::strtoul(argv[++i], nullptr, 10));
         else if (a == "--help")
         {
             Usage();
@@ -146,6 +167,11 @@ int main(int argc, char **argv)
 
     std::vector<float> frame(static_cast<size_t>(width) * height * 3);
     const auto t0 = std::chrono::steady_clock::now();
+    if (rng_mode != 0 && (on_cpu || gpus > 1))
+    {
+        std::fprintf(stderr, "[error] --rng pcg is a mode of the single-GPU renderer (the host path and the tiled renderer keep the reference's stream).\n");
+        return 2;
+    }
     if (on_cpu)
     {
         // the reference's `--cpu` (apps/main.cpp:130-137): the kernel body on host threads, from the optional
@@ -205,6 +231,11 @@ int main(int argc, char **argv)
         mcpt_config_destroy(config);
         if (rc != 0)
             return Fail("error when create renderer.");
+        if (rng_mode != 0 && mcpt_renderer_set_rng(renderer, rng_mode, rng_seed, 0) != 0)
+        {
+            mcpt_renderer_destroy(renderer);
+            return Fail("--rng: cannot select the random-number mode.");
+        }
         const auto t1 = std::chrono::steady_clock::now();
         mcpt_stats stats;
         if (mcpt_renderer_draw(renderer, frame.data(), &stats) != 0)

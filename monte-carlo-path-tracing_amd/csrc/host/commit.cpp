@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -1309,6 +1310,10 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
         // are "tied": the walk must visit both and decide like the reference (traversal.h, test_slot).
         // Offsets are at most (largest |coordinate| of the geometry or the eye) * 2.
         ig.walk_tie = 5e-6f * coordinate;
+        // TESTS ONLY: MCPT_WALK_TIE_SCALE shrinks the radius, to build a scene that lies OUTSIDE the ordered walk's bounds on
+        // purpose (the self-guard of mcpt_renderer_create must catch it: tests/test_gpu_parity.py)
+        if (const char *scale = std::getenv("MCPT_WALK_TIE_SCALE"))
+            ig.walk_tie *= static_cast<float>(std::atof(scale));
         ig.walk_extent = coordinate + largest_grow; // (every box plane lies within the geometry's coordinates, grown sliver boxes included)
         ig.walk_sliver_reach = largest_grow > 0.0f ? std::max(ig.walk_tie, largest_grow) : 0.0f; // 0: no slivers
         fs.walk_prims.reserve(3 * slot_prim.size());

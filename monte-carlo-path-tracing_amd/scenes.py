@@ -139,6 +139,34 @@ def cornell_box(width=512, height=512, spp=16) -> Scene:
     return b.s
 
 
+def grazing_strips(width=128, height=64, spp=1, offset=1000.0, length=8000.0, strip_width=63.5) -> Scene:
+    """TEST SCENE for the ordered walk's tie radius: two long coplanar strips (aspect ratio ~125, just below the sliver
+    threshold of 128) of different instances and colours that overlap, at coordinates of `offset` .. `offset + length`, seen
+    at grazing incidence — where the watertight test's distance is least accurate (a weighted mean of vertex depths with
+    ill-conditioned weights) while a flat leaf box's entry distance is exact: which of the two coplanar surfaces the reference
+    reports depends on its visiting order and on whether the second one's leaf box still passes.  Inside the production
+    radius (5e-6 x largest |coordinate|) the ordered walk replays that and agrees; with the radius shrunk
+    (MCPT_WALK_TIE_SCALE, tests only) it does not — the case the self-guard of mcpt_renderer_create exists for."""
+    K, L, hh = float(offset), float(length), float(strip_width)
+    s = cornell_box(width, height, spp)
+    light = s.instances[-1]
+    s.instances = []
+
+    def strip(x0, z0, angle):
+        c, sn = np.cos(angle), np.sin(angle)
+        pts = np.array([[0, 0], [L, 0], [L, hh], [0, hh]], np.float64)
+        return np.stack([x0 + c * pts[:, 0] - sn * pts[:, 1], np.full(4, K), z0 + sn * pts[:, 0] + c * pts[:, 1]], 1).astype(np.float32)
+    idx = np.array([[0, 2, 1], [0, 3, 2]], np.uint32)   # facing +y
+    s.instances.append(Instance(type=mcsd.INST_MESHES, id_bsdf=0, positions=strip(K, K, 0.0), indices=idx))          # red
+    s.instances.append(Instance(type=mcsd.INST_MESHES, id_bsdf=1, positions=strip(K + 3.0, K - 0.3 * hh, 0.002), indices=idx))  # green
+    light = Instance(type=mcsd.INST_MESHES, id_bsdf=light.id_bsdf)
+    light.positions = np.array([[K, K + 400, K - hh], [K + L, K + 400, K - hh], [K + L, K + 400, K + 2 * hh], [K, K + 400, K + 2 * hh]], np.float32)
+    light.indices = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)   # facing -y
+    s.instances.append(light)
+    s.camera = look_at_camera((K - 50.0, K + 6.0, K + 0.4 * hh), (K + 0.7 * L, K, K + 0.4 * hh), (0, 1, 0), 3.0, width, height, spp)
+    return s
+
+
 def volumetric_caustic(width=1280, height=720, spp=1024, g=0.5) -> Scene:
     """resources/scene/volumetric-caustic/scene_v0.6.xml (BASELINE config 5):
     volpath, HG medium on both sides of the walls, a null-BSDF front wall

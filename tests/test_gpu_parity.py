@@ -649,6 +649,46 @@ def test_pool_walk_does_not_change_the_image(name, pkg, scenes):
 
 
 @pytest.mark.gpu
+def test_renderer_guards_itself_against_a_scene_outside_the_tie_radius(pkg, oracle, tmp_path, monkeypatch, capfd):
+    """mcpt_renderer_create's self-check (csrc/capi.cpp): a sample of the film with the production walk and with the
+    reference-order walk, fallback to the latter when a pixel differs.  scenes.grazing_strips — coplanar overlapping strips
+    of two instances at coordinates of 10^3 .. 10^4, aspect ratio 125, seen at grazing incidence — lies INSIDE the
+    production tie radius (both walks agree, the ordered walk stays); with the radius shrunk to a thousandth
+    (MCPT_WALK_TIE_SCALE, a test knob of the commit) it lies outside: the ordered walk alone then renders pixels that are
+    not the reference's (triangle.cpp:82: a later visited primitive at t <= t_max wins, and a flat leaf box passes or not
+    with the first one's distance as the bound), the guard notices, and the renderer's frame is the oracle's again."""
+    scene = pkg.scenes.grazing_strips(128, 64, 4)
+    path = str(tmp_path / "strips.mcsd")
+    pkg.mcsd.dump(scene, path)
+    want, _ = oracle.render(path)
+    assert (want.sum(axis=2) > 0).mean() > 0.1
+
+    def render(expect_fallback):
+        r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
+        try:
+            assert r.walk() == (1 if expect_fallback else 0)
+            frame, _ = r.draw()
+            return frame, r.last_kernel()
+        finally:
+            r.close()
+
+    # inside the radius: nothing to guard against
+    frame, kernel = render(False)
+    assert np.array_equal(frame, want), kernel
+    assert "WARNING" not in capfd.readouterr().err
+    # outside (radius / 1000), check switched off: the ordered walk is NOT the reference on this scene
+    monkeypatch.setenv("MCPT_WALK_TIE_SCALE", "0.001")
+    monkeypatch.setenv("MCPT_CHECK_WALKS", "0")
+    frame, kernel = render(False)
+    assert not np.array_equal(frame, want), "the scene was meant to trip the shrunken tie radius"
+    # ... with the guard (the default): fallback, the reference's frame
+    monkeypatch.delenv("MCPT_CHECK_WALKS")
+    frame, kernel = render(True)
+    assert "reference walk" in kernel and np.array_equal(frame, want), kernel
+    assert "differ on" in capfd.readouterr().err
+
+
+@pytest.mark.gpu
 def test_pool_walk_full_film_hash_equals_the_per_lane_walk(pkg):
     """cornell-box 512 x 512 (BASELINE config 2's film) at spp 64: the pool walk's frame == the per-lane walk's, 20 repeated
     draws hash-identical (the candidate set of a closest query does not depend on the order its items were processed in)."""
