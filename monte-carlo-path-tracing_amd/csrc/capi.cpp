@@ -806,8 +806,9 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             const char *e = std::getenv("MCPT_POOL_WALK"); // (measurements: the library's choice when mcpt_renderer_set_pool_walk left it open)
             return e ? std::atoi(e) : MCPT_POOL_WALK_DEFAULT;
         }();
-        // 1: where it is the measured choice (the lean LDS instantiations); 2: wherever an instantiation exists (also the
-        // class-sorted full-feature kernels: volumetric-caustic 231.0 -> 241.3 ms with it, so not by default)
+        // 1: where it is the measured choice (the lean LDS instantiations, surface-material scenes outside LDS); 2: wherever an
+        // instantiation exists (also the class-sorted full-feature kernels: volumetric-caustic 231.0 -> 241.3 ms with it, so not
+        // by default)
         job.pool_walk = r->pool_walk_mode < 0 ? (pool_walk != 0 ? static_cast<uint32_t>(pool_walk) : 0u) : r->pool_walk_mode != 0 ? 2u : 0u;
     }
     // The library's choices (kernel_mode -1): the first draw of a renderer calibrates — BEFORE this draw sizes any of its
@@ -914,7 +915,11 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     }
     const bool can_stream = job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && (job.sample_split <= 1 || r->kernel_mode != 2);
     const int choice = r->auto_choice < 0 ? 1 : r->auto_choice;
-    const bool auto_stream = r->kernel_mode == -1 && kAutoCandidates[choice].kernel != 0 && !small_scene;
+    // (scenes outside LDS whose class the lane-owns-a-path kernel runs with the pool walk: that kernel is the library's choice —
+    //  matpreview rough conductor 106.3 -> 90.0 ms, rough dielectric 160.0 -> 121.4 ms against the stream kernel at spp 64)
+    // (a calibrated / stored choice — mcpt_renderer_calibrate — is kept: its lane-kernel candidates ran with the pool walk too)
+    const bool auto_pool = r->kernel_mode == -1 && r->auto_source == 0 && !small_scene && job.pool_walk != 0 && !job.reference_walk && mcpt::PoolBigSupports(r->dev);
+    const bool auto_stream = r->kernel_mode == -1 && kAutoCandidates[choice].kernel != 0 && !small_scene && !auto_pool;
     if (auto_stream)
         plan.wave_local = kAutoCandidates[choice].kernel == 4 ? 1u : 0u;
     const bool dynamic_work = r->kernel_mode == 5 || (r->work_mode == -1 ? kAutoCandidates[choice].work == 1 : r->work_mode == 1);
@@ -2060,7 +2065,7 @@ int mcpt_debug_intersect(mcpt_renderer *r, uint32_t n, const float *rays, const 
 {
     return RunUnit(r, n, rays, 6, seeds, out, 19, seeds_out,
                    [&](const float *a, const uint32_t *b, float *c, uint32_t *d)
-                   { return mcpt::LaunchIntersect(r->dev, n, a, b, c, d, r->reference_walk, nullptr); });
+                   { return mcpt::LaunchIntersect(r->dev, n, a, b, c, d, r->reference_walk, nullptr, r->pool_walk_mode == 1); }); // (mcpt_renderer_set_pool_walk(r, 1): the pool walk's answers)
 }
 
 int mcpt_debug_bsdf(mcpt_renderer *r, uint32_t id_bsdf, int mode, uint32_t n, const float *records,

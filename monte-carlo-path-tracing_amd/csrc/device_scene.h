@@ -275,6 +275,8 @@ enum SceneFeature : uint32_t
     // LDS-resident lane kernels only: the ray queries are the wavefront-cooperative pool walk (pool_walk.h) instead of one
     // walk per lane (scenes without slivers whose node and slot indices fit 10 bits)
     kFeatPoolWalk = 1u << 14,
+    // ... with 32-bit items (node / slot indices up to 2^26) on a hierarchy that is read through the caches: scenes outside LDS
+    kFeatPoolBig = 1u << 15,
 };
 
 // Device view: raw pointers into HBM + the scalar records.

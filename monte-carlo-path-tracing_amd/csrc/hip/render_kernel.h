@@ -107,6 +107,8 @@ struct StreamLaunch
 bool StreamSupports(const DeviceScene &sc, const RenderJob &job);
 // Scene class for which the lane-owns-a-path kernel is the faster one: traversal data small enough for LDS.
 bool StreamPrefersLanes(const DeviceScene &sc);
+// Scene class (outside LDS) that the lane-owns-a-path kernel can run with the wavefront-cooperative pool walk (pool_walk.h).
+bool PoolBigSupports(const DeviceScene &sc);
 // Chooses the instantiation and the launch shape; `name` receives a description.  The caller provides a scratch
 // buffer of at least blocks * scratch_words_per_block words and then calls LaunchRenderStream with the same cfg.
 hipError_t PlanRenderStream(const DeviceScene &sc, const RenderJob &job, bool counted, uint32_t n_cus, StreamLaunch *cfg,
@@ -181,8 +183,9 @@ hipError_t RunTraceRate(const DeviceScene &sc, uint32_t n, const float *rays_dev
                         uint32_t *found_dev, float *milliseconds, hipStream_t stream);
 
 // Unit kernels for diagnostics and parity tests (one query per lane).
+// pool_walk: through the wavefront-cooperative pool walk (32-bit items, quadrics, sliver rules) instead of walk_ordered.
 hipError_t LaunchIntersect(const DeviceScene &sc, uint32_t n, const float *rays, const uint32_t *seeds, float *out,
-                           uint32_t *seeds_out, bool reference_walk, hipStream_t stream);
+                           uint32_t *seeds_out, bool reference_walk, hipStream_t stream, bool pool_walk = false);
 hipError_t LaunchTracePixel(const DeviceScene &sc, uint32_t pixel, uint32_t capacity, float *out, uint32_t *n_steps,
                             hipStream_t stream);
 hipError_t LaunchBsdf(const DeviceScene &sc, uint32_t n, uint32_t id_bsdf, int mode, const float *recs,

@@ -41,6 +41,40 @@ __global__ void intersect_kernel(const DeviceScene sc, uint32_t n, const float *
         o[7 + 3 * k] = v[k].x, o[8 + 3 * k] = v[k].y, o[9 + 3 * k] = v[k].z;
 }
 
+// The same through the wavefront-cooperative pool walk (pool_walk.h) in its most general form: 32-bit items, the 4-wide
+// exact hierarchy through the caches, quadrics, sliver rules.  Every lane of a wavefront makes the call (the ones beyond
+// n only work on the others' rays).
+__global__ void intersect_pool_kernel(const DeviceScene sc, uint32_t n, const float *__restrict__ rays, float *__restrict__ out)
+{
+    extern __shared__ uint32_t lds_pool[];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool mine = i < n;
+    const uint32_t k = mine ? i : 0u;
+    Ray ray = make_ray(V3{rays[6 * k], rays[6 * k + 1], rays[6 * k + 2]}, V3{rays[6 * k + 3], rays[6 * k + 4], rays[6 * k + 5]});
+    HitRaw raw;
+    raw.inst = raw.prim = 0, raw.a = raw.b = raw.c = 0.0f, raw.inside = false;
+    TraceStats ts{0, 0, 0, 0};
+    uint32_t *pool = lds_pool + (threadIdx.x >> 6) * pool_wave_words(true, true);
+    const bool hit = sc.integrator.walk_sliver_reach > 0.0f ? walk_pool<false, true, false, true, true>(sc, pool, mine, ray, raw, ts)
+                                                           : walk_pool<false, true, false, true, false>(sc, pool, mine, ray, raw, ts);
+    if (!mine)
+        return;
+    float *o = out + 19 * static_cast<size_t>(i);
+    for (int c = 0; c < 19; ++c)
+        o[c] = 0.0f;
+    o[2] = o[3] = -1.0f;
+    o[4] = ray.t_max;
+    if (!hit)
+        return;
+    const Surface s = make_surface<true, true>(sc, ray, raw);
+    o[0] = 1.0f, o[1] = s.inside ? 1.0f : 0.0f, o[2] = static_cast<float>(s.inst);
+    o[3] = static_cast<float>(raw.prim - sc.instances[s.inst].prim_base);
+    o[5] = s.uv.u, o[6] = s.uv.v;
+    const V3 v[4] = {s.position, s.normal, s.tangent, s.bitangent};
+    for (int c = 0; c < 4; ++c)
+        o[7 + 3 * c] = v[c].x, o[8 + 3 * c] = v[c].y, o[9 + 3 * c] = v[c].z;
+}
+
 // The steps of one pixel, one lane, reference-order walk (both walks give the same frame):
 // per step 16 floats {ray origin[3], ray direction[3], throughput max, hit primitive (-1 = none),
 // distance, shadow queries, last shadow result, LCG state after the step (bits), L[3] so far,
@@ -110,10 +144,19 @@ __global__ void bsdf_kernel(const DeviceScene sc, uint32_t n, uint32_t id_bsdf, 
 }
 
 hipError_t LaunchIntersect(const DeviceScene &sc, uint32_t n, const float *rays, const uint32_t *seeds, float *out,
-                           uint32_t *seeds_out, bool reference_walk, hipStream_t stream)
+                           uint32_t *seeds_out, bool reference_walk, hipStream_t stream, bool pool_walk)
 {
     if (n == 0)
         return hipSuccess;
+    if (pool_walk && !reference_walk && !sc.integrator.has_masks)
+    {
+        if (sc.integrator.n_pool_nodes == 0 || sc.integrator.n_pool_nodes > kPoolMaxRefBig || sc.integrator.pool_depth > kPoolMaxDepth)
+            return hipErrorNotSupported;
+        hipLaunchKernelGGL(intersect_pool_kernel, dim3((n + 255) / 256), dim3(256), 4 * pool_wave_words(true, true) * sizeof(uint32_t), stream, sc, n,
+                           rays, out);
+        (void)hipMemcpyAsync(seeds_out, seeds, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream); // (the ordered walks draw nothing)
+        return hipGetLastError();
+    }
     if (reference_walk || sc.integrator.has_masks)
         hipLaunchKernelGGL(intersect_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, stream, sc, n, rays, seeds,
                            out, seeds_out);
@@ -145,6 +188,14 @@ thread_local bool g_last_transposed = false;
 void NoteTransposed(bool transposed) { g_last_transposed = transposed; }
 bool LastLaunchTransposed() { return g_last_transposed; }
 
+// Can the lane-owns-a-path kernel run this scene (outside LDS) with the pool walk?  Surface materials (no media, no
+// quadrics), no opacity masks, the 4-wide hierarchy within the items' 26 bits and the lists' head room.
+bool PoolBigSupports(const DeviceScene &sc)
+{
+    return (sc.features & ~kSurface) == 0 && !sc.integrator.has_masks && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kPoolMaxRefBig &&
+           sc.integrator.n_prims <= kPoolMaxRefBig && sc.integrator.pool_depth <= kPoolMaxDepth;
+}
+
 hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
                         hipStream_t stream, uint32_t n_cus, const char **variant)
 {
@@ -168,6 +219,13 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     {
         *variant = "all, reference walk";
         return Launch<kAll, false>(sc, job, out, nullptr, stream, n_cus);
+    }
+    // scenes outside LDS of the class the pool walk runs on (32-bit items, the 4-wide exact hierarchy through the caches): the
+    // surface-materials instantiation with it, whatever subset of its features the scene uses
+    if (job.pool_walk >= 1 && StagedBytes(sc, true) > kLdsGeometryBytes && PoolBigSupports(sc))
+    {
+        *variant = slivers ? "surface-materials+slivers+pool-walk" : "surface-materials+pool-walk";
+        return slivers ? Launch<kSurface | kPB | kS, false>(sc, job, out, nullptr, stream, n_cus) : Launch<kSurface | kPB, false>(sc, job, out, nullptr, stream, n_cus);
     }
     if (slivers)
     {

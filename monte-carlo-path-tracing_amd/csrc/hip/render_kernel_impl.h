@@ -52,7 +52,12 @@ struct Budget
 #ifndef MCPT_FULL_LDS_WAVES
 #define MCPT_FULL_LDS_WAVES 3
 #endif
-    static constexpr int kWavesPerSimd = (kFeatures & (kFeatVolPath | kFeatAnalytic)) ? (kLdsGeometry ? MCPT_FULL_LDS_WAVES : 3)
+#ifndef MCPT_POOL_BIG_WAVES
+#define MCPT_POOL_BIG_WAVES 4
+#endif
+    // (pool walk outside LDS: a wavefront's pool area is 9.5 KB of LDS, 16 of them fit a CU)
+    static constexpr int kWavesPerSimd = (kFeatures & kFeatPoolBig) ? MCPT_POOL_BIG_WAVES
+                                         : (kFeatures & (kFeatVolPath | kFeatAnalytic)) ? (kLdsGeometry ? MCPT_FULL_LDS_WAVES : 3)
 #ifdef MCPT_EXPERIMENT_MICROFACET_WAVES
                                          : (kFeatures & kFeatMicrofacet)              ? MCPT_EXPERIMENT_MICROFACET_WAVES
 #else
@@ -102,8 +107,12 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
         sc.tri_pos = lds_geometry + n_node_vec;
         if (C::kOrdered)
         {
-            sc.walk_nodes = lds_geometry + n_node_vec + n_tri_vec;
-            sc.pool_nodes = lds_geometry + n_node_vec + n_tri_vec; // (whichever form was staged)
+            // (whichever form was staged; pool walk: the binary form stays where it is, in HBM, for the rare ray that is walked
+            //  the per-lane way — pool_walk.h)
+            if (C::kPool)
+                sc.pool_nodes = lds_geometry + n_node_vec + n_tri_vec;
+            else
+                sc.walk_nodes = lds_geometry + n_node_vec + n_tri_vec;
             sc.walk_prims = lds_geometry + n_node_vec + n_tri_vec + n_walk_vec;
         }
         n_staged = n_node_vec + n_tri_vec + n_walk_vec + n_slot_vec;
@@ -121,7 +130,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     PathState st{}; // (every field defined: a lane that has not started a pixel yet can be moved by a compaction)
     st.alive = false;
     // (pool walk: the wavefront's pool area instead of the lane's stack column)
-    st.stack = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + (threadIdx.x >> 6) * pool_wave_words(C::kAnalytic)
+    st.stack = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + (threadIdx.x >> 6) * pool_wave_words(C::kAnalytic, C::kPoolBig)
                         : reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + threadIdx.x;
     bool has_pixel = false;
     uint32_t slot = 0; // where this pixel's result goes
@@ -140,7 +149,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     //  counters, which are read at every step, have their own words behind them)
     uint32_t *compact_words = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged)
                                        : reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + static_cast<size_t>(sc_in.integrator.walk_depth) * kBlockSize;
-    uint32_t *compact_count = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + (kBlockSize / 64u) * pool_wave_words(C::kAnalytic)
+    uint32_t *compact_count = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + (kBlockSize / 64u) * pool_wave_words(C::kAnalytic, C::kPoolBig)
                                        : compact_words + kCompactWords * kBlockSize; // [0..3]: live lanes per wavefront, [4]: retired lanes of the workgroup
     bool retired = false;
     uint32_t compact_events = 0; // events this wavefront has taken part in (event k: 64 (k + 1) lanes retired)
@@ -337,6 +346,7 @@ constexpr uint32_t kVolumeLean = kFeatVolPath | kFeatAnalytic | kFeatMicrofacet;
 #define MCPT_WIDE_WALK 0
 #endif
 constexpr uint32_t kP = kFeatOrderedWalk | kFeatPoolWalk; // the wavefront-cooperative pool walk (LDS-resident scenes)
+constexpr uint32_t kPB = kP | kFeatPoolBig;               // ... on scenes outside LDS
 constexpr uint32_t kO = kFeatOrderedWalk, kV = kFeatOrderedWalk | kFeatVoteWalk | (MCPT_WIDE_WALK ? kFeatWideWalk : 0u), kS = kFeatSlivers;
 // stack entries per lane in LDS: the ring of the short stack, or one entry per level of the binary hierarchy
 inline size_t WalkStackEntries(const DeviceScene &sc, uint32_t features)
@@ -360,10 +370,10 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
 {
     constexpr bool kOrdered = (kFeatures & kFeatOrderedWalk) != 0;
     constexpr bool kPool = (kFeatures & kFeatPoolWalk) != 0;
-    static_assert(!kPool || (kLdsGeometry && kOrdered), "the pool walk runs on hierarchies staged in LDS");
+    static_assert(!kPool || (kOrdered && (kLdsGeometry != ((kFeatures & kFeatPoolBig) != 0))), "pool walk: 16-bit items with the hierarchy staged in LDS, 32-bit items outside");
     static_assert((kBlockSize / 64u) * pool_wave_words(false) >= kCompactWords * kBlockSize, "the compaction's words travel through the pool areas");
     const size_t lds_bytes = (kLdsGeometry ? StagedBytes(sc, kOrdered, kPool) : 0) +
-                             (kPool      ? size_t(kBlockSize / 64u) * pool_wave_words((kFeatures & kFeatAnalytic) != 0) * sizeof(uint32_t) + 8 * sizeof(uint32_t)
+                             (kPool      ? size_t(kBlockSize / 64u) * pool_wave_words((kFeatures & kFeatAnalytic) != 0, (kFeatures & kFeatPoolBig) != 0) * sizeof(uint32_t) + 8 * sizeof(uint32_t)
                               : kOrdered ? WalkStackEntries(sc, kFeatures) * kBlockSize * sizeof(uint32_t)
                                          : 0) +
                              (!kPool && kLdsGeometry && !kCount && kOrdered && !(kFeatures & (kFeatVolPath | kFeatAnalytic))
@@ -445,6 +455,10 @@ extern template hipError_t Launch<kAll | kV | kS, true, false>(MCPT_LAUNCH_ARGS)
 #if !defined(MCPT_UNIT_LDS)
 extern template hipError_t Launch<kAll | kO, false, true>(MCPT_LAUNCH_ARGS);
 extern template hipError_t Launch<kVolumeLean | kO, false, true>(MCPT_LAUNCH_ARGS);
+#endif
+#if !defined(MCPT_UNIT_POOL)
+extern template hipError_t Launch<kSurface | kPB, false, false>(MCPT_LAUNCH_ARGS);
+extern template hipError_t Launch<kSurface | kPB | kS, false, false>(MCPT_LAUNCH_ARGS);
 #endif
 #if !defined(MCPT_UNIT_SURFACE)
 extern template hipError_t Launch<kSurface | kV, false, false>(MCPT_LAUNCH_ARGS);

@@ -78,8 +78,10 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
             lds_geometry[n_node_vec + n_tri_vec + n_walk_vec + i] = sc_in.walk_prims[i];
         sc.nodes = lds_geometry;
         sc.tri_pos = lds_geometry + n_node_vec;
-        sc.walk_nodes = lds_geometry + n_node_vec + n_tri_vec;
-        sc.pool_nodes = lds_geometry + n_node_vec + n_tri_vec; // (whichever form was staged)
+        if (C::kPool) // (whichever form was staged; the binary form stays in HBM for the rare ray walked the per-lane way)
+            sc.pool_nodes = lds_geometry + n_node_vec + n_tri_vec;
+        else
+            sc.walk_nodes = lds_geometry + n_node_vec + n_tri_vec;
         sc.walk_prims = lds_geometry + n_node_vec + n_tri_vec + n_walk_vec;
         n_staged = n_node_vec + n_tri_vec + n_walk_vec + n_slot_vec;
     }
@@ -88,12 +90,12 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     // one walk per lane: the lanes' stack columns, then the exchange words.  Pool walk: one pool area per wavefront, and the
     // exchange words travel THROUGH the pool areas (no wavefront is inside a query between the count barrier and the barrier
     // behind the last exchange read), the counters behind them.
-    static_assert(!C::kPool || kWaves * pool_wave_words(C::kAnalytic) >= kSortPassWords * kBlockSize, "the exchange fits the pool areas");
-    uint32_t *stack = C::kPool ? lds_words + (threadIdx.x >> 6) * pool_wave_words(C::kAnalytic) : lds_words + threadIdx.x;
+    static_assert(!C::kPool || kWaves * pool_wave_words(C::kAnalytic, false) >= kSortPassWords * kBlockSize, "the exchange fits the pool areas");
+    uint32_t *stack = C::kPool ? lds_words + (threadIdx.x >> 6) * pool_wave_words(C::kAnalytic, false) : lds_words + threadIdx.x;
     if (!C::kPool)
         lds_words += static_cast<size_t>(sc_in.integrator.walk_depth) * 256u;
     uint32_t *exchange = lds_words;                                  // kSortPassWords x 256 words, word-major
-    uint32_t *counts = C::kPool ? lds_words + kWaves * pool_wave_words(C::kAnalytic) : exchange + kSortPassWords * kBlockSize; // [parity][wavefront][class]
+    uint32_t *counts = C::kPool ? lds_words + kWaves * pool_wave_words(C::kAnalytic, false) : exchange + kSortPassWords * kBlockSize; // [parity][wavefront][class]
     __syncthreads(); // geometry staged
 
     const uint32_t stride = gridDim.x * blockDim.x;

@@ -209,7 +209,6 @@ int g_walk_tree_strategy = 0; // SetWalkTreeStrategyForTesting
 // children per item halve both.  The children's boxes are the binary hierarchy's own (a child here is a child or
 // grandchild there): a primitive is reachable under exactly the same conditions, interior boxes that disappear were
 // supersets of what they held (the slab test is monotone in the box).
-constexpr uint32_t kPoolTreeMaxNodes = 1024;
 
 void BuildPoolNodes(FlatScene &fs)
 {
@@ -217,7 +216,7 @@ void BuildPoolNodes(FlatScene &fs)
     fs.pool_nodes.clear();
     ig.n_pool_nodes = 0, ig.pool_depth = 0;
     const uint32_t n_binary = ig.n_walk_nodes;
-    if (n_binary == 0 || n_binary > kPoolTreeMaxNodes)
+    if (n_binary == 0)
     {
         fs.pool_nodes.assign(8, float4{0, 0, 0, 0});
         return;
@@ -994,7 +993,7 @@ DeviceScene FlatScene::HostView() const
 
 size_t FlatScene::GeometryBytes() const
 {
-    return nodes.size() * sizeof(float4) + walk_nodes.size() * sizeof(float4) + walk_prims.size() * sizeof(float4) +
+    return nodes.size() * sizeof(float4) + walk_nodes.size() * sizeof(float4) + pool_nodes.size() * sizeof(float4) + walk_prims.size() * sizeof(float4) +
            tri_pos.size() * sizeof(float4) + tri_attr.size() * sizeof(float4);
 }
 

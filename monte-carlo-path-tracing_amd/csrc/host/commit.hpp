@@ -24,7 +24,7 @@ struct FlatScene
     std::vector<float4> walk_nodes; // 4 per node (ordered-walk hierarchy)
     std::vector<float4> walk_prims; // 3 per slot
     std::vector<uint4> wide_nodes;  // 4 per node of the 4-wide quantised form of the ordered-walk hierarchy
-    std::vector<float4> pool_nodes; // 8 per node of its 4-wide EXACT form (scenes of at most kPoolTreeMaxNodes binary nodes)
+    std::vector<float4> pool_nodes; // 8 per node of its 4-wide EXACT form
     std::vector<float4> tri_pos;   // 3 per primitive slot
     std::vector<float4> tri_attr;  // 9 per primitive slot
     std::vector<InstanceRec> instances;

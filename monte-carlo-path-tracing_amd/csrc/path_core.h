@@ -51,6 +51,7 @@ struct Config
                                                                            : kAllKinds;
     static constexpr bool kWide = (kFeatures & kFeatWideWalk) != 0;       // ... on the 4-wide quantised hierarchy
     static constexpr bool kPool = (kFeatures & kFeatPoolWalk) != 0;       // ... as the wavefront-cooperative pool walk (pool_walk.h; device only)
+    static constexpr bool kPoolBig = (kFeatures & kFeatPoolBig) != 0;     // ... with 32-bit items, the hierarchy outside LDS
 };
 
 struct LaneCounters
@@ -168,7 +169,7 @@ MCPT_HD bool trace(const DeviceScene &sc, uint32_t *stack, Ray &r, uint32_t &rng
     {
 #if defined(__HIP_DEVICE_COMPILE__)
         if (C::kPool) // (`stack` = the wavefront's pool area)
-            return count ? walk_pool<kAny, C::kAnalytic, true>(sc, stack, true, r, hit, ts) : walk_pool<kAny, C::kAnalytic, false>(sc, stack, true, r, hit, ts);
+            return count ? walk_pool<kAny, C::kAnalytic, true, C::kPoolBig, C::kSlivers>(sc, stack, true, r, hit, ts) : walk_pool<kAny, C::kAnalytic, false, C::kPoolBig, C::kSlivers>(sc, stack, true, r, hit, ts);
 #endif
         if (C::kWide)
             return count ? walk_wide_vote<kAny, C::kAnalytic, true, C::kSlivers>(sc, stack, r, hit, ts)
@@ -624,7 +625,7 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
 template <class C, bool kAny>
 __device__ __forceinline__ bool trace_uniform(const DeviceScene &sc, uint32_t *pool, bool has_ray, Ray &r, HitRaw &hit, TraceStats &ts, bool count)
 {
-    return count ? walk_pool<kAny, C::kAnalytic, true>(sc, pool, has_ray, r, hit, ts) : walk_pool<kAny, C::kAnalytic, false>(sc, pool, has_ray, r, hit, ts);
+    return count ? walk_pool<kAny, C::kAnalytic, true, C::kPoolBig, C::kSlivers>(sc, pool, has_ray, r, hit, ts) : walk_pool<kAny, C::kAnalytic, false, C::kPoolBig, C::kSlivers>(sc, pool, has_ray, r, hit, ts);
 }
 
 template <class C>

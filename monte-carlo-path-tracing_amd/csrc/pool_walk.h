@@ -28,8 +28,7 @@
 //     neither does the result; the winner's record is then re-evaluated on the owner's own ray registers
 //     (the same values test_slot would have copied: hit_from_record's argument).
 //   * a ray that accepts more candidates than its list holds (kPoolCands; seen: up to 5 on cornell, 0.17 % of the rays
-//     beyond 4) is walked a second time with its final bound as the initial one: then only the hits within the tie
-//     radius of the nearest are accepted at all.
+//     beyond 4) is walked again by its owner alone, the per-lane way (walk_ordered on a private stack).
 // Not for scenes with slivers (kFeatSlivers: their reachability rules are test_slot's) or opacity masks.
 //
 // LDS per wavefront (kPoolWaveWords): 64 ray records of 12 words (16 with quadrics: the direction) — origin + bound |
@@ -38,6 +37,8 @@
 // live in scalar registers: the lists belong to ONE wavefront, no atomics on them.
 #ifndef MCPT_POOL_WALK_H
 #define MCPT_POOL_WALK_H
+
+#include <type_traits>
 
 #include "traversal.h"
 
@@ -50,12 +51,13 @@ constexpr uint32_t kPoolNodeFull = 384;
 constexpr uint32_t kPoolMaxDepth = 20;   // of the 4-wide hierarchy: 3 x depth <= the head room
 constexpr uint32_t kPoolPrimItems = 320; // (ray, slot) item slots: < kPoolPrimAt waiting + 4 x 64 pushed by one node step
 constexpr uint32_t kPoolPrimAt = 64;     // a primitive phase runs when this many slots wait
-constexpr uint32_t kPoolMaxRef = 1023;   // node and slot indices must fit 10 bits
+constexpr uint32_t kPoolMaxRef = 1023;   // node and slot indices must fit 10 bits (16-bit items: scenes in LDS)
+constexpr uint32_t kPoolMaxRefBig = (1u << 26) - 1u; // ... 26 bits (32-bit items: kFeatPoolBig)
 
 MCPT_HD constexpr uint32_t pool_ray_words(bool analytic) { return analytic ? 16u : 12u; }
-MCPT_HD constexpr uint32_t pool_wave_words(bool analytic)
+MCPT_HD constexpr uint32_t pool_wave_words(bool analytic, bool big = false)
 {
-    return 64u * pool_ray_words(analytic) + 64u + 64u * kPoolCands * 2u + (kPoolNodeItems + kPoolPrimItems) / 2u;
+    return 64u * pool_ray_words(analytic) + 64u + 64u * kPoolCands * 2u + (kPoolNodeItems + kPoolPrimItems) / (big ? 1u : 2u);
 }
 
 // The probe of one primitive slot WITHOUT any bound: does the ray's line hit it at t >= kEpsDistance, and where
@@ -104,9 +106,17 @@ __device__ __forceinline__ uint32_t pool_rank(unsigned long long mask, uint32_t 
 // `has_ray` also bring a ray — a lane without a path of its own (its pixel is finished, its sample ended at this vertex,
 // the launch gave it none: RenderJob::lane_spread) helps the others' rays along, which is what shortens a pixel's chain
 // when lanes are idle.  Returns whether the lane's ray hit anything; closest queries: `hit` and ray.t_max describe it.
-template <bool kAny, bool kAnalytic, bool kCount>
+// kSlivers (scenes with sliver triangles, IntegratorRec::walk_sliver_reach > 0; test_slot's rules): a sliver's leaf box in
+// the hierarchy is a grown one, so its hit counts only if the reference's own leaf box lets the ray in; the radius within
+// which two hits are candidates of one another is the sliver reach when one of them is a sliver and the tie radius
+// otherwise, and an accepted hit shrinks the bound to its distance + ITS radius (a candidate carries its sliver flag in
+// bit 31 of its slot word).  (One radius for everything — the reach — was tried first: in dense geometry, dragon/scene.xml's
+// cloth, a dozen ordinary hits lie within 0.06 of each other and the candidate lists overflowed.)
+template <bool kAny, bool kAnalytic, bool kCount, bool kBig = false, bool kSlivers = false>
 __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool, bool has_ray, Ray &ray, HitRaw &hit, TraceStats &stats)
 {
+    using Item = typename std::conditional<kBig, uint32_t, uint16_t>::type; // ray << kRefBits | node or slot
+    constexpr uint32_t kRefBits = kBig ? 26u : 10u, kRefMask = (1u << kRefBits) - 1u;
     if (sc.integrator.n_walk_nodes == 0)
         return false;
     constexpr uint32_t kRayVecs = pool_ray_words(kAnalytic) / 4u;
@@ -116,8 +126,8 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
     float4 *rays = reinterpret_cast<float4 *>(pool);
     uint32_t *counts = pool + 64u * pool_ray_words(kAnalytic);
     uint2 *cands = reinterpret_cast<uint2 *>(counts + 64u);
-    uint16_t *node_items = reinterpret_cast<uint16_t *>(counts + 64u + 64u * kPoolCands * 2u), *prim_items = node_items + kPoolNodeItems;
-    const float tie = sc.integrator.walk_tie;
+    Item *node_items = reinterpret_cast<Item *>(counts + 64u + 64u * kPoolCands * 2u), *prim_items = node_items + kPoolNodeItems;
+    const float tie = sc.integrator.walk_tie, reach = kSlivers ? sc.integrator.walk_sliver_reach : sc.integrator.walk_tie;
 
     // ---- the lane's ray becomes a record ----
     const unsigned long long m_rays = __ballot(has_ray);
@@ -136,12 +146,11 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
         if (kAnalytic)
             rays[kRayVecs * lane + 3] = float4{ray.dir.x, ray.dir.y, ray.dir.z, 0.0f};
         counts[lane] = 0;
-        node_items[pool_rank(m_rays)] = static_cast<uint16_t>(lane << 10); // (ray, top node)
+        node_items[pool_rank(m_rays)] = static_cast<Item>(lane << kRefBits); // (ray, top node)
     }
     // (wavefront-uniform values, kept in scalar registers: `uni` tells the compiler so where it cannot see it)
     auto uni = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
     uint32_t n_nodes = uni(static_cast<uint32_t>(__popcll(m_rays))), n_prims = 0;
-    for (uint32_t pass = 0;; ++pass)
     {
         pool_sync();
         for (;;)
@@ -158,7 +167,7 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
                 {
                     if (kCount)
                         ++stats.prim_tests;
-                    const uint32_t item = prim_items[n_prims - 1u - rank], r = item >> 10, slot = item & kPoolMaxRef;
+                    const uint32_t item = prim_items[n_prims - 1u - rank], r = item >> kRefBits, slot = item & kRefMask;
                     const float4 a = rays[kRayVecs * r], b = rays[kRayVecs * r + 1], c = rays[kRayVecs * r + 2];
                     Ray q;
                     q.origin = V3{a.x, a.y, a.z}, q.dir_rcp = V3{b.x, b.y, b.z}, q.shear = V3{c.x, c.y, c.z}, q.t_max = a.w;
@@ -173,23 +182,25 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
                     const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(slot);
                     const SlotHit h = probe_slot<kAnalytic>(sc, p, q);
                     float *bound = reinterpret_cast<float *>(&rays[kRayVecs * r]) + 3;
+                    // (a sliver reached through its grown box: would the reference's own leaf box let the ray in?)
+                    const bool sliver = kSlivers && (as_uint(p[2].w) & kWalkSliver) != 0;
                     if (kAny)
                     {
-                        if (h.hit && !(h.t > a.w)) // (test_slot, kAny)
+                        if (h.hit && !(h.t > a.w) && (!sliver || reference_leaf_box_passes<kAnalytic>(sc, as_uint(p[1].w), as_uint(p[0].w), q, a.w))) // (test_slot, kAny)
                         {
                             *bound = -1.0f; // occluded: whatever of the ray is still listed fails its test
                             counts[r] = 1u;
                         }
                     }
-                    else if (h.hit && h.t <= a.w)
+                    else if (h.hit && h.t <= a.w && (!sliver || reference_leaf_box_passes<kAnalytic>(sc, as_uint(p[1].w), as_uint(p[0].w), q, kMaxFloat)))
                     {
-                        // the bound shrinks to this distance + the tie radius (monotone: positive floats order like their bits)
-                        const uint32_t before = atomicMin(reinterpret_cast<uint32_t *>(bound), __float_as_uint(h.t + tie));
+                        // the bound shrinks to this distance + the hit's radius (monotone: positive floats order like their bits)
+                        const uint32_t before = atomicMin(reinterpret_cast<uint32_t *>(bound), __float_as_uint(h.t + (sliver ? reach : tie)));
                         if (!(h.t > __uint_as_float(before)))
                         {
                             const uint32_t at = atomicAdd(&counts[r], 1u);
                             if (at < kPoolCands)
-                                cands[kPoolCands * r + at] = uint2{__float_as_uint(h.t), slot};
+                                cands[kPoolCands * r + at] = uint2{__float_as_uint(h.t), slot | (sliver ? kWalkSliver : 0u)};
                         }
                     }
                 }
@@ -215,7 +226,7 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
                 if (kCount)
                     stats.node_tests += 4;
                 const uint32_t item = node_items[n_nodes - 1u - rank];
-                const uint32_t ray_bits = item & ~kPoolMaxRef, r = item >> 10, node = item & kPoolMaxRef;
+                const uint32_t ray_bits = item & ~kRefMask, r = item >> kRefBits, node = item & kRefMask;
                 const float4 a = rays[kRayVecs * r], b = rays[kRayVecs * r + 1];
                 const uint32_t pack = __float_as_uint(b.w);
                 const char *w = reinterpret_cast<const char *>(sc.pool_nodes) + 128u * node;
@@ -241,9 +252,9 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
                     const unsigned long long b_hit = __ballot(hit_c), b_leaf = __ballot(leaf_c);
                     const unsigned long long m_node = b_hit & ~b_leaf, m_leaf = b_hit & b_leaf;
                     if (hit_c && !leaf_c)
-                        (node_items + at_nodes)[pool_rank(m_node)] = static_cast<uint16_t>(ray_bits | ref[c]);
+                        (node_items + at_nodes)[pool_rank(m_node)] = static_cast<Item>(ray_bits | ref[c]);
                     if (hit_c && leaf_c)
-                        (prim_items + at_prims)[pool_rank(m_leaf)] = static_cast<uint16_t>(ray_bits | (ref[c] & kPoolMaxRef));
+                        (prim_items + at_prims)[pool_rank(m_leaf)] = static_cast<Item>(ray_bits | (ref[c] & kRefMask));
                     at_nodes += static_cast<uint32_t>(__popcll(m_node)), at_prims += static_cast<uint32_t>(__popcll(m_leaf));
                 }
                 next_nodes = at_nodes, next_prims = at_prims;
@@ -251,19 +262,6 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
             n_nodes = uni(next_nodes), n_prims = uni(next_prims); // (the first active lane has rank 0 < k: it took part)
             pool_sync();
         }
-        if (kAny)
-            break;
-        // a ray whose candidate list overflowed walks again, its final bound as the initial one
-        const bool again = pass == 0 && has_ray && counts[lane] > kPoolCands;
-        const unsigned long long m_again = __ballot(again);
-        if (m_again == 0)
-            break;
-        if (again)
-        {
-            counts[lane] = 0;
-            node_items[pool_rank(m_again)] = static_cast<uint16_t>(lane << 10);
-        }
-        n_nodes = uni(static_cast<uint32_t>(__popcll(m_again)));
     }
     if (!has_ray)
         return false;
@@ -274,7 +272,13 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
     uint32_t n = counts[lane];
     if (n == 0)
         return false;
-    n = n < kPoolCands ? n : kPoolCands;
+    if (n > kPoolCands)
+    {
+        // more accepted hits than the list holds (many near-coincident surfaces: the apex of dragon/scene.xml's stand-in wings,
+        // 20 sheets through one point): this lane walks its ray alone, the per-lane way, on a private stack
+        uint32_t own_stack[kWalkStackMax];
+        return walk_ordered<false, kAnalytic, false, kSlivers, 1u>(sc, own_stack, ray, hit, stats);
+    }
     const uint2 *mine = cands + kPoolCands * lane;
     float t_min = __uint_as_float(mine[0].x);
     uint32_t winner = mine[0].y;
@@ -284,12 +288,16 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
         if (t < t_min)
             t_min = t, winner = mine[i].y;
     }
+    // the nearest hit's rivals: within the tie radius of it — the sliver reach if either of the two is a sliver
+    const bool nearest_sliver = kSlivers && (winner & kWalkSliver) != 0;
+    auto rival = [&](uint32_t i) { return fabsf(__uint_as_float(mine[i].x) - t_min) <= ((kSlivers && (nearest_sliver || (mine[i].y & kWalkSliver))) ? reach : tie); };
     uint32_t n_tied = 0;
     for (uint32_t i = 0; i < n; ++i)
-        n_tied += fabsf(__uint_as_float(mine[i].x) - t_min) <= tie ? 1u : 0u;
+        n_tied += rival(i) ? 1u : 0u;
+    winner &= ~kWalkSliver;
     if (n_tied > 1)
     {
-        // rare: several hits within the tie radius of the nearest — the reference's own sequence on them, in rank order
+        // rare: several hits within the radius of the nearest — the reference's own sequence on them, in rank order
         // (test_slot's pair rule, applied along the whole list)
         uint32_t last_rank = 0;
         float cur_t = 0.0f;
@@ -298,14 +306,14 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
             uint32_t pick = 0, pick_rank = 0xFFFFFFFFu;
             for (uint32_t i = 0; i < n; ++i)
             {
-                if (!(fabsf(__uint_as_float(mine[i].x) - t_min) <= tie))
+                if (!rival(i))
                     continue;
-                const uint32_t rk = as_uint(sc.walk_prims[3 * static_cast<size_t>(mine[i].y) + 2].w);
+                const uint32_t rk = as_uint(sc.walk_prims[3 * static_cast<size_t>(mine[i].y & ~kWalkSliver) + 2].w) & ~kWalkSliver;
                 if ((step == 0 || rk > last_rank) && rk < pick_rank)
                     pick = i, pick_rank = rk;
             }
             const float t = __uint_as_float(mine[pick].x);
-            const uint32_t slot = mine[pick].y;
+            const uint32_t slot = mine[pick].y & ~kWalkSliver;
             const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(slot);
             if (step == 0 || (!(t > cur_t) && reference_leaf_box_passes<kAnalytic>(sc, as_uint(p[1].w), as_uint(p[0].w), ray, cur_t)))
                 cur_t = t, winner = slot;

@@ -618,7 +618,9 @@ MCPT_HD bool is_leading_lane()
 // primitive (or is done) before paying for one primitive phase; leaving the node
 // phase earlier (when only a few lanes are still searching) was measured and is
 // slower at every threshold (cornell: -2 % at 8 lanes ... -26 % at 64).
-template <bool kAny, bool kAnalytic, bool kCount, bool kSlivers = true>
+// (kStride: distance between a lane's consecutive stack entries — kWalkStackStride for the lane-interleaved stacks in LDS,
+//  1 for a private array)
+template <bool kAny, bool kAnalytic, bool kCount, bool kSlivers = true, uint32_t kStride = kWalkStackStride>
 MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitRaw &hit, TraceStats &stats)
 {
     if (sc.integrator.n_walk_nodes == 0)
@@ -711,8 +713,8 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
             // accesses cost less than the exec-mask regions of a three-way branch.
             const bool first0 = enter0 <= enter1, both = hit0 && hit1, none = !(hit0 || hit1);
             const uint32_t toward = (hit0 && (first0 || !hit1)) ? ref0 : ref1;
-            const uint32_t postponed = stack[(depth - 1) * kWalkStackStride];
-            stack[depth * kWalkStackStride] = first0 ? ref1 : ref0;
+            const uint32_t postponed = stack[(depth - 1) * kStride];
+            stack[depth * kStride] = first0 ? ref1 : ref0;
             depth = depth + (both ? 1u : 0u) - (none ? 1u : 0u);
             cur = none ? postponed : toward;
         }
@@ -734,7 +736,7 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
         if (test_slot<kAny, kAnalytic, kSlivers, kLeafCheck>(sc, cur & ~kWalkLeaf, ray, hit, best) && kAny)
             return true;
         --depth;
-        cur = stack[depth * kWalkStackStride];
+        cur = stack[depth * kStride];
     }
     if (!kAny)
         ray.t_max = best.found ? best.best_t : ray.t_max; // the exact distance, not the culling bound

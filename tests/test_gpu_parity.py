@@ -913,8 +913,8 @@ def test_lane_spread_does_not_change_the_image(name, pkg, scenes):
 
 @pytest.mark.gpu
 def test_calibration_is_on_request_and_its_choice_is_stored(pkg):
-    """A scene outside LDS.  A draw does not measure anything by itself: the built-in rule (stream kernel, wavefront
-    rounds, work counter).  mcpt_renderer_calibrate times four configurations on a sample of the frame, says so, and
+    """A scene outside LDS.  A draw does not measure anything by itself: the built-in rule (surface-material scenes: the
+    lane-owns-a-path kernel with the pool walk, pre-pass, work counter).  mcpt_renderer_calibrate times four configurations on a sample of the frame, says so, and
     stores the winner — in the process (a second renderer of the same scene starts with it) and in the calibration
     file.  Same frame all along."""
     scene = pkg.scenes.terrain_scene(64, 160, 120, 8)
@@ -923,7 +923,7 @@ def test_calibration_is_on_request_and_its_choice_is_stored(pkg):
     try:
         assert r.info()["primitives"] >= 2048
         a, _ = r.draw()
-        assert "calibrated" not in r.last_kernel() and "wavefront rounds" in r.last_kernel(), r.last_kernel()
+        assert "calibrated" not in r.last_kernel() and "pool-walk" in r.last_kernel() and "work counter" in r.last_kernel(), r.last_kernel()
         r.calibrate()
         c, _ = r.draw()
         assert "calibrated on this scene:" in r.last_kernel() and "stream wavefront rounds" in r.last_kernel()

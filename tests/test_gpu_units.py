@@ -52,9 +52,11 @@ def _same(a, b):
     return (a == b) | (np.isnan(a) & np.isnan(b))
 
 
-@pytest.mark.parametrize("walk", ["ordered", "reference"])
+@pytest.mark.parametrize("walk", ["ordered", "reference", "pool"])
 @pytest.mark.parametrize("shape", ["mesh", "flat_mesh", "sphere", "disk", "cylinder", "cube"])
 def test_intersection_records(shape, walk, pkg, oracle, mcsd_file):
+    """Closest-hit records of the unit kernel against the oracle's, for the production per-lane walk, the reference-order
+    walk and the wavefront-cooperative pool walk (csrc/pool_walk.h, in its general form: 32-bit items, quadrics)."""
     scene = pkg.scenes.material_preview("bumpy_diffuse", "area", shape, 8, 8, 1)
     path = mcsd_file(scene)
     rng = np.random.default_rng(17)
@@ -64,7 +66,7 @@ def test_intersection_records(shape, walk, pkg, oracle, mcsd_file):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     org, d = org.astype(np.float32), d.astype(np.float32)
     r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
-    r.set_walk(walk == "reference")
+    r.set_walk(walk == "reference").set_pool_walk(1 if walk == "pool" else 0)
     got, _ = r.debug_intersect(org, d)
     r.close()
     want = np.zeros_like(got)
@@ -87,6 +89,40 @@ def test_intersection_records(shape, walk, pkg, oracle, mcsd_file):
     assert bad.mean() < 0.001, bad.mean()
     # with the host libm's algorithms on the device (csrc/glibc_libm.h) every record is the oracle's
     assert _same(got, want).all(), (shape, walk, int((~_same(got, want).all(axis=1)).sum()))
+
+
+@pytest.mark.parametrize("name", ["dragon", "matpreview-rc", "volumetric", "cornell"])
+def test_pool_walk_answers_two_million_queries_like_the_reference_walk(name, pkg):
+    """The pool walk on the BASELINE scenes (dragon/scene.xml: 0.85 M triangles, 7 710 slivers, near-coincident sheets at
+    the stand-in wings' apex — the case whose candidate lists overflow and fall back to the per-lane walk; matpreview; the
+    volumetric scene's sphere; cornell): 2 000 000 closest-hit queries between jittered surface points — grazing and
+    near-coincident situations in abundance — answered like the reference-order walk answers them: same instance,
+    primitive and distance, every one."""
+    cfg = pkg.workloads.config(name, 64, 36, 1)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "w.mcsd")
+        cfg.save_mcsd(path)
+        scene = pkg.mcsd.loads(open(path, "rb").read())
+    pts = [np.asarray(i.positions, np.float32).reshape(-1, 3) for i in scene.instances if i.positions is not None and len(i.positions)]
+    pts = np.concatenate(pts) if pts else np.zeros((1, 3), np.float32)
+    if len(pts) < 64:   # (builtin cornell: rectangles and cubes without vertex lists)
+        pts = np.random.default_rng(5).uniform(-1, 2, (4096, 3)).astype(np.float32)
+    rng = np.random.default_rng(3)
+    n = 2_000_000
+    a = pts[rng.integers(0, len(pts), n)] + rng.normal(0, 0.02, (n, 3)).astype(np.float32)
+    b = pts[rng.integers(0, len(pts), n)] + rng.normal(0, 0.02, (n, 3)).astype(np.float32)
+    d = b - a
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-20)
+    r = pkg.capi.Renderer(cfg, device=0)
+    try:
+        want, _ = r.set_walk(True).debug_intersect(a, d)
+        got, _ = r.set_walk(False).set_pool_walk(1).debug_intersect(a, d)
+    finally:
+        r.close()
+    assert (want[:, 0] != 0).mean() > 0.2
+    bad = ~_same(got, want).all(axis=1)
+    assert not bad.any(), (name, int(bad.sum()), a[bad][:2], d[bad][:2], got[bad][:2, :5], want[bad][:2, :5])
 
 
 @pytest.mark.parametrize("material", ["diffuse", "rough_diffuse_full", "rough_conductor_aniso", "conductor",
