@@ -1,5 +1,7 @@
 // The lean render-kernel instantiations, the unit kernels and the dispatcher; the kernel template
 // itself is in render_kernel_impl.h.
+#include <cstdlib>
+
 #include "render_kernel_impl.h"
 
 namespace mcpt
@@ -188,6 +190,17 @@ thread_local bool g_last_transposed = false;
 void NoteTransposed(bool transposed) { g_last_transposed = transposed; }
 bool LastLaunchTransposed() { return g_last_transposed; }
 
+// (measurements: MCPT_POOL_SUBSETS=0 keeps the full BSDF set in the pool-walk kernels of scenes that need one model only)
+static bool PoolSubsets()
+{
+    static const bool on = []
+    {
+        const char *e = std::getenv("MCPT_POOL_SUBSETS");
+        return !e || std::atoi(e) != 0;
+    }();
+    return on;
+}
+
 // Can the lane-owns-a-path kernel run this scene (outside LDS) with the pool walk?  Surface materials (no media, no
 // quadrics), no opacity masks, the 4-wide hierarchy within the items' 26 bits and the lists' head room.
 bool PoolBigSupports(const DeviceScene &sc)
@@ -224,6 +237,22 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     // surface-materials instantiation with it, whatever subset of its features the scene uses
     if (job.pool_walk >= 1 && StagedBytes(sc, true) > kLdsGeometryBytes && PoolBigSupports(sc))
     {
+        if ((f & ~kFeatEmitters) == 0)
+        {
+            // diffuse surfaces only (dragon/scene.xml): the lean instantiations
+            *variant = slivers ? "diffuse-emitters+slivers+pool-walk" : "diffuse-emitters+pool-walk";
+            return slivers ? Launch<kFeatEmitters | kPB | kS, false>(sc, job, out, nullptr, stream, n_cus) : Launch<kFeatEmitters | kPB, false>(sc, job, out, nullptr, stream, n_cus);
+        }
+        if (!slivers && PoolSubsets() && !sc.integrator.has_non_conductor)
+        {
+            *variant = "surface-materials (diffuse + conductor only)+pool-walk";
+            return Launch<kSurface | kPB | kFeatConductorOnly, false>(sc, job, out, nullptr, stream, n_cus);
+        }
+        if (!slivers && PoolSubsets() && !sc.integrator.has_reflectors)
+        {
+            *variant = "surface-materials (diffuse + dielectric only)+pool-walk";
+            return Launch<kSurface | kPB | kFeatDielectricOnly, false>(sc, job, out, nullptr, stream, n_cus);
+        }
         *variant = slivers ? "surface-materials+slivers+pool-walk" : "surface-materials+pool-walk";
         return slivers ? Launch<kSurface | kPB | kS, false>(sc, job, out, nullptr, stream, n_cus) : Launch<kSurface | kPB, false>(sc, job, out, nullptr, stream, n_cus);
     }

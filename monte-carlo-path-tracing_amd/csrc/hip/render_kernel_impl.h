@@ -53,9 +53,11 @@ struct Budget
 #define MCPT_FULL_LDS_WAVES 3
 #endif
 #ifndef MCPT_POOL_BIG_WAVES
-#define MCPT_POOL_BIG_WAVES 4
+#define MCPT_POOL_BIG_WAVES 3
 #endif
-    // (pool walk outside LDS: a wavefront's pool area is 9.5 KB of LDS, 16 of them fit a CU)
+    // (pool walk outside LDS: a wavefront's pool area is 9.5 KB of LDS, 16 of them fit a CU.  Measured at 4 / 3 wavefronts per
+    //  SIMD — 128 VGPRs with 49-140 spilled / 156-168 with none: dragon/scene.xml 239.5 / 230.8 ms, matpreview rough conductor
+    //  652.0 / 613.6 ms, rough dielectric 902.8 / 905.9 ms)
     static constexpr int kWavesPerSimd = (kFeatures & kFeatPoolBig) ? MCPT_POOL_BIG_WAVES
                                          : (kFeatures & (kFeatVolPath | kFeatAnalytic)) ? (kLdsGeometry ? MCPT_FULL_LDS_WAVES : 3)
 #ifdef MCPT_EXPERIMENT_MICROFACET_WAVES
@@ -459,6 +461,14 @@ extern template hipError_t Launch<kVolumeLean | kO, false, true>(MCPT_LAUNCH_ARG
 #if !defined(MCPT_UNIT_POOL)
 extern template hipError_t Launch<kSurface | kPB, false, false>(MCPT_LAUNCH_ARGS);
 extern template hipError_t Launch<kSurface | kPB | kS, false, false>(MCPT_LAUNCH_ARGS);
+#endif
+#if !defined(MCPT_UNIT_POOL_2)
+extern template hipError_t Launch<kFeatEmitters | kPB, false, false>(MCPT_LAUNCH_ARGS);
+extern template hipError_t Launch<kFeatEmitters | kPB | kS, false, false>(MCPT_LAUNCH_ARGS);
+#endif
+#if !defined(MCPT_UNIT_POOL_3)
+extern template hipError_t Launch<kSurface | kPB | kFeatConductorOnly, false, false>(MCPT_LAUNCH_ARGS);
+extern template hipError_t Launch<kSurface | kPB | kFeatDielectricOnly, false, false>(MCPT_LAUNCH_ARGS);
 #endif
 #if !defined(MCPT_UNIT_SURFACE)
 extern template hipError_t Launch<kSurface | kV, false, false>(MCPT_LAUNCH_ARGS);

@@ -11,7 +11,7 @@ import checkers
 from mcpt_amd import capi
 orc = checkers.Oracle()
 CASES = [('config 2: cornell-box 512x512 spp 256', 'cornell'),
-         ('config 3: dragon/scene.xml 1280x720 spp 256 (12 shipped meshes + stand-ins, 831 580 triangles)', 'dragon'),
+         ('config 3: dragon/scene.xml 1280x720 spp 256 (12 shipped meshes + stand-ins, 845 808 triangles)', 'dragon'),
          ('config 4: matpreview rough_conductor 1024x1024 spp 512', 'matpreview-rc'),
          ('config 4: matpreview rough_dielectric 1024x1024 spp 512', 'matpreview-rd'),
          ('config 5: volumetric-caustic 1280x720 spp 1024', 'volumetric')]
