@@ -201,11 +201,11 @@ static bool PoolSubsets()
     return on;
 }
 
-// Can the lane-owns-a-path kernel run this scene (outside LDS) with the pool walk?  Surface materials (no media, no
-// quadrics), no opacity masks, the 4-wide hierarchy within the items' 26 bits and the lists' head room.
+// Can the lane-owns-a-path kernel run this scene (outside LDS) with the pool walk?  No opacity masks (they draw random numbers
+// during a walk: the visiting order is part of the image), the 4-wide hierarchy within the items' 26 bits and the lists' head room.
 bool PoolBigSupports(const DeviceScene &sc)
 {
-    return (sc.features & ~kSurface) == 0 && !sc.integrator.has_masks && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kPoolMaxRefBig &&
+    return !sc.integrator.has_masks && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kPoolMaxRefBig &&
            sc.integrator.n_prims <= kPoolMaxRefBig && sc.integrator.pool_depth <= kPoolMaxDepth;
 }
 
@@ -237,6 +237,11 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     // surface-materials instantiation with it, whatever subset of its features the scene uses
     if (job.pool_walk >= 1 && StagedBytes(sc, true) > kLdsGeometryBytes && PoolBigSupports(sc))
     {
+        if ((f & ~kSurface) != 0)
+        {
+            *variant = slivers ? "all+slivers+pool-walk" : "all+pool-walk";
+            return slivers ? Launch<kAll | kPB | kS, false>(sc, job, out, nullptr, stream, n_cus) : Launch<kAll | kPB, false>(sc, job, out, nullptr, stream, n_cus);
+        }
         if ((f & ~kFeatEmitters) == 0)
         {
             // diffuse surfaces only (dragon/scene.xml): the lean instantiations

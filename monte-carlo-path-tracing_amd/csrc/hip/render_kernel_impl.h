@@ -466,6 +466,10 @@ extern template hipError_t Launch<kSurface | kPB | kS, false, false>(MCPT_LAUNCH
 extern template hipError_t Launch<kFeatEmitters | kPB, false, false>(MCPT_LAUNCH_ARGS);
 extern template hipError_t Launch<kFeatEmitters | kPB | kS, false, false>(MCPT_LAUNCH_ARGS);
 #endif
+#if !defined(MCPT_UNIT_POOL_4)
+extern template hipError_t Launch<kAll | kPB, false, false>(MCPT_LAUNCH_ARGS);
+extern template hipError_t Launch<kAll | kPB | kS, false, false>(MCPT_LAUNCH_ARGS);
+#endif
 #if !defined(MCPT_UNIT_POOL_3)
 extern template hipError_t Launch<kSurface | kPB | kFeatConductorOnly, false, false>(MCPT_LAUNCH_ARGS);
 extern template hipError_t Launch<kSurface | kPB | kFeatDielectricOnly, false, false>(MCPT_LAUNCH_ARGS);
