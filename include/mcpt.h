@@ -251,10 +251,10 @@ int mcpt_renderer_set_tile_order(mcpt_renderer *r, int mode);
 
 /* Class sort of the lane-owns-a-path kernel (csrc/hip/sorted_kernel.hip); the image does not depend on it.  Scenes whose
  * traversal data sits in LDS and that need more than the diffuse model (a participating medium, quadrics, microfacet
- * BSDFs): between the closest-hit query and the shading, the paths of a 256-lane workgroup are counting-sorted by what
- * their ray found (came from a medium vertex or not x {miss, surface without BSDF, diffuse-like, specular / microfacet,
- * light}) and their state moves through LDS to its place in that order, so that a wavefront shades one or two kinds of
- * vertex instead of all of them.  The reference runs whatever each thread's path hit, diverged: the per-hit `switch` of
+ * BSDFs): between resolve / roulette and connect / scatter, the paths of a 128-lane workgroup are counting-sorted by the
+ * class of their vertex (10 classes: medium scattering event, surface without BSDF, the six BSDF kinds, finished sample,
+ * exhausted lane) and their state (36 words) moves through LDS to its place in that order, so that a wavefront shades one
+ * or two kinds of vertex instead of all of them.  The reference runs whatever each thread's path hit, diverged: the per-hit `switch` of
  * src/renderer/bsdfs/bsdf.cpp:188-211 inside the megakernel src/renderer/renderer.cpp:88-95.
  * mode -1 (default): on for those scenes; 0: off (the unsorted kernel); 1: same as -1. */
 int mcpt_renderer_set_class_sort(mcpt_renderer *r, int mode);

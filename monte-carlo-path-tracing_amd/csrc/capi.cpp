@@ -351,9 +351,14 @@ struct Rccl
 // of wide_stack entries per lane of a launch, up to kWalkSpillLanes lanes (launchers cap their grids at that).  Touched
 // only when a walk holds more than kWideRing postponed children.
 constexpr uint32_t kWalkSpillLanes = 1u << 21;
-void EnsureWalkSpill(mcpt_renderer *r)
+// (the backing store of the short traversal stacks, hundreds of MB for a mesh: only the experimental wide-walk builds
+//  — -DMCPT_WIDE_WALK=1 / -DMCPT_STREAM_WIDE=1 — and mcpt_debug_trace_rate read it; `force`: the caller is one of them)
+void EnsureWalkSpill(mcpt_renderer *r, bool force = false)
 {
-    if (r->walk_spill_dev || r->flat.integrator.n_wide_nodes == 0)
+#if (defined(MCPT_WIDE_WALK) && MCPT_WIDE_WALK) || (defined(MCPT_STREAM_WIDE) && MCPT_STREAM_WIDE)
+    force = true;
+#endif
+    if (!force || r->walk_spill_dev || r->flat.integrator.n_wide_nodes == 0)
         return;
     const size_t words = size_t(std::max(r->flat.integrator.wide_stack, 2u)) * kWalkSpillLanes;
     Check(hipMalloc(reinterpret_cast<void **>(&r->walk_spill_dev), words * sizeof(uint32_t)), "allocate traversal-stack backing store");
@@ -2091,7 +2096,7 @@ int mcpt_debug_trace_rate(mcpt_renderer *r, uint32_t n, const float *rays, int m
     try
     {
         Check(hipSetDevice(r->device), "select device");
-        EnsureWalkSpill(r);
+        EnsureWalkSpill(r, true);
         if (n > kWalkSpillLanes && mode == 3)
             throw std::runtime_error("mcpt_debug_trace_rate: at most 2^21 rays in mode 3");
         Check(hipMalloc(reinterpret_cast<void **>(&d_rays), size_t(n) * 24), "allocate");

@@ -94,7 +94,7 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     uint32_t *stack = C::kPool ? lds_words + (threadIdx.x >> 6) * pool_wave_words(C::kAnalytic, false) : lds_words + threadIdx.x;
     if (!C::kPool)
         lds_words += static_cast<size_t>(sc_in.integrator.walk_depth) * 256u;
-    uint32_t *exchange = lds_words;                                  // kSortPassWords x 256 words, word-major
+    uint32_t *exchange = lds_words;                                  // kSortPassWords x kSortLanes words, word-major
     uint32_t *counts = C::kPool ? lds_words + kWaves * pool_wave_words(C::kAnalytic, false) : exchange + kSortPassWords * kBlockSize; // [parity][wavefront][class]
     __syncthreads(); // geometry staged
 
