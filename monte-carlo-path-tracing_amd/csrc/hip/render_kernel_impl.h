@@ -132,7 +132,9 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     PathState st{}; // (every field defined: a lane that has not started a pixel yet can be moved by a compaction)
     st.alive = false;
     // (pool walk: the wavefront's pool area instead of the lane's stack column)
-    st.stack = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + (threadIdx.x >> 6) * pool_wave_words(C::kAnalytic, C::kPoolBig)
+    // (the wavefront's number as a scalar: every address inside its pool area is then a scalar base + a lane offset)
+    st.stack = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged) +
+                              static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6))) * pool_wave_words(C::kAnalytic, C::kPoolBig)
                         : reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + threadIdx.x;
     bool has_pixel = false;
     uint32_t slot = 0; // where this pixel's result goes

@@ -168,19 +168,37 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
                     if (kCount)
                         ++stats.prim_tests;
                     const uint32_t item = prim_items[n_prims - 1u - rank], r = item >> kRefBits, slot = item & kRefMask;
-                    const float4 a = rays[kRayVecs * r], b = rays[kRayVecs * r + 1], c = rays[kRayVecs * r + 2];
-                    Ray q;
-                    q.origin = V3{a.x, a.y, a.z}, q.dir_rcp = V3{b.x, b.y, b.z}, q.shear = V3{c.x, c.y, c.z}, q.t_max = a.w;
-                    const uint32_t axes = __float_as_uint(c.w);
-                    q.kx = static_cast<int>(axes & 3u), q.ky = static_cast<int>((axes >> 2) & 3u), q.kz = static_cast<int>((axes >> 4) & 3u);
-                    q.dir = V3{0.0f, 0.0f, 0.0f};
-                    if (kAnalytic)
-                    {
-                        const float4 d = rays[kRayVecs * r + 3];
-                        q.dir = V3{d.x, d.y, d.z};
-                    }
                     const float4 *p = sc.walk_prims + 3 * static_cast<size_t>(slot);
-                    const SlotHit h = probe_slot<kAnalytic>(sc, p, q);
+                    float4 a;   // origin + bound
+                    Ray q;      // (the whole ray: quadrics and the sliver rules need it)
+                    SlotHit h;
+                    if constexpr (!kAnalytic && !kSlivers)
+                    {
+                        // triangles only: the vertices' and the origin's components are READ in the ray's axis order (word kx, ky, kz of
+                        // each record) instead of being selected from whole records — 18 selects per test become addresses
+                        const float4 c = rays[kRayVecs * r + 2];
+                        const uint32_t axes = __float_as_uint(c.w), kx = axes & 3u, ky = (axes >> 2) & 3u, kz = (axes >> 4) & 3u;
+                        const float *ro = reinterpret_cast<const float *>(&rays[kRayVecs * r]), *pf = reinterpret_cast<const float *>(p);
+                        const float ox = ro[kx], oy = ro[ky], oz = ro[kz];
+                        a.x = a.y = a.z = 0.0f, a.w = ro[3];
+                        h = triangle_probe_permuted(pf[kx] - ox, pf[ky] - oy, pf[kz] - oz, pf[4 + kx] - ox, pf[4 + ky] - oy, pf[4 + kz] - oz, pf[8 + kx] - ox,
+                                                    pf[8 + ky] - oy, pf[8 + kz] - oz, V3{c.x, c.y, c.z});
+                    }
+                    else
+                    {
+                        a = rays[kRayVecs * r];
+                        const float4 b = rays[kRayVecs * r + 1], c = rays[kRayVecs * r + 2];
+                        q.origin = V3{a.x, a.y, a.z}, q.dir_rcp = V3{b.x, b.y, b.z}, q.shear = V3{c.x, c.y, c.z}, q.t_max = a.w;
+                        const uint32_t axes = __float_as_uint(c.w);
+                        q.kx = static_cast<int>(axes & 3u), q.ky = static_cast<int>((axes >> 2) & 3u), q.kz = static_cast<int>((axes >> 4) & 3u);
+                        q.dir = V3{0.0f, 0.0f, 0.0f};
+                        if (kAnalytic)
+                        {
+                            const float4 d = rays[kRayVecs * r + 3];
+                            q.dir = V3{d.x, d.y, d.z};
+                        }
+                        h = probe_slot<kAnalytic>(sc, p, q);
+                    }
                     float *bound = reinterpret_cast<float *>(&rays[kRayVecs * r]) + 3;
                     // (a sliver reached through its grown box: would the reference's own leaf box let the ray in?)
                     const bool sliver = kSlivers && (as_uint(p[2].w) & kWalkSliver) != 0;

@@ -415,13 +415,12 @@ struct SlotHit
     bool inside;
 };
 
-MCPT_HD SlotHit triangle_probe(const float4 *p, const Ray &ray)
+// (the test on the vertices' offsets from the origin, ALREADY in the ray's axis order: component kx, ky, kz of each)
+MCPT_HD SlotHit triangle_probe_permuted(float Akx, float Aky, float Akz, float Bkx, float Bky, float Bkz, float Ckx, float Cky, float Ckz, V3 shear)
 {
-    const V3 A = xyz(p[0]) - ray.origin, B = xyz(p[1]) - ray.origin, C = xyz(p[2]) - ray.origin;
-    const float Akz = comp(A, ray.kz), Bkz = comp(B, ray.kz), Ckz = comp(C, ray.kz);
-    const float Ax = comp(A, ray.kx) - ray.shear.x * Akz, Ay = comp(A, ray.ky) - ray.shear.y * Akz;
-    const float Bx = comp(B, ray.kx) - ray.shear.x * Bkz, By = comp(B, ray.ky) - ray.shear.y * Bkz;
-    const float Cx = comp(C, ray.kx) - ray.shear.x * Ckz, Cy = comp(C, ray.ky) - ray.shear.y * Ckz;
+    const float Ax = Akx - shear.x * Akz, Ay = Aky - shear.y * Akz;
+    const float Bx = Bkx - shear.x * Bkz, By = Bky - shear.y * Bkz;
+    const float Cx = Ckx - shear.x * Ckz, Cy = Cky - shear.y * Ckz;
     float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
     if (U == 0.0f || V == 0.0f || W == 0.0f)
     {
@@ -431,13 +430,20 @@ MCPT_HD SlotHit triangle_probe(const float4 *p, const Ray &ray)
     }
     const bool mixed_signs = (U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f);
     const float det = U + V + W;
-    const float T = U * (ray.shear.z * Akz) + V * (ray.shear.z * Bkz) + W * (ray.shear.z * Ckz);
+    const float T = U * (shear.z * Akz) + V * (shear.z * Bkz) + W * (shear.z * Ckz);
     const float det_inv = 1.0f / det;
     SlotHit h;
     h.t = T * det_inv;
     h.hit = !mixed_signs && det != 0.0f && !(h.t < kEpsDistance);
     h.a = U * det_inv, h.b = V * det_inv, h.c = W * det_inv, h.inside = det_inv < 0;
     return h;
+}
+
+MCPT_HD SlotHit triangle_probe(const float4 *p, const Ray &ray)
+{
+    const V3 A = xyz(p[0]) - ray.origin, B = xyz(p[1]) - ray.origin, C = xyz(p[2]) - ray.origin;
+    return triangle_probe_permuted(comp(A, ray.kx), comp(A, ray.ky), comp(A, ray.kz), comp(B, ray.kx), comp(B, ray.ky), comp(B, ray.kz), comp(C, ray.kx),
+                                   comp(C, ray.ky), comp(C, ray.kz), ray.shear);
 }
 
 // Would the reference's walk reach primitive `prim` of `inst` with the bound `t_max`?

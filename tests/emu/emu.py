@@ -139,6 +139,18 @@ class Emulator:
                                                         "commit_ms": {"geometry+lbvh": int(counts[4]), "walk_tree": int(counts[5]),
                                                                       "total": int(counts[6])}}
 
+    def pool_nodes(self, mcsd_path, capacity=1 << 21):
+        """The 4-wide exact hierarchy of the pool walk: (planes[n, 6, 4] float32 = lo.xyz / hi.xyz of the four children,
+        refs[n, 4] uint32, depth)."""
+        self.lib.mcpt_emu_pool_nodes.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+        nodes = np.zeros((capacity, 8, 4), dtype=np.float32)
+        counts = np.zeros(2, dtype=np.uint32)
+        rc = self.lib.mcpt_emu_pool_nodes(str(mcsd_path).encode(), nodes.ctypes.data, capacity, counts.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(self.lib.mcpt_emu_last_error().decode() if rc == -1 else "capacity too small")
+        nodes = nodes[:counts[0]]
+        return nodes[:, :6, :].copy(), nodes[:, 6, :].copy().view(np.uint32), int(counts[1])
+
     def nodes(self, mcsd_path, capacity=1 << 22):
         links = np.zeros((capacity, 2), dtype=np.uint32)
         geom = np.zeros((capacity, 7), dtype=np.float32)

@@ -1330,6 +1330,25 @@ int mcpt_emu_walk(const char *mcsd_path, float *nodes, float *prims, uint32_t no
     }
 }
 
+// The 4-wide exact form of the ordered-walk hierarchy (DeviceScene::pool_nodes): 32 words per node.  counts: nodes, depth.
+int mcpt_emu_pool_nodes(const char *mcsd_path, float *nodes, uint32_t node_capacity, uint32_t *counts)
+{
+    try
+    {
+        const FlatScene flat = CommitScene(mcsd::Load(mcsd_path));
+        counts[0] = flat.integrator.n_pool_nodes, counts[1] = flat.integrator.pool_depth;
+        if (flat.integrator.n_pool_nodes > node_capacity)
+            return -2;
+        std::memcpy(nodes, flat.pool_nodes.data(), size_t(flat.integrator.n_pool_nodes) * 128);
+        return 0;
+    }
+    catch (const std::exception &e)
+    {
+        g_error = e.what();
+        return -1;
+    }
+}
+
 // Committed tables of the product's host commit, for comparison with the
 // oracle's: nodes as (skip, object) u32 pairs + 6 box floats + area.
 int mcpt_emu_nodes(const char *mcsd_path, uint32_t *links, float *geom, uint32_t capacity)

@@ -529,3 +529,56 @@ def test_slivers_are_decided_like_the_reference(pkg, emulator, tmp_path):
     c_prim, c_t = emulator.closest(path, rays, ordered=2)
     bad = (c_prim != b_prim) | (c_t != b_t)
     assert not bad.any(), (int(bad.sum()), rays[bad][:3], c_prim[bad][:3], b_prim[bad][:3])
+
+
+@pytest.mark.parametrize("which", ["cornell", "terrain", "preview-sphere"])
+def test_pool_hierarchy_is_the_binary_one_collapsed(pkg, emulator, tmp_path, which):
+    """DeviceScene::pool_nodes (commit.cpp, BuildPoolNodes: the hierarchy of the wavefront-cooperative pool walk): four children per
+    node, each child's box bit-identical to a child box of the binary ordered-walk hierarchy whose subtree it stands for, every
+    primitive slot referenced exactly once, unused children with a box no ray enters, depth about half the binary one."""
+    S = pkg.scenes
+    scene = {"cornell": lambda: S.cornell_box(8, 8, 1), "terrain": lambda: S.terrain_scene(24, 8, 8, 1),
+             "preview-sphere": lambda: S.material_preview("diffuse", "area", "sphere", 8, 8, 1)}[which]()
+    path = tmp_path / "scene.mcsd"
+    pkg.mcsd.dump(scene, path)
+    bnodes, prims, info = emulator.walk(path)
+    planes, refs, depth = emulator.pool_nodes(path)
+    LEAF = np.uint32(0x80000000)
+    brefs = bnodes[:, :2, 3].copy().view(np.uint32)          # child references of the binary nodes
+    bbox = np.stack([bnodes[:, 0, :3], bnodes[:, 1, :3], bnodes[:, 2, :3], bnodes[:, 3, :3]], 1)   # lo0 hi0 lo1 hi1
+
+    def binary_boxes_under(node):
+        """(reference -> (lo, hi)) of every node / leaf below binary node `node`, itself excluded"""
+        out, todo = {}, [node]
+        while todo:
+            n = todo.pop()
+            for c in range(2):
+                lo, hi = bbox[n, 2 * c], bbox[n, 2 * c + 1]
+                if lo[0] > hi[0]:
+                    continue
+                ref = int(brefs[n, c])
+                out[ref] = (lo, hi)
+                if not ref & int(LEAF):
+                    todo.append(ref)
+        return out
+
+    below_root = binary_boxes_under(0)
+    seen_slots, n_children = [], 0
+    for k in range(len(planes)):
+        for c in range(4):
+            lo, hi, ref = planes[k, :3, c], planes[k, 3:, c], int(refs[k, c])
+            if lo[0] > hi[0]:
+                assert (lo == np.float32(3.402823466e+38)).all() and (hi == -np.float32(3.402823466e+38)).all() and ref == int(LEAF)
+                continue
+            n_children += 1
+            if ref & int(LEAF):
+                seen_slots.append(ref & 0x7FFFFFFF)
+                want = below_root[ref]
+                assert np.array_equal(lo, want[0]) and np.array_equal(hi, want[1])
+            else:
+                assert 0 < ref < len(planes)
+                # an inner child's box is a box of the binary hierarchy too
+                assert any(np.array_equal(lo, b[0]) and np.array_equal(hi, b[1]) for r, b in below_root.items() if not r & int(LEAF))
+    assert sorted(seen_slots) == list(range(len(prims)))
+    assert 1 <= depth <= info["depth"] and (len(prims) < 8 or 2 * depth <= info["depth"] + 3)
+    assert len(planes) <= len(bnodes)
