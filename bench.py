@@ -342,6 +342,8 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
         count_choice = choice if choice[0] != 5 else (1, 1, choice[2])   # (the queued renderer has no counting build: its rays are the stream kernel's)
         rc.set_kernel(count_choice[0]).set_work_distribution(count_choice[1]).set_prepass(count_choice[2])
         _, counts = rc.draw(counted=True)
+        counting_kernel = rc.last_kernel()
+        boxes_per_node_step = 4.0 if "pool-walk" in counting_kernel else 2.0   # a node item of the pool walk tests four children
         scene_info = rc.info()
         rc.close()
         rank_samples = samples if world == 1 else len(pkg.tiling.rank_tiles(0, world, W, H)) * 64 * SPP
@@ -360,7 +362,8 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
         out["grays_per_s"] = rays / counts["samples"] * samples * args.steps / elapsed / 1e9
         out["rays_per_sample"] = rays / counts["samples"]
         walk = {"rays_per_s": rays / counts["samples"] * rank_samples / (kernel_ms * 1e-3),
-                "node_phase_lane_util": (counts["node_tests"] / 2) / (64.0 * max(counts["wave_node_steps"], 1)),
+                "node_phase_lane_util": (counts["node_tests"] / boxes_per_node_step) / (64.0 * max(counts["wave_node_steps"], 1)),
+                "counting_kernel": counting_kernel,
                 "prim_phase_lane_util": counts["prim_tests"] / (64.0 * max(counts["wave_prim_steps"], 1))}
         hbm = {"algorithmic_gbs": algorithmic_gbs, "bytes_per_sample": b_per_sample,
                "stream_peak_gbs": hbm_peak, "stream_copy_gbs": bw["copy_gbs"], "stream_read_gbs": bw["read_gbs"],

@@ -222,6 +222,12 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     return job.pool_walk ? Launch<kP, false, true>(sc, job, out, nullptr, stream, n_cus) : Launch<kO, false, true>(sc, job, out, nullptr, stream, n_cus);
 #endif
     const bool slivers = sc.integrator.walk_sliver_reach > 0.0f;
+    if (counters != nullptr && ordered && job.pool_walk >= 1 && PoolBigSupports(sc))
+    {
+        // the counting mode of the production ray query: per-item counts of the pool walk (4 box tests per node item)
+        *variant = "all+count+pool-walk";
+        return Launch<kAll | kPB | kS, true, false>(sc, job, out, counters, stream, n_cus);
+    }
     if (counters != nullptr)
     {
         *variant = ordered ? "all+count" : "all+count, reference walk";

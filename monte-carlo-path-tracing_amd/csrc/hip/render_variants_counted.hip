@@ -7,5 +7,7 @@ namespace mcpt
 
 template hipError_t Launch<kAll, true, false>(MCPT_LAUNCH_ARGS);
 template hipError_t Launch<kAll | kV | kS, true, false>(MCPT_LAUNCH_ARGS);
+// ... and the counting mode of the pool-walk kernels (any scene class: the hierarchy through the caches, 32-bit items)
+template hipError_t Launch<kAll | kPB | kS, true, false>(MCPT_LAUNCH_ARGS);
 
 } // namespace mcpt

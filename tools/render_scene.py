@@ -58,9 +58,9 @@ def main():
         _, c = r.draw(counted=True)
         rays = c["closest_rays"] + c["shadow_rays"]
         out["counted"] = {
-            "rays_per_sample": rays / c["samples"], "node_visits_per_ray": c["node_tests"] / 2 / rays,
+            "rays_per_sample": rays / c["samples"], "node_visits_per_ray": c["node_tests"] / (4 if "pool-walk" in r.last_kernel() else 2) / rays,
             "prim_tests_per_ray": c["prim_tests"] / rays,
-            "node_phase_lane_utilisation": (c["node_tests"] / 2) / (64.0 * max(c["wave_node_steps"], 1)),
+            "node_phase_lane_utilisation": (c["node_tests"] / (4 if "pool-walk" in r.last_kernel() else 2)) / (64.0 * max(c["wave_node_steps"], 1)),
             "prim_phase_lane_utilisation": c["prim_tests"] / (64.0 * max(c["wave_prim_steps"], 1)),
         }
     print(json.dumps(out))
