@@ -1,4 +1,5 @@
-// The wavefront-cooperative ray query of LDS-resident scenes (round 4).
+// The wavefront-cooperative ray query (round 4): scenes in LDS (16-bit items) and outside (kFeatPoolBig: 32-bit items, the
+// hierarchy through the caches).
 //
 // What it cures.  walk_ordered (traversal.h) gives a ray to a lane: a wavefront's query lasts as long as its slowest
 // lane's walk (cornell: a ray needs ~10 node visits, the wavefront runs ~34 node steps and ~10 primitive phases per round:
@@ -29,11 +30,12 @@
 //     (the same values test_slot would have copied: hit_from_record's argument).
 //   * a ray that accepts more candidates than its list holds (kPoolCands; seen: up to 5 on cornell, 0.17 % of the rays
 //     beyond 4) is walked again by its owner alone, the per-lane way (walk_ordered on a private stack).
-// Not for scenes with slivers (kFeatSlivers: their reachability rules are test_slot's) or opacity masks.
+// Sliver triangles: kSlivers below.  Not for scenes with opacity masks (their test draws random numbers DURING a walk, so
+// the visiting order is part of the image: the reference-order walk, traversal.h).
 //
 // LDS per wavefront (kPoolWaveWords): 64 ray records of 12 words (16 with quadrics: the direction) — origin + bound |
 // reciprocal direction + byte offsets of the near planes | shear + axis permutation —, 64 candidate counters, 64 x
-// kPoolCands (distance, slot) pairs, 448 + 320 item slots of 16 bits (ray << 10 | node or slot).  The item counts
+// kPoolCands (distance, slot) pairs, 448 + 320 item slots of 16 bits (ray << 10 | node or slot; 32 bits, ray << 26, outside LDS).  The item counts
 // live in scalar registers: the lists belong to ONE wavefront, no atomics on them.
 #ifndef MCPT_POOL_WALK_H
 #define MCPT_POOL_WALK_H
