@@ -1174,6 +1174,24 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             job.tile_order = r->tile_keys_dev + r->tile_keys_capacity;
             job.scatter = 0;
         }
+        // LANES PER PATH of the pool-walk kernels outside LDS (RenderJob::lane_spread left open).  A lane without a path helps its
+        // wavefront's ray queries, so fewer paths per wavefront mean shorter rounds — which pays when the job is a few long chains
+        // rather than a throughput problem: when the EXPENSIVE pixels (camera ray hits something: the pre-pass's count, read in the
+        // first draw of the tile range) are few against the lanes.  Rule (the stream kernel's, §3b): the largest power of two with
+        // spread <= 3 x lanes / expensive pixels, at most 8.  Measured (profiles/r04_experiments/pool_walk_mesh_rank_shares.json),
+        // ms at spread 1 / 2 / 4 / 8: dragon/scene.xml whole frame 238 / 200 / 206 / -, its 1/2 share 213 / 140 / 124 / 165, 1/4 share
+        // 180 / 123 / 98 / 99, 1/8 share 135 / 90 / 76 / 70; matpreview rough conductor (spp 128) whole frame 154 / 207 / 338 / -, 1/4
+        // share 128 / 89 / 90 / 145, 1/8 share 112 / 84 / 68 / 77 (its 1/2 share, 137 / 109 / 172, is the one point the rule misses).
+        if (job.lane_spread == 0 && prepass && !small_scene && job.pool_walk != 0 && r->rng_mode == 0 && counters == nullptr && mcpt::PoolBigSupports(r->dev) &&
+            r->cost_order_tiles == n_tiles && r->cost_order_first == range.tile_first && r->cost_order_stride == range.tile_stride)
+        {
+            const unsigned long long expensive = std::max<unsigned long long>(1, r->range_hits / std::max(1u, r->dev.camera.spp));
+            const unsigned long long lanes = static_cast<unsigned long long>(r->n_cus) * 4u * 3u * 64u; // (3 wavefronts per SIMD: Budget, render_kernel_impl.h)
+            uint32_t spread = 1;
+            while (spread < 8u && expensive * (spread * 2u) <= 3u * lanes)
+                spread *= 2u;
+            job.lane_spread = spread;
+        }
         hipError_t sorted = hipErrorNotSupported;
         if (job.sort_classes && counters == nullptr)
             sorted = mcpt::LaunchRenderSorted(r->dev, job, render_target, stream, r->n_cus, &variant);
@@ -1201,6 +1219,8 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         else if (plan.lane_spread > 1)
             r->variant += ", 1 path per " + std::to_string(plan.lane_spread) + " lanes";
     }
+    if (!streamed && !wavefront && !queued && job.lane_spread > 1)
+        r->variant += ", 1 path per " + std::to_string(job.lane_spread) + " lanes";
     if (r->dev.prehit)
         r->variant += " + camera-ray pre-pass";
     if (dynamic_work)
