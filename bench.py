@@ -207,8 +207,8 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
     def make_renderer(spp):
         r = pkg.capi.Renderer(pkg.workloads.config(name, W, H, spp), device=local_rank)
         r.set_kernel(kernel_mode)
-        if args.rng == "pcg":
-            r.set_rng(1, seed=1, sample_split=args.sample_split)
+        if args.rng != "reference":
+            r.set_rng({"pcg": 1, "sobol": 2}[args.rng], seed=1, sample_split=args.sample_split)
         return r
 
     renderer = make_renderer(SPP)
@@ -322,7 +322,8 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
                        "step": ("blocking mcpt_renderer_draw into a pinned host frame (device-to-host copy included)" if not use_gather else
                                 "per rank: asynchronous draw of its tiles + ONE gather; rank 0: scatter + device-to-host copy of the frame"),
                        "rng": ("reference stream (Tea + LCG per pixel)" if args.rng == "reference" else
-                               "THROUGHPUT MODE, not per-pixel comparable: independent PCG-hashed stream per (pixel, sample)"),
+                               "THROUGHPUT MODE, not per-pixel comparable: independent PCG-hashed stream per (pixel, sample)" if args.rng == "pcg" else
+                               "THROUGHPUT MODE, not per-pixel comparable: Owen-scrambled Sobol points per (pixel, sample)"),
                        "kernel": kernel_name,
                        "partition": f"8x8 tiles round-robin over {world} GPU(s)"
                                     + (", one RCCL gather to rank 0" if world > 1 else ""),
@@ -341,6 +342,8 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
         rc = make_renderer(count_spp)
         count_choice = choice if choice[0] != 5 else (1, 1, choice[2])   # (the queued renderer has no counting build: its rays are the stream kernel's)
         rc.set_kernel(count_choice[0]).set_work_distribution(count_choice[1]).set_prepass(count_choice[2])
+        if args.rng == "sobol":   # (no counting build draws Sobol points: the rays per sample are counted on PCG-hashed streams)
+            rc.set_rng(1, seed=1, sample_split=args.sample_split)
         _, counts = rc.draw(counted=True)
         counting_kernel = rc.last_kernel()
         boxes_per_node_step = 4.0 if "pool-walk" in counting_kernel else 2.0   # a node item of the pool walk tests four children
@@ -457,8 +460,8 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
                 out["cpu_baseline_port"] = recs["port"]
             rg = pkg.capi.Renderer(pkg.workloads.config(name, cw, ch, cspp), device=local_rank)
             rg.set_kernel(kernel_mode)
-            if args.rng == "pcg":
-                rg.set_rng(1, seed=1, sample_split=args.sample_split)
+            if args.rng != "reference":
+                rg.set_rng({"pcg": 1, "sobol": 2}[args.rng], seed=1, sample_split=args.sample_split)
             gpu_frame, _ = rg.draw()
             rg.close()
             d = gpu_frame.astype(np.float64) - cpu_frame.astype(np.float64)
@@ -554,10 +557,11 @@ def main():
                          "cutting the workload's own film over the GPUs")
     ap.add_argument("--kernel", choices=["auto", "stream", "lanes", "queued"], default="auto",
                     help="kernel formulation (default: the library's choice by scene class / first-draw calibration)")
-    ap.add_argument("--rng", choices=["reference", "pcg"], default="reference",
+    ap.add_argument("--rng", choices=["reference", "pcg", "sobol"], default="reference",
                     help="reference: the reference's per-pixel random stream (the graded mode, frames comparable per "
                          "pixel).  pcg: throughput mode — an independent PCG-hashed stream per (pixel, sample), the "
-                         "samples of a pixel spread over lanes; compared with the CPU image by RMSE only")
+                         "samples of a pixel spread over lanes; compared with the CPU image by RMSE only.  sobol: the same with "
+                         "Owen-scrambled Sobol points (mcpt_renderer_set_rng mode 2)")
     ap.add_argument("--sample-split", type=int, default=0, help="--rng pcg: lanes per pixel (0 = auto)")
     ap.add_argument("--no-throughput-mode", action="store_true",
                     help="skip the second timed loop (same steps, same barriers) in the independent-sample RNG mode that the "

@@ -292,7 +292,7 @@ int mcpt_renderer_set_stream_waves(mcpt_renderer *r, int waves);
  * Scene::Intersect of ShadePath (src/renderer/integrators/path.cpp:18-21). */
 int mcpt_renderer_set_prepass(mcpt_renderer *r, int mode);
 
-/* Which random streams later draws use.  No reference counterpart for mode 1.
+/* Which random streams later draws use.  No reference counterpart for modes 1 and 2.
  *   mode 0 (default): the reference's — Tea-seeded LCG per pixel, threaded through ALL samples of the pixel
  *          (reference src/renderer/renderer.cpp:62-81, include/csrt/utils/math.hpp:43-63).  Frames are the CPU
  *          reference's bit for bit; the samples of a pixel are inherently sequential, so a pixel is one lane's work.
@@ -305,7 +305,17 @@ int mcpt_renderer_set_prepass(mcpt_renderer *r, int mode);
  *          lane), and short items handed out by the work counter balance what whole-pixel chains cannot (whole
  *          frames on one GPU: cornell-box 64 -> 45 ms, dragon/scene.xml 200 -> 92 ms).  Graded by mean-square error
  *          against a converged image, not per pixel.  Both kernel formulations, with the camera-ray pre-pass; whole
- *          frames or packed tile ranges. */
+ *          frames or packed tile ranges.
+ *   mode 2: mode 1 with LOW-DISCREPANCY points: draw d of sample s of a pixel is an Owen-scrambled Sobol point — draws come
+ *          in pairs (2k, 2k + 1), every pair is the first two Sobol dimensions (a (0,2)-sequence) over an Owen-shuffled
+ *          sample index, each dimension scrambled with its own hash of (seed, pixel, k) ("padded" sequences; hash-based
+ *          nested uniform scrambling), so every pair of consecutive draws of a pixel — a point on a light, a scattered
+ *          direction — is stratified over any power-of-two run of its samples (csrc/vecmath.h ld_next).  Same pixel
+ *          jitter (the reference's own radical inverse, include/csrt/utils/math.hpp:29-41), same estimator; cornell-box:
+ *          RMSE 0.72-0.84 x mode 1's at 16-256 spp, falling like N^-0.55 instead of N^-0.5.  At most 8192 samples per
+ *          pixel; runs in the lane-owns-a-path kernel (csrc/hip/render_variants_lowdisc.hip, full feature set), with
+ *          `sample_split` like mode 1; no counting mode.  Pinned bit for bit against the same kernel body compiled for
+ *          the host (tests/emu). */
 int mcpt_renderer_set_rng(mcpt_renderer *r, int mode, uint32_t seed, uint32_t sample_split);
 
 /* Which pixels the 64 lanes of a wavefront of the lane-owns-a-path kernel render.  0: one 8x8 tile (neighbouring camera

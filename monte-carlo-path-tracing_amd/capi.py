@@ -358,7 +358,8 @@ class Renderer:
 
     def set_rng(self, mode: int, seed: int = 0, sample_split: int = 0):
         """0: the reference's random stream (default; frames comparable per pixel).  1: throughput mode — an
-        independent PCG-hashed stream per (pixel, sample), samples of a pixel spread over `sample_split` lanes."""
+        independent PCG-hashed stream per (pixel, sample), samples of a pixel spread over `sample_split` lanes.  2: the same with
+        Owen-scrambled Sobol points instead of pseudo-random numbers (at most 8192 spp; smaller error at equal spp)."""
         _check(lib().mcpt_renderer_set_rng(self._h, mode, seed, sample_split))
         return self
 

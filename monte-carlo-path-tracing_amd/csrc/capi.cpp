@@ -805,7 +805,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             const char *e = std::getenv("MCPT_SORT"); // (measurements: 0 = render_kernel instead of the class-sorted kernel)
             return e ? std::atoi(e) : 1;
         }();
-        job.sort_classes = sort_classes != 0 && r->class_sort_mode != 0 ? 1u : 0u;
+        job.sort_classes = sort_classes != 0 && r->class_sort_mode != 0 && r->rng_mode != 2 ? 1u : 0u;
         static const int pool_walk = []
         {
             const char *e = std::getenv("MCPT_POOL_WALK"); // (measurements: the library's choice when mcpt_renderer_set_pool_walk left it open)
@@ -822,14 +822,18 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     if ((r->kernel_mode == -1 || r->work_mode == -1) && r->auto_choice < 0 && !counted)
     {
         r->auto_choice = r->work_mode == 0 ? 0 : 1; // lanes kernel, fixed lists / work counter
-        if (!small_scene && r->kernel_mode == -1 && job.n_items != 0)
+        if (!small_scene && r->kernel_mode == -1 && job.n_items != 0 && r->rng_mode != 2)
             ResolveAutoChoice(r, stream, mcpt::StreamSupports(r->dev, job), true);
     }
     float *render_target = out_device;
     const uint32_t out_pixels = packed ? job.n_items : static_cast<uint32_t>(r->flat.camera.width) * r->flat.camera.height;
-    if (r->rng_mode == 1 && job.n_items != 0)
+    if (r->rng_mode == 2 && counted)
+        throw std::runtime_error("the counting kernels draw from the reference's generator or the PCG-hashed streams, not Sobol points (mcpt_renderer_set_rng mode 2)");
+    if (r->rng_mode == 2 && r->dev.camera.spp > mcpt::kLowDiscMaxSpp)
+        throw std::runtime_error("mcpt_renderer_set_rng mode 2: a Sobol point's sample index has 13 bits (at most 8192 samples per pixel)");
+    if (r->rng_mode != 0 && job.n_items != 0)
     {
-        job.independent_samples = 1, job.rng_seed = r->rng_seed;
+        job.independent_samples = static_cast<uint32_t>(r->rng_mode), job.rng_seed = r->rng_seed; // (1 = PCG-hashed streams, 2 = Sobol points)
         uint32_t split = r->sample_split;
         if (split == 0)
         {
@@ -918,7 +922,8 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             Check(hipMalloc(reinterpret_cast<void **>(&r->hit_counters_dev), mcpt::kHitCounters * sizeof(uint32_t)), "allocate hit counters");
         job.hit_counters = r->hit_counters_dev;
     }
-    const bool can_stream = job.n_items != 0 && mcpt::StreamSupports(r->dev, job) && (job.sample_split <= 1 || r->kernel_mode != 2);
+    // (Sobol points — rng mode 2 — exist in the lane-owns-a-path kernel only: hip/render_variants_lowdisc.hip)
+    const bool can_stream = job.n_items != 0 && r->rng_mode != 2 && mcpt::StreamSupports(r->dev, job) && (job.sample_split <= 1 || r->kernel_mode != 2);
     const int choice = r->auto_choice < 0 ? 1 : r->auto_choice;
     // (scenes outside LDS whose class the lane-owns-a-path kernel runs with the pool walk: that kernel is the library's choice —
     //  matpreview rough conductor 106.3 -> 90.0 ms, rough dielectric 160.0 -> 121.4 ms against the stream kernel at spp 64)
@@ -1195,7 +1200,9 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         hipError_t sorted = hipErrorNotSupported;
         if (job.sort_classes && counters == nullptr)
             sorted = mcpt::LaunchRenderSorted(r->dev, job, render_target, stream, r->n_cus, &variant);
-        if (sorted == hipErrorNotSupported)
+        if (job.independent_samples == 2u)
+            Check(mcpt::LaunchRenderLowDiscrepancy(r->dev, job, render_target, stream, r->n_cus, &variant), "launch render kernel (Sobol points)");
+        else if (sorted == hipErrorNotSupported)
             Check(mcpt::LaunchRender(r->dev, job, render_target, counters, stream, r->n_cus, &variant), "launch render kernel");
         else
             Check(sorted, "launch class-sorted render kernel");
@@ -1237,7 +1244,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                       r->auto_source == 2 ? " (stored choice)" : "", r->auto_ms[0], r->auto_ms[1], r->auto_ms[2], r->auto_ms[3]);
         r->variant += note;
     }
-    if (r->rng_mode == 1)
+    if (r->rng_mode != 0)
         r->variant += ", independent samples x" + std::to_string(job.sample_split);
     r->dev.prehit = nullptr; // (the unit kernels launched with r->dev never use it)
     if (timed)
@@ -1963,8 +1970,10 @@ int mcpt_renderer_set_rng(mcpt_renderer *r, int mode, uint32_t seed, uint32_t sa
 {
     if (!r)
         return Fail("null argument");
-    if (mode != 0 && mode != 1)
-        return Fail("mcpt_renderer_set_rng: mode is 0 (reference stream) or 1 (independent PCG-hashed stream per sample)");
+    if (mode != 0 && mode != 1 && mode != 2)
+        return Fail("mcpt_renderer_set_rng: mode is 0 (reference stream), 1 (independent PCG-hashed stream per sample) or 2 (Owen-scrambled Sobol points per sample)");
+    if (mode == 2 && r->flat.camera.spp > mcpt::kLowDiscMaxSpp)
+        return Fail("mcpt_renderer_set_rng: mode 2 renders at most 8192 samples per pixel (13-bit sample index of a Sobol point)");
     if (mode == 0 && sample_split > 1)
         return Fail("mcpt_renderer_set_rng: the reference stream is sequential over a pixel's samples and cannot be split");
     if (sample_split > 1024)

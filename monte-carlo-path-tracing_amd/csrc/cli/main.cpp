@@ -32,14 +32,15 @@ void Usage()
                  "  mcpt_cli [-g|--gpu] -i|--input <scene.xml | scene.mcsd | builtin:cornell-box>\n"
                  "           [-o|--output <result.png|.exr|.pfm|.f32>] [-w|--width N] [-h|--height N]\n"
                  "           [-s|--spp N] [-d|--device N] [--gpus N] [-c|--cpu] [--threads N]\n"
-                 "           [--save-config <file.mcsd>] [--standins <table.txt>] [--rng reference|pcg] [--seed N]\n\n"
+                 "           [--save-config <file.mcsd>] [--standins <table.txt>] [--rng reference|pcg|sobol] [--seed N]\n\n"
                  "  --standins   procedural stand-ins for mesh files the scene names but that are not on disk\n"
                  "  --gpu        render with HIP on the selected device (the default)\n"
                  "  --gpus N     cut the frame over HIP devices 0 .. N-1 (one RCCL gather to device 0)\n"
                  "  --cpu        render on host threads (needs libmcpt_host.so next to this program)\n"
                  "  --rng        reference (default): the reference's random stream, one per pixel through all its samples\n"
                  "               (include/csrt/utils/math.hpp:43-63, renderer.cpp:62-81): frames comparable per pixel;\n"
-                 "               pcg: throughput mode, an independent PCG-hashed stream per (pixel, sample) from --seed\n",
+                 "               pcg: throughput mode, an independent PCG-hashed stream per (pixel, sample) from --seed;\n"
+                 "               sobol: the same with Owen-scrambled Sobol points (at most 8192 spp)\n",
                  mcpt_version());
 }
 
@@ -104,10 +105,13 @@ int main(int argc, char **argv)
                 rng_mode = 0;
             else if (v == "pcg")
                 rng_mode = 1;
+            else if (v == "sobol")
+                rng_mode = 2;
             else
             {
-                std::fprintf(stderr, "[error] --rng: reference (the reference's per-pixel stream: frames comparable per pixel) or pcg "
-                                     "(throughput mode: an independent PCG-hashed stream per sample).\n");
+                std::fprintf(stderr, "[error] --rng: reference (the reference's per-pixel stream: frames comparable per pixel), pcg "
+                                     "(throughput mode: an independent PCG-hashed stream per sample) or sobol (throughput mode with "
+                                     "Owen-scrambled Sobol points, at most 8192 spp).\n");
                 return 2;
             }
         }
@@ -169,7 +173,7 @@ int main(int argc, char **argv)
     const auto t0 = std::chrono::steady_clock::now();
     if (rng_mode != 0 && (on_cpu || gpus > 1))
     {
-        std::fprintf(stderr, "[error] --rng pcg is a mode of the single-GPU renderer (the host path and the tiled renderer keep the reference's stream).\n");
+        std::fprintf(stderr, "[error] --rng pcg | sobol are modes of the single-GPU renderer (the host path and the tiled renderer keep the reference's stream).\n");
         return 2;
     }
     if (on_cpu)

@@ -277,7 +277,11 @@ enum SceneFeature : uint32_t
     kFeatPoolWalk = 1u << 14,
     // ... with 32-bit items (node / slot indices up to 2^26) on a hierarchy that is read through the caches: scenes outside LDS
     kFeatPoolBig = 1u << 15,
+    // names the instantiations of the LOW-DISCREPANCY build (hip/render_variants_lowdisc.hip, compiled with MCPT_LOW_DISCREPANCY:
+    // what a draw of the random stream returns is decided by that macro in vecmath.h, for the whole translation unit)
+    kFeatLowDisc = 1u << 16,
 };
+constexpr uint32_t kLowDiscMaxSpp = 8192; // (a Sobol point's sample index has 13 bits: vecmath.h ld_pack)
 
 // Device view: raw pointers into HBM + the scalar records.
 struct DeviceScene

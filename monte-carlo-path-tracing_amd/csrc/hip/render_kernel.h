@@ -116,6 +116,11 @@ hipError_t PlanRenderStream(const DeviceScene &sc, const RenderJob &job, bool co
 hipError_t LaunchRenderStream(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
                               hipStream_t stream, uint32_t *scratch, const StreamLaunch &cfg);
 
+// Throughput mode 2 (job.independent_samples == 2): the instantiations whose random draws are Owen-scrambled Sobol points
+// (hip/render_variants_lowdisc.hip).
+hipError_t LaunchRenderLowDiscrepancy(const DeviceScene &sc, const RenderJob &job, float *out, hipStream_t stream, uint32_t n_cus,
+                                      const char **variant);
+
 hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
                         hipStream_t stream, uint32_t n_cus, const char **variant);
 // The class-sorted form of the lane-owns-a-path kernel (hip/sorted_kernel.hip); hipErrorNotSupported when the scene is

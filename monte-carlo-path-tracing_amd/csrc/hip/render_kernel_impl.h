@@ -87,6 +87,9 @@ template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
 __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const RenderJob &job, float *__restrict__ out, TraceCounters *__restrict__ counters)
 {
     using C = Config<kFeatures>;
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(((kFeatures & kFeatLowDisc) != 0) == (MCPT_LOW_DISCREPANCY_ACTIVE != 0), "low-discrepancy instantiations live in their own translation unit");
+#endif
     extern __shared__ float4 lds_geometry[];
     DeviceScene sc = sc_in;
     uint32_t n_staged = 0;

@@ -144,7 +144,13 @@ MCPT_HD void start_sample(const DeviceScene &sc, PathState &st, uint32_t step = 
     st.pdf_sample = 0;
     st.medium = kNone;
     if (independent)
+    {
+#if MCPT_LOW_DISCREPANCY_ACTIVE
+        st.rng = ld_pack(s, pcg_hash(pcg_hash(seed) + st.pixel)); // (sample index, the pixel's scramble, dimension 0: vecmath.h)
+#else
         st.rng = pcg_hash(pcg_hash(pcg_hash(seed) + st.pixel) + s);
+#endif
+    }
     st.sample += step;
 }
 
@@ -860,7 +866,7 @@ __device__ __forceinline__ void path_step_uniform(const DeviceScene &sc, PathSta
 
 // Convenience for CPU-side emulation and unit tests: a whole pixel.
 template <class C>
-MCPT_HD V3 render_pixel(const DeviceScene &sc, uint32_t pixel, LaneCounters *cnt)
+MCPT_HD V3 render_pixel(const DeviceScene &sc, uint32_t pixel, LaneCounters *cnt, bool independent = false, uint32_t seed = 0)
 {
     PathState st;
     uint32_t stack[kWalkStackMax * kWalkStackStride];
@@ -870,7 +876,7 @@ MCPT_HD V3 render_pixel(const DeviceScene &sc, uint32_t pixel, LaneCounters *cnt
     {
         if (!st.alive)
         {
-            start_sample(sc, st);
+            start_sample(sc, st, 1, independent, seed);
             if (cnt)
                 ++cnt->samples;
         }

@@ -143,10 +143,88 @@ MCPT_HD uint32_t tea4(uint32_t v0, uint32_t v1)
     return v0;
 }
 
+// ---- low-discrepancy build (throughput mode 2 of mcpt_renderer_set_rng; no reference counterpart) ----------------------
+// The random stream is ONE 32-bit word handed by reference to every sampling function (the reference's shape,
+// math.hpp:43-63).  A translation unit compiled with MCPT_LOW_DISCREPANCY (hip/render_variants_lowdisc.hip; the host twin
+// tests/emu/libmcpt_emu_ld.so also defines MCPT_LOW_DISCREPANCY_HOST) gives that word another meaning — no call site changes:
+//     bits 31..19  s = index of the sample within its pixel (at most 8192 spp)
+//     bits 18..7   p = 12 bits of a PCG hash of (seed, pixel): which of 4096 scrambles the pixel uses
+//     bits  6..0   d = draws made so far in this sample (mod 128) = the dimension
+// and a draw returns an Owen-scrambled Sobol point: dimensions come in pairs (d >> 1), every pair is the first two Sobol
+// dimensions — a (0,2)-sequence in base 2 — over an Owen-shuffled sample index, each dimension Owen-scrambled with its own
+// seed ("padded" (0,2)-sequences: Kollig & Keller 2002; the hash-based nested uniform scramble is Burley 2020 / Laine &
+// Karras 2011).  Every pair of draws of a pixel is therefore stratified over ANY power-of-two run of its samples, and pairs
+// are independent of each other and (up to the 4096 scrambles) across pixels.
+#if defined(MCPT_LOW_DISCREPANCY) && (defined(__HIP_DEVICE_COMPILE__) || defined(MCPT_LOW_DISCREPANCY_HOST))
+#define MCPT_LOW_DISCREPANCY_ACTIVE 1
+#else
+#define MCPT_LOW_DISCREPANCY_ACTIVE 0
+#endif
+
+MCPT_HD uint32_t ld_reverse_bits(uint32_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(x);
+#else
+    x = (x >> 16) | (x << 16);
+    x = ((x & 0xff00ff00u) >> 8) | ((x & 0x00ff00ffu) << 8);
+    x = ((x & 0xf0f0f0f0u) >> 4) | ((x & 0x0f0f0f0fu) << 4);
+    x = ((x & 0xccccccccu) >> 2) | ((x & 0x33333333u) << 2);
+    return ((x & 0xaaaaaaaau) >> 1) | ((x & 0x55555555u) << 1);
+#endif
+}
+
+// Laine-Karras permutation: a bijection whose output bit k depends on input bits <= k only; between two bit reversals it is a
+// nested uniform (Owen) scramble in base 2.
+MCPT_HD uint32_t ld_laine_karras(uint32_t x, uint32_t seed)
+{
+    x += seed;
+    x ^= x * 0x6c50b47cu;
+    x ^= x * 0xb82f1e52u;
+    x ^= x * 0xc7afe638u;
+    x ^= x * 0x8d22f6e6u;
+    return x;
+}
+
+// Second Sobol dimension, bit-reversed: its generator matrix is Pascal's triangle mod 2 (direction numbers v_0 = 2^31,
+// v_k = v_(k-1) ^ (v_(k-1) >> 1)), i.e. bit j of the reversed point = XOR of the index bits k that contain j as a bit
+// subset — a superset-sum butterfly over GF(2).
+MCPT_HD uint32_t ld_sobol1_reversed(uint32_t index)
+{
+    index ^= (index >> 1) & 0x55555555u;
+    index ^= (index >> 2) & 0x33333333u;
+    index ^= (index >> 4) & 0x0f0f0f0fu;
+    index ^= (index >> 8) & 0x00ff00ffu;
+    index ^= (index >> 16);
+    return index;
+}
+
+MCPT_HD uint32_t ld_pack(uint32_t sample, uint32_t pixel_hash) { return (sample << 19) | ((pixel_hash >> 20) << 7); }
+
+MCPT_HD float ld_next(uint32_t &word)
+{
+    const uint32_t d = word & 0x7fu, s = word >> 19, p = (word >> 7) & 0xfffu;
+    word = (word & ~0x7fu) | ((d + 1u) & 0x7fu);
+    // (pcg_hash below; written out here because it is declared after lcg_next)
+    const uint32_t state = ((d >> 1) * 4096u + p) * 747796405u + 2891336453u;
+    const uint32_t mixed = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    const uint32_t pair_seed = (mixed >> 22u) ^ mixed;
+    // Owen-shuffled sample index: scrambling the index in base 2 permutes every aligned power-of-two block within itself
+    const uint32_t index = ld_reverse_bits(ld_laine_karras(ld_reverse_bits(s), pair_seed));
+    // the point's bits, reversed (dimension 0 = van der Corput: the reversed point IS the index), scrambled, reversed back
+    const uint32_t reversed = (d & 1u) ? ld_sobol1_reversed(index) : index;
+    const uint32_t x = ld_reverse_bits(ld_laine_karras(reversed, pair_seed * 0x9e3779b9u + 0x7f4a7c15u + (d & 1u) * 0x632be5abu));
+    return static_cast<float>(x >> 8) / static_cast<float>(0x01000000u);
+}
+
 MCPT_HD float lcg_next(uint32_t &state)
 {
+#if MCPT_LOW_DISCREPANCY_ACTIVE
+    return ld_next(state);
+#else
     state = state * 1664525u + 1013904223u;
     return static_cast<float>(state & 0x00ffffffu) / static_cast<float>(0x01000000u);
+#endif
 }
 
 // PCG output hash (O'Neill's RXS-M-XS 32-bit permutation over one LCG step): seeds of the independent-sample

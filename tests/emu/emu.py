@@ -12,10 +12,16 @@ _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
 
 
+SO_LD = os.path.join(HERE, "libmcpt_emu_ld.so")
+
+
 class Emulator:
-    def __init__(self):
+    def __init__(self, low_discrepancy=False):
+        """low_discrepancy: the same source compiled with MCPT_LOW_DISCREPANCY (a draw of the random stream returns an
+        Owen-scrambled Sobol point: csrc/vecmath.h) — the host twin of mcpt_renderer_set_rng mode 2."""
         subprocess.run(["make", "-s", "-C", HERE], check=True)
-        lib = ctypes.CDLL(SO)
+        lib = ctypes.CDLL(SO_LD if low_discrepancy else SO)
+        assert bool(lib.mcpt_emu_low_discrepancy()) == bool(low_discrepancy)
         lib.mcpt_emu_last_error.restype = ctypes.c_char_p
         lib.mcpt_emu_render.restype = ctypes.c_int
         lib.mcpt_emu_render.argtypes = [ctypes.c_char_p, _f32p, ctypes.c_int, ctypes.c_void_p,
@@ -29,6 +35,23 @@ class Emulator:
         lib.mcpt_emu_walk.restype = ctypes.c_int
         lib.mcpt_emu_walk.argtypes = [ctypes.c_char_p, _f32p, _f32p, ctypes.c_uint32, ctypes.c_uint32, _u32p]
         self.lib = lib
+
+    def set_rng(self, independent, seed=0):
+        """mcpt_emu_render with one independent stream per (pixel, sample), like mcpt_renderer_set_rng modes 1 / 2."""
+        self.lib.mcpt_emu_set_rng(int(bool(independent)), ctypes.c_uint32(seed))
+        return self
+
+    def draws(self, word, n):
+        """n successive draws of this build's generator from the state `word`."""
+        self.lib.mcpt_emu_draws.argtypes = [ctypes.c_uint32, ctypes.c_uint32, _f32p]
+        out = np.zeros(n, dtype=np.float32)
+        self.lib.mcpt_emu_draws(word, n, out)
+        return out
+
+    def ld_pack(self, sample, seed, pixel):
+        self.lib.mcpt_emu_ld_pack.restype = ctypes.c_uint32
+        self.lib.mcpt_emu_ld_pack.argtypes = [ctypes.c_uint32] * 3
+        return int(self.lib.mcpt_emu_ld_pack(sample, seed, pixel))
 
     def render(self, mcsd_path, width, height, variant=-1, counted=False):
         frame = np.zeros((height, width, 3), dtype=np.float32)

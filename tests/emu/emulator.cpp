@@ -28,6 +28,10 @@ namespace
 using namespace mcpt;
 
 thread_local std::string g_error;
+// the throughput random modes of mcpt_renderer_set_rng in RenderAll: independent stream per (pixel, sample) — PCG-hashed in
+// libmcpt_emu.so, Owen-scrambled Sobol points in libmcpt_emu_ld.so (the same source compiled with MCPT_LOW_DISCREPANCY)
+bool g_independent = false;
+uint32_t g_rng_seed = 0;
 
 template <uint32_t kFeatures>
 void RenderAll(const DeviceScene &sc, float *frame, LaneCounters *total)
@@ -47,7 +51,7 @@ void RenderAll(const DeviceScene &sc, float *frame, LaneCounters *total)
             for (uint32_t p = begin; p < std::min(begin + 64, n); ++p)
             {
                 LaneCounters c{};
-                const V3 v = render_pixel<C>(sc, p, total ? &c : nullptr);
+                const V3 v = render_pixel<C>(sc, p, total ? &c : nullptr, g_independent, g_rng_seed);
                 frame[3 * p] = v.x, frame[3 * p + 1] = v.y, frame[3 * p + 2] = v.z;
                 counts[tid].closest_rays += c.closest_rays, counts[tid].shadow_rays += c.shadow_rays;
                 counts[tid].node_tests += c.node_tests, counts[tid].prim_tests += c.prim_tests;
@@ -428,6 +432,18 @@ const char *mcpt_emu_last_error(void) { return g_error.c_str(); }
 // 0 = production split rule of the ordered-walk hierarchy, 1 = exact sweep, 2 = median,
 // 3 = children swapped (commit.hpp).  Process-wide.
 void mcpt_emu_set_walk_tree(int strategy) { SetWalkTreeStrategyForTesting(strategy); }
+
+// mcpt_emu_render with one independent stream per (pixel, sample) (mcpt_renderer_set_rng modes 1 / 2)
+void mcpt_emu_set_rng(int independent, uint32_t seed) { g_independent = independent != 0, g_rng_seed = seed; }
+int mcpt_emu_low_discrepancy() { return MCPT_LOW_DISCREPANCY_ACTIVE; }
+// n successive draws of the random stream from the state `word` (this build's generator: vecmath.h)
+void mcpt_emu_draws(uint32_t word, uint32_t n, float *out)
+{
+    for (uint32_t k = 0; k < n; ++k)
+        out[k] = lcg_next(word);
+}
+// the word a sample of the low-discrepancy build starts from
+uint32_t mcpt_emu_ld_pack(uint32_t sample, uint32_t seed, uint32_t pixel) { return ld_pack(sample, pcg_hash(pcg_hash(seed) + pixel)); }
 
 // variant: -1 = pick like the GPU launcher does, otherwise a feature mask to
 // force (must be a superset of the scene's features).  Bit kFeatOrderedWalk of a

@@ -428,6 +428,26 @@ def test_cli_gpus_switch(pkg, tmp_path):
     np.testing.assert_array_equal(np.fromfile(out, dtype=np.float32).reshape(40, 72, 3), want)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["reference", "pcg", "sobol"])
+def test_cli_rng_switch(mode, pkg, tmp_path):
+    """`mcpt_cli --rng reference|pcg|sobol --seed N` = mcpt_renderer_set_rng modes 0 / 1 / 2 (SURVEY section 5's flag)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.capi.LIB_PATH), "mcpt_cli")
+    out = tmp_path / "f.f32"
+    r = subprocess.run([exe, "-i", "builtin:cornell-box", "-w", "72", "-h", "40", "-s", "8", "--rng", mode, "--seed", "5", "-o", str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lib = pkg.capi.Renderer(pkg.capi.Config.builtin("cornell-box").set_film(72, 40, 8))
+    try:
+        want, _ = lib.set_rng({"reference": 0, "pcg": 1, "sobol": 2}[mode], seed=5).draw()
+    finally:
+        lib.close()
+    np.testing.assert_array_equal(np.fromfile(out, dtype=np.float32).reshape(40, 72, 3), want)
+    bad = subprocess.run([exe, "-i", "builtin:cornell-box", "--rng", "halton", "-o", str(out)], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2 and "--rng" in bad.stderr
+
+
 # ---- throughput RNG mode (mcpt_renderer_set_rng mode 1): graded statistically, not per pixel -------------
 @pytest.mark.gpu
 def test_independent_sample_mode_is_an_unbiased_twin_of_the_reference_stream(pkg):
@@ -523,6 +543,93 @@ def test_independent_sample_mode_is_the_same_frame_in_both_kernel_formulations(n
         r.close()
 
 
+# ---- throughput RNG mode 2: Owen-scrambled Sobol points (csrc/vecmath.h ld_next; hip/render_variants_lowdisc.hip) -------------
+_SOBOL_TWINS = {   # scene -> the instantiation of the low-discrepancy build it must run (hip/render_variants_lowdisc*.hip)
+    "cornell_96_spp32": "diffuse-area+lds+pool-walk, Sobol points",
+    "rough_dielectric_envmap": "surface-materials+pool-walk, Sobol points",
+    "masked_area_flat": "all, reference walk, Sobol points",
+    "volpath_medium_mixed": "all+pool-walk, Sobol points",
+    "volumetric_96x54_spp16": "volume-quadrics-microfacet+lds, Sobol points",
+    "terrain_directional": "Sobol points",
+    "grazing_strips": "Sobol points",          # (outside the tie radius: the renderer's self-check picks the reference-order walk)
+    "dragon_fixture": "diffuse-emitters+slivers+pool-walk, Sobol points",   # BASELINE config 3's scene, 96 x 54 spp 2
+    "terrain_192": "diffuse-emitters+pool-walk, Sobol points",
+    "preview_mesh_conductor": "surface-materials+pool-walk, Sobol points",
+    "preview_mesh_volpath": "all+pool-walk, Sobol points",
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(_SOBOL_TWINS))
+def test_sobol_mode_renders_its_host_twin_bit_for_bit(name, pkg, scenes, mcsd_file, tmp_path):
+    """No oracle exists for the low-discrepancy mode (the reference has no such sampler), so its frames are pinned against the
+    SAME kernel body compiled for the host with the same generator (tests/emu/libmcpt_emu_ld.so): one lane per pixel, samples
+    in order — every float of the frame must agree.  LDS-resident scenes, a scene with opacity masks (reference-order walk),
+    volume paths, and sliver triangles outside the tie radius (the vote-scheduled walk with the sliver rules)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu"))
+    import emu
+    S = pkg.scenes
+    made = {"grazing_strips": lambda: S.grazing_strips(),
+            "terrain_192": lambda: S.terrain_scene(192, 64, 40, 4),   # 73 000 triangles: outside LDS
+            "preview_mesh_conductor": lambda: S.material_preview("rough_conductor", "envmap", "mesh", 48, 48, 4),
+            "preview_mesh_volpath": lambda: S.material_preview("rough_dielectric", "mixed", "mesh", 48, 48, 4, integrator="volpath", medium=True)}
+    if name == "dragon_fixture":
+        cfg = pkg.workloads.config("dragon", 96, 54, 2)
+        path, (w, h, spp) = str(tmp_path / "dragon.mcsd"), (96, 54, 2)
+        cfg.save_mcsd(path)
+    else:
+        scene = made[name]() if name in made else scenes[name]
+        cfg, path, (w, h, spp) = pkg.capi.Config.from_scene(scene), mcsd_file(scene), (scene.camera.width, scene.camera.height, scene.camera.spp)
+    twin = emu.Emulator(low_discrepancy=True)
+    try:
+        want, _ = twin.set_rng(True, 9).render(path, w, h)
+    finally:
+        twin.set_rng(False)
+    r = pkg.capi.Renderer(cfg, device=0)
+    try:
+        got, st = r.set_rng(2, seed=9, sample_split=1).draw()
+        kernel = r.last_kernel()
+        again, _ = r.draw()
+        split, _ = r.set_rng(2, seed=9, sample_split=4).draw()      # the same points, partial sums per lane
+        other, _ = r.set_rng(2, seed=10, sample_split=1).draw()
+        pcg, _ = r.set_rng(1, seed=9, sample_split=1).draw()
+    finally:
+        r.close()
+    assert "Sobol points" in kernel and "independent samples" in kernel and _SOBOL_TWINS[name] in kernel, kernel
+    assert st["samples"] == w * h * spp
+    assert np.array_equal(got, want), (kernel, float(np.abs(got - want).max()), float((got != want).mean()))
+    assert np.array_equal(got, again)
+    np.testing.assert_allclose(split, got, rtol=0, atol=2e-6)
+    assert not np.array_equal(got, other) and not np.array_equal(got, pcg)
+
+
+@pytest.mark.gpu
+def test_sobol_mode_is_an_unbiased_twin_with_a_smaller_error(pkg):
+    """cornell-box 128 x 128 on the GPU: against a 4096-spp frame of the reference stream, Sobol points at 16 / 64 / 256 spp
+    give the same mean, a smaller RMSE than PCG-hashed independent streams at every spp, and an error that falls faster than
+    N^-1/2 (the CPU-side twin of this test: tests/test_low_discrepancy.py)."""
+    frames = {}
+    truth = None
+    for spp in (16, 64, 256, 4096):
+        r = pkg.capi.Renderer(pkg.capi.Config.builtin("cornell-box").set_film(128, 128, spp), device=0)
+        try:
+            if spp == 4096:
+                truth = r.draw()[0].astype(np.float64)
+            else:
+                frames[spp] = (r.set_rng(2, seed=1).draw()[0].astype(np.float64), r.set_rng(1, seed=1).draw()[0].astype(np.float64))
+        finally:
+            r.close()
+    rmse = lambda x: float(np.sqrt(((x - truth) ** 2).mean()))
+    spps = (16, 64, 256)
+    sobol, pcg = [rmse(frames[n][0]) for n in spps], [rmse(frames[n][1]) for n in spps]
+    assert abs(frames[256][0].mean() - truth.mean()) < 2e-3 * truth.mean()
+    for a, b in zip(sobol, pcg):
+        assert a < 0.92 * b, (sobol, pcg)
+    slope = lambda e: float(np.polyfit(np.log(spps), np.log(e), 1)[0])
+    assert slope(sobol) < min(-0.52, slope(pcg) - 0.02), (slope(sobol), slope(pcg), sobol, pcg)
+
+
 @pytest.mark.gpu
 def test_rng_mode_arguments(pkg):
     import torch
@@ -533,6 +640,12 @@ def test_rng_mode_arguments(pkg):
         r.set_rng(0, 0, 4)
     with pytest.raises(pkg.capi.McptError, match="mode is 0"):
         r.set_rng(3)
+    r = pkg.capi.Renderer(pkg.capi.Config.builtin("cornell-box").set_film(16, 16, 8193), device=0)
+    try:
+        with pytest.raises(RuntimeError):   # a Sobol point's sample index has 13 bits
+            r.set_rng(2)
+    finally:
+        r.close()
     r.close()
 
 
