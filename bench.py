@@ -368,6 +368,14 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
                 "node_phase_lane_util": (counts["node_tests"] / boxes_per_node_step) / (64.0 * max(counts["wave_node_steps"], 1)),
                 "counting_kernel": counting_kernel,
                 "prim_phase_lane_util": counts["prim_tests"] / (64.0 * max(counts["wave_prim_steps"], 1))}
+        if "pool-walk" in counting_kernel and "+lds" not in kernel_name:
+            # scenes outside LDS: a node item of the pool walk is one 128-byte record = one cache line, a primitive test one 48-byte
+            # record (1.375 lines on average) — against the rate a dependent gather of such records reaches on this GPU whatever
+            # the occupancy (tools/experiments/gather_rate.hip, profiles/r04_experiments/gather_rate.json: 86.9 G lines/s)
+            lines = (counts["node_tests"] / boxes_per_node_step + 1.375 * counts["prim_tests"]) / counts["samples"]
+            g_lines = lines * rank_samples / (kernel_ms * 1e-3) / 1e9
+            walk["l2_lines"] = {"lines_per_sample": lines, "G_lines_per_s": g_lines, "measured_gather_ceiling_G_lines_per_s": 86.9,
+                                "frac": g_lines / 86.9}
         hbm = {"algorithmic_gbs": algorithmic_gbs, "bytes_per_sample": b_per_sample,
                "stream_peak_gbs": hbm_peak, "stream_copy_gbs": bw["copy_gbs"], "stream_read_gbs": bw["read_gbs"],
                "spec_peak_gbs": HBM_SPEC_GBS, "frac_algorithmic_of_stream_peak": algorithmic_gbs / hbm_peak,
