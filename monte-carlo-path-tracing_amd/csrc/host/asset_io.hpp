@@ -41,6 +41,8 @@ enum class ImageKind
 MeshData LoadObj(const std::string &path, bool flip_texcoords, bool face_normals);
 MeshData LoadSerialized(const std::string &path, int shape_index);
 MeshData LoadPly(const std::string &path, bool face_normals);
+// glTF 2.0 (.gltf / .glb; gltf_io.cpp): the reference's assimp import + ProcessAssimpNode restated (node transforms ignored, like there)
+MeshData LoadGltf(const std::string &path, bool face_normals);
 // `gamma` is applied per the file type's rule; the result is what the reference's
 // image_io::Read returns (before its optional down-scaling).
 ImageData LoadFloatImage(const std::string &path, float gamma = 0.0f);

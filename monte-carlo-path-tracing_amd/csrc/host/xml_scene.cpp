@@ -806,7 +806,7 @@ private:
             const Node *radius = n.Child("float");
             in.cyl_radius = radius ? radius->Float("value", 1.0f) : 1.0f;
         }
-        else if (type == "obj" || type == "serialized" || type == "ply")
+        else if (type == "obj" || type == "serialized" || type == "ply" || type == "gltf")
         {
             in.type = MCSD_INST_MESHES;
             const Node *file = n.Child("string");
@@ -822,6 +822,8 @@ private:
                 mesh = LoadObj(path, ReadBool(n, {"flip_tex_coords", "flipTexCoords"}, true), face_normals);
             else if (type == "ply")
                 mesh = LoadPly(path, face_normals);
+            else if (type == "gltf")
+                mesh = LoadGltf(path, face_normals); // (parser.cpp:1189: no texture-coordinate flip is requested for this type)
             else
             {
                 const Node *index = n.Child("integer");

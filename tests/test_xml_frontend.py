@@ -484,6 +484,116 @@ f -4/1/1 -3/2/1 -2/3/1
         translate(pkg, tmp_path, scene_xml('<shape type="obj"><string name="filename" value="missing.obj"/></shape>'))
 
 
+def _gltf_document(positions, normals, texcoords, indices, index_type=np.uint16, mode=None, nodes=None, scene_roots=None, extra_meshes=()):
+    """A glTF 2.0 document (dict) + its binary buffer for ONE primitive (+ `extra_meshes`: more (positions, indices) meshes)."""
+    blob, views, accessors = b"", [], []
+
+    def add(array, ctype, kind, target=None):
+        nonlocal blob
+        blob += b"\0" * (-len(blob) % 4)
+        raw = np.ascontiguousarray(array).tobytes()
+        views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": len(raw)})
+        accessors.append({"bufferView": len(views) - 1, "componentType": ctype, "count": len(array), "type": kind})
+        blob += raw
+        return len(accessors) - 1
+
+    ctype = {np.uint8: 5121, np.uint16: 5123, np.uint32: 5125}[index_type]
+    attributes = {"POSITION": add(np.asarray(positions, np.float32), 5126, "VEC3")}
+    if normals is not None:
+        attributes["NORMAL"] = add(np.asarray(normals, np.float32), 5126, "VEC3")
+    if texcoords is not None:
+        attributes["TEXCOORD_0"] = add(np.asarray(texcoords, np.float32), 5126, "VEC2")
+    primitive = {"attributes": attributes}
+    if indices is not None:
+        primitive["indices"] = add(np.asarray(indices, index_type).ravel(), ctype, "SCALAR")
+    if mode is not None:
+        primitive["mode"] = mode
+    meshes = [{"primitives": [primitive]}]
+    for pos, idx in extra_meshes:
+        meshes.append({"primitives": [{"attributes": {"POSITION": add(np.asarray(pos, np.float32), 5126, "VEC3")},
+                                       "indices": add(np.asarray(idx, np.uint16).ravel(), 5123, "SCALAR")}]})
+    doc = {"asset": {"version": "2.0"}, "scene": 0,
+           "scenes": [{"nodes": scene_roots if scene_roots is not None else [0]}],
+           "nodes": nodes if nodes is not None else [{"mesh": 0, "name": "a \"quoted\" \u00e9 name", "translation": [5, 6, 7]}],
+           "meshes": meshes, "accessors": accessors, "bufferViews": views, "buffers": [{"byteLength": len(blob)}]}
+    return doc, blob
+
+
+def _glb(doc, blob):
+    import json as _json
+    text = _json.dumps(doc).encode()
+    text += b" " * (-len(text) % 4)
+    blob = blob + b"\0" * (-len(blob) % 4)
+    body = struct.pack("<II", len(text), 0x4E4F534A) + text + struct.pack("<II", len(blob), 0x004E4942) + blob
+    return b"glTF" + struct.pack("<II", 2, 12 + len(body)) + body
+
+
+def test_gltf_shapes(pkg, tmp_path):
+    """`<shape type="gltf">` (parser.cpp:1165): .gltf with an external buffer, with a base64 buffer, and .glb — the primitive's
+    indexed vertices as they are, v flipped (what assimp's importer hands over), node transforms ignored like the reference's
+    ProcessAssimpNode ignores them (model_loader.cpp:335-419), importer steps in assimp's order."""
+    import base64
+    import json as _json
+    pos = [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]]
+    nrm = [[0, 0, 1]] * 4
+    uv = [[0, 0], [1, 0], [1, 0.75], [0, 0.75]]
+    idx = [[0, 1, 2], [0, 2, 3]]
+    doc, blob = _gltf_document(pos, nrm, uv, idx)
+    external = dict(doc, buffers=[{"byteLength": len(blob), "uri": "quad%20data.bin"}])
+    embedded = dict(doc, buffers=[{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}])
+    bare, bare_blob = _gltf_document(pos, None, None, idx, index_type=np.uint32)   # no normals, no texture coordinates
+    files = {"models/a.gltf": _json.dumps(external, indent=1).encode(), "models/quad data.bin": blob,
+             "models/b.gltf": _json.dumps(embedded).encode(), "models/c.glb": _glb(doc, blob), "models/d.glb": _glb(bare, bare_blob)}
+    body = "".join(f'<shape type="gltf"><string name="filename" value="models/{n}"/></shape>' for n in ("a.gltf", "b.gltf", "c.glb", "d.glb"))
+    body += '<shape type="gltf"><string name="filename" value="models/d.glb"/><boolean name="faceNormals" value="true"/></shape>'
+    s = translate(pkg, tmp_path, scene_xml(body), files=files)
+    a, b, c, d, flat = s.instances
+    for inst in (a, b, c):
+        assert inst.type == pkg.mcsd.INST_MESHES
+        np.testing.assert_array_equal(inst.positions, np.asarray(pos, np.float32))          # (the node's translation is ignored)
+        np.testing.assert_array_equal(inst.indices, idx)
+        np.testing.assert_array_equal(inst.normals, np.asarray(nrm, np.float32))
+        np.testing.assert_array_equal(inst.texcoords, np.asarray([[u, 1 - v] for u, v in uv], np.float32))
+        assert inst.tangents.shape == (4, 3) and inst.bitangents.shape == (4, 3)             # CalcTangentSpace ran
+        np.testing.assert_array_equal(inst.tangents, a.tangents)
+    # without normals: smooth normals are generated (a flat quad: +z everywhere); no texture coordinates -> no tangent frames
+    np.testing.assert_array_equal(d.positions, np.asarray(pos, np.float32))
+    np.testing.assert_allclose(d.normals, np.tile([0, 0, 1], (4, 1)), atol=1e-7)
+    assert d.texcoords.size == 0 and d.tangents.size == 0
+    assert flat.normals.size == 0                                                            # faceNormals: none handed over
+    # the same quad through the OBJ reader renders the same surface: equal positions per triangle corner
+    np.testing.assert_array_equal(a.positions[np.asarray(idx).ravel()], [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 0, 0], [1, 1, 0], [0, 1, 0]])
+
+
+def test_gltf_strips_fans_and_the_reference_flattening(pkg, tmp_path):
+    """Strips and fans are expanded to triangles (assimp triangulates); a file with several meshes is flattened with the
+    REFERENCE's index offset — the number of triangles gathered so far, not of vertices (model_loader.cpp:345-347, 395-396):
+    a child mesh placed after a parent mesh of 2 triangles gets its indices shifted by 2."""
+    import json as _json
+    pos = [[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0, 2, 0]]
+    strip, blob_s = _gltf_document(pos, None, None, None, mode=5)
+    fan, blob_f = _gltf_document(pos, None, None, [0, 1, 3, 2], mode=6)
+    quad = [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]]
+    tri = [[0, 0, 1], [1, 0, 1], [0, 1, 1]]
+    # node 0 holds the quad (2 triangles) and has node 1 (the triangle, mesh 1) as its child
+    two, blob_t = _gltf_document(quad, None, None, [[0, 1, 2], [0, 2, 3]], nodes=[{"mesh": 0, "children": [1]}, {"mesh": 1}],
+                                 extra_meshes=[(tri, [[0, 1, 2]])])
+    points, blob_p = _gltf_document(pos, None, None, None, mode=0)
+    files = {"m/strip.glb": _glb(strip, blob_s), "m/fan.glb": _glb(fan, blob_f), "m/two.glb": _glb(two, blob_t), "m/points.glb": _glb(points, blob_p),
+             "m/broken.gltf": b'{"asset": {"version": "2.0"}, "scenes": [', "m/notgltf.glb": b"glTF" + struct.pack("<II", 1, 12)}
+    shape = lambda n: f'<shape type="gltf"><string name="filename" value="m/{n}"/></shape>'
+    s = translate(pkg, tmp_path, scene_xml(shape("strip.glb") + shape("fan.glb") + shape("two.glb")), files=files)
+    st, fn, tw = s.instances
+    np.testing.assert_array_equal(st.indices, [[0, 1, 2], [2, 1, 3], [2, 3, 4]])      # every other triangle turned: all wind alike
+    np.testing.assert_array_equal(fn.indices, [[0, 1, 3], [0, 3, 2]])
+    np.testing.assert_array_equal(tw.positions, np.asarray(quad + tri, np.float32))
+    np.testing.assert_array_equal(tw.indices, [[0, 1, 2], [0, 2, 3], [2, 3, 4]])       # the child's 0 1 2 shifted by 2 TRIANGLES (quirk)
+    for name, message in (("points.glb", "no triangles"), ("broken.gltf", "malformed JSON"), ("notgltf.glb", "version-2 binary glTF"),
+                          ("missing.gltf", "read file .* failed")):
+        with pytest.raises(RuntimeError, match=message):
+            translate(pkg, tmp_path, scene_xml(shape(name)), name="bad.xml", files=files)
+
+
 def test_uv_derived_tangents_switch(pkg, tmp_path, monkeypatch):
     """MCPT_MESH_TANGENTS=uv (SURVEY.md section 8c's pin): an OBJ mesh is handed over without per-vertex tangents, so the
     commit builds the reference's own per-triangle UV-derived frame (scene.cpp:63-80) instead of the restated importer's."""
