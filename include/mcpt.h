@@ -311,8 +311,8 @@ int mcpt_renderer_set_prepass(mcpt_renderer *r, int mode);
  *          sample index, each dimension scrambled with its own hash of (seed, pixel, k) ("padded" sequences; hash-based
  *          nested uniform scrambling), so every pair of consecutive draws of a pixel — a point on a light, a scattered
  *          direction — is stratified over any power-of-two run of its samples (csrc/vecmath.h ld_next).  Same pixel
- *          jitter (the reference's own radical inverse, include/csrt/utils/math.hpp:29-41), same estimator; cornell-box:
- *          RMSE 0.72-0.84 x mode 1's at 16-256 spp, falling like N^-0.55 instead of N^-0.5.  At most 8192 samples per
+ *          jitter (the reference's own radical inverse, include/csrt/utils/math.hpp:29-41), same estimator; RMSE at 256
+ *          spp: 0.57 (dragon/scene.xml) ... 0.70 (cornell-box) x mode 1's, falling like N^-0.55 ... N^-0.62 instead of N^-0.5.  At most 8192 samples per
  *          pixel; runs in the lane-owns-a-path kernel (csrc/hip/render_variants_lowdisc.hip, full feature set), with
  *          `sample_split` like mode 1; no counting mode.  Pinned bit for bit against the same kernel body compiled for
  *          the host (tests/emu). */
