@@ -51,8 +51,15 @@ constexpr uint32_t kPoolCands = 6;       // candidate hits a closest ray can hol
 constexpr uint32_t kPoolNodeItems = 448; // (ray, node) item slots: 384 in normal operation + 64 of head room (see below)
 constexpr uint32_t kPoolNodeFull = 384;
 constexpr uint32_t kPoolMaxDepth = 20;   // of the 4-wide hierarchy: 3 x depth <= the head room
-constexpr uint32_t kPoolPrimItems = 320; // (ray, slot) item slots: < kPoolPrimAt waiting + 4 x 64 pushed by one node step
-constexpr uint32_t kPoolPrimAt = 64;     // a primitive phase runs when this many slots wait
+#ifndef MCPT_POOL_PRIM_ITEMS
+#define MCPT_POOL_PRIM_ITEMS 320
+#endif
+constexpr uint32_t kPoolPrimItems = MCPT_POOL_PRIM_ITEMS; // (ray, slot) item slots: < kPoolPrimAt waiting + 4 x 64 pushed by one node step
+#ifndef MCPT_POOL_PRIM_AT
+#define MCPT_POOL_PRIM_AT 64
+#endif
+constexpr uint32_t kPoolPrimAt = MCPT_POOL_PRIM_AT; // a primitive phase runs when this many slots wait (32 ... 128 measured on cornell: R4-9)
+static_assert(kPoolPrimItems >= kPoolPrimAt + 256u, "a node step of 64 lanes can push 256 slots on top of the waiting ones");
 constexpr uint32_t kPoolMaxRef = 1023;   // node and slot indices must fit 10 bits (16-bit items: scenes in LDS)
 constexpr uint32_t kPoolMaxRefBig = (1u << 26) - 1u; // ... 26 bits (32-bit items: kFeatPoolBig)
 
