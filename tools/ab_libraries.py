@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""A/B of BUILDS of libmcpt_hip.so on one box (compiler flags, build parameters): every (library, workload) is a process
+of its own (capi.py binds the library named by MCPT_LIB), the libraries take turns `--rounds` times, medians of the draws'
+kernel times, frames compared by hash across libraries.
+
+    python tools/ab_libraries.py [--workloads cornell,dragon,...] [--draws 3] [--rounds 2] name=path.so name=path.so ...
+"""
+import argparse
+import hashlib
+import json
+import os
+import statistics
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def child(workload, draws):
+    from _pkg import load_package
+    pkg = load_package()
+    r = pkg.capi.Renderer(pkg.workloads.config(workload), device=0)
+    ms, frame = [], None
+    for _ in range(draws + 1):
+        frame, st = r.draw()
+        ms.append(st["kernel_milliseconds"])
+    print(json.dumps({"ms": ms[1:], "sha": hashlib.sha256(frame.tobytes()).hexdigest()[:16], "kernel": r.last_kernel()}))
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        return child(sys.argv[2], int(sys.argv[3]))
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workloads", default="cornell,dragon,matpreview-rc,matpreview-rd,volumetric")
+    ap.add_argument("--draws", type=int, default=3)
+    ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("libs", nargs="+")
+    a = ap.parse_args()
+    libs = [l.split("=", 1) for l in a.libs]
+    out = {}
+    for w in a.workloads.split(","):
+        rec = {n: {"ms": [], "sha": set()} for n, _ in libs}
+        for _ in range(a.rounds):
+            for n, path in libs:
+                env = dict(os.environ, MCPT_LIB=os.path.abspath(path))
+                p = subprocess.run([sys.executable, __file__, "--child", w, str(a.draws)], env=env, capture_output=True, text=True)
+                if p.returncode != 0:
+                    rec[n]["error"] = p.stderr[-400:]
+                    continue
+                d = json.loads(p.stdout.strip().split("\n")[-1])
+                rec[n]["ms"] += d["ms"]
+                rec[n]["sha"].add(d["sha"])
+                rec[n]["kernel"] = d["kernel"]
+        shas = set().union(*(rec[n]["sha"] for n in rec))
+        out[w] = {"frames_identical": len(shas) == 1,
+                  **{n: {"median_ms": statistics.median(rec[n]["ms"]) if rec[n]["ms"] else None, "min_ms": min(rec[n]["ms"], default=None),
+                         "n": len(rec[n]["ms"]), "kernel": rec[n].get("kernel"), **({"error": rec[n]["error"]} if "error" in rec[n] else {})}
+                     for n in rec}}
+        print(json.dumps({w: out[w]}), flush=True)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "ab_libraries.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
