@@ -3,7 +3,7 @@
 of its own (capi.py binds the library named by MCPT_LIB), the libraries take turns `--rounds` times, medians of the draws'
 kernel times, frames compared by hash across libraries.
 
-    python tools/ab_libraries.py [--workloads cornell,dragon,...] [--draws 3] [--rounds 2] name=path.so name=path.so ...
+    python tools/ab_libraries.py [--workloads cornell,dragon,other:classroom,...] [--draws 3] [--rounds 2] name=path.so name=path.so ...
 """
 import argparse
 import hashlib
@@ -20,7 +20,12 @@ sys.path.insert(0, ROOT)
 def child(workload, draws):
     from _pkg import load_package
     pkg = load_package()
-    r = pkg.capi.Renderer(pkg.workloads.config(workload), device=0)
+    if workload.startswith("other:"):  # the reference's other scenes (tools/convert_other_scenes.py -> scratch/other), at tools/rule_vs_calibrated.py's film
+        import gzip
+        cfg = pkg.capi.Config.from_mcsd_bytes(gzip.open(os.path.join(ROOT, "scratch", "other", workload[6:] + ".mcsd.gz"), "rb").read()).set_film(640, 360, 64)
+    else:
+        cfg = pkg.workloads.config(workload)
+    r = pkg.capi.Renderer(cfg, device=0)
     ms, frame = [], None
     for _ in range(draws + 1):
         frame, st = r.draw()
