@@ -26,6 +26,8 @@ def child(workload, draws):
     else:
         cfg = pkg.workloads.config(workload)
     r = pkg.capi.Renderer(cfg, device=0)
+    if os.environ.get("MCPT_AB_RNG"):  # throughput modes: 1 PCG-hashed streams, 2 Sobol points (--rng)
+        r.set_rng(int(os.environ["MCPT_AB_RNG"]))
     ms, frame = [], None
     for _ in range(draws + 1):
         frame, st = r.draw()
@@ -40,8 +42,11 @@ def main():
     ap.add_argument("--workloads", default="cornell,dragon,matpreview-rc,matpreview-rd,volumetric")
     ap.add_argument("--draws", type=int, default=3)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--rng", type=int, default=0, help="mcpt_renderer_set_rng mode of every renderer (0: the reference's stream)")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
+    if a.rng:
+        os.environ["MCPT_AB_RNG"] = str(a.rng)
     libs = [l.split("=", 1) for l in a.libs]
     out = {}
     for w in a.workloads.split(","):
