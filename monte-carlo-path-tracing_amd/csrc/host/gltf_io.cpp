@@ -66,7 +66,7 @@ struct Json
     long Index(const char *key) const // a non-negative integer member, -1 if absent
     {
         const Json *v = Find(key);
-        return v && v->kind == kNumber && v->number >= 0 ? static_cast<long>(v->number) : -1;
+        return v && v->kind == kNumber && v->number >= 0 && v->number <= 9.0e15 ? static_cast<long>(v->number) : -1; // (beyond that: not an index)
     }
     std::string String(const char *key) const
     {
@@ -362,6 +362,36 @@ int TypeComponents(const std::string &type)
     return type == "SCALAR" ? 1 : type == "VEC2" ? 2 : type == "VEC3" ? 3 : type == "VEC4" ? 4 : 0;
 }
 
+// A byte count / offset / element count from the (untrusted) JSON: a finite, non-negative number no larger than `limit`.
+// (A double cast to size_t outside its range is undefined behaviour, and `count * stride` of two huge values wraps.)
+size_t CheckedSize(const Document &doc, double v, size_t limit, const char *what)
+{
+    if (!(v >= 0.0) || !(v <= static_cast<double>(limit)) || v != std::floor(v))
+        throw std::runtime_error("'" + doc.path + "': " + what + " out of range.");
+    return static_cast<size_t>(v);
+}
+
+// Where an accessor's bytes are: [base, base + (count - 1) * stride + element) must lie inside its buffer view, and the view
+// inside its buffer.  All comparisons are made without a product that could wrap.
+struct AccessorSpan
+{
+    const uint8_t *data;
+    size_t stride;
+};
+AccessorSpan SpanOf(Document &doc, const Json &a, const Json &view, size_t count, size_t element)
+{
+    const std::vector<uint8_t> &buffer = doc.Buffer(view.Index("buffer"));
+    const size_t view_offset = CheckedSize(doc, view.Number("byteOffset", 0.0), buffer.size(), "bufferView.byteOffset");
+    const size_t view_length = view.Find("byteLength") ? CheckedSize(doc, view.Number("byteLength", 0.0), buffer.size() - view_offset, "bufferView.byteLength")
+                                                       : buffer.size() - view_offset;
+    const size_t offset = CheckedSize(doc, a.Number("byteOffset", 0.0), view_length, "accessor.byteOffset");
+    const size_t stride = view.Find("byteStride") && view.Number("byteStride", 0.0) != 0.0 ? CheckedSize(doc, view.Number("byteStride", 0.0), size_t(1) << 20, "bufferView.byteStride") : element;
+    const size_t room = view_length - offset; // bytes from the first element to the end of the view
+    if (element == 0 || stride == 0 || room < element || (count - 1) > (room - element) / stride)
+        throw std::runtime_error("'" + doc.path + "': accessor reaches beyond its buffer.");
+    return AccessorSpan{buffer.data() + view_offset + offset, stride};
+}
+
 // An accessor as `components` floats per element (integers converted, normalised ones scaled as the specification says).
 // Sparse accessors are not read.
 std::vector<float> ReadFloats(Document &doc, long accessor, int components, size_t *count_out)
@@ -369,25 +399,23 @@ std::vector<float> ReadFloats(Document &doc, long accessor, int components, size
     const Json &a = doc.Entry("accessors", accessor);
     const long ctype = a.Index("componentType"), view_index = a.Index("bufferView");
     const int cbytes = ComponentBytes(ctype), n = TypeComponents(a.String("type"));
-    const size_t count = static_cast<size_t>(a.Number("count", 0.0));
+    // (an element count beyond 2^32 cannot be indexed by a 32-bit face index anyway; it also keeps count * components small)
+    const size_t count = CheckedSize(doc, a.Number("count", 0.0), size_t(1) << 32, "accessor.count");
     if (cbytes == 0 || n < components || a.Find("sparse") != nullptr)
         throw std::runtime_error("'" + doc.path + "': accessor of an unsupported kind.");
     *count_out = count;
-    std::vector<float> out(count * static_cast<size_t>(components), 0.0f);
     if (view_index < 0 || count == 0)
-        return out; // (an accessor without a buffer view is all zeros)
+        return std::vector<float>(count * static_cast<size_t>(components), 0.0f); // (an accessor without a buffer view is all zeros)
     const Json &view = doc.Entry("bufferViews", view_index);
-    const std::vector<uint8_t> &buffer = doc.Buffer(view.Index("buffer"));
-    const size_t base = static_cast<size_t>(view.Number("byteOffset", 0.0)) + static_cast<size_t>(a.Number("byteOffset", 0.0));
     const size_t element = static_cast<size_t>(cbytes) * static_cast<size_t>(n);
-    const size_t stride = view.Index("byteStride") > 0 ? static_cast<size_t>(view.Index("byteStride")) : element;
-    if (base + (count - 1) * stride + element > buffer.size())
-        throw std::runtime_error("'" + doc.path + "': accessor reaches beyond its buffer.");
+    const AccessorSpan span = SpanOf(doc, a, view, count, element); // (throws before anything of `count` elements is allocated)
+    const size_t stride = span.stride;
+    std::vector<float> out(count * static_cast<size_t>(components), 0.0f);
     const bool normalized = a.Find("normalized") != nullptr && a.Find("normalized")->boolean;
     for (size_t i = 0; i < count; ++i)
         for (int c = 0; c < components; ++c)
         {
-            const uint8_t *p = buffer.data() + base + i * stride + static_cast<size_t>(c) * static_cast<size_t>(cbytes);
+            const uint8_t *p = span.data + i * stride + static_cast<size_t>(c) * static_cast<size_t>(cbytes);
             float v = 0.0f;
             switch (ctype)
             {
@@ -407,19 +435,18 @@ std::vector<uint32_t> ReadIndices(Document &doc, long accessor)
 {
     const Json &a = doc.Entry("accessors", accessor);
     const long ctype = a.Index("componentType"), view_index = a.Index("bufferView");
-    const size_t count = static_cast<size_t>(a.Number("count", 0.0));
+    const size_t count = CheckedSize(doc, a.Number("count", 0.0), size_t(1) << 32, "accessor.count");
     const int cbytes = ComponentBytes(ctype);
     if ((ctype != 5121 && ctype != 5123 && ctype != 5125) || a.String("type") != "SCALAR" || view_index < 0 || a.Find("sparse") != nullptr)
         throw std::runtime_error("'" + doc.path + "': index accessor of an unsupported kind.");
+    if (count == 0)
+        return {};
     const Json &view = doc.Entry("bufferViews", view_index);
-    const std::vector<uint8_t> &buffer = doc.Buffer(view.Index("buffer"));
-    const size_t base = static_cast<size_t>(view.Number("byteOffset", 0.0)) + static_cast<size_t>(a.Number("byteOffset", 0.0));
-    if (count != 0 && base + count * static_cast<size_t>(cbytes) > buffer.size())
-        throw std::runtime_error("'" + doc.path + "': index accessor reaches beyond its buffer.");
+    const AccessorSpan span = SpanOf(doc, a, view, count, static_cast<size_t>(cbytes)); // (indices are tightly packed or strided alike)
     std::vector<uint32_t> out(count);
     for (size_t i = 0; i < count; ++i)
     {
-        const uint8_t *p = buffer.data() + base + i * static_cast<size_t>(cbytes);
+        const uint8_t *p = span.data + i * span.stride;
         if (ctype == 5121)
             out[i] = *p;
         else if (ctype == 5123)

@@ -149,7 +149,8 @@ MCPT_HD uint32_t tea4(uint32_t v0, uint32_t v1)
 // tests/emu/libmcpt_emu_ld.so also defines MCPT_LOW_DISCREPANCY_HOST) gives that word another meaning — no call site changes:
 //     bits 31..19  s = index of the sample within its pixel (at most 8192 spp)
 //     bits 18..7   p = 12 bits of a PCG hash of (seed, pixel): which of 4096 scrambles the pixel uses
-//     bits  6..0   d = draws made so far in this sample (mod 128) = the dimension
+//     bits  6..0   d = draws made so far in this sample (mod 128) = the dimension; draw 128 carries into p: the sample goes
+//                      on with the next scramble (fresh pair seeds), 2^19 draws before anything repeats
 // and a draw returns an Owen-scrambled Sobol point: dimensions come in pairs (d >> 1), every pair is the first two Sobol
 // dimensions — a (0,2)-sequence in base 2 — over an Owen-shuffled sample index, each dimension Owen-scrambled with its own
 // seed ("padded" (0,2)-sequences: Kollig & Keller 2002; the hash-based nested uniform scramble is Burley 2020 / Laine &
@@ -204,7 +205,10 @@ MCPT_HD uint32_t ld_pack(uint32_t sample, uint32_t pixel_hash) { return (sample 
 MCPT_HD float ld_next(uint32_t &word)
 {
     const uint32_t d = word & 0x7fu, s = word >> 19, p = (word >> 7) & 0xfffu;
-    word = (word & ~0x7fu) | ((d + 1u) & 0x7fu);
+    // (the increment carries from the 7 dimension bits into the 12 scramble bits — never into the sample's: after 128 draws a
+    //  sample goes on with the NEXT scramble's pair seeds instead of repeating its own first 128 numbers, which biased paths
+    //  longer than about 12 vertices: volumetric-caustic, chains through glass — round 4's advisor)
+    word = (word & 0xfff80000u) | ((word + 1u) & 0x0007ffffu);
     // (pcg_hash below; written out here because it is declared after lcg_next)
     const uint32_t state = ((d >> 1) * 4096u + p) * 747796405u + 2891336453u;
     const uint32_t mixed = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;

@@ -65,7 +65,7 @@ def _restated_draw(word):
     point = _sobol_dimension_1(index) if d & 1 else int(_reverse(index))
     seed = (pair_seed * 0x9E3779B9 + 0x7F4A7C15 + (d & 1) * 0x632BE5AB) & 0xFFFFFFFF
     x = int(_reverse(_laine_karras(int(_reverse(point)), seed)))
-    return np.float32(x >> 8) / np.float32(1 << 24), (word & ~0x7F) | ((d + 1) & 0x7F)
+    return np.float32(x >> 8) / np.float32(1 << 24), (word & 0xFFF80000) | ((word + 1) & 0x7FFFF)
 
 
 def test_draws_are_the_restated_construction(sobol):
@@ -117,11 +117,15 @@ def test_every_pair_of_draws_is_stratified_over_every_aligned_run_of_samples(sob
 def test_pixels_and_seeds_have_their_own_scrambles(sobol):
     a, b, c = points(sobol, 1, 100, 64, 4), points(sobol, 1, 101, 64, 4), points(sobol, 2, 100, 64, 4)
     assert np.abs(a - b).max() > 0.5 and np.abs(a - c).max() > 0.5
-    # the dimension counter wraps at 128 draws instead of running into the pixel's bits
+    # draw 128 of a sample carries into the scramble field: it goes on with the NEXT scramble's numbers (the pixel whose hash is
+    # one larger), not with its own first 128 again (that repeat biased long paths), and never touches the sample index
     word = sobol.ld_pack(3, 1, 100)
-    sobol.draws(word, 1)
-    many = sobol.draws(word, 256)
-    assert np.array_equal(many[:128], many[128:])
+    many = sobol.draws(word, 384)
+    assert not np.array_equal(many[:128], many[128:256]) and not np.array_equal(many[128:256], many[256:])
+    assert len(set(many.tolist())) > 380
+    assert np.array_equal(many[128:256], sobol.draws((word & 0xFFF80000) | ((word + 128) & 0x7FFFF), 128))
+    last = (word & 0xFFF80000) | 0x7FFFF                      # the last draw of the last scramble wraps to scramble 0, draw 0
+    assert np.array_equal(sobol.draws(last, 3)[1:], sobol.draws(word & 0xFFF80000, 2))
 
 
 # ---- (c) what it is for ------------------------------------------------------------------------------------
@@ -154,3 +158,34 @@ def test_sobol_points_estimate_the_same_image_with_a_smaller_error(sobol, plain,
     slope = lambda e: float(np.polyfit(np.log(spps), np.log(e), 1)[0])
     assert -0.58 < slope(err_pcg) < -0.42, (slope(err_pcg), err_pcg)
     assert slope(err_sobol) < min(-0.52, slope(err_pcg) - 0.025), (slope(err_sobol), slope(err_pcg), err_sobol, err_pcg)
+
+
+def test_long_paths_keep_the_estimate_unbiased(sobol, plain, tmp_path):
+    """Paths far longer than 128 draws (round 4's advisor: the dimension counter used to wrap back onto the sample's own first
+    numbers, so vertex 13 re-used vertex 1's draws; now draw 128 goes on with fresh pair seeds — pinned draw by draw in
+    test_pixels_and_seeds_have_their_own_scrambles): a bright cornell-box (albedo 0.9, 48 bounces, no roulette — 150 to 350
+    draws per sample).  The Sobol frame's mean must agree with the reference stream's and with the PCG mode's to 1 %.  (A
+    regression guard on the estimator, not a detector of the old wrap: on this scene the wrapped generator's mean was within
+    the same 1 % — the repeat correlated distant vertices, which this film's mean does not resolve.)"""
+    from _pkg import load_package
+    pkg = load_package()
+    scene = pkg.scenes.cornell_box(16, 16, 1)
+    scene.integrator.depth_max, scene.integrator.depth_rr = 48, 49
+    for t in scene.textures[:7]:
+        t.color = (0.9, 0.9, 0.9)
+
+    def frame(e, spp, independent, seed=0):
+        scene.camera.spp = spp
+        path = str(tmp_path / f"bright{spp}.mcsd")
+        pkg.mcsd.dump(scene, path)
+        e.set_rng(independent, seed)
+        try:
+            return e.render(path, 16, 16)[0].astype(np.float64)
+        finally:
+            e.set_rng(False)
+
+    truth = frame(plain, 4096, False).mean()
+    got = np.mean([frame(sobol, 512, True, seed).mean() for seed in (1, 2)])
+    twin = np.mean([frame(plain, 512, True, seed).mean() for seed in (1, 2)])
+    assert abs(twin - truth) < 1e-2 * truth, (twin, truth)
+    assert abs(got - truth) < 1e-2 * truth, (got, truth)

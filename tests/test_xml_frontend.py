@@ -594,6 +594,53 @@ def test_gltf_strips_fans_and_the_reference_flattening(pkg, tmp_path):
             translate(pkg, tmp_path, scene_xml(shape(name)), name="bad.xml", files=files)
 
 
+def test_gltf_hostile_accessors_are_refused(pkg, tmp_path):
+    """Counts, offsets and strides of an accessor come from untrusted JSON: values whose products wrap a 64-bit size (round 4's
+    advisor: count = 2^64 / 3 made `count * components` small and the bounds check pass), negative or non-integral numbers, and
+    views that reach beyond their buffer are all refused before anything is read (csrc/host/gltf_io.cpp, SpanOf)."""
+    import copy
+    pos = [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]]
+    idx = [[0, 1, 2], [0, 2, 3]]
+    good, blob = _gltf_document(pos, None, None, idx)
+    blob = blob + b"\0" * 16384                                    # (the advisor's example needs a buffer of >= 8 KiB)
+    good["buffers"][0]["byteLength"] = len(blob)
+    shape = lambda n: f'<shape type="gltf"><string name="filename" value="m/{n}"/></shape>'
+
+    def variant(edit):
+        d = copy.deepcopy(good)
+        edit(d)
+        return _glb(d, blob)
+
+    def set_(path, value):
+        def edit(d):
+            node = d
+            for k in path[:-1]:
+                node = node[k]
+            node[path[-1]] = value
+        return edit
+
+    cases = {
+        "wrap_count.glb": set_(("accessors", 0, "count"), 6148914691236517888),       # 2^64 / 3: count * 3 floats wraps to 2048
+        "huge_count.glb": set_(("accessors", 0, "count"), 1e300),
+        "negative_count.glb": set_(("accessors", 0, "count"), -4),
+        "fraction_count.glb": set_(("accessors", 0, "count"), 3.5),
+        "accessor_offset.glb": set_(("accessors", 0, "byteOffset"), 1 << 62),
+        "view_offset.glb": set_(("bufferViews", 0, "byteOffset"), 1e19),
+        "view_length.glb": set_(("bufferViews", 0, "byteLength"), len(blob) + 1),
+        "stride.glb": set_(("bufferViews", 0, "byteStride"), 9007199254740992),       # 2^53: (count - 1) * stride wraps
+        "short_view.glb": set_(("bufferViews", 0, "byteLength"), 40),                  # 4 x VEC3 float need 48 bytes
+        "index_count.glb": set_(("accessors", 1, "count"), 1 << 63),
+        "index_past_view.glb": set_(("accessors", 1, "count"), 7),                     # the view holds 6 indices
+    }
+    files = {"m/" + n: variant(e) for n, e in cases.items()}
+    files["m/good.glb"] = _glb(good, blob)
+    s = translate(pkg, tmp_path, scene_xml(shape("good.glb")), files=files)
+    np.testing.assert_array_equal(s.instances[0].indices, idx)
+    for n in cases:
+        with pytest.raises(RuntimeError, match="out of range|beyond its buffer|unsupported"):
+            translate(pkg, tmp_path, scene_xml(shape(n)), name="bad.xml", files=files)
+
+
 def test_uv_derived_tangents_switch(pkg, tmp_path, monkeypatch):
     """MCPT_MESH_TANGENTS=uv (SURVEY.md section 8c's pin): an OBJ mesh is handed over without per-vertex tangents, so the
     commit builds the reference's own per-triangle UV-derived frame (scene.cpp:63-80) instead of the restated importer's."""
