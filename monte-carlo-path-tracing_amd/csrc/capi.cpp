@@ -165,6 +165,7 @@ struct mcpt_renderer
     // cost-ordered wavefronts of the lanes kernel (experiment, MCPT_COST_ORDER): per-tile step counts of a low-spp probe
     uint32_t *tile_steps_dev = nullptr;
     uint32_t tile_steps_capacity = 0;
+    unsigned long long *wave_clock_dev = nullptr; // diagnostic: MCPT_WAVE_CLOCK
     unsigned long long *mesh_table_dev = nullptr; // probed hand-out table of a scene outside LDS (cost_order_* say for which range)
     uint32_t mesh_table_capacity = 0;
     bool mesh_table_ready = false;
@@ -208,6 +209,8 @@ struct mcpt_renderer
             (void)hipFree(walk_spill_dev);
         if (tile_steps_dev)
             (void)hipFree(tile_steps_dev);
+        if (wave_clock_dev)
+            (void)hipFree(wave_clock_dev);
         if (mesh_table_dev)
             (void)hipFree(mesh_table_dev);
         if (tile_keys_dev)
@@ -1197,6 +1200,17 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                 spread *= 2u;
             job.lane_spread = spread;
         }
+        // DIAGNOSTIC: MCPT_WAVE_CLOCK=<file> — start and end time (100 MHz clock) of every wavefront of the render launch, written
+        // to <file> after a blocking draw (RenderJob::wave_clock; tools/experiments/wave_timeline.py reads it)
+        static const char *wave_clock_file = std::getenv("MCPT_WAVE_CLOCK");
+        constexpr size_t kWaveClockWords = 2u * 8u * 4u; // per CU: at most 8 workgroups of 4 wavefronts, two words each
+        if (wave_clock_file && blocking)
+        {
+            if (!r->wave_clock_dev)
+                Check(hipMalloc(reinterpret_cast<void **>(&r->wave_clock_dev), r->n_cus * kWaveClockWords * sizeof(unsigned long long)), "allocate wave clocks");
+            Check(hipMemsetAsync(r->wave_clock_dev, 0, r->n_cus * kWaveClockWords * sizeof(unsigned long long), stream), "clear wave clocks");
+            job.wave_clock = r->wave_clock_dev;
+        }
         hipError_t sorted = hipErrorNotSupported;
         if (job.sort_classes && counters == nullptr)
             sorted = mcpt::LaunchRenderSorted(r->dev, job, render_target, stream, r->n_cus, &variant);
@@ -1251,6 +1265,16 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         Check(hipEventRecord(r->ev_end, stream), "record event");
     if (blocking)
         Check(hipStreamSynchronize(stream), "draw");
+    if (blocking && job.wave_clock)
+    {
+        std::vector<unsigned long long> clocks(size_t(r->n_cus) * 64u);
+        Check(hipMemcpy(clocks.data(), r->wave_clock_dev, clocks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost), "read wave clocks");
+        if (FILE *f = std::fopen(std::getenv("MCPT_WAVE_CLOCK"), "wb"))
+        {
+            std::fwrite(clocks.data(), sizeof(unsigned long long), clocks.size(), f);
+            std::fclose(f);
+        }
+    }
     if (stats)
     {
         *stats = mcpt_stats{};

@@ -83,6 +83,9 @@ struct RenderJob
     // lean instantiations (where it is the measured choice), 2 = wherever an instantiation with it exists (also the class-sorted
     // full-feature kernels).  The image does not depend on it.
     uint32_t pool_walk;
+    // DIAGNOSTIC (may be null; MCPT_WAVE_CLOCK=<file> sets it, capi.cpp): two words per wavefront of the launch — the constant
+    // 100 MHz clock (s_memrealtime) when the wavefront starts and when it leaves the kernel.  What a frame's tail looks like.
+    unsigned long long *wave_clock;
 };
 
 // ---- stream kernel (stream_core.h, stream_kernel_impl.h) ------------------------------------------

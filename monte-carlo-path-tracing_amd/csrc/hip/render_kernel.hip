@@ -152,7 +152,8 @@ hipError_t LaunchIntersect(const DeviceScene &sc, uint32_t n, const float *rays,
         return hipSuccess;
     if (pool_walk && !reference_walk && !sc.integrator.has_masks)
     {
-        if (sc.integrator.n_pool_nodes == 0 || sc.integrator.n_pool_nodes > kPoolMaxRefBig || sc.integrator.pool_depth > kPoolMaxDepth)
+        if (sc.integrator.n_pool_nodes == 0 || sc.integrator.n_pool_nodes > kPoolMaxRefBig || sc.integrator.pool_depth > kPoolMaxDepth ||
+            (MCPT_POOL_QUANT != 0 && (sc.integrator.n_wide_nodes == 0 || sc.integrator.n_wide_nodes > kPoolMaxRefBig)))
             return hipErrorNotSupported;
         hipLaunchKernelGGL(intersect_pool_kernel, dim3((n + 255) / 256), dim3(256), 4 * pool_wave_words(true, true) * sizeof(uint32_t), stream, sc, n,
                            rays, out);
@@ -205,7 +206,9 @@ static bool PoolSubsets()
 // during a walk: the visiting order is part of the image), the 4-wide hierarchy within the items' 26 bits and the lists' head room.
 bool PoolBigSupports(const DeviceScene &sc)
 {
+    // (MCPT_POOL_QUANT: the node items name records of wide_nodes — the same collapse, plus its padding records)
     return !sc.integrator.has_masks && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kPoolMaxRefBig &&
+           (MCPT_POOL_QUANT == 0 || (sc.integrator.n_wide_nodes != 0 && sc.integrator.n_wide_nodes <= kPoolMaxRefBig)) &&
            sc.integrator.n_prims <= kPoolMaxRefBig && sc.integrator.pool_depth <= kPoolMaxDepth;
 }
 

@@ -91,6 +91,8 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     static_assert(((kFeatures & kFeatLowDisc) != 0) == (MCPT_LOW_DISCREPANCY_ACTIVE != 0), "low-discrepancy instantiations live in their own translation unit");
 #endif
     extern __shared__ float4 lds_geometry[];
+    if (job.wave_clock && (threadIdx.x & 63u) == 0)
+        job.wave_clock[2u * (blockIdx.x * (kBlockSize / 64u) + (threadIdx.x >> 6))] = wall_clock64();
     DeviceScene sc = sc_in;
     uint32_t n_staged = 0;
     if (kLdsGeometry)
@@ -310,6 +312,8 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
         steps += helper ? 0u : 1u;
     }
 
+    if (job.wave_clock && (threadIdx.x & 63u) == 0)
+        job.wave_clock[2u * (blockIdx.x * (kBlockSize / 64u) + (threadIdx.x >> 6)) + 1u] = wall_clock64();
     if (kCount)
     {
         atomicAdd(&counters->closest_rays, static_cast<unsigned long long>(local.closest_rays));

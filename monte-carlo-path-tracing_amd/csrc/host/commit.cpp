@@ -370,8 +370,26 @@ void BuildWideNodes(FlatScene &fs)
     std::vector<Todo> todo{{0u, 1u}};
     std::vector<uint4> &out = fs.wide_nodes;
     uint32_t worst_stack = 1;
+    // Two 64-byte records share a 128-byte cache line, the inner children of a node get consecutive numbers (breadth-first), and
+    // the pool walk (pool_walk.h) lists the children a ray entered next to each other: neighbouring lanes of its next step read
+    // sibling records with ONE instruction.  MCPT_WIDE_ALIGN=1 starts the inner children of a node with two or more of them on an
+    // even number (a padding record nobody references fills the odd slot before), so that four siblings lie in two lines, never
+    // three.  Measured (round 5, profiles/r05_experiments/quantised_pool_nodes_ab.json): no gain — dragon/scene.xml +-0 inside its
+    // spread, matpreview 1.2-1.6 % slower (more records under the same caches) — so it is off unless asked for.
+    static const bool align_pairs = []
+    {
+        const char *e = std::getenv("MCPT_WIDE_ALIGN");
+        return e != nullptr && std::atoi(e) != 0;
+    }();
+    constexpr uint32_t kPadding = 0xFFFFFFFFu;
     for (size_t k = 0; k < todo.size(); ++k)
     {
+        if (todo[k].binary == kPadding)
+        {
+            for (int v = 0; v < 4; ++v)
+                out.push_back(v == 1 ? uint4{kWalkDone, kWalkDone, kWalkDone, kWalkDone} : uint4{0u, 0u, 0u, 0u});
+            continue;
+        }
         Child kids[4];
         int n = children_of(todo[k].binary, kids);
         // take grandchildren, largest surface first, while there is room
@@ -429,6 +447,11 @@ void BuildWideNodes(FlatScene &fs)
         uint32_t refs[4] = {kWalkDone, kWalkDone, kWalkDone, kWalkDone};
         const uint32_t pushes = n > 0 ? static_cast<uint32_t>(n - 1) : 0u;
         worst_stack = std::max(worst_stack, todo[k].stack_above + pushes);
+        int inner = 0;
+        for (int i = 0; i < n; ++i)
+            inner += (kids[i].ref & kWalkLeaf) ? 0 : 1;
+        if (align_pairs && inner >= 2 && (todo.size() & 1u))
+            todo.push_back(Todo{kPadding, 0u});
         for (int i = 0; i < n; ++i)
         {
             if (kids[i].ref & kWalkLeaf)

@@ -63,6 +63,28 @@ static_assert(kPoolPrimItems >= kPoolPrimAt + 256u, "a node step of 64 lanes can
 constexpr uint32_t kPoolMaxRef = 1023;   // node and slot indices must fit 10 bits (16-bit items: scenes in LDS)
 constexpr uint32_t kPoolMaxRefBig = (1u << 26) - 1u; // ... 26 bits (32-bit items: kFeatPoolBig)
 
+// Scenes outside LDS (kBig): the node step reads the QUANTISED 4-wide form of the hierarchy (DeviceScene::wide_nodes: 64 bytes per
+// node — four children's boxes as 8-bit offsets on the node's own grid, decoded boxes contain the exact ones, siblings adjacent, two
+// nodes per 128-byte cache line) instead of the exact one (pool_nodes: 128 bytes), and the primitive step applies the primitive's
+// own leaf-box test, which is what the exact hierarchy's last box test was (test_slot's kLeafCheck; commit.cpp, BuildWideNodes).
+// Same reachability, same candidates, same answers — half the bytes per node visit through L2 / the memory-side cache, which is what
+// the mesh kernels wait for (round 5).  -DMCPT_POOL_QUANT=0 builds the exact form for A/B measurements.
+#ifndef MCPT_POOL_QUANT
+#define MCPT_POOL_QUANT 1
+#endif
+#ifndef MCPT_POOL_CHILD_PARALLEL
+#define MCPT_POOL_CHILD_PARALLEL 1 // node steps with 4 / 2 lanes per item when the items are few (walk_pool); 0: always one lane per item
+#endif
+
+// The leaf-box test of a TRIANGLE slot on the slot's own copy of the vertices (reference_leaf_box_passes reads tri_pos: the same
+// values, one more gather): triangle.cpp:9-15's box = the bounds of the three vertices, aabb.cpp:29-48's slab test with `t_max`.
+MCPT_HD bool slot_leaf_box_passes(const float4 *p, Ray ray, float t_max)
+{
+    ray.t_max = t_max;
+    const V3 lo = vmin(vmin(xyz(p[0]), xyz(p[1])), xyz(p[2])), hi = vmax(vmax(xyz(p[0]), xyz(p[1])), xyz(p[2]));
+    return box_hit(float4{lo.x, lo.y, lo.z, 0.0f}, float4{hi.x, hi.y, hi.z, 0.0f}, ray);
+}
+
 MCPT_HD constexpr uint32_t pool_ray_words(bool analytic) { return analytic ? 16u : 12u; }
 MCPT_HD constexpr uint32_t pool_wave_words(bool analytic, bool big = false)
 {
@@ -126,6 +148,7 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
 {
     using Item = typename std::conditional<kBig, uint32_t, uint16_t>::type; // ray << kRefBits | node or slot
     constexpr uint32_t kRefBits = kBig ? 26u : 10u, kRefMask = (1u << kRefBits) - 1u;
+    constexpr bool kQuant = kBig && (MCPT_POOL_QUANT != 0); // the quantised node records + the leaf-box test at the primitive
     if (sc.integrator.n_walk_nodes == 0)
         return false;
     constexpr uint32_t kRayVecs = pool_ray_words(kAnalytic) / 4u;
@@ -160,6 +183,102 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
     // (wavefront-uniform values, kept in scalar registers: `uni` tells the compiler so where it cannot see it)
     auto uni = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
     uint32_t n_nodes = uni(static_cast<uint32_t>(__popcll(m_rays))), n_prims = 0;
+    // One node step over the top `k` items with G lanes per item (G = 1, 2, 4), each lane testing kPer = 4 / G children of its
+    // item's node.  Everything inside ONE region of the working lanes — ballots included, they only see those lanes: predicates
+    // that leave the region would travel as 0 / 1 words through vector registers.
+    auto node_step = [&](auto g_tag, const uint32_t k)
+    {
+        constexpr uint32_t G = decltype(g_tag)::value, kPer = 4u / G;
+        uint32_t next_nodes = 0, next_prims = 0;
+        if (rank < k * G)
+        {
+            const uint32_t sub = rank & (G - 1u), first = sub * kPer; // this lane's children: first ... first + kPer - 1 (G = 1: all four)
+            if (kCount)
+                stats.node_tests += kPer;
+            const uint32_t item = node_items[n_nodes - 1u - rank / G];
+            const uint32_t ray_bits = item & ~kRefMask, r = item >> kRefBits, node = item & kRefMask;
+            const float4 a = rays[kRayVecs * r], b = rays[kRayVecs * r + 1];
+            const uint32_t pack = __float_as_uint(b.w);
+            float enter[kPer], leave[kPer];
+            uint32_t ref[kPer];
+            if constexpr (kQuant)
+            {
+                // one 64-byte record (16-byte reads of one half cache line): grid origin + exponents | references | the planes
+                // lo.x lo.y lo.z hi.x | hi.y hi.z, one byte per child.  Planes are decoded to world space — origin + 2^e * q, the
+                // operations the quantiser verified (the product is exact, so the fused form rounds once, to the same value) — and
+                // go through the same slab test as the exact boxes they contain.
+                const uint4 *wq = sc.wide_nodes + 4u * static_cast<size_t>(node);
+                const uint4 n0 = wq[0], n2 = wq[2], n3 = wq[3];
+                if constexpr (G == 1)
+                {
+                    const uint4 refs = wq[1];
+                    ref[0] = refs.x, ref[1] = refs.y, ref[2] = refs.z, ref[3] = refs.w;
+                }
+                else if constexpr (G == 2)
+                {
+                    const uint2 refs = reinterpret_cast<const uint2 *>(wq + 1)[sub];
+                    ref[0] = refs.x, ref[1] = refs.y;
+                }
+                else
+                    ref[0] = reinterpret_cast<const uint32_t *>(wq + 1)[sub];
+                const float gx = __uint_as_float(n0.x), gy = __uint_as_float(n0.y), gz = __uint_as_float(n0.z);
+                const float sx = __uint_as_float((n0.w & 0xFFu) << 23), sy = __uint_as_float(((n0.w >> 8) & 0xFFu) << 23), sz = __uint_as_float(((n0.w >> 16) & 0xFFu) << 23);
+                const bool px = (pack & 0xffu) == 0u, py = ((pack >> 8) & 0xffu) == 16u, pz = ((pack >> 16) & 0xffu) == 32u; // (dir_rcp > 0)
+                const uint32_t near_x = px ? n2.x : n2.w, far_x = px ? n2.w : n2.x;
+                const uint32_t near_y = py ? n2.y : n3.x, far_y = py ? n3.x : n2.y;
+                const uint32_t near_z = pz ? n2.z : n3.y, far_z = pz ? n3.y : n2.z;
+#pragma unroll
+                for (uint32_t j = 0; j < kPer; ++j)
+                {
+                    const uint32_t shift = 8u * (first + j); // (a constant when G = 1)
+                    auto plane = [shift](uint32_t word, float scale, float origin) { return __builtin_fmaf(scale, static_cast<float>((word >> shift) & 0xFFu), origin); };
+                    enter[j] = fmaxf(fmaxf(fmaxf(kEpsDistance, (plane(near_x, sx, gx) - a.x) * b.x), (plane(near_y, sy, gy) - a.y) * b.y), (plane(near_z, sz, gz) - a.z) * b.z);
+                    leave[j] = fminf(fminf(fminf(a.w, (plane(far_x, sx, gx) - a.x) * b.x), (plane(far_y, sy, gy) - a.y) * b.y), (plane(far_z, sz, gz) - a.z) * b.z);
+                }
+            }
+            else
+            {
+                // the planes the ray enters / leaves through, of this lane's children: lo.x at 0, lo.y 16, lo.z 32, hi.x 48, hi.y 64,
+                // hi.z 80 of the 128-byte record, four children each; the references at 96
+                const char *w = reinterpret_cast<const char *>(sc.pool_nodes) + 128u * node + 4u * first;
+                const uint32_t ox = pack & 0xffu, oy = (pack >> 8) & 0xffu, oz = (pack >> 16) & 0xffu;
+                struct Planes
+                {
+                    float v[kPer];
+                };
+                const Planes nx = *reinterpret_cast<const Planes *>(w + ox), fx = *reinterpret_cast<const Planes *>(w + (48u - ox));
+                const Planes ny = *reinterpret_cast<const Planes *>(w + oy), fy = *reinterpret_cast<const Planes *>(w + (80u - oy));
+                const Planes nz = *reinterpret_cast<const Planes *>(w + oz), fz = *reinterpret_cast<const Planes *>(w + (112u - oz));
+                const Planes rf = *reinterpret_cast<const Planes *>(w + 96u);
+#pragma unroll
+                for (uint32_t j = 0; j < kPer; ++j)
+                {
+                    enter[j] = fmaxf(fmaxf(fmaxf(kEpsDistance, (nx.v[j] - a.x) * b.x), (ny.v[j] - a.y) * b.y), (nz.v[j] - a.z) * b.z);
+                    leave[j] = fminf(fminf(fminf(a.w, (fx.v[j] - a.x) * b.x), (fy.v[j] - a.y) * b.y), (fz.v[j] - a.z) * b.z);
+                    ref[j] = __float_as_uint(rf.v[j]);
+                }
+            }
+            uint32_t at_nodes = n_nodes - k, at_prims = n_prims;
+#pragma unroll
+            for (uint32_t j = 0; j < kPer; ++j)
+            {
+                // (quantised form: an unused child — kWalkDone, an inverted box — is never entered, whatever a degenerate grid or a NaN
+                //  ray says; exact form: an unused child names slot 0 behind a box that only a NaN ray "enters", like the reference's)
+                const bool hit_c = enter[j] <= leave[j] && (!kQuant || ref[j] != kWalkDone), leaf_c = static_cast<int32_t>(ref[j]) < 0; // kWalkLeaf = the sign bit
+                // (ballots of plain comparisons, combined as 64-bit masks: a ballot of a combined predicate goes through a
+                //  vector register as a 0 / 1 word)
+                const unsigned long long b_hit = __ballot(hit_c), b_leaf = __ballot(leaf_c);
+                const unsigned long long m_node = b_hit & ~b_leaf, m_leaf = b_hit & b_leaf;
+                if (hit_c && !leaf_c)
+                    (node_items + at_nodes)[pool_rank(m_node)] = static_cast<Item>(ray_bits | ref[j]);
+                if (hit_c && leaf_c)
+                    (prim_items + at_prims)[pool_rank(m_leaf)] = static_cast<Item>(ray_bits | (ref[j] & kRefMask));
+                at_nodes += static_cast<uint32_t>(__popcll(m_node)), at_prims += static_cast<uint32_t>(__popcll(m_leaf));
+            }
+            next_nodes = at_nodes, next_prims = at_prims;
+        }
+        n_nodes = uni(next_nodes), n_prims = uni(next_prims); // (the first active lane has rank 0 < k G: it took part)
+    };
     {
         pool_sync();
         for (;;)
@@ -190,8 +309,23 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
                         const float *ro = reinterpret_cast<const float *>(&rays[kRayVecs * r]), *pf = reinterpret_cast<const float *>(p);
                         const float ox = ro[kx], oy = ro[ky], oz = ro[kz];
                         a.x = a.y = a.z = 0.0f, a.w = ro[3];
-                        h = triangle_probe_permuted(pf[kx] - ox, pf[ky] - oy, pf[kz] - oz, pf[4 + kx] - ox, pf[4 + ky] - oy, pf[4 + kz] - oz, pf[8 + kx] - ox,
-                                                    pf[8 + ky] - oy, pf[8 + kz] - oz, V3{c.x, c.y, c.z});
+                        const float Ax = pf[kx] - ox, Ay = pf[ky] - oy, Az = pf[kz] - oz, Bx = pf[4 + kx] - ox, By = pf[4 + ky] - oy, Bz = pf[4 + kz] - oz;
+                        const float Cx = pf[8 + kx] - ox, Cy = pf[8 + ky] - oy, Cz = pf[8 + kz] - oz;
+                        h = triangle_probe_permuted(Ax, Ay, Az, Bx, By, Bz, Cx, Cy, Cz, V3{c.x, c.y, c.z});
+                        if (kQuant)
+                        {
+                            // the primitive's own leaf box (box_hit on the bounds of the three vertices) under the ray's current
+                            // bound, on the offsets that are already here: min / max commute with subtracting the origin (rounding is
+                            // monotone) and the slab test treats the axes alike, so their permuted order changes nothing
+                            const float *rb = reinterpret_cast<const float *>(&rays[kRayVecs * r + 1]);
+                            const float ix = rb[kx], iy = rb[ky], iz = rb[kz];
+                            const float lx = fminf(fminf(Ax, Bx), Cx), ly = fminf(fminf(Ay, By), Cy), lz = fminf(fminf(Az, Bz), Cz);
+                            const float hx = fmaxf(fmaxf(Ax, Bx), Cx), hy = fmaxf(fmaxf(Ay, By), Cy), hz = fmaxf(fmaxf(Az, Bz), Cz);
+                            const bool px = ix > 0, py = iy > 0, pz = iz > 0;
+                            const float t_enter = fmaxf(fmaxf(fmaxf(kEpsDistance, (px ? lx : hx) * ix), (py ? ly : hy) * iy), (pz ? lz : hz) * iz);
+                            const float t_exit = fminf(fminf(fminf(a.w, (px ? hx : lx) * ix), (py ? hy : ly) * iy), (pz ? hz : lz) * iz);
+                            h.hit = h.hit && t_enter <= t_exit;
+                        }
                     }
                     else
                     {
@@ -207,6 +341,10 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
                             q.dir = V3{d.x, d.y, d.z};
                         }
                         h = probe_slot<kAnalytic>(sc, p, q);
+                        // (a sliver's box in the hierarchy is a grown one in both forms and its own rules below decide)
+                        if (kQuant && h.hit && !(kSlivers && (as_uint(p[2].w) & kWalkSliver) != 0))
+                            h.hit = (!kAnalytic || sc.instances[as_uint(p[1].w)].kind == kInstTriangles) ? slot_leaf_box_passes(p, q, a.w)
+                                                                                                        : reference_leaf_box_passes<kAnalytic>(sc, as_uint(p[1].w), as_uint(p[0].w), q, a.w);
                     }
                     float *bound = reinterpret_cast<float *>(&rays[kRayVecs * r]) + 3;
                     // (a sliver reached through its grown box: would the reference's own leaf box let the ray in?)
@@ -235,58 +373,31 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
                 pool_sync();
                 continue;
             }
-            // ---- node phase: the top items, one per lane; the FOUR children of a node (DeviceScene::pool_nodes) tested, the
-            //      hit ones pushed (in the order the node stores them: a model of this schedule with near children on top of far
+            // ---- node phase: the top items of the node list; the FOUR children of a node (DeviceScene::pool_nodes / wide_nodes) tested,
+            //      the hit ones pushed (in the order the node stores them: a model of this schedule with near children on top of far
             //      ones gave 11.9 instead of 12.4 steps per round on cornell — not worth a sort per item) ----
-            // (head room: a step with k lanes grows the list by at most 3 k.  Below kPoolNodeFull every worker takes an item
+            // (head room: a step with k items grows the list by at most 3 k.  Below kPoolNodeFull every worker takes an item
             //  if that fits; above, ONE does — a depth-first walk, which adds at most 3 x the tree's depth to the list)
             uint32_t k = uni(n_nodes < n_workers ? n_nodes : n_workers);
             const uint32_t room = uni(n_nodes < kPoolNodeFull ? (kPoolNodeFull - n_nodes + 2u) / 3u : 1u);
             k = uni(k < room ? k : room);
             if (kCount && rank == 0)
                 ++stats.wave_node_steps;
-            // (everything inside ONE region of the k working lanes — ballots included, they only see those lanes: predicates that
-            //  leave the region would travel as 0 / 1 words through vector registers)
-            uint32_t next_nodes = 0, next_prims = 0;
-            if (rank < k)
-            {
-                if (kCount)
-                    stats.node_tests += 4;
-                const uint32_t item = node_items[n_nodes - 1u - rank];
-                const uint32_t ray_bits = item & ~kRefMask, r = item >> kRefBits, node = item & kRefMask;
-                const float4 a = rays[kRayVecs * r], b = rays[kRayVecs * r + 1];
-                const uint32_t pack = __float_as_uint(b.w);
-                const char *w = reinterpret_cast<const char *>(sc.pool_nodes) + 128u * node;
-                const uint32_t ox = pack & 0xffu, oy = (pack >> 8) & 0xffu, oz = (pack >> 16) & 0xffu;
-                // the planes the ray enters / leaves through, of all four children: lo.x at 0, lo.y 16, lo.z 32, hi.x 48, hi.y 64, hi.z 80
-                const float4 nx4 = *reinterpret_cast<const float4 *>(w + ox), fx4 = *reinterpret_cast<const float4 *>(w + (48u - ox));
-                const float4 ny4 = *reinterpret_cast<const float4 *>(w + oy), fy4 = *reinterpret_cast<const float4 *>(w + (80u - oy));
-                const float4 nz4 = *reinterpret_cast<const float4 *>(w + oz), fz4 = *reinterpret_cast<const float4 *>(w + (112u - oz));
-                const uint4 refs = *reinterpret_cast<const uint4 *>(w + 96u);
-                const float nxs[4] = {nx4.x, nx4.y, nx4.z, nx4.w}, fxs[4] = {fx4.x, fx4.y, fx4.z, fx4.w};
-                const float nys[4] = {ny4.x, ny4.y, ny4.z, ny4.w}, fys[4] = {fy4.x, fy4.y, fy4.z, fy4.w};
-                const float nzs[4] = {nz4.x, nz4.y, nz4.z, nz4.w}, fzs[4] = {fz4.x, fz4.y, fz4.z, fz4.w};
-                const uint32_t ref[4] = {refs.x, refs.y, refs.z, refs.w};
-                uint32_t at_nodes = n_nodes - k, at_prims = n_prims;
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                {
-                    const float enter = fmaxf(fmaxf(fmaxf(kEpsDistance, (nxs[c] - a.x) * b.x), (nys[c] - a.y) * b.y), (nzs[c] - a.z) * b.z);
-                    const float leave = fminf(fminf(fminf(a.w, (fxs[c] - a.x) * b.x), (fys[c] - a.y) * b.y), (fzs[c] - a.z) * b.z);
-                    const bool hit_c = enter <= leave, leaf_c = static_cast<int32_t>(ref[c]) < 0; // kWalkLeaf = the sign bit
-                    // (ballots of plain comparisons, combined as 64-bit masks: a ballot of a combined predicate goes through a
-                    //  vector register as a 0 / 1 word)
-                    const unsigned long long b_hit = __ballot(hit_c), b_leaf = __ballot(leaf_c);
-                    const unsigned long long m_node = b_hit & ~b_leaf, m_leaf = b_hit & b_leaf;
-                    if (hit_c && !leaf_c)
-                        (node_items + at_nodes)[pool_rank(m_node)] = static_cast<Item>(ray_bits | ref[c]);
-                    if (hit_c && leaf_c)
-                        (prim_items + at_prims)[pool_rank(m_leaf)] = static_cast<Item>(ray_bits | (ref[c] & kRefMask));
-                    at_nodes += static_cast<uint32_t>(__popcll(m_node)), at_prims += static_cast<uint32_t>(__popcll(m_leaf));
-                }
-                next_nodes = at_nodes, next_prims = at_prims;
-            }
-            n_nodes = uni(next_nodes), n_prims = uni(next_prims); // (the first active lane has rank 0 < k: it took part)
+            // CHILD-PARALLEL steps (round 5).  With k items and 64 lanes, one lane per item leaves 64 - k lanes idle while the k busy ones
+            // test four children one after the other.  When the items are few — the start and the tail of every query, and every step of
+            // a wavefront that holds a handful of paths (a rank's small tile share, the end of a frame: the lanes without a path are
+            // workers here) — G = 4 or 2 lanes share an item and test 4 / G children each: the same tests, pushes and items in a
+            // quarter / half of the instructions, which is what a near-empty wavefront's step costs (its chain of dependent
+            // instructions), and what a VALU-bound kernel pays per item.  Which lane tests which child changes the ORDER of the pushed
+            // items only; the walk's answers do not depend on it.
+#if MCPT_POOL_CHILD_PARALLEL
+            if (k * 4u <= n_workers)
+                node_step(std::integral_constant<uint32_t, 4u>{}, k);
+            else if (k * 2u <= n_workers)
+                node_step(std::integral_constant<uint32_t, 2u>{}, k);
+            else
+#endif
+                node_step(std::integral_constant<uint32_t, 1u>{}, k);
             pool_sync();
         }
     }

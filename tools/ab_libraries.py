@@ -29,7 +29,16 @@ def child(workload, draws):
     if os.environ.get("MCPT_AB_RNG"):  # throughput modes: 1 PCG-hashed streams, 2 Sobol points (--rng)
         r.set_rng(int(os.environ["MCPT_AB_RNG"]))
     ms, frame = [], None
-    for _ in range(draws + 1):
+    share = int(os.environ.get("MCPT_AB_SHARE", "1"))  # > 1: rank 0's packed tile share of an N-GPU job (a near-empty GPU)
+    if share > 1:
+        import numpy as np
+        import torch
+        rng = pkg.capi.TileRange(0, share, 0)
+        buf = torch.zeros(r.tiles_in(rng) * 64 * 3, dtype=torch.float32, device="cuda:0")
+        for _ in range(draws + 1):
+            ms.append(r.draw_device(buf.data_ptr(), rng, packed=True)["kernel_milliseconds"])
+        frame = buf.cpu().numpy()
+    for _ in range(draws + 1 if share <= 1 else 0):
         frame, st = r.draw()
         ms.append(st["kernel_milliseconds"])
     print(json.dumps({"ms": ms[1:], "sha": hashlib.sha256(frame.tobytes()).hexdigest()[:16], "kernel": r.last_kernel()}))
@@ -43,17 +52,26 @@ def main():
     ap.add_argument("--draws", type=int, default=3)
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--rng", type=int, default=0, help="mcpt_renderer_set_rng mode of every renderer (0: the reference's stream)")
+    ap.add_argument("--share", type=int, default=1, help="N > 1: time rank 0's tile share of an N-GPU job instead of the whole frame")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     if a.rng:
         os.environ["MCPT_AB_RNG"] = str(a.rng)
-    libs = [l.split("=", 1) for l in a.libs]
+    if a.share > 1:
+        os.environ["MCPT_AB_SHARE"] = str(a.share)
+    # name=path.so[@VAR=value[@VAR=value ...]]: environment of that arm's processes (commit-time switches)
+    libs, arm_env = [], {}
+    for l in a.libs:
+        n, rest = l.split("=", 1)
+        path, *envs = rest.split("@")
+        libs.append([n, path])
+        arm_env[n] = dict(e.split("=", 1) for e in envs)
     out = {}
     for w in a.workloads.split(","):
         rec = {n: {"ms": [], "sha": set()} for n, _ in libs}
         for _ in range(a.rounds):
             for n, path in libs:
-                env = dict(os.environ, MCPT_LIB=os.path.abspath(path))
+                env = dict(os.environ, MCPT_LIB=os.path.abspath(path), **arm_env[n])
                 p = subprocess.run([sys.executable, __file__, "--child", w, str(a.draws)], env=env, capture_output=True, text=True)
                 if p.returncode != 0:
                     rec[n]["error"] = p.stderr[-400:]
