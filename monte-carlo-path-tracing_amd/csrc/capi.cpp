@@ -169,6 +169,7 @@ struct mcpt_renderer
     unsigned long long *mesh_table_dev = nullptr; // probed hand-out table of a scene outside LDS (cost_order_* say for which range)
     uint32_t mesh_table_capacity = 0;
     bool mesh_table_ready = false;
+    uint32_t mesh_level_until[2][3] = {{0, 0, 0}, {0, 0, 0}}; // RenderJob::level_until of the probed table, for 3 / 4 wavefronts per SIMD
     bool range_fresh = false;             // the range's statistics were just (re)read: tables made from them are stale
     unsigned long long range_hits = 0;    // camera rays of the range that hit something (pre-pass)
     int stream_waves_mode = -1;           // mcpt_renderer_set_stream_waves: -1 the library's rule, 2 / 3 / 4
@@ -779,6 +780,53 @@ std::vector<unsigned long long> CostOrderedTable(const std::vector<uint32_t> &st
     return table;
 }
 
+// LANES PER PATH BY TILE COST (RenderJob::level_until).  `steps`: the probe's cost per tile.  A wavefront's fair share of the
+// frame is m = (sum of all costs) / (resident wavefronts); a tile of cost c, rendered by one wavefront alone (64 paths: dense),
+// takes about c / m of the whole frame — with c / m near 1 that tile IS the frame, however the rest is balanced, because its 64
+// pixels are 64 sequential chains.  Handed out to every 2nd / 4th / 8th lane, the chains run with helper lanes at about
+// 0.7 / 0.55 / 0.5 of their dense time (measured on rank shares: profiles/r04_experiments/pool_walk_mesh_rank_shares.json,
+// profiles/r05_experiments/child_parallel_node_steps_ab_share8.json).  Rule: the sparsest of 1 / 2 / 4 / 8 lanes per path that is
+// needed to bring c / m x (relative chain time) under kappa (MCPT_LEVEL_KAPPA, default 0.6); thresholds are POSITIONS (items) in
+// the most-expensive-first order, so they are monotone by construction.  MCPT_LEVELS=0 switches it off.
+void LevelThresholds(const std::vector<uint32_t> &steps, uint32_t resident_wavefronts, uint32_t out[3])
+{
+    out[0] = out[1] = out[2] = 0;
+    static const bool on = []
+    {
+        const char *e = std::getenv("MCPT_LEVELS");
+        return !e || std::atoi(e) != 0;
+    }();
+    static const double kappa = []
+    {
+        const char *e = std::getenv("MCPT_LEVEL_KAPPA");
+        return e ? std::atof(e) : 0.6;
+    }();
+    if (!on || steps.empty())
+        return;
+    std::vector<uint32_t> sorted(steps);
+    std::sort(sorted.begin(), sorted.end(), std::greater<uint32_t>());
+    double sum = 0.0;
+    for (uint32_t c : sorted)
+        sum += c;
+    if (!(sum > 0.0))
+        return;
+    const double share = sum / std::max(1u, resident_wavefronts);
+    const double relative_time[3] = {0.55, 0.7, 1.0}; // of the NEXT denser level: 8 lanes per path are needed when 4 do not do, ...
+    for (int level = 0; level < 3; ++level)
+    {
+        uint32_t n = 0;
+        while (n < sorted.size() && sorted[n] / share * relative_time[level] > kappa)
+            ++n;
+        out[level] = n * 64u;
+    }
+    // (never the whole job: what is handed out last runs among lanes that are running out of work anyway)
+    for (int level = 0; level < 3; ++level)
+        out[level] = std::min<uint32_t>(out[level], static_cast<uint32_t>(sorted.size() / 2u) * 64u);
+    if (std::getenv("MCPT_COST_DEBUG"))
+        std::fprintf(stderr, "lanes per path by tile cost: %u resident wavefronts, most expensive tile %.2f of a wavefront's share; 8 / 4 / 2 lanes per path until item %u / %u / %u of %zu\n",
+                     resident_wavefronts, sorted[0] / share, out[0], out[1], out[2], sorted.size() * 64u);
+}
+
 // Enqueues one render launch; optionally waits and reports timings.
 void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, bool packed, hipStream_t stream,
           bool blocking, bool counted, mcpt_stats *stats)
@@ -1057,7 +1105,8 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                     if (r->range_fresh)
                     {
                         r->range_fresh = false;
-                        r->mesh_table_ready = 2ull * r->range_hits >= static_cast<unsigned long long>(job.n_items) * r->dev.camera.spp;
+                        // (MCPT_COST_ORDER=4, measurements: every mesh job is ordered by probed cost, whatever its hit count)
+                        r->mesh_table_ready = CostOrderEnv() >= 4 || 2ull * r->range_hits >= static_cast<unsigned long long>(job.n_items) * r->dev.camera.spp;
                         if (r->mesh_table_ready)
                         {
                             Check(hipMemsetAsync(r->tile_steps_dev, 0, n_tiles * sizeof(uint32_t), stream), "clear tile step counts");
@@ -1073,6 +1122,8 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                             Check(hipMemcpyAsync(steps.data(), r->tile_steps_dev, n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "read tile step counts");
                             Check(hipStreamSynchronize(stream), "wait for the cost probe");
                             const std::vector<unsigned long long> table = CostOrderedTable(steps, r->n_cus, 0);
+                            LevelThresholds(steps, r->n_cus * 12u, r->mesh_level_until[0]);
+                            LevelThresholds(steps, r->n_cus * 16u, r->mesh_level_until[1]);
                             Check(hipMemcpyAsync(r->mesh_table_dev, table.data(), n_tiles * sizeof(unsigned long long), hipMemcpyHostToDevice, stream), "upload the tile table");
                             Check(hipStreamSynchronize(stream), "wait for the tile table");
                             Check(hipMemsetAsync(r->work_counter_dev, 0, sizeof(uint32_t), stream), "clear work counter");
@@ -1081,7 +1132,13 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                     probed = r->mesh_table_ready;
                 }
                 if (probed)
+                {
                     job.tile_order = r->mesh_table_dev;
+                    // (reference random stream only: the independent-sample modes cut the chains instead)
+                    if (r->rng_mode == 0 && !counted && !small_scene)
+                        for (int i = 0; i < 3; ++i)
+                            job.level_until[i] = r->mesh_level_until[0][i], job.level_until_4[i] = r->mesh_level_until[1][i];
+                }
                 else if (CostOrderEnv() >= 1 && range_stats)
                     job.tile_order = nullptr; // (not of the ordered class — the host knows the hit count: image order, no table)
                 else
@@ -1203,7 +1260,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         // DIAGNOSTIC: MCPT_WAVE_CLOCK=<file> — start and end time (100 MHz clock) of every wavefront of the render launch, written
         // to <file> after a blocking draw (RenderJob::wave_clock; tools/experiments/wave_timeline.py reads it)
         static const char *wave_clock_file = std::getenv("MCPT_WAVE_CLOCK");
-        constexpr size_t kWaveClockWords = 2u * 8u * 4u; // per CU: at most 8 workgroups of 4 wavefronts, two words each
+        constexpr size_t kWaveClockWords = 4u * 8u * 4u; // per CU: at most 8 workgroups of 4 wavefronts, four words each
         if (wave_clock_file && blocking)
         {
             if (!r->wave_clock_dev)
@@ -1246,6 +1303,8 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         r->variant += " + camera-ray pre-pass";
     if (dynamic_work)
         r->variant += job.tile_order && r->dev.prehit ? ", work counter (tiles most expensive first)" : ", work counter";
+    if (!streamed && !wavefront && !queued && (job.level_until[2] != 0 || job.level_until_4[2] != 0))
+        r->variant += ", 2-8 lanes per path on the most expensive tiles";
     if (job.tile_order && !r->dev.prehit)
         r->variant += uint64_t(job.n_items) > uint64_t(r->n_cus) * 1024u ? ", tiles handed out by probed cost" : ", wavefronts laid out by probed tile cost";
     r->last_tile_order = job.tile_order ? 1 : 0;
@@ -1267,7 +1326,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         Check(hipStreamSynchronize(stream), "draw");
     if (blocking && job.wave_clock)
     {
-        std::vector<unsigned long long> clocks(size_t(r->n_cus) * 64u);
+        std::vector<unsigned long long> clocks(size_t(r->n_cus) * 128u);
         Check(hipMemcpy(clocks.data(), r->wave_clock_dev, clocks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost), "read wave clocks");
         if (FILE *f = std::fopen(std::getenv("MCPT_WAVE_CLOCK"), "wb"))
         {

@@ -83,8 +83,16 @@ struct RenderJob
     // lean instantiations (where it is the measured choice), 2 = wherever an instantiation with it exists (also the class-sorted
     // full-feature kernels).  The image does not depend on it.
     uint32_t pool_walk;
-    // DIAGNOSTIC (may be null; MCPT_WAVE_CLOCK=<file> sets it, capi.cpp): two words per wavefront of the launch — the constant
-    // 100 MHz clock (s_memrealtime) when the wavefront starts and when it leaves the kernel.  What a frame's tail looks like.
+    // LANES PER PATH BY TILE COST (pool-walk kernels with a probed tile_order; all 0: off).  The tiles are handed out most expensive
+    // first, and a pixel is one sequential chain: a tile whose 64 chains would fill a wavefront for most of the frame is the frame's
+    // critical path.  Positions below level_until[0] / [1] / [2] are therefore handed out to every 8th / 4th / 2nd lane of a wavefront
+    // only — the lanes in between are helpers of the wavefront's ray queries (pool_walk.h), so those chains run at 0.5 - 0.7 of the
+    // dense time — and a wavefront stays that sparse while it holds a pixel of such a position (render_kernel_impl.h).  Computed by
+    // the host from the probe's tile costs (capi.cpp, LevelThresholds); the second set is for launches at 4 wavefronts per SIMD.
+    uint32_t level_until[3], level_until_4[3];
+    // DIAGNOSTIC (may be null; MCPT_WAVE_CLOCK=<file> sets it, capi.cpp): four words per wavefront of the launch — the constant
+    // 100 MHz clock (s_memrealtime) when the wavefront starts, when it leaves the kernel and when it last took a pixel, and the
+    // number of pixels it took.  What a frame's tail looks like.
     unsigned long long *wave_clock;
 };
 

@@ -73,6 +73,7 @@ struct Budget
 #define MCPT_POOL_MAX_SPREAD 16
 #endif
 constexpr uint32_t kPoolMaxSpread = MCPT_POOL_MAX_SPREAD; // lanes per path at most, when a launch has fewer pixels than lanes (pool walk)
+constexpr uint32_t kFetchNext = 0xFFFFFFFFu; // a lane's item variable: "ask the work counter when the current pixel is done"
 constexpr uint32_t kCompactWords = 8, kCompactPasses = 4; // a path's 30 state words travel through LDS in four passes of eight
 
 // kLdsGeometry: the arrays the ray queries and the light sampler read (both
@@ -92,7 +93,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
 #endif
     extern __shared__ float4 lds_geometry[];
     if (job.wave_clock && (threadIdx.x & 63u) == 0)
-        job.wave_clock[2u * (blockIdx.x * (kBlockSize / 64u) + (threadIdx.x >> 6))] = wall_clock64();
+        job.wave_clock[4u * (blockIdx.x * (kBlockSize / 64u) + (threadIdx.x >> 6))] = wall_clock64();
     DeviceScene sc = sc_in;
     uint32_t n_staged = 0;
     if (kLdsGeometry)
@@ -174,8 +175,39 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     const bool independent = job.independent_samples != 0;
     if (lane_id % spread != 0)
         q = n_work;
+    // lanes per path by tile cost (RenderJob::level_until): every item comes from the work counter, the first ones too — which lanes
+    // may take one depends on what is being handed out
+    // (kernels outside LDS only: the LDS kernels' compaction retires a lane that waits for its turn, and moves paths to other lanes)
+    const bool levels = C::kPoolBig && job.work_counter != nullptr && job.level_until[2] != 0;
+    const uint32_t counter_base = levels ? 0u : stride;
+    uint32_t my_lg = 0; // log2 of the lanes per path this lane's pixel was handed out with
+    if (levels && q < n_work)
+        q = kFetchNext;
     for (;;)
     {
+        // WORK COUNTER: a lane that needs a new item takes the first one nobody has taken yet — NOW, when it is free, not ahead
+        // of time.  (Rounds 2-4 reserved a lane's next item when it STARTED the current one, to hide the atomic's latency: every
+        // lane then held one item hostage while it worked on another — at the end of a frame the items waiting behind the longest
+        // pixel chains, with the rest of the GPU drained; with the most expensive tiles handed out first, the first TWO items of
+        // every lane were fixed at time 0.  Measured with the wavefront clocks (RenderJob::wave_clock, round 5): dragon/scene.xml's
+        // counter ran dry at 46 % of the frame and half of the wavefront slots were empty on average; matpreview rough conductor
+        // ran its last 40 % on 2 % of its wavefronts.)
+        if (job.work_counter)
+        {
+            bool want = !has_pixel && q == kFetchNext;
+            if (levels && __ballot(want) != 0)
+            {
+                // the sparsest level among the pixels this wavefront holds and the position the counter stands at (an agent-scope
+                // load: the vector cache is not coherent; a stale value is a smaller position, i.e. a sparser level — harmless)
+                const uint32_t held = __ballot(has_pixel && my_lg >= 3u) ? 3u : __ballot(has_pixel && my_lg >= 2u) ? 2u : __ballot(has_pixel && my_lg >= 1u) ? 1u : 0u;
+                const uint32_t at = __hip_atomic_load(job.work_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t next = at < job.level_until[0] ? 3u : at < job.level_until[1] ? 2u : at < job.level_until[2] ? 1u : 0u;
+                const uint32_t lg = held > next ? held : next;
+                want = want && ((threadIdx.x & 63u) & ((1u << lg) - 1u)) == 0u;
+            }
+            if (want)
+                q = counter_base + wave_reserve(job.work_counter, true);
+        }
         // (pool walk: a lane without work of its own stays in the loop as a HELPER of its wavefront's ray queries)
         bool helper = false;
         if (kCompact && job.compact)
@@ -278,12 +310,20 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
             const uint32_t tile = job.tile_first + local_tile * job.tile_stride;
             const uint32_t x = (tile % job.tiles_x) * 8u + (r & 7u), y = (tile / job.tiles_x) * 8u + (r >> 3);
             my_tile = local_tile, steps = 0;
-            // the lane's NEXT item: the first one nobody has taken yet (the launch's lanes start on items 0 .. stride-1),
-            // or, without a counter, the next of its fixed list
-            q = job.work_counter ? stride + wave_reserve(job.work_counter, true) : q + stride;
+            my_lg = !levels ? 0u : position < job.level_until[0] ? 3u : position < job.level_until[1] ? 2u : position < job.level_until[2] ? 1u : 0u;
+            // the lane's NEXT item: whatever the work counter hands out when the lane is free again (the launch's lanes start on
+            // items 0 .. stride-1), or, without a counter, the next of its fixed list
+            q = job.work_counter ? kFetchNext : q + stride;
             if (x >= width || y >= height)
                 continue; // padding of an edge tile
             const uint32_t pixel = y * width + x;
+            if (job.wave_clock)
+            {
+                // (diagnostic: when this wavefront last took a pixel, and how many it took)
+                unsigned long long *wc = job.wave_clock + 4u * (blockIdx.x * (kBlockSize / 64u) + (threadIdx.x >> 6));
+                wc[2] = wall_clock64();
+                atomicAdd(&wc[3], 1ull);
+            }
             start_pixel(st, pixel);
             st.sample = k;
             slot = (job.packed ? item : pixel) + k * job.plane_stride;
@@ -313,7 +353,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     }
 
     if (job.wave_clock && (threadIdx.x & 63u) == 0)
-        job.wave_clock[2u * (blockIdx.x * (kBlockSize / 64u) + (threadIdx.x >> 6)) + 1u] = wall_clock64();
+        job.wave_clock[4u * (blockIdx.x * (kBlockSize / 64u) + (threadIdx.x >> 6)) + 1u] = wall_clock64();
     if (kCount)
     {
         atomicAdd(&counters->closest_rays, static_cast<unsigned long long>(local.closest_rays));
@@ -427,6 +467,9 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
     }
     if (kPool && spread_job.lane_spread > 1)
         spread_job.compact = 0; // (the compaction would gather the paths into the first wavefronts again)
+    if (per_cu >= 4)
+        for (int i = 0; i < 3; ++i)
+            spread_job.level_until[i] = job.level_until_4[i];
     if (spread_job.scatter == kScatterAuto)
         // (measured on the diffuse instantiations; volumetric-caustic lost 6 % with it at 3.5 pixels per lane)
         spread_job.scatter = kLdsGeometry && (kFeatures & kAll & ~kFeatEmitters) == 0 &&

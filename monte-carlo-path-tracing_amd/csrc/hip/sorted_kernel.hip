@@ -118,6 +118,9 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         {
             if (!has_pixel)
             {
+                // (the next item is taken from the work counter when the lane is free, not reserved ahead: render_kernel_impl.h)
+                if (job.work_counter && q == kFetchNext)
+                    q = stride + wave_reserve(job.work_counter, true);
                 if (q >= n_work)
                     break; // exhausted
                 const uint32_t qs = job.scatter ? (q & 63u) * (n_work >> 6) + (q >> 6) : q;
@@ -126,7 +129,7 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
                 const uint32_t local_tile = item >> 6, r = item & 63u;
                 const uint32_t tile = job.tile_first + local_tile * job.tile_stride;
                 const uint32_t x = (tile % job.tiles_x) * 8u + (r & 7u), y = (tile / job.tiles_x) * 8u + (r >> 3);
-                q = job.work_counter ? stride + wave_reserve(job.work_counter, true) : q + stride;
+                q = job.work_counter ? kFetchNext : q + stride;
                 if (x >= width || y >= height)
                     continue; // padding of an edge tile
                 const uint32_t pixel = y * width + x;

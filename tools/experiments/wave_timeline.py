@@ -38,8 +38,11 @@ def main():
         draw = lambda: r.draw()[1]
     draw()
     st = draw()
-    c = np.fromfile(path, dtype=np.uint64).reshape(-1, 2)
+    c = np.fromfile(path, dtype=np.uint64).reshape(-1, 4) if os.path.exists(path) else np.zeros((0, 4), np.uint64)
     c = c[c[:, 1] > 0].astype(np.int64)
+    if len(c) == 0:   # (a kernel without the clocks: the class-sorted one)
+        print(json.dumps({"workload": a.workload, "kernel": r.last_kernel(), "kernel_ms": st["kernel_milliseconds"], "kernel_ms_third_draw": draw()["kernel_milliseconds"]}))
+        return
     t0, t1 = c[:, 0].min(), c[:, 1].max()
     span = float(t1 - t0)
     grid = np.linspace(0.0, 1.0, 21)
@@ -51,6 +54,13 @@ def main():
            "mean_occupancy_of_the_launch": float(life.mean()),
            "wavefront_lifetime_quantiles_10_50_90_100": [float(np.quantile(life, q)) for q in (0.1, 0.5, 0.9, 1.0)],
            "end_time_quantiles_10_50_90": [float(np.quantile((c[:, 1] - t0) / span, q)) for q in (0.1, 0.5, 0.9)]}
+    # the wavefronts that end last: when did they take their last pixel, how long did that last batch run, how many pixels had they
+    last = np.argsort(c[:, 1])[-16:]
+    rec["last_16_wavefronts"] = [{"end": round(float((c[i, 1] - t0) / span), 3), "last_pixel_taken_at": round(float((c[i, 2] - t0) / span), 3),
+                                  "pixels": int(c[i, 3])} for i in last]
+    took = c[c[:, 3] > 0]
+    rec["last_pixel_taken_at_quantiles_50_90_100"] = [float(np.quantile((took[:, 2] - t0) / span, q)) for q in (0.5, 0.9, 1.0)]
+    rec["pixels_per_wavefront_quantiles_10_50_90_100"] = [float(np.quantile(c[:, 3], q)) for q in (0.1, 0.5, 0.9, 1.0)]
     print(json.dumps(rec))
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
