@@ -67,6 +67,12 @@ PMC_GROUPS = [
     ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
      "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_SALU", "SQ_INSTS_VMEM"],
 ]
+# memory side, scenes outside LDS only (round 5): vector-cache and L2 hit rates, the cycles the vector cache spends stalled on
+# pending misses, the L2's requests to the fabric — what says whether a mesh kernel waits for bandwidth, for a queue or for latency
+PMC_GROUPS_MEMORY = [
+    ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_GATE_EN1_sum"],
+    ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_REQ_sum"],
+]
 KERNEL_WORDS = ("render_kernel", "sorted_kernel", "stream_kernel", "primary_kernel", "queued_")
 # Issue cost per wave64 VALU instruction by class, from this repository's microbenchmark on MI355X
 # (tools/microbench/valu_rate.hip, profiles/r02_experiments/valu_issue_rate_microbench.jsonl): plain fp32
@@ -112,7 +118,7 @@ def stream_bandwidth(torch, device):
     return out
 
 
-def pmc_leg(workload, film, choice, timeout_s=300):
+def pmc_leg(workload, film, choice, timeout_s=300, memory_side=False):
     """Hardware counters of the render kernel for one full-size launch of the workload: rocprofv3 runs
     tools/render_scene.py (one draw) once per counter group.  Returns None when rocprofv3 is not there."""
     if shutil.which("rocprofv3") is None:
@@ -122,7 +128,7 @@ def pmc_leg(workload, film, choice, timeout_s=300):
         env.pop(k, None)
     counters, kernels, failed, duration_ns = {}, set(), [], []
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-        for gi, group in enumerate(PMC_GROUPS):
+        for gi, group in enumerate(PMC_GROUPS + (PMC_GROUPS_MEMORY if memory_side else [])):
             d = os.path.join(tmp, f"pass{gi}")
             target = [sys.executable, os.path.join(ROOT, "tools", "render_scene.py"), f"workload:{workload}",
                       "--film", *map(str, film), "--draws", "1", "--kernel-mode", str(choice[0]), "--work", str(choice[1]),
@@ -306,6 +312,17 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
         rank_kernel_ms = [float(v.item()) for v in every]
         kernel_ms = rank_kernel_ms[0]
 
+    # N > 1: the line verifies itself — the communicator's own count of its ranks, and the gathered frame against the frame ONE
+    # renderer draws alone (rank 0, outside the timed region), bit for bit
+    rccl, frame_check = None, None
+    if use_gather:
+        rccl = pkg.tiling.communicator_report(device)
+        step()
+        sync()
+        single = renderer.draw()[0] if rank == 0 else None
+        frame_check = pkg.tiling.self_check(fg, single)
+        sync()
+
     out = None
     if rank == 0:
         samples = W * H * SPP
@@ -330,6 +347,9 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
                        "film": (f"{W}x{H}: side scaled with sqrt(N) so that every GPU renders 512x512 pixels' worth "
                                 "of tiles (weak scaling)") if weak else f"{W}x{H}"},
         }
+        if rccl is not None:
+            out["rccl"] = rccl
+            out["frame_check"] = frame_check
         if rank_kernel_ms is not None:
             out["per_rank_kernel_ms"] = rank_kernel_ms
         if gather_ms is not None:
@@ -368,14 +388,6 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
                 "node_phase_lane_util": (counts["node_tests"] / boxes_per_node_step) / (64.0 * max(counts["wave_node_steps"], 1)),
                 "counting_kernel": counting_kernel,
                 "prim_phase_lane_util": counts["prim_tests"] / (64.0 * max(counts["wave_prim_steps"], 1))}
-        if "pool-walk" in counting_kernel and "+lds" not in kernel_name:
-            # scenes outside LDS: a node item of the pool walk is one 128-byte record = one cache line, a primitive test one 48-byte
-            # record (1.375 lines on average) — against the rate a dependent gather of such records reaches on this GPU whatever
-            # the occupancy (tools/experiments/gather_rate.hip, profiles/r04_experiments/gather_rate.json: 86.9 G lines/s)
-            lines = (counts["node_tests"] / boxes_per_node_step + 1.375 * counts["prim_tests"]) / counts["samples"]
-            g_lines = lines * rank_samples / (kernel_ms * 1e-3) / 1e9
-            walk["l2_lines"] = {"lines_per_sample": lines, "G_lines_per_s": g_lines, "measured_gather_ceiling_G_lines_per_s": 86.9,
-                                "frac": g_lines / 86.9}
         hbm = {"algorithmic_gbs": algorithmic_gbs, "bytes_per_sample": b_per_sample,
                "stream_peak_gbs": hbm_peak, "stream_copy_gbs": bw["copy_gbs"], "stream_read_gbs": bw["read_gbs"],
                "spec_peak_gbs": HBM_SPEC_GBS, "frac_algorithmic_of_stream_peak": algorithmic_gbs / hbm_peak,
@@ -385,7 +397,8 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
                 "kernel": kernel_name, "kernel_ms": kernel_ms, "per_sample": per_sample, "walk": walk, "hbm": hbm,
                 "scene": {"walk_nodes": scene_info["walk_nodes"], "primitives": scene_info["primitives"],
                           "geometry_bytes": scene_info["geometry_bytes"]}}
-        pmc = None if (args.no_pmc or world > 1 or args.rng != "reference") else pmc_leg(name, (W, H, SPP), choice)
+        outside_lds = "+lds" not in kernel_name
+        pmc = None if (args.no_pmc or world > 1 or args.rng != "reference") else pmc_leg(name, (W, H, SPP), choice, memory_side=outside_lds)
         if pmc and pmc["counters"].get("SQ_INSTS_VALU") and pmc["kernel_ns"]:
             c = pmc["counters"]
             pmc_ms = pmc["kernel_ns"] * 1e-6
@@ -421,6 +434,17 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
                     if k in c:
                         valu[k.lower() + "_per_valu"] = c[k] / c["SQ_INSTS_VALU"]
             roof["valu"] = valu
+            if c.get("TCP_TOTAL_CACHE_ACCESSES_sum") and c.get("TCC_REQ_sum"):
+                # (round 4 priced the mesh kernels against a "ceiling" from a gather microbenchmark; these are the counters instead)
+                l2_requests = c["TCC_HIT_sum"] + c["TCC_MISS_sum"]
+                roof["memory"] = {
+                    "tcp_hit_rate": 1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"],
+                    "l2_hit_rate": c["TCC_HIT_sum"] / max(l2_requests, 1.0),
+                    "l2_requests_per_sample": c["TCC_REQ_sum"] / samples,
+                    "l2_fabric_read_bytes": c["TCC_EA0_RDREQ_sum"] * 128.0,   # (128-byte requests on gfx950; FETCH_SIZE tallies them at 64)
+                    "l2_fabric_read_gbs": c["TCC_EA0_RDREQ_sum"] * 128.0 / (pmc_ms * 1e-3) / 1e9,
+                    "tcp_pending_stall_per_active_cycle": c["TCP_PENDING_STALL_CYCLES_sum"] / max(c.get("TCP_GATE_EN1_sum", 0.0), 1.0),
+                    "note": "vector-cache hits include the 3 further 16-byte reads of a 64-byte node record already fetched"}
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 # rocprofv3 reports KiB; FETCH_SIZE counts 64-byte requests where gfx950 moves 128 (guide's
                 # gfx950 note): doubled
@@ -450,6 +474,15 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
                 roof["note"] = ("memory bound: achieved = HBM bytes moved per launch (PMC) / kernel time, peak = stream "
                                 "bandwidth measured in this process; VALU issue %.0f %% x lane utilisation %.0f %%"
                                 % (100 * issue, 100 * lanes))
+            # WHAT LIMITS the kernel, from the counters (the `bound` above names the nearer of the two roofs the contract knows):
+            # issue slots, HBM bytes — or neither: wavefronts that wait (dependent steps of a ray query, a frame's tail of long
+            # pixel chains) while issue slots and bandwidth are free
+            wait = valu["wait_any_per_wave_cycle"]
+            hbm_frac = hbm.get("measured_frac_of_stream_peak", 0.0)
+            waves_resident = c.get("SQ_WAVE_CYCLES", 0.0) * 4.0 / max(n_simd * cycles, 1.0)
+            roof["limiter"] = {"kind": ("valu-issue" if issue >= 0.6 else "hbm" if hbm_frac >= 0.6 else "latency / occupancy"),
+                               "valu_issue_frac": issue, "hbm_frac_of_stream_peak": hbm_frac, "wave_cycles_waiting": wait,
+                               "mean_wavefronts_per_simd": waves_resident}
             roof["pmc"] = {"kernels": pmc["kernels"], "failed": pmc["failed"],
                            "command": "rocprofv3 --kernel-trace --pmc <group> -- python tools/render_scene.py "
                                       f"workload:{name} --film {W} {H} {SPP} --draws 1 --kernel-mode {choice[0]} --work {choice[1]} "
@@ -508,6 +541,13 @@ def compact(full, detail_path):
         if v:
             o.update(lane_util=round(v["lane_util"], 3), issue_frac_sq=round(v["issue_frac"], 3),
                      frac_at_16_lanes=round(v["frac_at_16_lanes_per_clk"], 3))
+        if "limiter" in r:
+            o["limiter"] = r["limiter"]["kind"]
+            o["waiting"] = round(r["limiter"]["wave_cycles_waiting"], 2)
+            o["waves_per_simd"] = round(r["limiter"]["mean_wavefronts_per_simd"], 2)
+        if "memory" in r:
+            o["tcp_hit"] = round(r["memory"]["tcp_hit_rate"], 3)
+            o["l2_hit"] = round(r["memory"]["l2_hit_rate"], 3)
         for k in ("achieved", "peak", "frac"):
             o[k] = float("%.4g" % o[k])
         return o
@@ -515,7 +555,10 @@ def compact(full, detail_path):
     def one(m):
         o = {k: m[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                "scaling", "vs_baseline", "dtype", "data", "grays_per_s", "rays_per_sample",
-                               "first_draw_ms", "gather_ms", "per_rank_kernel_ms") if k in m}
+                               "first_draw_ms", "gather_ms", "per_rank_kernel_ms", "rccl") if k in m}
+        if m.get("frame_check"):
+            o["frame_check"] = {"equals_single_gpu_frame": m["frame_check"]["equals_single_gpu_frame"],
+                                "sha256": m["frame_check"]["gathered_frame_sha256"][:16]}
         for k in ("value", "ms_per_step", "grays_per_s", "rays_per_sample", "first_draw_ms"):
             if k in o:
                 o[k] = round(o[k], 3)
@@ -548,6 +591,47 @@ def compact(full, detail_path):
         line["also"] = {"dragon": a}
     line["detail"] = detail_path
     return line
+
+
+def cpu_tiles_line(pkg, args):
+    """`--cpu-tiles` (the CPU test of the N > 1 code path, tests/test_multi_gpu_host.py): the same partition, packed blocks, gather,
+    communicator report and frame self-check as a `--gpus N` run, with gloo as the backend and the rank's tiles written by the
+    product's HOST build of the kernel body (libmcpt_host.so, mcpt_host_render_tiles) — no GPU, no timing claim."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    dist.init_process_group("gloo")
+    W, H, SPP = args.width or 64, args.height or 64, args.spp or 8
+    cfg = pkg.capi.Config.builtin("cornell-box").set_film(W, H, SPP)
+    fg = pkg.tiling.FrameGather(world, rank, W, H, torch.device("cpu"))
+    rng = pkg.capi.TileRange(rank, world, 0)
+    n_tiles = len(pkg.tiling.rank_tiles(rank, world, W, H))
+    t0 = time.perf_counter()
+    block = np.full((n_tiles, 64, 3), -1.0, dtype=np.float32)
+    pkg.capi.host_render(cfg, threads=2, rng=rng, packed=True, out=block)
+    mine_ms = 1e3 * (time.perf_counter() - t0)
+    packed = np.full((fg.max_tiles, 64, 3), -1.0, dtype=np.float32)   # (poison: padding must never reach the frame)
+    packed[:n_tiles] = block
+    fg.packed.copy_(torch.from_numpy(packed.reshape(-1)))
+    g0 = time.perf_counter()
+    fg.gather()
+    gather_ms = 1e3 * (time.perf_counter() - g0)
+    every = [None] * world
+    dist.all_gather_object(every, mine_ms)
+    rccl = pkg.tiling.communicator_report(torch.device("cpu"))
+    single = pkg.capi.host_render(cfg, threads=2)[0] if rank == 0 else None
+    check = pkg.tiling.self_check(fg, single)
+    if rank == 0:
+        elapsed = max(every) * 1e-3 + gather_ms * 1e-3
+        print(json.dumps({"metric": "Msamples/sec (W*H*spp/s)", "value": W * H * SPP / elapsed / 1e6, "unit": "Msamples/s", "n_gpus": world,
+                          "steps": 1, "warmup": 0, "ms_per_step": 1e3 * elapsed, "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic; HOST tile writer (CPU test of the N > 1 code path, not a measurement)",
+                          "config": {"workload": f"cornell-box {W}x{H} spp={SPP}", "partition": f"8x8 tiles round-robin over {world} rank(s), one gather to rank 0"},
+                          "rccl": rccl, "frame_check": check, "per_rank_kernel_ms": every, "gather_ms": gather_ms}))
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0 and not check["equals_single_gpu_frame"]:
+        sys.exit(3)
 
 
 def main():
@@ -585,7 +669,12 @@ def main():
     ap.add_argument("--force-gather", action="store_true",
                     help="take the multi-GPU code path (RCCL process group, packed tiles, gather, scatter) "
                          "even with one rank: lets a 1-GPU box exercise it")
+    ap.add_argument("--cpu-tiles", action="store_true",
+                    help="CPU test of the N > 1 code path: gloo + the product's host tile writer, no GPU (tests/test_multi_gpu_host.py)")
     args = ap.parse_args()
+    if args.cpu_tiles:
+        from _pkg import load_package
+        return cpu_tiles_line(load_package(), args)
 
     import torch
     import torch.distributed as dist
@@ -643,6 +732,9 @@ def main():
             print(json.dumps(compact(out, detail_path), separators=(",", ":")))
     if use_gather:
         dist.destroy_process_group()
+    if rank == 0 and out.get("frame_check") and not out["frame_check"]["equals_single_gpu_frame"]:
+        print("bench.py: the gathered frame differs from the single-GPU frame", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -180,6 +180,8 @@ struct mcpt_renderer
     uint32_t cost_order_tiles = 0, cost_order_first = 0, cost_order_stride = 0; // range statistics of the pre-pass
     uint32_t lds_table_tiles = 0, lds_table_first = 0, lds_table_stride = 0;    // probed wavefront layout / hand-out table, LDS path
     int class_sort_mode = -1; // mcpt_renderer_set_class_sort: -1 / 1 on where the scene is of that class, 0 off
+    bool guard_draws = false; // mcpt_renderer_create's walk self-check is drawing (1 spp, a sample of the tiles): nothing it times may be
+                              // stored as this scene's calibrated choice (round 4's advisor: the store's key has no spp in it)
     int pool_walk_mode = -1;  // mcpt_renderer_set_pool_walk: -1 the library's choice (MCPT_POOL_WALK), 0 one walk per lane, 1 the cooperative pool walk
     int tile_order_mode = -1; // -1 the library's choice (on with the pre-pass and the work counter), 0 image order, 1 cost order
     unsigned long long *tile_keys_dev = nullptr;
@@ -874,7 +876,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     {
         r->auto_choice = r->work_mode == 0 ? 0 : 1; // lanes kernel, fixed lists / work counter
         if (!small_scene && r->kernel_mode == -1 && job.n_items != 0 && r->rng_mode != 2)
-            ResolveAutoChoice(r, stream, mcpt::StreamSupports(r->dev, job), true);
+            ResolveAutoChoice(r, stream, mcpt::StreamSupports(r->dev, job), !r->guard_draws);
     }
     float *render_target = out_device;
     const uint32_t out_pixels = packed ? job.n_items : static_cast<uint32_t>(r->flat.camera.width) * r->flat.camera.height;
@@ -1659,6 +1661,7 @@ int mcpt_renderer_create(const mcpt_config *cfg, int device, mcpt_renderer **out
             uint32_t first = 0;
             float worst = 0;
             int rc = 0;
+            r->guard_draws = true;
             if (want > 0)
                 rc = mcpt_renderer_check_walks(r.get(), &differing, &first, &worst);
             else
@@ -1691,6 +1694,7 @@ int mcpt_renderer_create(const mcpt_config *cfg, int device, mcpt_renderer **out
                 if (dev)
                     (void)hipFree(dev);
             }
+            r->guard_draws = false;
             r->dev.camera.spp = r->flat.camera.spp = spp, r->dev.camera.spp_inv = r->flat.camera.spp_inv = spp_inv;
             r->auto_choice = -1; // (the check's draws chose / calibrated at the reduced film: decide again for the real one)
             r->InvalidateRangeCaches();
@@ -1876,6 +1880,10 @@ int mcpt_debug_lbvh_build(uint32_t n, const float *boxes, const float *areas, in
         return Fail(e.what());
     }
 }
+
+// TEST HOOK, not part of include/mcpt.h: the scale of the ordered walk's tie radius for scenes committed from now on (1 = production).
+// tests/test_gpu_parity.py builds a scene that lies outside a shrunken radius to see mcpt_renderer_create's self-check catch it.
+void mcpt_testing_set_walk_tie_scale(float scale) { mcpt::SetWalkTieScaleForTesting(scale); }
 
 int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order)
 {

@@ -225,9 +225,21 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     return job.pool_walk ? Launch<kP, false, true>(sc, job, out, nullptr, stream, n_cus) : Launch<kO, false, true>(sc, job, out, nullptr, stream, n_cus);
 #endif
     const bool slivers = sc.integrator.walk_sliver_reach > 0.0f;
-    if (counters != nullptr && ordered && job.pool_walk >= 1 && PoolBigSupports(sc))
+    // The counting instantiation follows the PRODUCTION launch's ray query (round 4's advisor: it used to count a pool walk for every
+    // scene the big form supports, also where the timed kernel walks per lane — volumetric-caustic's class-sorted kernel): the pool
+    // walk's per-item counts (4 box tests per node item) where the uncounted launch below uses the pool walk — its LDS form
+    // (exact 128-byte records) for the lean LDS-resident scenes, the quantised form outside LDS —, the per-lane walk's otherwise.
+    const bool lds_scene = StagedBytes(sc, true) <= kLdsGeometryBytes;
+    const bool lds_pool = lds_scene && !slivers && job.pool_walk != 0 && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kPoolMaxRef + 1u &&
+                          sc.integrator.n_prims <= kPoolMaxRef + 1u && sc.integrator.pool_depth <= kPoolMaxDepth && StagedBytes(sc, true, true) <= kLdsGeometryBytes &&
+                          ((f & ~kFeatEmitters) == 0 || job.pool_walk >= 2);
+    if (counters != nullptr && ordered && lds_pool)
     {
-        // the counting mode of the production ray query: per-item counts of the pool walk (4 box tests per node item)
+        *variant = "all+count+lds+pool-walk";
+        return Launch<kAll | kP, true, true>(sc, job, out, counters, stream, n_cus);
+    }
+    if (counters != nullptr && ordered && !lds_scene && job.pool_walk >= 1 && PoolBigSupports(sc))
+    {
         *variant = "all+count+pool-walk";
         return Launch<kAll | kPB | kS, true, false>(sc, job, out, counters, stream, n_cus);
     }

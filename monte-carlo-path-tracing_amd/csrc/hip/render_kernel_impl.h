@@ -506,6 +506,7 @@ extern template hipError_t Launch<kAll | kV | kS, false, false>(MCPT_LAUNCH_ARGS
 extern template hipError_t Launch<kAll, true, false>(MCPT_LAUNCH_ARGS);
 extern template hipError_t Launch<kAll | kV | kS, true, false>(MCPT_LAUNCH_ARGS);
 extern template hipError_t Launch<kAll | kPB | kS, true, false>(MCPT_LAUNCH_ARGS);
+extern template hipError_t Launch<kAll | kP, true, true>(MCPT_LAUNCH_ARGS);
 #endif
 #if !defined(MCPT_UNIT_LDS)
 extern template hipError_t Launch<kAll | kO, false, true>(MCPT_LAUNCH_ARGS);

@@ -62,6 +62,10 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     using C = Config<kFeatures>;
     constexpr uint32_t kBlockSize = kSortLanes; // (shadows mcpt::kBlockSize: the traversal stacks keep their stride of 256 words)
     extern __shared__ float4 lds_geometry[];
+    // (diagnostic, RenderJob::wave_clock: four words per wavefront — start, end, last pixel taken, pixels taken)
+    unsigned long long *const wave_clock = job.wave_clock ? job.wave_clock + 4u * (blockIdx.x * (kBlockSize / 64u) + (threadIdx.x >> 6)) : nullptr;
+    if (wave_clock && (threadIdx.x & 63u) == 0)
+        wave_clock[0] = wall_clock64();
     DeviceScene sc = sc_in;
     uint32_t n_staged = 0;
     {
@@ -133,6 +137,8 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
                 if (x >= width || y >= height)
                     continue; // padding of an edge tile
                 const uint32_t pixel = y * width + x;
+                if (wave_clock)
+                    wave_clock[2] = wall_clock64(), atomicAdd(&wave_clock[3], 1ull);
                 start_pixel(st, pixel);
                 st.sample = k;
                 slot = (job.packed ? item : pixel) + k * job.plane_stride;
@@ -253,6 +259,8 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         else if (st.alive)
             path_connect_scatter<C>(sc, st, nullptr, surf);
     }
+    if (wave_clock && (threadIdx.x & 63u) == 0)
+        wave_clock[1] = wall_clock64();
 }
 
 template <uint32_t kFeatures>

@@ -202,6 +202,8 @@ private:
 // differ.  The depth is bounded (kWalkDepthMax) because it sizes the per-lane
 // traversal stack.
 int g_walk_tree_strategy = 0; // SetWalkTreeStrategyForTesting
+float g_walk_tie_scale = 1.0f; // SetWalkTieScaleForTesting: shrinks the tie radius, to build a scene that lies OUTSIDE the ordered
+                               // walk's bounds on purpose (the self-guard of mcpt_renderer_create must catch it: tests/test_gpu_parity.py)
 
 // ---- 4-wide, exact form of the ordered-walk hierarchy (device_scene.h: pool_nodes) --------------
 // For the wavefront-cooperative pool walk of small scenes (pool_walk.h): a (ray, node) item of that walk costs a fixed
@@ -1035,6 +1037,7 @@ size_t FlatScene::GeometryBytes() const
 }
 
 void SetWalkTreeStrategyForTesting(int strategy) { g_walk_tree_strategy = strategy; }
+void SetWalkTieScaleForTesting(float scale) { g_walk_tie_scale = scale; }
 
 void BuildReferenceLbvh(uint32_t n, const float *boxes, const float *areas, std::vector<float4> &nodes,
                         std::vector<float> &node_area)
@@ -1346,10 +1349,8 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
         // are "tied": the walk must visit both and decide like the reference (traversal.h, test_slot).
         // Offsets are at most (largest |coordinate| of the geometry or the eye) * 2.
         ig.walk_tie = 5e-6f * coordinate;
-        // TESTS ONLY: MCPT_WALK_TIE_SCALE shrinks the radius, to build a scene that lies OUTSIDE the ordered walk's bounds on
-        // purpose (the self-guard of mcpt_renderer_create must catch it: tests/test_gpu_parity.py)
-        if (const char *scale = std::getenv("MCPT_WALK_TIE_SCALE"))
-            ig.walk_tie *= static_cast<float>(std::atof(scale));
+        // (SetWalkTieScaleForTesting: 1 in production — no environment variable reaches the walk's correctness bound)
+        ig.walk_tie *= g_walk_tie_scale;
         ig.walk_extent = coordinate + largest_grow; // (every box plane lies within the geometry's coordinates, grown sliver boxes included)
         ig.walk_sliver_reach = largest_grow > 0.0f ? std::max(ig.walk_tie, largest_grow) : 0.0f; // 0: no slivers
         fs.walk_prims.reserve(3 * slot_prim.size());

@@ -65,6 +65,7 @@ struct LbvhAccelerator
 // 1 = exact SAH sweep, 2 = object median, 3 = binned SAH with the children swapped.  The
 // image must not depend on it (tests/test_host.py::test_image_does_not_depend_on_the_walk_tree).
 void SetWalkTreeStrategyForTesting(int strategy);
+void SetWalkTieScaleForTesting(float scale); // 1 = production; tests shrink the ordered walk's tie radius with it
 
 // Throws std::runtime_error with the reference's wording on invalid input.
 FlatScene CommitScene(const mcsd::Scene &scene, LbvhAccelerator *lbvh = nullptr);

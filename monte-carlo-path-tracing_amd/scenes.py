@@ -146,7 +146,7 @@ def grazing_strips(width=128, height=64, spp=1, offset=1000.0, length=8000.0, st
     ill-conditioned weights) while a flat leaf box's entry distance is exact: which of the two coplanar surfaces the reference
     reports depends on its visiting order and on whether the second one's leaf box still passes.  Inside the production
     radius (5e-6 x largest |coordinate|) the ordered walk replays that and agrees; with the radius shrunk
-    (MCPT_WALK_TIE_SCALE, tests only) it does not — the case the self-guard of mcpt_renderer_create exists for."""
+    (mcpt_testing_set_walk_tie_scale, tests only) it does not — the case the self-guard of mcpt_renderer_create exists for."""
     K, L, hh = float(offset), float(length), float(strip_width)
     s = cornell_box(width, height, spp)
     light = s.instances[-1]

@@ -76,3 +76,28 @@ class FrameGather:
         if self.rank == 0:
             self.frame.view(-1, 3)[self.dst] = torch.cat(self.blocks).view(-1, 3)[self.src]
         return self.frame
+
+
+def communicator_report(device):
+    """What the process group itself says about the run: its size counted BY the collective (an all-reduce of ones — not
+    WORLD_SIZE from the environment), the backend, and this rank's number."""
+    import torch
+    import torch.distributed as dist
+    ones = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(ones)
+    return {"ranks": int(round(float(ones.item()))), "backend": dist.get_backend(), "group_size": dist.get_world_size()}
+
+
+def self_check(fg: "FrameGather", single_frame):
+    """Rank 0: the frame the gather assembled against the frame ONE renderer draws alone (`single_frame`: H x W x 3 float32, or
+    None on the other ranks) — sha256 of both and whether they are equal, bit for bit.  A tiling, packing or exchange error
+    cannot hide behind a plausible throughput number."""
+    import hashlib
+    import numpy as np
+    if fg.rank != 0:
+        return None
+    got = fg.frame.detach().cpu().numpy().reshape(fg.height, fg.width, 3)
+    want = np.ascontiguousarray(single_frame, dtype=np.float32)
+    return {"gathered_frame_sha256": hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest(),
+            "single_gpu_frame_sha256": hashlib.sha256(want.tobytes()).hexdigest(),
+            "equals_single_gpu_frame": bool(np.array_equal(got, want))}

@@ -767,7 +767,7 @@ def test_renderer_guards_itself_against_a_scene_outside_the_tie_radius(pkg, orac
     reference-order walk, fallback to the latter when a pixel differs.  scenes.grazing_strips — coplanar overlapping strips
     of two instances at coordinates of 10^3 .. 10^4, aspect ratio 125, seen at grazing incidence — lies INSIDE the
     production tie radius (both walks agree, the ordered walk stays); with the radius shrunk to a thousandth
-    (MCPT_WALK_TIE_SCALE, a test knob of the commit) it lies outside: the ordered walk alone then renders pixels that are
+    (mcpt_testing_set_walk_tie_scale, a test hook of the library) it lies outside: the ordered walk alone then renders pixels that are
     not the reference's (triangle.cpp:82: a later visited primitive at t <= t_max wins, and a flat leaf box passes or not
     with the first one's distance as the bound), the guard notices, and the renderer's frame is the oracle's again."""
     scene = pkg.scenes.grazing_strips(128, 64, 4)
@@ -790,15 +790,21 @@ def test_renderer_guards_itself_against_a_scene_outside_the_tie_radius(pkg, orac
     assert np.array_equal(frame, want), kernel
     assert "WARNING" not in capfd.readouterr().err
     # outside (radius / 1000), check switched off: the ordered walk is NOT the reference on this scene
-    monkeypatch.setenv("MCPT_WALK_TIE_SCALE", "0.001")
-    monkeypatch.setenv("MCPT_CHECK_WALKS", "0")
-    frame, kernel = render(False)
-    assert not np.array_equal(frame, want), "the scene was meant to trip the shrunken tie radius"
-    # ... with the guard (the default): fallback, the reference's frame
-    monkeypatch.delenv("MCPT_CHECK_WALKS")
-    frame, kernel = render(True)
-    assert "reference walk" in kernel and np.array_equal(frame, want), kernel
-    assert "differ on" in capfd.readouterr().err
+    import ctypes
+    hook = pkg.capi.lib().mcpt_testing_set_walk_tie_scale   # (a test hook of the library, not part of include/mcpt.h)
+    hook.argtypes, hook.restype = [ctypes.c_float], None
+    hook(0.001)
+    try:
+        monkeypatch.setenv("MCPT_CHECK_WALKS", "0")
+        frame, kernel = render(False)
+        assert not np.array_equal(frame, want), "the scene was meant to trip the shrunken tie radius"
+        # ... with the guard (the default): fallback, the reference's frame
+        monkeypatch.delenv("MCPT_CHECK_WALKS")
+        frame, kernel = render(True)
+        assert "reference walk" in kernel and np.array_equal(frame, want), kernel
+        assert "differ on" in capfd.readouterr().err
+    finally:
+        hook(1.0)
 
 
 @pytest.mark.gpu

@@ -113,3 +113,25 @@ def test_partition_covers_every_pixel_once(pkg):
             assert len(np.unique(src)) == len(src)
             counts = [len(pkg.tiling.rank_tiles(r, world, w, h)) for r in range(world)]
             assert max(counts) - min(counts) <= 1 and max(counts) == pkg.tiling.max_tiles_per_rank(world, w, h)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_line_of_an_n_rank_run_verifies_itself(world, pkg, tmp_path):
+    """`bench.py --gpus N` prints, for N > 1, the communicator's own count of its ranks (`rccl.ranks`, an all-reduce of ones — not
+    WORLD_SIZE), per-rank times, the gather time and `frame_check`: the gathered frame's sha256 against the frame one renderer
+    draws alone.  Here the same code path (tiling.FrameGather / communicator_report / self_check) runs under torch.distributed.run
+    with gloo and the product's host tile writer (`bench.py --cpu-tiles`); the frame is also the compiled reference's golden."""
+    import hashlib
+    import json
+    import subprocess
+    port = 33500 + (os.getpid() % 2000) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--cpu-tiles"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == world and line["rccl"]["ranks"] == world and line["rccl"]["backend"] == "gloo"
+    assert len(line["per_rank_kernel_ms"]) == world and line["gather_ms"] >= 0.0
+    assert line["frame_check"]["equals_single_gpu_frame"] is True
+    golden = np.load(os.path.join(ROOT, "tests", "golden", "cornell_64_spp8.npz"))["frame"]
+    assert line["frame_check"]["gathered_frame_sha256"] == hashlib.sha256(np.ascontiguousarray(golden).tobytes()).hexdigest()

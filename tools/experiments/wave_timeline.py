@@ -19,6 +19,8 @@ def main():
     ap.add_argument("workload")
     ap.add_argument("--share", type=int, default=1)
     ap.add_argument("--spread", type=int, default=0)
+    ap.add_argument("--pool", type=int, default=-1, help="mcpt_renderer_set_pool_walk")
+    ap.add_argument("--sort", type=int, default=-1, help="mcpt_renderer_set_class_sort")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     path = os.path.join(tempfile.mkdtemp(dir="/tmp"), "clock.bin")
@@ -29,6 +31,10 @@ def main():
     r = pkg.capi.Renderer(pkg.workloads.config(a.workload), device=0)
     if a.spread:
         r.set_lane_spread(a.spread)
+    if a.pool >= 0:
+        r.set_pool_walk(a.pool)
+    if a.sort >= 0:
+        r.set_class_sort(a.sort)
     if a.share > 1:
         import torch
         rng = pkg.capi.TileRange(0, a.share, 0)
