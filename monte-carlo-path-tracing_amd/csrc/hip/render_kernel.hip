@@ -202,14 +202,17 @@ static bool PoolSubsets()
     return on;
 }
 
+// (the references an item of the production pool walks can hold: one bit less with merged queries, pool_walk.h)
+constexpr uint32_t kLdsPoolLimit = kPoolMaxRef, kBigPoolLimit = MCPT_POOL_MERGE ? kPoolMaxRefBigDual : kPoolMaxRefBig;
+
 // Can the lane-owns-a-path kernel run this scene (outside LDS) with the pool walk?  No opacity masks (they draw random numbers
 // during a walk: the visiting order is part of the image), the 4-wide hierarchy within the items' 26 bits and the lists' head room.
 bool PoolBigSupports(const DeviceScene &sc)
 {
     // (MCPT_POOL_QUANT: the node items name records of wide_nodes — the same collapse, plus its padding records)
-    return !sc.integrator.has_masks && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kPoolMaxRefBig &&
-           (MCPT_POOL_QUANT == 0 || (sc.integrator.n_wide_nodes != 0 && sc.integrator.n_wide_nodes <= kPoolMaxRefBig)) &&
-           sc.integrator.n_prims <= kPoolMaxRefBig && sc.integrator.pool_depth <= kPoolMaxDepth;
+    return !sc.integrator.has_masks && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kBigPoolLimit &&
+           (MCPT_POOL_QUANT == 0 || (sc.integrator.n_wide_nodes != 0 && sc.integrator.n_wide_nodes <= kBigPoolLimit)) &&
+           sc.integrator.n_prims <= kBigPoolLimit && sc.integrator.pool_depth <= kPoolMaxDepth;
 }
 
 hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,
@@ -230,8 +233,8 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     // walk's per-item counts (4 box tests per node item) where the uncounted launch below uses the pool walk — its LDS form
     // (exact 128-byte records) for the lean LDS-resident scenes, the quantised form outside LDS —, the per-lane walk's otherwise.
     const bool lds_scene = StagedBytes(sc, true) <= kLdsGeometryBytes;
-    const bool lds_pool = lds_scene && !slivers && job.pool_walk != 0 && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kPoolMaxRef + 1u &&
-                          sc.integrator.n_prims <= kPoolMaxRef + 1u && sc.integrator.pool_depth <= kPoolMaxDepth && StagedBytes(sc, true, true) <= kLdsGeometryBytes &&
+    const bool lds_pool = lds_scene && !slivers && job.pool_walk != 0 && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kLdsPoolLimit + 1u &&
+                          sc.integrator.n_prims <= kLdsPoolLimit + 1u && sc.integrator.pool_depth <= kPoolMaxDepth && StagedBytes(sc, true, true) <= kLdsGeometryBytes &&
                           ((f & ~kFeatEmitters) == 0 || job.pool_walk >= 2);
     if (counters != nullptr && ordered && lds_pool)
     {
@@ -295,8 +298,8 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     }
     const bool lds = StagedBytes(sc, true) <= kLdsGeometryBytes;
     // the wavefront-cooperative pool walk (pool_walk.h): its items hold node and slot indices in 10 bits
-    const bool pool = lds && job.pool_walk != 0 && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kPoolMaxRef + 1u &&
-                      sc.integrator.n_prims <= kPoolMaxRef + 1u && sc.integrator.pool_depth <= kPoolMaxDepth &&
+    const bool pool = lds && job.pool_walk != 0 && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kLdsPoolLimit + 1u &&
+                      sc.integrator.n_prims <= kLdsPoolLimit + 1u && sc.integrator.pool_depth <= kPoolMaxDepth &&
                       StagedBytes(sc, true, true) <= kLdsGeometryBytes;
     if (f == 0)
     {

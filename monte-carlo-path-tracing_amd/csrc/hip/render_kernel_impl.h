@@ -137,10 +137,12 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
 
     PathState st{}; // (every field defined: a lane that has not started a pixel yet can be moved by a compaction)
     st.alive = false;
+    PendingShadow pend{}; // merged queries (path_step_merged): the last vertex's shadow ray, waiting for the next walk
+    pend.shadow = pend.finish = false;
     // (pool walk: the wavefront's pool area instead of the lane's stack column)
     // (the wavefront's number as a scalar: every address inside its pool area is then a scalar base + a lane offset)
     st.stack = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged) +
-                              static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6))) * pool_wave_words(C::kAnalytic, C::kPoolBig)
+                              static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6))) * pool_wave_words(C::kAnalytic, C::kPoolBig, C::kPoolDual)
                         : reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + threadIdx.x;
     bool has_pixel = false;
     uint32_t slot = 0; // where this pixel's result goes
@@ -159,7 +161,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     //  counters, which are read at every step, have their own words behind them)
     uint32_t *compact_words = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged)
                                        : reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + static_cast<size_t>(sc_in.integrator.walk_depth) * kBlockSize;
-    uint32_t *compact_count = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + (kBlockSize / 64u) * pool_wave_words(C::kAnalytic, C::kPoolBig)
+    uint32_t *compact_count = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + (kBlockSize / 64u) * pool_wave_words(C::kAnalytic, C::kPoolBig, C::kPoolDual)
                                        : compact_words + kCompactWords * kBlockSize; // [0..3]: live lanes per wavefront, [4]: retired lanes of the workgroup
     bool retired = false;
     uint32_t compact_events = 0; // events this wavefront has taken part in (event k: 64 (k + 1) lanes retired)
@@ -249,7 +251,8 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
                 in[6] = as_uint(st.pdf_sample);
                 auto put = [&](uint32_t at, V3 v) { in[at] = as_uint(v.x), in[at + 1] = as_uint(v.y), in[at + 2] = as_uint(v.z); };
                 put(7, st.origin), put(10, st.dir), put(13, st.wo), put(16, st.wi), put(19, st.throughput), put(22, st.L), put(25, st.pixel_sum);
-                in[28] = slot, in[29] = q, in[30] = 0, in[31] = 0;
+                in[28] = slot, in[29] = q, in[30] = 0, in[31] = 0; // (no pending shadow ray travels: merged queries run outside LDS, the compaction inside)
+                static_assert(!(kCompact && C::kPoolDual), "the compaction does not carry a pending shadow ray");
 #pragma unroll
                 for (uint32_t pass = 0; pass < kCompactPasses; ++pass)
                 {
@@ -329,7 +332,8 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
             slot = (job.packed ? item : pixel) + k * job.plane_stride;
             has_pixel = true;
         }
-        if (!helper && !st.alive)
+        // (merged queries: a pixel whose last sample still waits for its last shadow ray is written one step later)
+        if (!helper && !st.alive && !(C::kPoolDual && pend.shadow && st.sample >= sc.camera.spp))
         {
             if (st.sample >= sc.camera.spp)
             {
@@ -345,7 +349,9 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
             if (kCount)
                 ++local.samples;
         }
-        if constexpr (C::kPool)
+        if constexpr (C::kPoolDual)
+            path_step_merged<C>(sc, st, pend, cnt, !helper && st.alive);
+        else if constexpr (C::kPool)
             path_step_uniform<C>(sc, st, cnt, !helper);
         else
             path_step<C>(sc, st, cnt);
@@ -424,7 +430,7 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
     static_assert(!kPool || (kOrdered && (kLdsGeometry != ((kFeatures & kFeatPoolBig) != 0))), "pool walk: 16-bit items with the hierarchy staged in LDS, 32-bit items outside");
     static_assert((kBlockSize / 64u) * pool_wave_words(false) >= kCompactWords * kBlockSize, "the compaction's words travel through the pool areas");
     const size_t lds_bytes = (kLdsGeometry ? StagedBytes(sc, kOrdered, kPool) : 0) +
-                             (kPool      ? size_t(kBlockSize / 64u) * pool_wave_words((kFeatures & kFeatAnalytic) != 0, (kFeatures & kFeatPoolBig) != 0) * sizeof(uint32_t) + 8 * sizeof(uint32_t)
+                             (kPool      ? size_t(kBlockSize / 64u) * pool_wave_words((kFeatures & kFeatAnalytic) != 0, (kFeatures & kFeatPoolBig) != 0, Config<kFeatures>::kPoolDual) * sizeof(uint32_t) + 8 * sizeof(uint32_t)
                               : kOrdered ? WalkStackEntries(sc, kFeatures) * kBlockSize * sizeof(uint32_t)
                                          : 0) +
                              (!kPool && kLdsGeometry && !kCount && kOrdered && !(kFeatures & (kFeatVolPath | kFeatAnalytic))

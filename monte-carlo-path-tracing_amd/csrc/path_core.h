@@ -29,6 +29,10 @@
 #include "traversal.h"
 #include "pool_walk.h"
 
+#ifndef MCPT_POOL_MERGE
+#define MCPT_POOL_MERGE 1
+#endif
+
 namespace mcpt
 {
 
@@ -52,6 +56,25 @@ struct Config
     static constexpr bool kWide = (kFeatures & kFeatWideWalk) != 0;       // ... on the 4-wide quantised hierarchy
     static constexpr bool kPool = (kFeatures & kFeatPoolWalk) != 0;       // ... as the wavefront-cooperative pool walk (pool_walk.h; device only)
     static constexpr bool kPoolBig = (kFeatures & kFeatPoolBig) != 0;     // ... with 32-bit items, the hierarchy outside LDS
+    // ... with MERGED queries: a vertex's last shadow query travels with the next segment's closest query (path_step_merged; the
+    // path integrator's pool-walk kernels; -DMCPT_POOL_MERGE=0 builds the two-queries-per-vertex form for A/B measurements)
+    // (scenes outside LDS only.  The LDS kernels keep two queries per vertex: with two ray records per lane their pool areas leave
+    //  room for 3 wavefronts per SIMD instead of 4 on a VALU-bound kernel — and the LDS form with an AREA light's pending ray gave
+    //  wrong visibility in round 5's tests for a reason that was not found, while every other combination is exact: EXPERIMENTS R5-6)
+    static constexpr bool kPoolDual = kPool && kPoolBig && !kVolPath && (MCPT_POOL_MERGE != 0);
+};
+
+// What a vertex leaves behind for the NEXT step's merged query (path_step_merged): its last light's shadow ray and what the sample's
+// radiance gains with either answer — and, when the path ended at that vertex's scattering, the sample's radiance so far, to be
+// clamped and added to the pixel once the answer is known.
+struct PendingShadow
+{
+    bool shadow;  // a shadow ray waits
+    bool finish;  // ... and the sample it belongs to is over: `old_L` is its radiance (st.L belongs to the next sample already)
+    V3 origin, dir;
+    float t_max;
+    V3 add_visible, add_occluded; // throughput x (the vertex's direct light with / without the pending light), path.cpp:98
+    V3 old_L;
 };
 
 struct LaneCounters
@@ -861,6 +884,201 @@ __device__ __forceinline__ void path_step_uniform(const DeviceScene &sc, PathSta
     if (has_path)
         path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
     path_connect_scatter_uniform<C>(sc, st, cnt, surf, has_path && st.alive);
+}
+
+// ---- MERGED QUERIES (round 5) -----------------------------------------------------------------------------------
+// The reference traces, at every vertex, one shadow ray per light and then the next segment (path.cpp:144-205, 268-296), and
+// nothing between a vertex's last shadow query and the next closest query draws a random number (the walks draw none; the
+// scattering's draws come BEFORE it is known whether the light was visible, and the radiance of the light is only ADDED to the
+// sample).  So the last shadow ray of a vertex can travel together with the next segment's ray: one pool walk with up to two
+// rays per lane (pool_walk.h, kDual) instead of two walks of one — half the query rounds of a path (each a chain of dependent
+// steps), twice the items per step.  What the vertex would add to the sample is kept with either answer (PendingShadow) and
+// added, in the reference's order of additions, right after the walk — before the next vertex adds anything.  A path that ends
+// at the scattering of a vertex with a pending ray is finished (clamped, added to the pixel) one step later, while its lane's
+// next sample is already under way; samples are still finished in order.  Lights before the last one are queried on the spot.
+template <class C>
+__device__ __forceinline__ void connect_lights_merged(const DeviceScene &sc, uint32_t *pool, bool active, const Surface &s, V3 position, V3 wo, V3 throughput,
+                                                      uint32_t &rng, V3 &sample_L, PendingShadow &pd, LaneCounters *cnt)
+{
+    static_assert(!C::kVolPath, "merged queries: the path integrator");
+    V3 L = V3{0, 0, 0};
+    const LightTables LT = light_tables<C>(sc);
+    const uint32_t bsdf = !active ? kNone : sc.instances[s.inst].bsdf;
+    auto weigh = [&](V3 wi, V3 &att, float &pdf) -> bool
+    {
+        if (dot(-wi, s.normal) < kEpsFloat)
+            return false;
+        const BsdfQuery q = eval_at<C>(sc, s, bsdf, wi, wo);
+        if (!q.valid)
+            return false;
+        att = q.attenuation, pdf = q.pdf;
+        return true;
+    };
+    bool wait = false; // this lane's last light waits for the next walk
+    V3 last = V3{0, 0, 0};
+    if (C::kEmitters)
+    {
+        for (uint32_t k = 0; k < sc.integrator.n_emitters; ++k)
+        {
+            const EmitterRec &e = sc.emitters[k];
+            const bool deferred = sc.integrator.n_area_lights == 0 && k + 1 == sc.integrator.n_emitters; // (uniform)
+            LightSample ls{};
+            if (active)
+            {
+                const float xi0 = lcg_next(rng), xi1 = lcg_next(rng);
+                ls = emitter_sample(LT, e, position, xi0, xi1);
+            }
+            bool occluded = false;
+            if (!deferred)
+                occluded = shadow_walk_uniform<C>(sc, pool, active, position, -ls.wi, ls.distance - kEpsDistance, cnt);
+            V3 att;
+            float pdf;
+            if (!active || occluded || !weigh(ls.wi, att, pdf))
+                continue;
+            const V3 radiance = emitter_eval_sample(LT, e, ls);
+            V3 c = V3{0, 0, 0};
+            bool some = false;
+            if (ls.harsh)
+                c = radiance * att, some = true; // path.cpp:170
+            else
+            {
+                const float pdf_direct = emitter_pdf(LT, e, -ls.wi);
+                if (pdf_direct > kEpsFloat)
+                    c = power_heuristic(pdf_direct, pdf) * radiance * (att / pdf_direct), some = true; // path.cpp:178
+            }
+            if (!some)
+                continue;
+            if (!deferred)
+                L += c;
+            else
+            {
+                wait = true, last = c;
+                pd.origin = position, pd.dir = -ls.wi, pd.t_max = ls.distance - kEpsDistance;
+            }
+        }
+    }
+    if (sc.integrator.n_area_lights != 0)
+    {
+        if (active)
+        {
+            const float xi_pick = lcg_next(rng);
+            const uint32_t light = cdf_search(sc.integrator.n_area_lights + 1, sc.light_cdf, xi_pick) - 1;
+            const uint32_t inst = sc.light_inst[light];
+            const float xi0 = lcg_next(rng), xi1 = lcg_next(rng), xi2 = lcg_next(rng);
+            const LightPoint lp = sample_instance<C::kAnalytic>(sc, inst, xi0, xi1, xi2);
+            const V3 d = position - lp.position;
+            const float distance = length(d);
+            const V3 wi = normalize(d);
+            const float cos_light = dot(wi, lp.normal);
+            V3 att;
+            float pdf;
+            if (!(cos_light < kEpsFloat) && weigh(wi, att, pdf))
+            {
+                const float pdf_direct = area_light_pdf(sc, light, inst, distance, cos_light), w = power_heuristic(pdf_direct, pdf);
+                const V3 radiance = texture_color(sc.textures, sc.texels, sc.bsdfs[sc.instances[inst].bsdf].tex0, lp.uv, !C::kTextures);
+                wait = true, last = w * radiance * (att / pdf_direct); // path.cpp:232
+                // the shadow ray starts ON THE LIGHT and travels to the shading point
+                pd.origin = lp.position, pd.dir = wi, pd.t_max = distance - kEpsDistance;
+            }
+        }
+    }
+    if (!active)
+        return;
+    // path.cpp:98: L += throughput * direct, direct = (((0 + c_1) + c_2) ... + c_last): the same sums and products, the last term
+    // with both answers
+    if (wait)
+    {
+        pd.shadow = true;
+        pd.add_occluded = throughput * L, pd.add_visible = throughput * (L + last);
+    }
+    else
+        sample_L += throughput * L;
+}
+
+// One step of every lane of the wavefront with merged queries.  `has_path`: the lane's path is alive; a lane may also only have a
+// pending shadow ray (its sample's path ended at the last vertex), or nothing (a helper of the others' rays).
+template <class C>
+__device__ __forceinline__ void path_step_merged(const DeviceScene &sc, PathState &st, PendingShadow &pd, LaneCounters *cnt, bool has_path)
+{
+    static_assert(C::kOrdered && C::kPoolDual, "merged queries run on the pool walk");
+    // ---- the walk: this segment's closest query + the last vertex's pending shadow query ----
+    Ray ray = make_ray(has_path ? st.origin : V3{0, 0, 0}, has_path ? st.dir : V3{0, 0, 1});
+    HitRaw raw;
+    raw.inst = raw.prim = 0, raw.a = raw.b = raw.c = 0.0f, raw.inside = false;
+    TraceStats ts{0, 0, 0, 0};
+    const bool known = has_path && st.primary && sc.prehit != nullptr; // the pre-pass traced this camera ray
+    bool hit_valid = false;
+    if (known)
+    {
+        const uint32_t *rec = prehit_record(sc, st.pixel, st.sample - sc.prehit_step);
+        hit_valid = rec[0] != kNone;
+        if (hit_valid)
+            hit_from_record<C::kAnalytic>(sc, rec[1], rec[0], ray, raw);
+    }
+    Ray shadow = make_ray(pd.shadow ? pd.origin : V3{0, 0, 0}, pd.shadow ? pd.dir : V3{0, 0, 1});
+    shadow.t_max = pd.t_max;
+    bool occluded = false;
+    const bool traced = cnt ? walk_pool<false, C::kAnalytic, true, C::kPoolBig, C::kSlivers, true>(sc, st.stack, has_path && !known, ray, raw, ts, pd.shadow, &shadow, &occluded)
+                            : walk_pool<false, C::kAnalytic, false, C::kPoolBig, C::kSlivers, true>(sc, st.stack, has_path && !known, ray, raw, ts, pd.shadow, &shadow, &occluded);
+    if (cnt)
+    {
+        cnt->closest_rays += has_path && !known ? 1u : 0u, cnt->shadow_rays += pd.shadow ? 1u : 0u;
+        cnt->node_tests += ts.node_tests, cnt->prim_tests += ts.prim_tests;
+        cnt->wave_node_steps += ts.wave_node_steps, cnt->wave_prim_steps += ts.wave_prim_steps;
+    }
+    hit_valid = known ? hit_valid : traced;
+    // ---- what the last vertex adds to its sample, now that its light's visibility is known ----
+    if (pd.shadow)
+    {
+        const V3 add = occluded ? pd.add_occluded : pd.add_visible;
+        if (pd.finish)
+        {
+            pd.old_L += add;
+            st.pixel_sum += V3{fminf(pd.old_L.x, 1.0f), fminf(pd.old_L.y, 1.0f), fminf(pd.old_L.z, 1.0f)}; // finish_sample, one step late
+        }
+        else
+            st.L += add;
+        pd.shadow = pd.finish = false;
+    }
+    // ---- resolve this segment's vertex, connect (the last light waits), scatter ----
+    Surface surf;
+    surf.inside = false, surf.inst = 0, surf.uv = V2{0, 0};
+    surf.position = surf.normal = surf.tangent = surf.bitangent = V3{0, 0, 0};
+    if (has_path)
+        path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
+    const bool active = has_path && st.alive;
+    connect_lights_merged<C>(sc, st.stack, active, surf, surf.position, st.wo, st.throughput, st.rng, st.L, pd, cnt);
+    if (!active)
+        return;
+    // (scatter of path_connect_scatter, path.cpp:268-296; a sample that ends here with a light pending is finished after the next walk)
+    auto end_sample = [&]()
+    {
+        if (pd.shadow)
+            pd.finish = true, pd.old_L = st.L, st.alive = false;
+        else
+            finish_sample(st);
+    };
+    const uint32_t bsdf = sc.instances[surf.inst].bsdf;
+    BsdfQuery q = query_at(surf, st.wo, st.wo);
+    if (bsdf != kNone)
+        bsdf_sample<C::kMicrofacet, 0, C::kKinds>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
+    else
+        q.wi = st.wo, q.pdf = 1.0f, q.attenuation = V3{1.0f, 1.0f, 1.0f}, q.valid = true; // pass-through surface (quirk Q8)
+    if (!q.valid)
+    {
+        end_sample();
+        return;
+    }
+    st.wi = q.wi;
+    st.pdf_sample = q.pdf;
+    st.throughput *= q.attenuation / q.pdf;
+    st.origin = surf.position;
+    if (max_component(st.throughput) < kEps)
+    {
+        end_sample();
+        return;
+    }
+    st.dir = -st.wi;
 }
 #endif // __HIPCC__
 

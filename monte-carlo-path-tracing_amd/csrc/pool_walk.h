@@ -47,7 +47,8 @@
 namespace mcpt
 {
 
-constexpr uint32_t kPoolCands = 6;       // candidate hits a closest ray can hold
+constexpr uint32_t kPoolCands = 5;       // candidate hits a closest ray can hold (seen on cornell: up to 5, 0.17 % of the rays beyond 4; a ray
+                                         // with more walks alone — below.  6 until merged queries needed the 3 KB per workgroup)
 constexpr uint32_t kPoolNodeItems = 448; // (ray, node) item slots: 384 in normal operation + 64 of head room (see below)
 constexpr uint32_t kPoolNodeFull = 384;
 constexpr uint32_t kPoolMaxDepth = 20;   // of the 4-wide hierarchy: 3 x depth <= the head room
@@ -62,6 +63,7 @@ constexpr uint32_t kPoolPrimAt = MCPT_POOL_PRIM_AT; // a primitive phase runs wh
 static_assert(kPoolPrimItems >= kPoolPrimAt + 256u, "a node step of 64 lanes can push 256 slots on top of the waiting ones");
 constexpr uint32_t kPoolMaxRef = 1023;   // node and slot indices must fit 10 bits (16-bit items: scenes in LDS)
 constexpr uint32_t kPoolMaxRefBig = (1u << 26) - 1u; // ... 26 bits (32-bit items: kFeatPoolBig)
+constexpr uint32_t kPoolMaxRefDual = 511, kPoolMaxRefBigDual = (1u << 25) - 1u; // ... 9 / 25 bits with two rays per lane (merged queries)
 
 // Scenes outside LDS (kBig): the node step reads the QUANTISED 4-wide form of the hierarchy (DeviceScene::wide_nodes: 64 bytes per
 // node — four children's boxes as 8-bit offsets on the node's own grid, decoded boxes contain the exact ones, siblings adjacent, two
@@ -86,9 +88,15 @@ MCPT_HD bool slot_leaf_box_passes(const float4 *p, Ray ray, float t_max)
 }
 
 MCPT_HD constexpr uint32_t pool_ray_words(bool analytic) { return analytic ? 16u : 12u; }
-MCPT_HD constexpr uint32_t pool_wave_words(bool analytic, bool big = false)
+// MERGED QUERIES (round 5, path_core.h path_step_merged): a lane brings up to TWO rays to one query — the closest-hit query of its
+// path's next segment and the shadow query its previous vertex left pending (nothing between the two draws a random number, so they
+// can be walked together: half the query rounds per path, twice the items per step).  `dual`: 128 ray records and counters per
+// wavefront (record 64 + lane = the lane's shadow ray), one reference bit less in an item, a longer node list.
+constexpr uint32_t kPoolNodeItemsDual = 640, kPoolNodeFullDual = 576;
+MCPT_HD constexpr uint32_t pool_wave_words(bool analytic, bool big = false, bool dual = false)
 {
-    return 64u * pool_ray_words(analytic) + 64u + 64u * kPoolCands * 2u + (kPoolNodeItems + kPoolPrimItems) / (big ? 1u : 2u);
+    return (dual ? 128u : 64u) * pool_ray_words(analytic) + (dual ? 128u : 64u) + 64u * kPoolCands * 2u +
+           ((dual ? kPoolNodeItemsDual : kPoolNodeItems) + kPoolPrimItems) / (big ? 1u : 2u);
 }
 
 // The probe of one primitive slot WITHOUT any bound: does the ray's line hit it at t >= kEpsDistance, and where
@@ -143,11 +151,16 @@ __device__ __forceinline__ uint32_t pool_rank(unsigned long long mask, uint32_t 
 // otherwise, and an accepted hit shrinks the bound to its distance + ITS radius (a candidate carries its sliver flag in
 // bit 31 of its slot word).  (One radius for everything — the reach — was tried first: in dense geometry, dragon/scene.xml's
 // cloth, a dozen ordinary hits lie within 0.06 of each other and the candidate lists overflowed.)
-template <bool kAny, bool kAnalytic, bool kCount, bool kBig = false, bool kSlivers = false>
-__device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool, bool has_ray, Ray &ray, HitRaw &hit, TraceStats &stats)
+// kDual (merged queries): the lane may bring a SECOND ray, a shadow ray (`shadow`, `has_shadow`; kAny must be false: the first ray is
+// a closest query); `*occluded` tells whether that one hit anything.
+template <bool kAny, bool kAnalytic, bool kCount, bool kBig = false, bool kSlivers = false, bool kDual = false>
+__device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool, bool has_ray, Ray &ray, HitRaw &hit, TraceStats &stats, bool has_shadow = false,
+                                          const Ray *shadow = nullptr, bool *occluded = nullptr)
 {
+    static_assert(!(kDual && kAny), "merged queries: the first ray is the closest query");
     using Item = typename std::conditional<kBig, uint32_t, uint16_t>::type; // ray << kRefBits | node or slot
-    constexpr uint32_t kRefBits = kBig ? 26u : 10u, kRefMask = (1u << kRefBits) - 1u;
+    constexpr uint32_t kRefBits = (kBig ? 26u : 10u) - (kDual ? 1u : 0u), kRefMask = (1u << kRefBits) - 1u;
+    constexpr uint32_t kRecords = kDual ? 128u : 64u, kNodeItems = kDual ? kPoolNodeItemsDual : kPoolNodeItems, kNodeFull = kDual ? kPoolNodeFullDual : kPoolNodeFull;
     constexpr bool kQuant = kBig && (MCPT_POOL_QUANT != 0); // the quantised node records + the leaf-box test at the primitive
     if (sc.integrator.n_walk_nodes == 0)
         return false;
@@ -156,16 +169,41 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
     const unsigned long long workers = __ballot(1);
     const uint32_t rank = pool_rank(workers), n_workers = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__popcll(workers))));
     float4 *rays = reinterpret_cast<float4 *>(pool);
-    uint32_t *counts = pool + 64u * pool_ray_words(kAnalytic);
-    uint2 *cands = reinterpret_cast<uint2 *>(counts + 64u);
-    Item *node_items = reinterpret_cast<Item *>(counts + 64u + 64u * kPoolCands * 2u), *prim_items = node_items + kPoolNodeItems;
+    uint32_t *counts = pool + kRecords * pool_ray_words(kAnalytic);
+    uint2 *cands = reinterpret_cast<uint2 *>(counts + kRecords);
+    Item *node_items = reinterpret_cast<Item *>(counts + kRecords + 64u * kPoolCands * 2u), *prim_items = node_items + kNodeItems;
     const float tie = sc.integrator.walk_tie, reach = kSlivers ? sc.integrator.walk_sliver_reach : sc.integrator.walk_tie;
 
     // ---- the lane's ray becomes a record ----
-    const unsigned long long m_rays = __ballot(has_ray);
-    if (m_rays == 0)
+    const unsigned long long m_rays = __ballot(has_ray), m_shadows = kDual ? __ballot(has_shadow) : 0ull;
+    if (kDual && occluded)
+        *occluded = false;
+    if ((m_rays | m_shadows) == 0)
         return false;
-    if (has_ray)
+    auto write_record = [&](uint32_t at, const Ray &q)
+    {
+        const uint32_t nx = q.dir_rcp.x > 0 ? 0u : 48u, ny = q.dir_rcp.y > 0 ? 16u : 64u, nz = q.dir_rcp.z > 0 ? 32u : 80u;
+        const uint32_t pack = nx | (ny << 8) | (nz << 16);
+        const uint32_t axes = static_cast<uint32_t>(q.kx) | (static_cast<uint32_t>(q.ky) << 2) | (static_cast<uint32_t>(q.kz) << 4);
+        rays[kRayVecs * at + 0] = float4{q.origin.x, q.origin.y, q.origin.z, q.t_max};
+        rays[kRayVecs * at + 1] = float4{q.dir_rcp.x, q.dir_rcp.y, q.dir_rcp.z, __uint_as_float(pack)};
+        rays[kRayVecs * at + 2] = float4{q.shear.x, q.shear.y, q.shear.z, __uint_as_float(axes)};
+        if (kAnalytic)
+            rays[kRayVecs * at + 3] = float4{q.dir.x, q.dir.y, q.dir.z, 0.0f};
+        counts[at] = 0;
+    };
+    if (kDual && has_shadow)
+    {
+        // (record 64 + lane; its top-node item behind the closest rays')
+        write_record(64u + lane, *shadow);
+        node_items[static_cast<uint32_t>(__popcll(m_rays)) + pool_rank(m_shadows)] = static_cast<Item>((64u + lane) << kRefBits);
+    }
+    if (has_ray && kDual)
+    {
+        write_record(lane, ray);
+        node_items[pool_rank(m_rays)] = static_cast<Item>(lane << kRefBits);
+    }
+    if (has_ray && !kDual)
     {
         // byte offsets, inside a node's 128-byte record {lo.x lo.y lo.z hi.x hi.y hi.z of the four children | references}, of
         // the planes the ray enters through (walk_ordered's sign-addressed reads): x: 0 or 48, y: 16 or 64, z: 32 or 80
@@ -182,7 +220,7 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
     }
     // (wavefront-uniform values, kept in scalar registers: `uni` tells the compiler so where it cannot see it)
     auto uni = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
-    uint32_t n_nodes = uni(static_cast<uint32_t>(__popcll(m_rays))), n_prims = 0;
+    uint32_t n_nodes = uni(static_cast<uint32_t>(__popcll(m_rays) + __popcll(m_shadows))), n_prims = 0;
     // One node step over the top `k` items with G lanes per item (G = 1, 2, 4), each lane testing kPer = 4 / G children of its
     // item's node.  Everything inside ONE region of the working lanes — ballots included, they only see those lanes: predicates
     // that leave the region would travel as 0 / 1 words through vector registers.
@@ -349,7 +387,8 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
                     float *bound = reinterpret_cast<float *>(&rays[kRayVecs * r]) + 3;
                     // (a sliver reached through its grown box: would the reference's own leaf box let the ray in?)
                     const bool sliver = kSlivers && (as_uint(p[2].w) & kWalkSliver) != 0;
-                    if (kAny)
+                    const bool any = kDual ? r >= 64u : kAny; // (merged queries: the upper records are the shadow rays)
+                    if (any)
                     {
                         if (h.hit && !(h.t > a.w) && (!sliver || reference_leaf_box_passes<kAnalytic>(sc, as_uint(p[1].w), as_uint(p[0].w), q, a.w))) // (test_slot, kAny)
                         {
@@ -379,7 +418,7 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
             // (head room: a step with k items grows the list by at most 3 k.  Below kPoolNodeFull every worker takes an item
             //  if that fits; above, ONE does — a depth-first walk, which adds at most 3 x the tree's depth to the list)
             uint32_t k = uni(n_nodes < n_workers ? n_nodes : n_workers);
-            const uint32_t room = uni(n_nodes < kPoolNodeFull ? (kPoolNodeFull - n_nodes + 2u) / 3u : 1u);
+            const uint32_t room = uni(n_nodes < kNodeFull ? (kNodeFull - n_nodes + 2u) / 3u : 1u);
             k = uni(k < room ? k : room);
             if (kCount && rank == 0)
                 ++stats.wave_node_steps;
@@ -401,6 +440,8 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
             pool_sync();
         }
     }
+    if (kDual && occluded && has_shadow)
+        *occluded = counts[64u + lane] != 0;
     if (!has_ray)
         return false;
     if (kAny)

@@ -808,6 +808,38 @@ def test_renderer_guards_itself_against_a_scene_outside_the_tie_radius(pkg, orac
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("lights", ["area", "area+directional", "directional"])
+def test_merged_queries_outside_lds_equal_the_oracle(lights, pkg, oracle, tmp_path):
+    """Merged queries (round 5; path_core.h path_step_merged, pool_walk.h kDual): a vertex's last shadow ray travels with the next
+    segment's closest query — scenes outside LDS.  A cornell box with a mesh sphere inside (2 300 triangles: outside LDS), lit by its
+    area light (the pending ray starts ON the light), by the area light and a directional emitter (the emitter is queried on the spot,
+    the area light waits) or by the emitter alone: GPU frame == oracle frame, with the camera-ray pre-pass and without."""
+    M = pkg.mcsd
+    scene = pkg.scenes.cornell_box(96, 96, 8)
+    sp = pkg.scenes.uv_sphere_mesh(24, 48, 0.3, (0.0, 0.6, 0.0))
+    light = scene.instances[-1]
+    if lights == "directional":
+        scene.instances = scene.instances[:-1]
+    scene.instances.append(M.Instance(type=M.INST_MESHES, id_bsdf=2, to_world=M.IDENTITY.copy(), positions=sp["positions"],
+                                      normals=sp["normals"], texcoords=sp["texcoords"], indices=sp["indices"]))
+    if lights == "area":   # (keep the light the last instance or not: both orders are the reference's business, not the walk's)
+        scene.instances.remove(light), scene.instances.append(light)
+    if "directional" in lights:
+        scene.emitters.append(M.Emitter(type=M.EMIT_DIRECTIONAL, direction=(0.2, -0.7, -0.68), radiance=(3, 3, 3)))
+    path = str(tmp_path / "scene.mcsd")
+    M.dump(scene, path)
+    want, _ = oracle.render(path)
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
+    try:
+        for prepass in (1, 0):
+            frame, _ = r.set_prepass(prepass).draw()
+            assert "pool-walk" in r.last_kernel() and "lds" not in r.last_kernel(), r.last_kernel()
+            assert np.array_equal(frame, want), (lights, prepass, r.last_kernel())
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
 def test_pool_walk_full_film_hash_equals_the_per_lane_walk(pkg):
     """cornell-box 512 x 512 (BASELINE config 2's film) at spp 64: the pool walk's frame == the per-lane walk's, 20 repeated
     draws hash-identical (the candidate set of a closest query does not depend on the order its items were processed in)."""
