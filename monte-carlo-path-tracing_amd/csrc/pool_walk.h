@@ -28,7 +28,7 @@
 //     (stale candidates — accepted before a much nearer hit was known — lie outside the tie radius and are ignored), so
 //     neither does the result; the winner's record is then re-evaluated on the owner's own ray registers
 //     (the same values test_slot would have copied: hit_from_record's argument).
-//   * a ray that accepts more candidates than its list holds (kPoolCands; seen: up to 5 on cornell, 0.17 % of the rays
+//   * a ray that accepts more candidates than its list holds (pool_cands(); seen: up to 5 on cornell, 0.17 % of the rays
 //     beyond 4) is walked again by its owner alone, the per-lane way (walk_ordered on a private stack).
 // Sliver triangles: kSlivers below.  Not for scenes with opacity masks (their test draws random numbers DURING a walk, so
 // the visiting order is part of the image: the reference-order walk, traversal.h).
@@ -47,8 +47,10 @@
 namespace mcpt
 {
 
-constexpr uint32_t kPoolCands = 5;       // candidate hits a closest ray can hold (seen on cornell: up to 5, 0.17 % of the rays beyond 4; a ray
-                                         // with more walks alone — below.  6 until merged queries needed the 3 KB per workgroup)
+// candidate hits a closest ray can hold (a ray with more walks alone — below).  6; 5 with merged queries, whose 13.3 KB per wavefront
+// must leave room for three workgroups per CU (a ray through a vertex of valence 6 has six: dense smooth meshes — matpreview lost
+// 2-3 % to the shorter list, so the unit without merged queries keeps six)
+MCPT_HD constexpr uint32_t pool_cands(bool dual) { return dual ? 5u : 6u; }
 constexpr uint32_t kPoolNodeItems = 448; // (ray, node) item slots: 384 in normal operation + 64 of head room (see below)
 constexpr uint32_t kPoolNodeFull = 384;
 constexpr uint32_t kPoolMaxDepth = 20;   // of the 4-wide hierarchy: 3 x depth <= the head room
@@ -95,7 +97,7 @@ MCPT_HD constexpr uint32_t pool_ray_words(bool analytic) { return analytic ? 16u
 constexpr uint32_t kPoolNodeItemsDual = 640, kPoolNodeFullDual = 576;
 MCPT_HD constexpr uint32_t pool_wave_words(bool analytic, bool big = false, bool dual = false)
 {
-    return (dual ? 128u : 64u) * pool_ray_words(analytic) + (dual ? 128u : 64u) + 64u * kPoolCands * 2u +
+    return (dual ? 128u : 64u) * pool_ray_words(analytic) + (dual ? 128u : 64u) + 64u * pool_cands(dual) * 2u +
            ((dual ? kPoolNodeItemsDual : kPoolNodeItems) + kPoolPrimItems) / (big ? 1u : 2u);
 }
 
@@ -160,6 +162,7 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
     static_assert(!(kDual && kAny), "merged queries: the first ray is the closest query");
     using Item = typename std::conditional<kBig, uint32_t, uint16_t>::type; // ray << kRefBits | node or slot
     constexpr uint32_t kRefBits = (kBig ? 26u : 10u) - (kDual ? 1u : 0u), kRefMask = (1u << kRefBits) - 1u;
+    constexpr uint32_t kPoolCands = pool_cands(kDual);
     constexpr uint32_t kRecords = kDual ? 128u : 64u, kNodeItems = kDual ? kPoolNodeItemsDual : kPoolNodeItems, kNodeFull = kDual ? kPoolNodeFullDual : kPoolNodeFull;
     constexpr bool kQuant = kBig && (MCPT_POOL_QUANT != 0); // the quantised node records + the leaf-box test at the primitive
     if (sc.integrator.n_walk_nodes == 0)

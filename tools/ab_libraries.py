@@ -82,7 +82,7 @@ def main():
                 rec[n]["kernel"] = d["kernel"]
         shas = set().union(*(rec[n]["sha"] for n in rec))
         out[w] = {"frames_identical": len(shas) == 1,
-                  **{n: {"median_ms": statistics.median(rec[n]["ms"]) if rec[n]["ms"] else None, "min_ms": min(rec[n]["ms"], default=None),
+                  **{n: {"median_ms": statistics.median(rec[n]["ms"]) if rec[n]["ms"] else None, "min_ms": min(rec[n]["ms"], default=None), "max_ms": max(rec[n]["ms"], default=None), "all_ms": [round(v, 2) for v in rec[n]["ms"]],
                          "n": len(rec[n]["ms"]), "kernel": rec[n].get("kernel"), **({"error": rec[n]["error"]} if "error" in rec[n] else {})}
                      for n in rec}}
         print(json.dumps({w: out[w]}), flush=True)
