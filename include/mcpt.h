@@ -216,6 +216,11 @@ int mcpt_renderer_set_walk_schedule(mcpt_renderer *r, uint32_t leave_below, uint
  *          and the per-pixel random stream makes a frame a chain of rounds: DESIGN.md section 3e), so the library never
  *          picks it by itself. */
 int mcpt_renderer_set_kernel(mcpt_renderer *r, int mode, uint32_t slots, uint32_t refill_at);
+/* Whether modes 1 - 5 above (and mcpt_debug_trace_rate) are part of this build.  Since round 5 the default build of the library
+ * holds the lane-owns-a-path kernels only — the one formulation its rule chooses on every scene measured, by 1.4 - 4 x
+ * (csrc/hip/formulations_not_built.hip) — and a request for another mode renders with them, like on any scene a mode does not
+ * cover; `make EXPERIMENTAL=1` builds the others in.  No reference counterpart. */
+int mcpt_build_has_formulations(void);
 /* Times the kernel configurations on this renderer's scene and film now (blocking, eight sample launches) and stores
  * the winner for mode -1 — see mcpt_renderer_set_kernel.  No reference counterpart. */
 int mcpt_renderer_calibrate(mcpt_renderer *r);

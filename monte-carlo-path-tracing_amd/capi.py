@@ -53,6 +53,11 @@ def build(quiet: bool = True) -> str:
 _lib = None
 
 
+def has_formulations() -> bool:
+    """Whether the stream kernel, the queued renderer, mode 3 and the trace-rate experiment are part of the library (make EXPERIMENTAL=1)."""
+    return bool(lib().mcpt_build_has_formulations())
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -144,7 +149,7 @@ EXPORTED_SYMBOLS = [
     "mcpt_renderer_table", "mcpt_renderer_info", "mcpt_renderer_set_walk", "mcpt_renderer_set_walk_schedule",
     "mcpt_renderer_set_kernel", "mcpt_renderer_last_kernel", "mcpt_renderer_check_walks", "mcpt_renderer_set_rng", "mcpt_renderer_set_prepass", "mcpt_renderer_set_lane_spread", "mcpt_renderer_set_pixel_order", "mcpt_renderer_set_work_distribution", "mcpt_renderer_last_choice",
     "mcpt_renderer_destroy",
-    "mcpt_renderer_calibrate", "mcpt_renderer_set_tile_order", "mcpt_renderer_set_class_sort", "mcpt_renderer_set_pool_walk", "mcpt_renderer_get_walk", "mcpt_renderer_set_stream_waves", "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_cost_table", "mcpt_debug_trace_pixel", "mcpt_debug_trace_rate",
+    "mcpt_renderer_calibrate", "mcpt_renderer_set_tile_order", "mcpt_renderer_set_class_sort", "mcpt_renderer_set_pool_walk", "mcpt_renderer_get_walk", "mcpt_renderer_set_stream_waves", "mcpt_debug_intersect", "mcpt_debug_bsdf", "mcpt_debug_lbvh_build", "mcpt_debug_cost_table", "mcpt_debug_trace_pixel", "mcpt_debug_trace_rate", "mcpt_build_has_formulations",
     "mcpt_write_image", "mcpt_last_error", "mcpt_version",
     "mcpt_config_serialize", "mcpt_tiled_renderer_create", "mcpt_tiled_renderer_draw",
     "mcpt_tiled_renderer_set_kernel", "mcpt_tiled_renderer_destroy", "mcpt_render_tiled", "mcpt_device_count",

@@ -1881,6 +1881,8 @@ int mcpt_debug_lbvh_build(uint32_t n, const float *boxes, const float *areas, in
     }
 }
 
+int mcpt_build_has_formulations(void) { return mcpt::FormulationsBuilt() ? 1 : 0; }
+
 // TEST HOOK, not part of include/mcpt.h: the scale of the ordered walk's tie radius for scenes committed from now on (1 = production).
 // tests/test_gpu_parity.py builds a scene that lies outside a shrunken radius to see mcpt_renderer_create's self-check catch it.
 void mcpt_testing_set_walk_tie_scale(float scale) { mcpt::SetWalkTieScaleForTesting(scale); }

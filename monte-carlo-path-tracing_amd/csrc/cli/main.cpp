@@ -32,7 +32,8 @@ void Usage()
                  "  mcpt_cli [-g|--gpu] -i|--input <scene.xml | scene.mcsd | builtin:cornell-box>\n"
                  "           [-o|--output <result.png|.exr|.pfm|.f32>] [-w|--width N] [-h|--height N]\n"
                  "           [-s|--spp N] [-d|--device N] [--gpus N] [-c|--cpu] [--threads N]\n"
-                 "           [--save-config <file.mcsd>] [--standins <table.txt>] [--rng reference|pcg|sobol] [--seed N]\n\n"
+                 "           [--save-config <file.mcsd>] [--standins <table.txt>] [--rng reference|pcg|sobol] [--seed N]\n"
+                 "           [--check-walks]\n\n"
                  "  --standins   procedural stand-ins for mesh files the scene names but that are not on disk\n"
                  "  --gpu        render with HIP on the selected device (the default)\n"
                  "  --gpus N     cut the frame over HIP devices 0 .. N-1 (one RCCL gather to device 0)\n"
@@ -40,7 +41,9 @@ void Usage()
                  "  --rng        reference (default): the reference's random stream, one per pixel through all its samples\n"
                  "               (include/csrt/utils/math.hpp:43-63, renderer.cpp:62-81): frames comparable per pixel;\n"
                  "               pcg: throughput mode, an independent PCG-hashed stream per (pixel, sample) from --seed;\n"
-                 "               sobol: the same with Owen-scrambled Sobol points (at most 8192 spp)\n",
+                 "               sobol: the same with Owen-scrambled Sobol points (at most 8192 spp)\n"
+                 "  --check-walks  (one GPU) render the whole film with the production ray query AND with the reference's visiting order\n"
+                 "               first; pixels that differ are reported and the frame is rendered with the reference-order walk\n",
                  mcpt_version());
 }
 
@@ -64,6 +67,7 @@ int main(int argc, char **argv)
     int width = 0, height = 0, spp = 0, device = 0, gpus = 1, threads = 0;
     bool on_cpu = false;
     int rng_mode = 0; // --rng reference | pcg | sobol (mcpt_renderer_set_rng)
+    bool check_walks = false; // --check-walks: the user's whole film with the production ray query and with the reference-order walk
     unsigned rng_seed = 1;
     for (int i = 1; i < argc; ++i)
     {
@@ -115,6 +119,8 @@ int main(int argc, char **argv)
                 return 2;
             }
         }
+        else if (a == "--check-walks")
+            check_walks = true;
         else if (a == "--seed" && has_value)
             rng_seed = static_cast<unsigned>(std::strtoul(argv[++i], nullptr, 10));
         else if (a == "--help")
@@ -239,6 +245,30 @@ int main(int argc, char **argv)
         {
             mcpt_renderer_destroy(renderer);
             return Fail("--rng: cannot select the random-number mode.");
+        }
+        if (check_walks)
+        {
+            // The production ray query (ordered / pool walk: its tie radius and sliver reach are engineering bounds)
+            // against the reference's own visiting order on THIS scene, every pixel, full spp: a scene outside the bounds is reported
+            // and rendered with the reference-order walk (slower, the reference's image).  mcpt_renderer_create checks a sample of
+            // the film at 1 spp by default; this is the thorough form.
+            uint64_t differing = 0;
+            uint32_t first = 0;
+            float worst = 0.0f;
+            if (mcpt_renderer_check_walks(renderer, &differing, &first, &worst) != 0)
+            {
+                mcpt_renderer_destroy(renderer);
+                return Fail("--check-walks: the comparison could not run.");
+            }
+            if (differing != 0)
+            {
+                std::fprintf(stderr, "[warning] --check-walks: %llu pixel(s) differ between the production walk and the reference-order walk "
+                                     "(first: pixel %u, largest difference %g): rendering with the reference-order walk.\n",
+                             static_cast<unsigned long long>(differing), first, worst);
+                mcpt_renderer_set_walk(renderer, 1);
+            }
+            else
+                std::fprintf(stderr, "[info] --check-walks: both walks agree on every pixel.\n");
         }
         const auto t1 = std::chrono::steady_clock::now();
         mcpt_stats stats;

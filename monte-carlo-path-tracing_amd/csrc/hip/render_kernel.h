@@ -120,6 +120,9 @@ bool StreamSupports(const DeviceScene &sc, const RenderJob &job);
 bool StreamPrefersLanes(const DeviceScene &sc);
 // Scene class (outside LDS) that the lane-owns-a-path kernel can run with the wavefront-cooperative pool walk (pool_walk.h).
 bool PoolBigSupports(const DeviceScene &sc);
+// Whether the formulations the rule no longer chooses (stream kernel, queued renderer, mode 3, the trace-rate experiment) are part
+// of this build (`make EXPERIMENTAL=1`; hip/formulations_not_built.hip otherwise: their `...Supports` say no)
+bool FormulationsBuilt();
 // Chooses the instantiation and the launch shape; `name` receives a description.  The caller provides a scratch
 // buffer of at least blocks * scratch_words_per_block words and then calls LaunchRenderStream with the same cfg.
 hipError_t PlanRenderStream(const DeviceScene &sc, const RenderJob &job, bool counted, uint32_t n_cus, StreamLaunch *cfg,

@@ -203,7 +203,8 @@ static bool PoolSubsets()
 }
 
 // (the references an item of the production pool walks can hold: one bit less with merged queries, pool_walk.h)
-constexpr uint32_t kLdsPoolLimit = kPoolMaxRef, kBigPoolLimit = MCPT_POOL_MERGE ? kPoolMaxRefBigDual : kPoolMaxRefBig;
+constexpr uint32_t kLdsPoolLimit = kPoolMaxRef;
+constexpr uint32_t kBigPoolLimit = MCPT_POOL_MERGE ? kPoolMaxRefBigDual : kPoolMaxRefBig;
 
 // Can the lane-owns-a-path kernel run this scene (outside LDS) with the pool walk?  No opacity masks (they draw random numbers
 // during a walk: the visiting order is part of the image), the 4-wide hierarchy within the items' 26 bits and the lists' head room.

@@ -156,7 +156,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     // irrelevant, the frame is unchanged.
     // (measured: cornell 1074 -> 1098 Msamples/s; the full-feature instantiation — volumetric-caustic, 3 wavefronts per
     //  SIMD, 3.5 pixels per lane from the work counter — 1012 -> 1007, so not there)
-    constexpr bool kCompact = kLdsGeometry && !kCount && C::kOrdered && !(C::kVolPath || C::kAnalytic);
+    constexpr bool kCompact = kLdsGeometry && !kCount && C::kOrdered && !(C::kVolPath || C::kAnalytic) && !C::kPoolDual; // (the compaction carries no pending shadow ray)
     // (pool walk: the words travel through the pool areas — no wavefront is inside a query during an event — and the
     //  counters, which are read at every step, have their own words behind them)
     uint32_t *compact_words = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged)

@@ -279,6 +279,7 @@ def test_walk_check_at_renderer_creation(pkg):
     assert outs[0][0] == outs[1][0]
 
 
+@pytest.mark.formulations
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["dragon", "matpreview-rc", "matpreview-rd"])
 def test_queued_renderer_on_the_mesh_configurations(pkg, oracle, tmp_path, name):

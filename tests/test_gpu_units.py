@@ -196,6 +196,7 @@ def test_device_lbvh_builder_on_a_mesh(pkg):
     assert np.array_equal(h_links, d_links) and np.array_equal(h_geom.view(np.uint32), d_geom.view(np.uint32))
 
 
+@pytest.mark.formulations
 @pytest.mark.gpu
 def test_lean_trace_kernel_experiment_agrees_with_the_unit_query(pkg):
     """mcpt_debug_trace_rate (the lean trace-only kernels behind DESIGN.md section 9's measurement): one ray per lane and
