@@ -66,6 +66,15 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     unsigned long long *const wave_clock = job.wave_clock ? job.wave_clock + 4u * (blockIdx.x * (kBlockSize / 64u) + (threadIdx.x >> 6)) : nullptr;
     if (wave_clock && (threadIdx.x & 63u) == 0)
         wave_clock[0] = wall_clock64();
+#if MCPT_PHASE_CLOCK
+    if ((threadIdx.x & 63u) == 0)
+    {
+        unsigned long long *a = phase_area();
+        for (uint32_t k = 1; k < 1 + 3 * kPhaseCount; ++k)
+            a[k] = 0;
+        a[0] = clock64();
+    }
+#endif
     DeviceScene sc = sc_in;
     uint32_t n_staged = 0;
     {
@@ -155,6 +164,7 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
             start_sample(sc, st, split, independent, job.rng_seed);
         }
 
+        phase_mark(kPhaseRegenerate);
         // ---- extend, resolve, roulette ----
         Surface surf;
         surf.inside = false, surf.inst = 0, surf.uv = V2{0, 0};
@@ -173,7 +183,9 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
             Ray ray;
             HitRaw raw;
             const bool hit_valid = path_extend<C>(sc, st, nullptr, ray, raw);
+            phase_mark(kPhaseExtend);
             path_resolve<C>(sc, st, nullptr, ray, raw, hit_valid, surf);
+            phase_mark(kPhaseResolve);
         }
 
         // ---- class sort over the workgroup ----
@@ -250,6 +262,7 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         surf.uv = V2{as_float(got[31]), as_float(got[32])};
         slot = got[33], q = got[34];
 
+        phase_mark(kPhaseSort, st.alive); // (the lanes counted are the paths that go on to connect and scatter)
         // ---- connect, scatter ----
         if constexpr (C::kPool)
         {
@@ -257,10 +270,22 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
             path_connect_scatter_uniform<C>(sc, st, nullptr, surf, st.alive);
         }
         else if (st.alive)
+        {
             path_connect_scatter<C>(sc, st, nullptr, surf);
+            phase_mark(kPhaseScatter);
+        }
     }
     if (wave_clock && (threadIdx.x & 63u) == 0)
         wave_clock[1] = wall_clock64();
+#if MCPT_PHASE_CLOCK
+    // (the sums of all wavefronts, behind the per-wavefront words: the last 64 words of the 256 x 128 words capi.cpp allocates)
+    if (job.wave_clock && (threadIdx.x & 63u) == 0)
+    {
+        const unsigned long long *a = phase_area();
+        for (uint32_t k = 1; k < 1 + 3 * kPhaseCount; ++k)
+            atomicAdd(job.wave_clock + (256u * 128u - 64u) + k, a[k]);
+    }
+#endif
 }
 
 template <uint32_t kFeatures>

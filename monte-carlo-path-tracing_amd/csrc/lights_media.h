@@ -170,11 +170,29 @@ MCPT_HD MediumEvent medium_event_init()
     return m;
 }
 
-MCPT_HD V3 transmittance3(V3 sigma_t, float d) // exp() is the double one
+// exp(-sigma_t d) per channel, the double one (homogeneous.cpp evaluates it per channel and per use).  The values are functions of
+// their arguments' bits alone, so they are computed once per distance — and once for all three channels of a gray medium (equal
+// coefficients: the three arguments are the same float product), which is what most media are.
+struct Exp3
 {
-    return V3{static_cast<float>(gl::exp(D(-sigma_t.x * d))), static_cast<float>(gl::exp(D(-sigma_t.y * d))),
-              static_cast<float>(gl::exp(D(-sigma_t.z * d)))};
+    double x, y, z;
+};
+MCPT_HD Exp3 exp3(V3 sigma_t, float d)
+{
+    Exp3 e;
+    e.x = gl::exp(D(-sigma_t.x * d));
+    if (sigma_t.x == sigma_t.y && sigma_t.x == sigma_t.z)
+    {
+        e.y = e.z = e.x;
+        return e;
+    }
+    e.y = gl::exp(D(-sigma_t.y * d));
+    e.z = gl::exp(D(-sigma_t.z * d));
+    return e;
 }
+MCPT_HD V3 to_float3(const Exp3 &e) { return V3{static_cast<float>(e.x), static_cast<float>(e.y), static_cast<float>(e.z)}; }
+
+MCPT_HD V3 transmittance3(V3 sigma_t, float d) { return to_float3(exp3(sigma_t, d)); }
 
 MCPT_HD void medium_sample_distance(const MediumRec &m, float max_distance, uint32_t &rng, MediumEvent &r) // :9-53
 {
@@ -185,26 +203,28 @@ MCPT_HD void medium_sample_distance(const MediumRec &m, float max_distance, uint
         xi0 /= m.sampling_weight;
         const int channel = static_cast<int>(lcg_next(rng) * 3);
         r.distance = static_cast<float>(-gl::log(D(1.0f - xi0)) / D(comp(st, channel)));
-        if (r.distance < max_distance)
-        {
-            // accumulated on top of the record's initial pdf of 1
-            r.pdf = static_cast<float>(D(r.pdf) + D(st.x) * gl::exp(D(-st.x * r.distance)));
-            r.pdf = static_cast<float>(D(r.pdf) + D(st.y) * gl::exp(D(-st.y * r.distance)));
-            r.pdf = static_cast<float>(D(r.pdf) + D(st.z) * gl::exp(D(-st.z * r.distance)));
-            r.pdf *= m.sampling_weight * (1.0f / 3.0f);
-            r.scattered = true;
-        }
+        r.scattered = r.distance < max_distance;
     }
     if (!r.scattered)
-    {
         r.distance = max_distance;
+    const Exp3 e = exp3(st, r.distance); // (the pdf's terms and the transmittance: the same three values)
+    if (r.scattered)
+    {
+        // accumulated on top of the record's initial pdf of 1
+        r.pdf = static_cast<float>(D(r.pdf) + D(st.x) * e.x);
+        r.pdf = static_cast<float>(D(r.pdf) + D(st.y) * e.y);
+        r.pdf = static_cast<float>(D(r.pdf) + D(st.z) * e.z);
+        r.pdf *= m.sampling_weight * (1.0f / 3.0f);
+    }
+    else
+    {
         r.pdf = 0;
-        r.pdf = static_cast<float>(D(r.pdf) + gl::exp(D(-st.x * r.distance)));
-        r.pdf = static_cast<float>(D(r.pdf) + gl::exp(D(-st.y * r.distance)));
-        r.pdf = static_cast<float>(D(r.pdf) + gl::exp(D(-st.z * r.distance)));
+        r.pdf = static_cast<float>(D(r.pdf) + e.x);
+        r.pdf = static_cast<float>(D(r.pdf) + e.y);
+        r.pdf = static_cast<float>(D(r.pdf) + e.z);
         r.pdf = m.sampling_weight * (1.0f / 3.0f) * r.pdf + (1.0f - m.sampling_weight);
     }
-    r.attenuation = transmittance3(st, r.distance);
+    r.attenuation = to_float3(e);
     if (r.attenuation.x > kEpsFloat || r.attenuation.y > kEpsFloat || r.attenuation.z > kEpsFloat)
         r.valid = true;
     if (r.scattered)
@@ -248,8 +268,18 @@ struct PhaseQuery // medium.hpp:27-34
 
 MCPT_HD void hg_value(V3 g, float cos_t, PhaseQuery &r)
 {
-    const V3 temp = 1.0f + sqr(g) + 2.0f * cos_t * g;
-    r.attenuation = k1Div4Pi * (1.0f - sqr(g)) / (temp * vsqrt(temp));
+    if (g.x == g.y && g.x == g.z)
+    {
+        // (one asymmetry parameter for the three channels: one division and one square root instead of three, the same bits)
+        const float temp = 1.0f + sqr(g.x) + 2.0f * cos_t * g.x;
+        const float k = 1.0f / (temp * sqrtf(temp)); // (V3 / V3 multiplies by the reciprocal: vecmath.h)
+        r.attenuation = splat((k1Div4Pi * (1.0f - sqr(g.x))) * k);
+    }
+    else
+    {
+        const V3 temp = 1.0f + sqr(g) + 2.0f * cos_t * g;
+        r.attenuation = k1Div4Pi * (1.0f - sqr(g)) / (temp * vsqrt(temp));
+    }
     r.pdf = 0;
     r.pdf += r.attenuation.x;
     r.pdf += r.attenuation.y;

@@ -36,6 +36,37 @@
 namespace mcpt
 {
 
+// ---- diagnostic, experiment builds only (-DMCPT_PHASE_CLOCK=1 on hip/sorted_kernel.hip; tools/experiments/phase_clock.py) ----
+// Where a wavefront's time goes inside a step.  phase_mark(p) books the shader-clock cycles since the wavefront's previous mark
+// to phase p, together with the number of lanes that arrive at the mark (the exec mask there).  One lane per wavefront does the
+// booking, into that wavefront's words of LDS; the kernel adds them up into RenderJob::wave_clock when it ends.  Compiled out
+// (an empty function) everywhere else.
+#ifndef MCPT_PHASE_CLOCK
+#define MCPT_PHASE_CLOCK 0
+#endif
+enum : uint32_t { kPhaseRegenerate, kPhaseExtend, kPhaseSurface, kPhaseMedium, kPhaseResolve, kPhaseSort, kPhaseEmitter, kPhaseShadow, kPhaseWeigh,
+                  kPhaseAreaLight, kPhasePhase, kPhaseBsdf, kPhaseScatter, kPhaseCount };
+#if MCPT_PHASE_CLOCK && defined(__HIPCC__)
+__device__ __forceinline__ unsigned long long *phase_area()
+{
+    __shared__ unsigned long long area[4][1 + 3 * kPhaseCount]; // per wavefront: last mark, then cycles / visits / lanes per phase
+    return area[threadIdx.x >> 6];
+}
+__device__ __forceinline__ void phase_mark(uint32_t p, bool counted = true)
+{
+    const unsigned long long here = __ballot(true), lanes = __ballot(counted);
+    if (__lane_id() == static_cast<uint32_t>(__ffsll(static_cast<long long>(here))) - 1u)
+    {
+        unsigned long long *a = phase_area();
+        const unsigned long long now = clock64();
+        a[1 + p] += now - a[0], a[1 + kPhaseCount + p] += 1, a[1 + 2 * kPhaseCount + p] += static_cast<unsigned long long>(__popcll(lanes));
+        a[0] = clock64();
+    }
+}
+#else
+MCPT_HD void phase_mark(uint32_t, bool = true) {}
+#endif
+
 template <uint32_t kFeatures>
 struct Config
 {
@@ -347,7 +378,10 @@ MCPT_HD V3 connect_lights(const DeviceScene &sc, uint32_t *stack, bool at_medium
             const EmitterRec &e = sc.emitters[k];
             const float xi0 = lcg_next(rng), xi1 = lcg_next(rng);
             const LightSample ls = emitter_sample(LT, e, position, xi0, xi1);
-            if (shadow_walk<C>(sc, stack, position, -ls.wi, ls.distance - kEpsDistance, rng, cnt))
+            phase_mark(kPhaseEmitter);
+            const bool occluded = shadow_walk<C>(sc, stack, position, -ls.wi, ls.distance - kEpsDistance, rng, cnt);
+            phase_mark(kPhaseShadow);
+            if (occluded)
                 continue;
             V3 tr, att;
             float pdf;
@@ -374,6 +408,7 @@ MCPT_HD V3 connect_lights(const DeviceScene &sc, uint32_t *stack, bool at_medium
         }
     }
 
+    phase_mark(kPhaseWeigh);
     if (sc.integrator.n_area_lights != 0)
     {
         const float xi_pick = lcg_next(rng);
@@ -384,7 +419,10 @@ MCPT_HD V3 connect_lights(const DeviceScene &sc, uint32_t *stack, bool at_medium
         const V3 d = position - lp.position;
         const float distance = length(d);
         // the shadow ray starts ON THE LIGHT and travels to the shading point
-        if (shadow_walk<C>(sc, stack, lp.position, normalize(d), distance - kEpsDistance, rng, cnt))
+        phase_mark(kPhaseAreaLight);
+        const bool occluded = shadow_walk<C>(sc, stack, lp.position, normalize(d), distance - kEpsDistance, rng, cnt);
+        phase_mark(kPhaseShadow);
+        if (occluded)
             return L;
         const V3 wi = normalize(d);
         const float cos_light = dot(wi, lp.normal);
@@ -466,6 +504,7 @@ MCPT_HD void path_resolve(const DeviceScene &sc, PathState &st, LaneCounters *cn
         surf.inside = false, surf.inst = 0, surf.uv = V2{0, 0};
         surf.position = surf.normal = surf.tangent = surf.bitangent = V3{0, 0, 0};
     }
+    phase_mark(kPhaseSurface);
 
     // ---- resolve -------------------------------------------------------------
     if (st.primary && !hit_valid)
@@ -504,6 +543,7 @@ MCPT_HD void path_resolve(const DeviceScene &sc, PathState &st, LaneCounters *cn
         }
     }
 
+    phase_mark(kPhaseMedium);
     const uint32_t bsdf = hit_valid ? sc.instances[surf.inst].bsdf : kNone;
     if (!st.in_medium)
     {
@@ -579,6 +619,7 @@ MCPT_HD void path_connect_scatter(const DeviceScene &sc, PathState &st, LaneCoun
     // ---- connect -------------------------------------------------------------
     const V3 vertex = st.in_medium ? st.origin : surf.position;
     st.L += st.throughput * connect_lights<C>(sc, st.stack, st.in_medium, surf, vertex, st.medium, st.wo, st.rng, cnt);
+    phase_mark(kPhaseWeigh);
 
     // ---- scatter -------------------------------------------------------------
     if (vol && st.in_medium)
@@ -586,6 +627,7 @@ MCPT_HD void path_connect_scatter(const DeviceScene &sc, PathState &st, LaneCoun
         PhaseQuery p; // volpath.cpp:96-110
         p.wo = st.wo;
         phase_sample(sc.media[st.medium], st.rng, p);
+        phase_mark(kPhasePhase);
         if (!p.valid)
         {
             finish_sample(st);
@@ -607,6 +649,7 @@ MCPT_HD void path_connect_scatter(const DeviceScene &sc, PathState &st, LaneCoun
             // a shape without BSDF is a pass-through surface (quirk Q8)
             q.wi = st.wo, q.pdf = 1.0f, q.attenuation = V3{1.0f, 1.0f, 1.0f}, q.valid = true;
         }
+        phase_mark(kPhaseBsdf);
         if (!q.valid)
         {
             finish_sample(st);

@@ -21,7 +21,8 @@ for spec in "$@"; do
 done
 printf '%s\n' "${list[@]}" | xargs -P $JOBS -I{} bash -c 'spec="{}"; u=${spec%%|*}; f=${spec#*|}; /opt/rocm/bin/hipcc --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -Wall -Wno-unused-function -I../../include -I. $f -c hip/$u.hip -o '$OBJ'/$u.o || echo "FAILED $u"'
 objs=()
-for o in $(find build -name '*.o'); do
+# (the objects of the default library: make's own list, not everything an EXPERIMENTAL=1 build may have left under build/)
+for o in $(make -n -B ../libmcpt_hip.so 2>/dev/null | grep -- '-shared' | tr ' ' '\n' | grep '^build/.*\.o$'); do
   stem=$(basename $o .o)
   if [ -f $OBJ/$stem.o ]; then objs+=($OBJ/$stem.o); else objs+=($o); fi
 done
