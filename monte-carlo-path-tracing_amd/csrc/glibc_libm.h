@@ -37,8 +37,12 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define MCPT_GL_HD __host__ __device__ __forceinline__
+// (paths no render ever takes — |x| >= 120 in sinf / cosf — stay out of line: one copy per code object instead of ~250
+//  instructions at each of the ~25 call sites of a full-feature kernel)
+#define MCPT_GL_COLD __host__ __device__ inline __attribute__((noinline))
 #else
 #define MCPT_GL_HD inline
+#define MCPT_GL_COLD inline
 #endif
 
 namespace mcpt
@@ -142,33 +146,39 @@ MCPT_GL_HD double reduce_large(uint32_t xi, int &np)
     return x * kPi63;
 }
 
+// |y| >= 120 (finite): the exact reduction.  Out of line, see MCPT_GL_COLD.
+template <bool kCosine>
+MCPT_GL_COLD float sin_or_cos_large(float y)
+{
+    const int flip = kCosine ? 1 : 0;
+    const uint32_t xi = bits(y);
+    const int sign = static_cast<int>(xi >> 31);
+    int n;
+    const double x = reduce_large(xi, n);
+    const int q = n + sign;
+    const double s = ((q + 1) & 2) ? -1.0 : 1.0;
+    return sincos_poly(x * s, x * x, (q & 2) != 0, n ^ flip);
+}
+
+// The statement of glibc's sinf / cosf has two ranges below 120: |y| < pi/4 (0.75, by the granularity of its comparison) without a
+// reduction, and the rest with reduce_fast.  Here both run the second one's code: below 0.75 the scaled product is below 2^23 in
+// magnitude, so the quadrant n is 0, reduce_fast returns fma(-0.0, pi/2, y) = y, the sign factor is 1 and the polynomial's
+// arguments are the first range's, bit for bit (the sweep over all 2^32 arguments in the tests says so too) — lanes of one
+// wavefront on either side of 0.75 then share one polynomial evaluation instead of executing two.
 template <bool kCosine>
 MCPT_GL_HD float sin_or_cos(float y)
 {
-    double x = y;
-    int n;
     const int flip = kCosine ? 1 : 0;
-    if (abstop12(y) < abstop12(0x1.921FB6p-1f))
-    {
-        if (abstop12(y) < abstop12(0x1p-12f))
-            return kCosine ? 1.0f : y;
-        return sincos_poly(x, x * x, false, flip);
-    }
     if (abstop12(y) < abstop12(120.0f))
     {
-        x = reduce_fast(x, n);
+        int n;
+        const double x = reduce_fast(static_cast<double>(y), n);
         const double s = ((n + 1) & 2) ? -1.0 : 1.0; // {1, -1, -1, 1}[n & 3]
-        return sincos_poly(x * s, x * x, (n & 2) != 0, n ^ flip);
+        const float r = sincos_poly(x * s, x * x, (n & 2) != 0, n ^ flip);
+        return abstop12(y) < abstop12(0x1p-12f) ? (kCosine ? 1.0f : y) : r;
     }
     if (abstop12(y) < abstop12(__builtin_inff()))
-    {
-        const uint32_t xi = bits(y);
-        const int sign = static_cast<int>(xi >> 31);
-        x = reduce_large(xi, n);
-        const int q = n + sign;
-        const double s = ((q + 1) & 2) ? -1.0 : 1.0;
-        return sincos_poly(x * s, x * x, (q & 2) != 0, n ^ flip);
-    }
+        return sin_or_cos_large<kCosine>(y);
     return __builtin_nanf("");
 }
 
@@ -194,24 +204,25 @@ MCPT_GL_HD float acosf(float x)
         return hx > 0 ? 0.0f : pi + 2.0f * pio2_lo;
     if (ix > 0x3f800000)
         return __builtin_nanf("");
-    if (ix < 0x3f000000) // |x| < 0.5
-    {
-        if (ix <= 0x32800000)
-            return pio2_hi + pio2_lo;
-        const float r = acos_ratio(x * x);
+    // e_acosf.c has three ranges, each with its own rational p(z) / q(z) of a range-specific z: |x| < 0.5 (z = x^2), x < -0.5
+    // (z = (1 + x) / 2) and x > 0.5 (z = (1 - x) / 2, with sqrt z split into head and tail).  The ratio and the square root are
+    // evaluated ONCE here, on the z of the lane's range: the same operations on the same operands, once per wavefront instead of
+    // once per range present in it.
+    const bool small = ix < 0x3f000000, negative = hx < 0;
+    if (small && ix <= 0x32800000)
+        return pio2_hi + pio2_lo;
+    const float z = small ? x * x : (negative ? (1.0f + x) * 0.5f : (1.0f - x) * 0.5f);
+    const float r = acos_ratio(z);
+    if (small)
         return pio2_hi - (x - (pio2_lo - x * r));
-    }
-    if (hx < 0) // x < -0.5
+    const float s = ::sqrtf(z);
+    if (negative) // x < -0.5
     {
-        const float z = (1.0f + x) * 0.5f;
-        const float r = acos_ratio(z), s = ::sqrtf(z);
         const float w = r * s - pio2_lo;
         return pi - 2.0f * (s + w);
     }
-    const float z = (1.0f - x) * 0.5f, s = ::sqrtf(z);
     const float df = from_bits(bits(s) & 0xfffff000u);
     const float c = (z - df * df) / (s + df);
-    const float r = acos_ratio(z);
     const float w = r * s + c;
     return 2.0f * (df + w);
 }
@@ -240,21 +251,24 @@ MCPT_GL_HD float atanf(float x)
     }
     else
     {
+        // (s_atanf.c divides in each of its four ranges; numerator and denominator are picked per range here and divided once)
         x = ::fabsf(x);
+        float num, den;
         if (ix < 0x3f980000)
         {
             if (ix < 0x3f300000)
-                id = 0, x = (2.0f * x - 1.0f) / (2.0f + x);
+                id = 0, num = 2.0f * x - 1.0f, den = 2.0f + x;
             else
-                id = 1, x = (x - 1.0f) / (x + 1.0f);
+                id = 1, num = x - 1.0f, den = x + 1.0f;
         }
         else
         {
             if (ix < 0x401c0000)
-                id = 2, x = (x - 1.5f) / (1.0f + 1.5f * x);
+                id = 2, num = x - 1.5f, den = 1.0f + 1.5f * x;
             else
-                id = 3, x = -1.0f / x;
+                id = 3, num = -1.0f, den = x;
         }
+        x = num / den;
     }
     const float z = x * x, w = z * z;
     const float s1 = z * (a0 + w * (a2 + w * (a4 + w * (a6 + w * (a8 + w * a10)))));

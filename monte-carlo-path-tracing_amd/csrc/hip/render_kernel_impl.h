@@ -94,6 +94,15 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     extern __shared__ float4 lds_geometry[];
     if (job.wave_clock && (threadIdx.x & 63u) == 0)
         job.wave_clock[4u * (blockIdx.x * (kBlockSize / 64u) + (threadIdx.x >> 6))] = wall_clock64();
+#if MCPT_PHASE_CLOCK
+    if ((threadIdx.x & 63u) == 0) // (diagnostic builds: path_core.h, phase_mark)
+    {
+        unsigned long long *a = phase_area();
+        for (uint32_t k = 1; k < 1 + 3 * kPhaseCount; ++k)
+            a[k] = 0;
+        a[0] = clock64();
+    }
+#endif
     DeviceScene sc = sc_in;
     uint32_t n_staged = 0;
     if (kLdsGeometry)
@@ -349,6 +358,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
             if (kCount)
                 ++local.samples;
         }
+        phase_mark(kPhaseRegenerate, !helper);
         if constexpr (C::kPoolDual)
             path_step_merged<C>(sc, st, pend, cnt, !helper && st.alive);
         else if constexpr (C::kPool)
@@ -360,6 +370,14 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
 
     if (job.wave_clock && (threadIdx.x & 63u) == 0)
         job.wave_clock[4u * (blockIdx.x * (kBlockSize / 64u) + (threadIdx.x >> 6)) + 1u] = wall_clock64();
+#if MCPT_PHASE_CLOCK
+    if (job.wave_clock && (threadIdx.x & 63u) == 0)
+    {
+        const unsigned long long *a = phase_area();
+        for (uint32_t k = 1; k < 1 + 3 * kPhaseCount; ++k)
+            atomicAdd(job.wave_clock + (256u * 128u - 64u) + k, a[k]);
+    }
+#endif
     if (kCount)
     {
         atomicAdd(&counters->closest_rays, static_cast<unsigned long long>(local.closest_rays));

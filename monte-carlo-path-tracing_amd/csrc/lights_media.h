@@ -68,8 +68,8 @@ MCPT_HD LightSample emitter_sample(const LightTables &T, const EmitterRec &e, V3
         break;
     case kEmitEnvMap: // envmap.cpp:70-88
     {
-        const uint32_t row = cdf_search(e.height + 1, T.env_tables + e.cdf_rows, xi0) - 1;
-        const uint32_t col = cdf_search(e.width + 1, T.env_tables + e.cdf_cols + row * (e.width + 1), xi1) - 1;
+        const uint32_t row = cdf_search_long(e.height + 1, T.env_tables + e.cdf_rows, xi0) - 1;
+        const uint32_t col = cdf_search_long(e.width + 1, T.env_tables + e.cdf_cols + row * (e.width + 1), xi1) - 1;
         s.harsh = false;
         s.wi = transform_dir(e.to_world, from_spherical(row * kPi / e.height, col * k2Pi / e.width, 1.0f));
         break;
@@ -135,24 +135,57 @@ MCPT_HD V3 emitter_eval_dir(const LightTables &T, const EmitterRec &e, V3 look)
     }
 }
 
-MCPT_HD float emitter_pdf(const LightTables &T, const EmitterRec &e, V3 look) // emitter.cpp:250-261
+// Environment map: the radiance along a direction (given in the map's frame) and the pdf of having sampled it, from ONE lookup.
+// envmap.cpp:90-133 looks the texel up once for the radiance and once more inside the pdf — the same angles, the same four
+// texels; the callers that need both (an escaped ray's MIS weight, a sampled connection's) ask here.
+MCPT_HD V3 envmap_eval_pdf(const LightTables &T, const EmitterRec &e, V3 local_dir, float &pdf)
 {
-    if (e.kind == kEmitConstant)
-        return k1Div4Pi;
-    if (e.kind != kEmitEnvMap)
-        return 0;
     // envmap.cpp:109-133: the row index comes from texcoord.u (quirk Q7)
     float theta;
     V2 uv;
-    const V3 c = latlong_lookup(T, e.texture, transform_dir(e.to_local, look), theta, uv);
+    const V3 c = latlong_lookup(T, e.texture, local_dir, theta, uv);
     const float *wr = T.env_tables + e.weight_rows;
     const float row = fminf(fmaxf(uv.u * e.height, 0), e.height - 1);
     const int ri = static_cast<int>(row);
     const float t = row - ri;
     const float denom = fmaxf(fabsf(gl::sinf(theta)), 1e-4f);
     if (t == 0)
-        return luminance(c) * wr[ri] * e.normalization / denom;
-    return luminance(c) * lerp(wr[ri], wr[ri + 1], t) * e.normalization / denom;
+        pdf = luminance(c) * wr[ri] * e.normalization / denom;
+    else
+        pdf = luminance(c) * lerp(wr[ri], wr[ri + 1], t) * e.normalization / denom;
+    return c;
+}
+
+MCPT_HD float emitter_pdf(const LightTables &T, const EmitterRec &e, V3 look) // emitter.cpp:250-261
+{
+    if (e.kind == kEmitConstant)
+        return k1Div4Pi;
+    if (e.kind != kEmitEnvMap)
+        return 0;
+    float pdf;
+    envmap_eval_pdf(T, e, transform_dir(e.to_local, look), pdf);
+    return pdf;
+}
+
+// Radiance AND sampling pdf of a non-harsh emitter's sampled connection (emitter_eval_sample + emitter_pdf(-wi)).  For the
+// environment map the two directions are -M wi and M (-wi): negatives of each other component by component, except that a
+// component that is exactly zero may come out with either sign — which changes neither angle (acosf(+-0), atan2f(z, +-0), and
+// atan2f(+-0, x) gives +-0 or, wrapped, pi) nor a texel nor a weight (u = +-0: tap 0 with fraction +-0), so one lookup serves both.
+MCPT_HD V3 emitter_eval_sample_pdf(const LightTables &T, const EmitterRec &e, const LightSample &s, float &pdf_direct)
+{
+    if (e.kind == kEmitEnvMap)
+        return envmap_eval_pdf(T, e, -transform_dir(e.to_local, s.wi), pdf_direct);
+    pdf_direct = emitter_pdf(T, e, -s.wi);
+    return emitter_eval_sample(T, e, s);
+}
+
+// Radiance along an escaping ray AND the pdf of sampling that direction (emitter_eval_dir + emitter_pdf: the same lookup twice).
+MCPT_HD V3 emitter_eval_dir_pdf(const LightTables &T, const EmitterRec &e, V3 look, float &pdf_direct)
+{
+    if (e.kind == kEmitEnvMap)
+        return envmap_eval_pdf(T, e, transform_dir(e.to_local, look), pdf_direct);
+    pdf_direct = emitter_pdf(T, e, look);
+    return emitter_eval_dir(T, e, look);
 }
 
 // ---- homogeneous medium (homogeneous.cpp) -----------------------------------

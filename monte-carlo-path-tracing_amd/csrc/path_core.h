@@ -387,7 +387,8 @@ MCPT_HD V3 connect_lights(const DeviceScene &sc, uint32_t *stack, bool at_medium
             float pdf;
             if (!weigh(ls.wi, ls.distance, tr, att, pdf))
                 continue;
-            const V3 radiance = emitter_eval_sample(LT, e, ls);
+            float pdf_direct = 0.0f;
+            const V3 radiance = ls.harsh ? emitter_eval_sample(LT, e, ls) : emitter_eval_sample_pdf(LT, e, ls, pdf_direct);
             if (ls.harsh)
             {
                 // path.cpp:170 / volpath.cpp:297,413 (tr == 1 exactly without a medium)
@@ -395,7 +396,6 @@ MCPT_HD V3 connect_lights(const DeviceScene &sc, uint32_t *stack, bool at_medium
             }
             else
             {
-                const float pdf_direct = emitter_pdf(LT, e, -ls.wi);
                 if (pdf_direct > kEpsFloat)
                 {
                     const float w = power_heuristic(pdf_direct, pdf);
@@ -553,8 +553,9 @@ MCPT_HD void path_resolve(const DeviceScene &sc, PathState &st, LaneCounters *cn
             if (ig.id_envmap != kNone)
             {
                 const EmitterRec &env = sc.emitters[ig.id_envmap];
-                const V3 radiance = emitter_eval_dir(LT, env, -st.wi);
-                const float pdf_direct = emitter_pdf(LT, env, -st.wi), w = power_heuristic(st.pdf_sample, pdf_direct);
+                float pdf_direct;
+                const V3 radiance = emitter_eval_dir_pdf(LT, env, -st.wi, pdf_direct);
+                const float w = power_heuristic(st.pdf_sample, pdf_direct);
                 st.L += w * st.throughput * radiance;
             }
             finish_sample(st);
@@ -776,17 +777,19 @@ __device__ __forceinline__ V3 connect_lights_uniform(const DeviceScene &sc, uint
                 const float xi0 = lcg_next(rng), xi1 = lcg_next(rng);
                 ls = emitter_sample(LT, e, position, xi0, xi1);
             }
+            phase_mark(kPhaseEmitter, active);
             const bool occluded = shadow_walk_uniform<C>(sc, pool, active, position, -ls.wi, ls.distance - kEpsDistance, cnt);
+            phase_mark(kPhaseShadow, active);
             V3 tr, att;
             float pdf;
             if (!active || occluded || !weigh(ls.wi, ls.distance, tr, att, pdf))
                 continue;
-            const V3 radiance = emitter_eval_sample(LT, e, ls);
+            float pdf_direct = 0.0f;
+            const V3 radiance = ls.harsh ? emitter_eval_sample(LT, e, ls) : emitter_eval_sample_pdf(LT, e, ls, pdf_direct);
             if (ls.harsh)
                 L += vol ? radiance * tr * att : radiance * att; // path.cpp:170 / volpath.cpp:297,413
             else
             {
-                const float pdf_direct = emitter_pdf(LT, e, -ls.wi);
                 if (pdf_direct > kEpsFloat)
                 {
                     const float w = power_heuristic(pdf_direct, pdf);
@@ -815,7 +818,9 @@ __device__ __forceinline__ V3 connect_lights_uniform(const DeviceScene &sc, uint
             distance = length(d);
         }
         // the shadow ray starts ON THE LIGHT and travels to the shading point
+        phase_mark(kPhaseAreaLight, active);
         const bool occluded = shadow_walk_uniform<C>(sc, pool, active, lp.position, normalize(d), distance - kEpsDistance, cnt);
+        phase_mark(kPhaseShadow, active);
         if (active && !occluded)
         {
             const V3 wi = normalize(d);
@@ -869,6 +874,7 @@ __device__ __forceinline__ void path_connect_scatter_uniform(const DeviceScene &
     // ---- connect ----
     const V3 vertex = at_medium ? st.origin : surf.position;
     const V3 direct = connect_lights_uniform<C>(sc, st.stack, active, at_medium, surf, vertex, st.medium, st.wo, st.rng, cnt);
+    phase_mark(kPhaseWeigh, active);
     if (!active)
         return;
     st.L += st.throughput * direct;
@@ -895,6 +901,7 @@ __device__ __forceinline__ void path_connect_scatter_uniform(const DeviceScene &
             bsdf_sample<C::kMicrofacet, 0, C::kKinds>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
         else
             q.wi = st.wo, q.pdf = 1.0f, q.attenuation = V3{1.0f, 1.0f, 1.0f}, q.valid = true; // pass-through surface (quirk Q8)
+        phase_mark(kPhaseBsdf);
         if (!q.valid)
         {
             finish_sample(st);
@@ -921,12 +928,15 @@ __device__ __forceinline__ void path_step_uniform(const DeviceScene &sc, PathSta
     Ray ray;
     HitRaw raw;
     const bool hit_valid = path_extend_uniform<C>(sc, st, cnt, has_path, ray, raw);
+    phase_mark(kPhaseExtend, has_path);
     Surface surf;
     surf.inside = false, surf.inst = 0, surf.uv = V2{0, 0};
     surf.position = surf.normal = surf.tangent = surf.bitangent = V3{0, 0, 0};
     if (has_path)
         path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
+    phase_mark(kPhaseResolve, has_path && st.alive);
     path_connect_scatter_uniform<C>(sc, st, cnt, surf, has_path && st.alive);
+    phase_mark(kPhaseScatter, has_path && st.alive);
 }
 
 // ---- MERGED QUERIES (round 5) -----------------------------------------------------------------------------------
@@ -978,14 +988,14 @@ __device__ __forceinline__ void connect_lights_merged(const DeviceScene &sc, uin
             float pdf;
             if (!active || occluded || !weigh(ls.wi, att, pdf))
                 continue;
-            const V3 radiance = emitter_eval_sample(LT, e, ls);
+            float pdf_direct = 0.0f;
+            const V3 radiance = ls.harsh ? emitter_eval_sample(LT, e, ls) : emitter_eval_sample_pdf(LT, e, ls, pdf_direct);
             V3 c = V3{0, 0, 0};
             bool some = false;
             if (ls.harsh)
                 c = radiance * att, some = true; // path.cpp:170
             else
             {
-                const float pdf_direct = emitter_pdf(LT, e, -ls.wi);
                 if (pdf_direct > kEpsFloat)
                     c = power_heuristic(pdf_direct, pdf) * radiance * (att / pdf_direct), some = true; // path.cpp:178
             }

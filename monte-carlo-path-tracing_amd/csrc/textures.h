@@ -86,15 +86,20 @@ MCPT_HD V3 checker_color(const TextureRec &t, V2 uv) // checkboard.cpp:6-21
 // scene is a constant; passed as a compile-time constant from the kernel
 // instantiations for such scenes so that the checkerboard / bitmap code (with its
 // wrap-around loops) is not compiled into them at every call site.
+MCPT_COLD V3 texture_color_varying(const TextureRec *textures, const float *texels, uint32_t id, V2 uv)
+{
+    const TextureRec &t = textures[id];
+    if (t.kind == kTexChecker)
+        return checker_color(t, uv);
+    return bitmap_color(t, texels, uv);
+}
 MCPT_HD V3 texture_color(const TextureRec *textures, const float *texels, uint32_t id, V2 uv,
                          bool all_constant = false) // texture.cpp:63-78
 {
     const TextureRec &t = textures[id];
     if (all_constant || t.kind == kTexConstant)
         return from(t.color);
-    if (t.kind == kTexChecker)
-        return checker_color(t, uv);
-    return bitmap_color(t, texels, uv);
+    return texture_color_varying(textures, texels, id, uv);
 }
 
 MCPT_HD V2 texture_gradient(const TextureRec *textures, const float *texels, uint32_t id, V2 uv) // texture.cpp:80-95
