@@ -278,7 +278,7 @@ MCPT_HD void dielectric_sample(const ShadeTables &T, const BsdfRec &b, uint32_t 
     float Dh;
     ggx_sample_aniso(xi0, xi1, au, av, h_local, Dh);
     const V3 h = to_world(q, h_local);
-    float h_o = dot(q.wo, h);
+    const float h_o = dot(q.wo, h);
     if (h_o < kEpsFloat)
         return;
     float eta = b.eta, eta_inv = b.eta_inv;
@@ -290,46 +290,42 @@ MCPT_HD void dielectric_sample(const ShadeTables &T, const BsdfRec &b, uint32_t 
     }
     V3 wt = V3{0, 0, 0};
     const bool total_reflection = !refract(-q.wo, h, eta, wt);
-    float F = schlick(h_o, b.reflectivity);
+    const float F = schlick(h_o, b.reflectivity);
     const V3 lo = to_local(q, q.wo);
-    if (total_reflection || lcg_next(rng) < F)
-    {
-        q.wi = -reflect(-q.wo, h);
-        const float n_i = dot(-q.wi, q.normal);
-        if (n_i < kEpsFloat)
-            return;
-        q.pdf = F * Dh / (4.0f * h_o);
-        if (q.pdf < kEps)
-            return;
-        const V3 li = to_local(q, -q.wi);
-        const float G = smith_g1_aniso(au, av, li, h_local) * smith_g1_aniso(au, av, lo, h_local), n_o = lo.z;
-        float a = (F * Dh * G) / (4.0f * n_o);
-        if (au == av)
-            a += dielectric_multiscatter(T, b, n_i, n_o, au, q.inside, true);
-        q.attenuation = splat(a) * tex(T, b.tex2, q.uv);
-    }
+    // dielectric.cpp:80-138 continues in two arms, reflection and refraction.  The lanes of a wavefront take both, so what the arms
+    // share — the incident direction's local frame, both shadowing terms, the multiple-scattering term with its table lookups, the
+    // texture — is written ONCE here, fed with the lane's arm's operands: the same operations per lane, in one pass of the wavefront.
+    const bool reflected = total_reflection || lcg_next(rng) < F; // (no draw after a total reflection)
+    q.wi = reflected ? -reflect(-q.wo, h) : -wt;
+    V3 li = to_local(q, -q.wi);
+    float n_i, h_i = 0.0f, F_t = 0.0f, h_o_t = 0.0f;
+    if (reflected)
+        n_i = dot(-q.wi, q.normal);
     else
     {
-        q.wi = -wt;
-        V3 li = to_local(q, -q.wi);
         li.z = -li.z;
-        const float n_i = li.z;
-        if (n_i < kEpsFloat)
-            return;
-        const float h_i = -dot(wt, h);
-        if (h_i < kEpsFloat)
-            return;
-        h_o = -h_o;
-        F = schlick(h_i, b.reflectivity);
-        q.pdf = ((1.0f - F) * Dh) * fabsf(h_o / sqr(eta_inv * h_i + h_o));
-        if (q.pdf < kEps)
-            return;
-        const float G = smith_g1_aniso(au, av, li, h_local) * smith_g1_aniso(au, av, lo, h_local), n_o = lo.z;
-        float a = ((fabsf(h_i) * fabsf(h_o)) * ((1.0f - F) * G * Dh)) / fabsf(n_o * sqr(eta_inv * h_i + h_o));
-        if (au == av)
-            a += dielectric_multiscatter(T, b, n_i, n_o, au, !q.inside, false);
-        q.attenuation = (splat(a) * sqr(eta)) * tex(T, b.tex3, q.uv);
+        n_i = li.z;
+        h_i = -dot(wt, h);
     }
+    if (n_i < kEpsFloat || (!reflected && h_i < kEpsFloat))
+        return;
+    if (reflected)
+        q.pdf = F * Dh / (4.0f * h_o);
+    else
+    {
+        h_o_t = -h_o;
+        F_t = schlick(h_i, b.reflectivity);
+        q.pdf = ((1.0f - F_t) * Dh) * fabsf(h_o_t / sqr(eta_inv * h_i + h_o_t));
+    }
+    if (q.pdf < kEps)
+        return;
+    const float G = smith_g1_aniso(au, av, li, h_local) * smith_g1_aniso(au, av, lo, h_local), n_o = lo.z;
+    float a = reflected ? (F * Dh * G) / (4.0f * n_o)
+                        : ((fabsf(h_i) * fabsf(h_o_t)) * ((1.0f - F_t) * G * Dh)) / fabsf(n_o * sqr(eta_inv * h_i + h_o_t));
+    if (au == av)
+        a += dielectric_multiscatter(T, b, n_i, n_o, au, reflected ? q.inside : !q.inside, reflected);
+    const V3 weight = reflected ? splat(a) : splat(a) * sqr(eta);
+    q.attenuation = weight * tex(T, reflected ? b.tex2 : b.tex3, q.uv);
     q.valid = true;
 }
 

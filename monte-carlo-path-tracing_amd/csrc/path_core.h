@@ -982,8 +982,12 @@ __device__ __forceinline__ void connect_lights_merged(const DeviceScene &sc, uin
                 ls = emitter_sample(LT, e, position, xi0, xi1);
             }
             bool occluded = false;
+            phase_mark(kPhaseEmitter, active);
             if (!deferred)
+            {
                 occluded = shadow_walk_uniform<C>(sc, pool, active, position, -ls.wi, ls.distance - kEpsDistance, cnt);
+                phase_mark(kPhaseShadow, active);
+            }
             V3 att;
             float pdf;
             if (!active || occluded || !weigh(ls.wi, att, pdf))
@@ -1080,6 +1084,7 @@ __device__ __forceinline__ void path_step_merged(const DeviceScene &sc, PathStat
         cnt->wave_node_steps += ts.wave_node_steps, cnt->wave_prim_steps += ts.wave_prim_steps;
     }
     hit_valid = known ? hit_valid : traced;
+    phase_mark(kPhaseExtend, has_path);
     // ---- what the last vertex adds to its sample, now that its light's visibility is known ----
     if (pd.shadow)
     {
@@ -1100,7 +1105,9 @@ __device__ __forceinline__ void path_step_merged(const DeviceScene &sc, PathStat
     if (has_path)
         path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
     const bool active = has_path && st.alive;
+    phase_mark(kPhaseResolve, active);
     connect_lights_merged<C>(sc, st.stack, active, surf, surf.position, st.wo, st.throughput, st.rng, st.L, pd, cnt);
+    phase_mark(kPhaseWeigh, active);
     if (!active)
         return;
     // (scatter of path_connect_scatter, path.cpp:268-296; a sample that ends here with a light pending is finished after the next walk)
@@ -1117,6 +1124,7 @@ __device__ __forceinline__ void path_step_merged(const DeviceScene &sc, PathStat
         bsdf_sample<C::kMicrofacet, 0, C::kKinds>(shade_tables<C>(sc), sc.bsdfs[bsdf], st.rng, q);
     else
         q.wi = st.wo, q.pdf = 1.0f, q.attenuation = V3{1.0f, 1.0f, 1.0f}, q.valid = true; // pass-through surface (quirk Q8)
+    phase_mark(kPhaseBsdf);
     if (!q.valid)
     {
         end_sample();
