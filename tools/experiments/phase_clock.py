@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 PHASES = ["regenerate", "extend (closest-hit walk)", "resolve: surface frame", "resolve: medium on the segment (free-flight sampling)",
           "resolve: escape / light / back face / roulette", "class sort (barriers included)", "connect: emitter sampling", "connect: shadow walks",
           "connect: transmittance, BSDF / phase value, MIS", "connect: area-light sampling", "scatter: phase function", "scatter: BSDF",
-          "scatter: rest"]
+          "scatter: rest", "resolve: surface frame of a triangle", "resolve: surface frame of a quadric"]
 
 
 def main():
