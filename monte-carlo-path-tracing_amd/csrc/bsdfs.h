@@ -347,25 +347,15 @@ MCPT_HD void dielectric_eval(const ShadeTables &T, const BsdfRec &b, BsdfQuery &
     if (q.pdf < kEps)
         return;
     q.valid = true;
+    // (dielectric.cpp:186-222 in two arms; what they share is evaluated once per wavefront, as in dielectric_sample)
     const V3 li = to_local(q, -q.wi);
-    if (reflected)
-    {
-        const V3 lo = to_local(q, q.wo);
-        const float G = smith_g1_aniso(au, av, li, h_local) * smith_g1_aniso(au, av, lo, h_local);
-        float a = (F * Dh * G) / (4.0f * n_o);
-        if (au == av)
-            a += dielectric_multiscatter(T, b, dot(-q.wi, q.normal), n_o, au, q.inside, true);
-        q.attenuation = splat(a) * tex(T, b.tex2, q.uv);
-    }
-    else
-    {
-        const V3 lo = to_local(q, -q.wo);
-        const float G = smith_g1_aniso(au, av, li, h_local) * smith_g1_aniso(au, av, lo, h_local);
-        float a = ((fabsf(h_i) * fabsf(h_o)) * ((1.0f - F) * G * Dh)) / fabsf(n_o * sqr(eta_inv * h_i + h_o));
-        if (au == av)
-            a += dielectric_multiscatter(T, b, dot(q.normal, -q.wi), n_o, au, q.inside, false);
-        q.attenuation = (splat(a) * sqr(eta)) * tex(T, b.tex3, q.uv);
-    }
+    const V3 lo = to_local(q, reflected ? q.wo : -q.wo);
+    const float G = smith_g1_aniso(au, av, li, h_local) * smith_g1_aniso(au, av, lo, h_local);
+    float a = reflected ? (F * Dh * G) / (4.0f * n_o) : ((fabsf(h_i) * fabsf(h_o)) * ((1.0f - F) * G * Dh)) / fabsf(n_o * sqr(eta_inv * h_i + h_o));
+    if (au == av)
+        a += dielectric_multiscatter(T, b, dot(-q.wi, q.normal), n_o, au, q.inside, reflected);
+    const V3 weight = reflected ? splat(a) : splat(a) * sqr(eta);
+    q.attenuation = weight * tex(T, reflected ? b.tex2 : b.tex3, q.uv);
 }
 
 // ---- thin dielectric (thin_dielectric.cpp) ----------------------------------

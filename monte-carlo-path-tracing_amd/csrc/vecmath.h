@@ -328,41 +328,51 @@ MCPT_HD uint32_t cdf_search(uint32_t num, const float *cdf, float target) // mat
 // cdf_search for LONG tables in memory (an environment map's row and column tables: 10 + 11 levels, each a load that waits for the
 // one before — a fifth of a matpreview step's time, measured by the phase clock).  The same bisection, the same comparisons on the
 // same entries in the same order, hence the same index for ANY table content (quirk Q7 makes the reference search tables that are
-// not even monotone) — but three levels per round trip: the entry at the midpoint, at both possible next midpoints and at the four
-// possible ones after those are loaded together (seven independent loads, all inside [lo, hi)), then the three levels are decided
-// from registers.  11 levels: 4 round trips instead of 11.
+// not even monotone) — but several levels per round trip: the entries at the midpoint, at both possible next midpoints, at the four
+// possible ones after those ... are loaded together (2^levels - 1 independent loads, all inside [lo, hi)), then those levels are
+// decided from registers.  Three levels (seven loads): 11 levels in 4 round trips instead of 11; four levels (fifteen loads and
+// the selects that pick among them) measured slower: matpreview rough dielectric 681 -> 703 ms.
+#ifndef MCPT_CDF_LEVELS
+#define MCPT_CDF_LEVELS 3
+#endif
 MCPT_HD uint32_t cdf_search_rounds(uint32_t num, const float *cdf, float target)
 {
+    // kLevels levels per round trip: the bisection tree below (lo, hi) in heap order, node k's children 2k and 2k + 1
+    constexpr uint32_t kLevels = MCPT_CDF_LEVELS, kNodes = 1u << kLevels;
     uint32_t lo = 0, hi = num;
     while (lo + 1 != hi)
     {
-        const uint32_t m = (lo + hi) >> 1;
-        const uint32_t ml = (lo + m) >> 1, mr = (m + hi) >> 1;
-        const uint32_t mll = (lo + ml) >> 1, mlr = (ml + m) >> 1, mrl = (m + mr) >> 1, mrr = (mr + hi) >> 1;
-        const float c = cdf[m], cl = cdf[ml], cr = cdf[mr], cll = cdf[mll], clr = cdf[mlr], crl = cdf[mrl], crr = cdf[mrr];
-        // level 1
-        if (!(c < target) && !(c > target))
-            return m;
-        const bool right = c < target;
-        lo = right ? m : lo, hi = right ? hi : m;
-        if (lo + 1 == hi)
-            break;
-        // level 2: the midpoint of the new interval is mr or ml
-        const uint32_t m2 = right ? mr : ml;
-        const float c2 = right ? cr : cl;
-        if (!(c2 < target) && !(c2 > target))
-            return m2;
-        const bool right2 = c2 < target;
-        lo = right2 ? m2 : lo, hi = right2 ? hi : m2;
-        if (lo + 1 == hi)
-            break;
-        // level 3
-        const uint32_t m3 = right ? (right2 ? mrr : mrl) : (right2 ? mlr : mll);
-        const float c3 = right ? (right2 ? crr : crl) : (right2 ? clr : cll);
-        if (!(c3 < target) && !(c3 > target))
-            return m3;
-        const bool right3 = c3 < target;
-        lo = right3 ? m3 : lo, hi = right3 ? hi : m3;
+        uint32_t l[kNodes], h[kNodes], m[kNodes];
+        float c[kNodes];
+        l[1] = lo, h[1] = hi;
+#pragma unroll
+        for (uint32_t k = 1; k < kNodes; ++k)
+        {
+            m[k] = (l[k] + h[k]) >> 1;
+            if (2 * k + 1 < kNodes)
+                l[2 * k] = l[k], h[2 * k] = m[k], l[2 * k + 1] = m[k], h[2 * k + 1] = h[k];
+        }
+#pragma unroll
+        for (uint32_t k = 1; k < kNodes; ++k)
+            c[k] = cdf[m[k]]; // (independent loads, every index inside [lo, hi): a degenerate interval's midpoint is its lower end)
+        uint32_t k = 1;
+#pragma unroll
+        for (uint32_t level = 0; level < kLevels; ++level)
+        {
+            if (level != 0 && lo + 1 == hi)
+                return hi;
+            // entry and midpoint of node k (k is one of 2^level values: selects, no indexed registers)
+            float ck = c[1u << level];
+            uint32_t mk = m[1u << level];
+#pragma unroll
+            for (uint32_t n = (1u << level) + 1; n < (2u << level); ++n)
+                ck = k == n ? c[n] : ck, mk = k == n ? m[n] : mk;
+            if (!(ck < target) && !(ck > target))
+                return mk;
+            const bool right = ck < target;
+            lo = right ? mk : lo, hi = right ? hi : mk;
+            k = 2 * k + (right ? 1u : 0u);
+        }
     }
     return hi;
 }

@@ -1,4 +1,4 @@
-// Test harness (tests/test_host_units.py): cdf_search_rounds (vecmath.h: three bisection levels per round trip, the form the
+// Test harness (tests/test_host_units.py): cdf_search_rounds (vecmath.h: MCPT_CDF_LEVELS bisection levels per round trip, the form the
 // device uses for an environment map's tables) returns cdf_search's index for ANY table — monotone, with runs of equal entries,
 // not monotone at all (the reference's quirk Q7 searches such tables), with NaNs — and any target, table entries included.
 #include "vecmath.h"

@@ -2,15 +2,19 @@
 import os
 import subprocess
 
+import pytest
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "monte-carlo-path-tracing_amd", "csrc")
 
 
-def test_three_level_bisection_returns_the_plain_bisections_index(tmp_path):
-    """vecmath.h, cdf_search_rounds: seven entries loaded per round trip, three levels decided from registers — the index
-    math.cpp:40-55's loop returns, on monotone and non-monotone tables (quirk Q7), duplicates, NaNs, exact hits."""
+@pytest.mark.parametrize("levels", [2, 3, 4])
+def test_bisection_in_rounds_returns_the_plain_bisections_index(tmp_path, levels):
+    """vecmath.h, cdf_search_rounds: 2^levels - 1 entries loaded per round trip, that many levels decided from registers (the
+    device form for an environment map's tables: 3) — the index math.cpp:40-55's loop returns, on monotone and non-monotone
+    tables (quirk Q7), duplicates, NaNs, exact hits."""
     exe = str(tmp_path / "cdf_search_check")
-    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-I", CSRC, "-I", os.path.join(os.path.dirname(HERE), "include"),
+    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", f"-DMCPT_CDF_LEVELS={levels}", "-I", CSRC, "-I", os.path.join(os.path.dirname(HERE), "include"),
                     os.path.join(HERE, "host_units", "cdf_search_check.cpp"), "-o", exe], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
