@@ -255,6 +255,14 @@ MCPT_HD void conductor_eval(const ShadeTables &T, const BsdfRec &b, BsdfQuery &q
 }
 
 // ---- dielectric (dielectric.cpp) --------------------------------------------
+// dielectric.cpp:30-33: (1 - F_avg)(1 - F_avg_inv) eta^2 / ((1 - F_avg) + (1 - F_avg_inv) eta^2), in double, rounded to float.
+// host/commit.cpp stores it for eta (seen from outside) and 1 / eta (from inside) in the record.
+MCPT_HD float dielectric_ms_ratio_t(const BsdfRec &b, float eta)
+{
+    const double eta2 = pow2d(eta);
+    return static_cast<float>(D((1.0f - b.f_avg) * (1.0f - b.f_avg_inv)) * eta2 / (D(1.0f - b.f_avg) + D(1.0f - b.f_avg_inv) * eta2));
+}
+
 MCPT_HD float dielectric_multiscatter(const ShadeTables &T, const BsdfRec &b, float n_i, float n_o, float alpha,
                                       bool inside, bool reflected) // :14-38
 {
@@ -262,9 +270,7 @@ MCPT_HD float dielectric_multiscatter(const ShadeTables &T, const BsdfRec &b, fl
                 e_avg = lut_average(T, alpha), f_ms = (1.0f - e_i) * (1.0f - e_o) / (kPi * (1.0f - e_avg));
     const float F = inside ? b.f_avg_inv : b.f_avg, eta = inside ? b.eta_inv : b.eta;
     const float f_add = static_cast<float>(pow2d(F) * D(e_avg) / D(1.0f - F * (1.0f - e_avg)));
-    const double eta2 = pow2d(eta);
-    const float ratio_t = static_cast<float>(D((1.0f - b.f_avg) * (1.0f - b.f_avg_inv)) * eta2 /
-                                             (D(1.0f - b.f_avg) + D(1.0f - b.f_avg_inv) * eta2));
+    const float ratio_t = inside ? b.ms_ratio_t_inside : b.ms_ratio_t; // (dielectric_ms_ratio_t(b, eta), evaluated at commit)
     const float ret = f_ms * f_add * n_i;
     return reflected ? (1.0f - ratio_t) * ret : ratio_t * ret;
 }

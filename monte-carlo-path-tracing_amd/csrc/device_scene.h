@@ -171,7 +171,9 @@ struct BsdfRec
     float reflectivity;  // dielectric / plastic: ((eta-1)/(eta+1))^2
     float eta, eta_inv;
     float f_avg, f_avg_inv;
-    uint32_t pad[1];
+    // dielectric: the transmitted share of the multiple-scattering term (dielectric.cpp:30-33 evaluates it per call, in double, from
+    // the four constants above: a function of the record and of the side alone) seen from outside / from inside
+    float ms_ratio_t, ms_ratio_t_inside;
 };
 
 struct MediumRec

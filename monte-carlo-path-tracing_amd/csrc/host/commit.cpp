@@ -24,6 +24,7 @@
 #include <string>
 #include <thread>
 
+#include "../bsdfs.h"
 #include "../textures.h"
 #include "../vecmath.h"
 #include "matrix.hpp"
@@ -1488,6 +1489,9 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
             check(o.tex0, false), check(o.tex1, false), check(o.tex2, false), check(o.tex3, false);
             o.eta = b.eta, o.eta_inv = 1.0f / b.eta;
             o.reflectivity = sqr(b.eta - 1.0f) / sqr(b.eta + 1.0f);
+            // (the multiple-scattering term's transmitted share: constants of the record and the side, bsdfs.h)
+            if (b.type == MCSD_BSDF_DIELECTRIC)
+                o.ms_ratio_t = dielectric_ms_ratio_t(o, o.eta), o.ms_ratio_t_inside = dielectric_ms_ratio_t(o, o.eta_inv);
             fs.features |= kFeatMicrofacet;
             break;
         case MCSD_BSDF_PLASTIC:

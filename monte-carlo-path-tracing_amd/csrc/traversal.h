@@ -935,7 +935,7 @@ MCPT_HD Surface make_surface(const DeviceScene &sc, const Ray &ray, const HitRaw
         s.tangent = normalize(u * xyz(at[3]) + v * xyz(at[4]) + w * xyz(at[5]));
         s.bitangent = normalize(u * xyz(at[6]) + v * xyz(at[7]) + w * xyz(at[8]));
         bump(s.normal, s.tangent, s.bitangent);
-        phase_mark(13u); // (diagnostic builds, path_core.h: kPhaseTriangleFrame)
+        phase_mark(kPhaseTriangleFrame); // (diagnostic builds: phase_clock.h)
     }
     else
     {
@@ -999,7 +999,7 @@ MCPT_HD Surface make_surface(const DeviceScene &sc, const Ray &ray, const HitRaw
             s.bitangent = normalize(cross(s.normal, s.tangent));
             bump(s.normal, s.tangent, s.bitangent);
         }
-        phase_mark(14u); // (kPhaseQuadricFrame)
+        phase_mark(kPhaseQuadricFrame);
     }
     if (h.inside)
     {
