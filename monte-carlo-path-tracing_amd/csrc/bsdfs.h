@@ -268,7 +268,7 @@ MCPT_HD float dielectric_multiscatter(const ShadeTables &T, const BsdfRec &b, fl
 {
     const float e_i = lut_directional(T, n_i, alpha), e_o = lut_directional(T, n_o, alpha),
                 e_avg = lut_average(T, alpha), f_ms = (1.0f - e_i) * (1.0f - e_o) / (kPi * (1.0f - e_avg));
-    const float F = inside ? b.f_avg_inv : b.f_avg, eta = inside ? b.eta_inv : b.eta;
+    const float F = inside ? b.f_avg_inv : b.f_avg;
     const float f_add = static_cast<float>(pow2d(F) * D(e_avg) / D(1.0f - F * (1.0f - e_avg)));
     const float ratio_t = inside ? b.ms_ratio_t_inside : b.ms_ratio_t; // (dielectric_ms_ratio_t(b, eta), evaluated at commit)
     const float ret = f_ms * f_add * n_i;

@@ -19,6 +19,13 @@
 // at the end of the order hold only finished samples: they skip that half and start their next camera rays together.
 // Which lane carries a path is irrelevant to its pixel (the state is all there is) — the frame is bit for bit
 // render_kernel's.
+// (this unit's kernels run workgroups of kSortLanes lanes: the per-lane traversal stacks interleave at that stride instead of 256)
+#ifndef MCPT_SORT_LANES
+#define MCPT_SORT_LANES 128
+#endif
+#ifndef MCPT_WALK_STACK_STRIDE
+#define MCPT_WALK_STACK_STRIDE MCPT_SORT_LANES
+#endif
 #include "render_kernel_impl.h"
 
 namespace mcpt
@@ -106,7 +113,7 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
     static_assert(!C::kPool || kWaves * pool_wave_words(C::kAnalytic, false) >= kSortPassWords * kBlockSize, "the exchange fits the pool areas");
     uint32_t *stack = C::kPool ? lds_words + (threadIdx.x >> 6) * pool_wave_words(C::kAnalytic, false) : lds_words + threadIdx.x;
     if (!C::kPool)
-        lds_words += static_cast<size_t>(sc_in.integrator.walk_depth) * 256u;
+        lds_words += static_cast<size_t>(sc_in.integrator.walk_depth) * MCPT_WALK_STACK_STRIDE;
     uint32_t *exchange = lds_words;                                  // kSortPassWords x kSortLanes words, word-major
     uint32_t *counts = C::kPool ? lds_words + kWaves * pool_wave_words(C::kAnalytic, false) : exchange + kSortPassWords * kBlockSize; // [parity][wavefront][class]
     __syncthreads(); // geometry staged
@@ -294,7 +301,7 @@ static hipError_t LaunchSorted(const DeviceScene &sc, const RenderJob &job, floa
     constexpr uint32_t kBlockSize = kSortLanes;
     constexpr bool kPool = (kFeatures & kFeatPoolWalk) != 0;
     const size_t lds_bytes = kPool ? StagedBytes(sc, true, true) + (size_t(kBlockSize / 64u) * pool_wave_words((kFeatures & kFeatAnalytic) != 0) + 2u * (kBlockSize / 64u) * 16u) * sizeof(uint32_t)
-                                   : StagedBytes(sc, true) + size_t(sc.integrator.walk_depth) * 256u * sizeof(uint32_t) + // (the stacks' stride is 256 words whatever the workgroup size)
+                                   : StagedBytes(sc, true) + size_t(sc.integrator.walk_depth) * MCPT_WALK_STACK_STRIDE * sizeof(uint32_t) + // (the stacks: one column per lane of the workgroup)
                                          (size_t(kSortPassWords) * kBlockSize + 2u * (kBlockSize / 64u) * 16u) * sizeof(uint32_t);
     int per_cu = 0;
     hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sorted_kernel<kFeatures>, kBlockSize, lds_bytes);

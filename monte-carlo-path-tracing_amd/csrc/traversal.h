@@ -387,8 +387,12 @@ MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &
 // Stack: `stack[level * kWalkStackStride]`; on the GPU the lanes of a workgroup
 // interleave their stacks in LDS (stride = workgroup size, conflict free), the
 // host build uses a plain array.
+// (MCPT_WALK_STACK_STRIDE: a translation unit whose kernels all run smaller workgroups says so — hip/sorted_kernel.hip: 128)
+#ifndef MCPT_WALK_STACK_STRIDE
+#define MCPT_WALK_STACK_STRIDE 256
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
-constexpr uint32_t kWalkStackStride = 256;
+constexpr uint32_t kWalkStackStride = MCPT_WALK_STACK_STRIDE;
 #else
 constexpr uint32_t kWalkStackStride = 1;
 #endif
