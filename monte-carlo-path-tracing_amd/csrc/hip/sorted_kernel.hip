@@ -32,15 +32,27 @@ namespace mcpt
 {
 
 #ifndef MCPT_SORT_PASSES
-#define MCPT_SORT_PASSES 2
+#define MCPT_SORT_PASSES 3
 #endif
 constexpr uint32_t kSortWords = 36, kSortPasses = MCPT_SORT_PASSES, kSortPassWords = kSortWords / kSortPasses;
 constexpr uint32_t kSortClasses = 10; // medium vertex, surface without BSDF, 6 BSDF kinds, finished sample, exhausted lane
 constexpr uint32_t kClassIdle = 8, kClassExhausted = 9;
 
+// Wavefronts per SIMD the instantiations are compiled for.  Round 3 measured 2 / 3 / 4 on volumetric-caustic's (lean) instantiation as
+// 150.8 / 116.4 / 138.8 ms at spp 128: four spilled too much and LDS held too few workgroups.  Since round 5 the lean instantiation
+// spills 18 VGPRs at four (the medium and library code got shorter: EXPERIMENTS R5-9), the stacks interleave at 128 lanes and the
+// exchange runs in three passes of 12 words — 17.8 KB per workgroup, eight workgroups per CU: **800.9 -> 717.4 ms** at full size
+// (R5-11).  The instantiations with every feature spill 140-270 VGPRs at four and stay at three.
 #ifndef MCPT_SORTED_WAVES
 #define MCPT_SORTED_WAVES 3
 #endif
+#ifndef MCPT_SORTED_WAVES_LEAN
+#define MCPT_SORTED_WAVES_LEAN 4
+#endif
+constexpr uint32_t sorted_waves(uint32_t features)
+{
+    return (features & (kFeatEmitters | kFeatTextures)) == 0 ? MCPT_SORTED_WAVES_LEAN : MCPT_SORTED_WAVES;
+}
 
 // Class of a path after resolve + roulette.  Order = order of the sorted sequence.
 __device__ __forceinline__ uint32_t path_class(const DeviceScene &sc, const PathState &st, const Surface &surf)
@@ -56,14 +68,14 @@ __device__ __forceinline__ uint32_t path_class(const DeviceScene &sc, const Path
 
 // Measured on volumetric-caustic (1280 x 720 spp 128, one box, unsorted kernel 120.5 ms): 256 lanes 116.7-117.8 ms, 128
 // lanes 115.8-116.6 (a smaller group sorts less purely but waits for fewer wavefronts at its barriers); 1 / 2 / 3 exchange
-// passes: 136.8 (LDS costs a workgroup per CU) / 116.4 / 116.2; 2 / 3 / 4 wavefronts per SIMD: 150.8 / 116.4 / 138.8.
+// passes: 136.8 (LDS costs a workgroup per CU) / 116.4 / 116.2; (round 3's code) 2 / 3 / 4 wavefronts per SIMD: 150.8 / 116.4 / 138.8.
 #ifndef MCPT_SORT_LANES
 #define MCPT_SORT_LANES 128
 #endif
 constexpr uint32_t kSortLanes = MCPT_SORT_LANES; // lanes of a workgroup = paths sorted together
 
 template <uint32_t kFeatures>
-__global__ void __launch_bounds__(kSortLanes, MCPT_SORTED_WAVES)
+__global__ void __launch_bounds__(kSortLanes, sorted_waves(kFeatures))
 sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ out)
 {
     using C = Config<kFeatures>;
