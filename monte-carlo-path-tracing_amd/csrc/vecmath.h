@@ -326,14 +326,14 @@ MCPT_HD uint32_t cdf_search(uint32_t num, const float *cdf, float target) // mat
 }
 
 // cdf_search for LONG tables in memory (an environment map's row and column tables: 10 + 11 levels, each a load that waits for the
-// one before — a fifth of a matpreview step's time, measured by the phase clock).  The same bisection, the same comparisons on the
-// same entries in the same order, hence the same index for ANY table content (quirk Q7 makes the reference search tables that are
-// not even monotone) — but several levels per round trip: the entries at the midpoint, at both possible next midpoints, at the four
-// possible ones after those ... are loaded together (2^levels - 1 independent loads, all inside [lo, hi)), then those levels are
-// decided from registers.  Three levels (seven loads): 11 levels in 4 round trips instead of 11; four levels (fifteen loads and
-// the selects that pick among them) measured slower: matpreview rough dielectric 681 -> 703 ms.
+// one before).  The same bisection, the same comparisons on the same entries in the same order, hence the same index for ANY table
+// content (quirk Q7 makes the reference search tables that are not even monotone) — but several levels per round trip: the entries at
+// the midpoint and at the possible next midpoints are loaded together (2^levels - 1 independent loads, all inside [lo, hi)), then those
+// levels are decided from registers.  Measured on matpreview (issue-bound kernels: waiting less buys little, selecting among more
+// loaded entries costs instructions), rough dielectric / rough conductor, ms: 1 level per round 674.9 / 419.4, **2: 673.0 / 418.5**,
+// 3: 679.5 / 423.6, 4: 703 / 433 (profiles/r05_experiments/envmap_bisection_levels_per_round_ab.json).
 #ifndef MCPT_CDF_LEVELS
-#define MCPT_CDF_LEVELS 3
+#define MCPT_CDF_LEVELS 2
 #endif
 MCPT_HD uint32_t cdf_search_rounds(uint32_t num, const float *cdf, float target)
 {

@@ -11,7 +11,7 @@ CSRC = os.path.join(os.path.dirname(HERE), "monte-carlo-path-tracing_amd", "csrc
 @pytest.mark.parametrize("levels", [2, 3, 4])
 def test_bisection_in_rounds_returns_the_plain_bisections_index(tmp_path, levels):
     """vecmath.h, cdf_search_rounds: 2^levels - 1 entries loaded per round trip, that many levels decided from registers (the
-    device form for an environment map's tables: 3) — the index math.cpp:40-55's loop returns, on monotone and non-monotone
+    device form for an environment map's tables: 2) — the index math.cpp:40-55's loop returns, on monotone and non-monotone
     tables (quirk Q7), duplicates, NaNs, exact hits."""
     exe = str(tmp_path / "cdf_search_check")
     subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", f"-DMCPT_CDF_LEVELS={levels}", "-I", CSRC, "-I", os.path.join(os.path.dirname(HERE), "include"),
