@@ -185,6 +185,14 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
 
         phase_mark(kPhaseRegenerate);
         // ---- extend, resolve, roulette ----
+        // Instantiations without textures build the surface record in two halves (traversal.h, make_surface_part): resolve gets
+        // position and shading normal, the raw hit travels through the exchange in the tangent frame's words, and the frame is built
+        // behind the sort for the paths that go on from a surface vertex — 45 % of volumetric-caustic's vertices are medium vertices
+        // that never use one, and a quadric's frame (two inverse trigonometric functions, four sinf / cosf) ran for 4 lanes of a
+        // wavefront in 9 of 10 steps while the lanes of its BSDF kind were spread over the workgroup (EXPERIMENTS R5-9, R5-12).
+        constexpr bool kLazyFrame = !C::kTextures;
+        HitRaw hit;
+        hit.inst = hit.prim = 0, hit.a = hit.b = hit.c = 0.0f, hit.inside = false;
         Surface surf;
         surf.inside = false, surf.inst = 0, surf.uv = V2{0, 0};
         surf.position = surf.normal = surf.tangent = surf.bitangent = V3{0, 0, 0};
@@ -192,18 +200,16 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         {
             // (every lane makes the query call; the ones without a path work on the others' rays)
             Ray ray;
-            HitRaw raw;
-            const bool hit_valid = path_extend_uniform<C>(sc, st, nullptr, st.alive, ray, raw);
+            const bool hit_valid = path_extend_uniform<C>(sc, st, nullptr, st.alive, ray, hit);
             if (st.alive)
-                path_resolve<C>(sc, st, nullptr, ray, raw, hit_valid, surf);
+                path_resolve<C, kLazyFrame>(sc, st, nullptr, ray, hit, hit_valid, surf);
         }
         else if (st.alive)
         {
             Ray ray;
-            HitRaw raw;
-            const bool hit_valid = path_extend<C>(sc, st, nullptr, ray, raw);
+            const bool hit_valid = path_extend<C>(sc, st, nullptr, ray, hit);
             phase_mark(kPhaseExtend);
-            path_resolve<C>(sc, st, nullptr, ray, raw, hit_valid, surf);
+            path_resolve<C, kLazyFrame>(sc, st, nullptr, ray, hit, hit_valid, surf);
             phase_mark(kPhaseResolve);
         }
 
@@ -254,8 +260,12 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         in[5] = st.medium, in[6] = surf.inst;
         auto put = [&](uint32_t at, V3 v) { in[at] = as_uint(v.x), in[at + 1] = as_uint(v.y), in[at + 2] = as_uint(v.z); };
         put(7, vertex), put(10, st.wo), put(13, st.throughput), put(16, st.L), put(19, st.pixel_sum);
-        put(22, surf.normal), put(25, surf.tangent), put(28, surf.bitangent);
-        in[31] = as_uint(surf.uv.u), in[32] = as_uint(surf.uv.v), in[33] = slot, in[34] = q, in[35] = 0;
+        put(22, surf.normal);
+        if (kLazyFrame)
+            in[25] = as_uint(hit.a), in[26] = as_uint(hit.b), in[27] = as_uint(hit.c), in[28] = hit.prim, in[29] = in[30] = in[31] = in[32] = 0;
+        else
+            put(25, surf.tangent), put(28, surf.bitangent), in[31] = as_uint(surf.uv.u), in[32] = as_uint(surf.uv.v);
+        in[33] = slot, in[34] = q, in[35] = 0;
 #pragma unroll
         for (uint32_t pass = 0; pass < kSortPasses; ++pass)
         {
@@ -277,8 +287,23 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         auto get = [&](uint32_t at) { return V3{as_float(got[at]), as_float(got[at + 1]), as_float(got[at + 2])}; };
         st.origin = surf.position = get(7);
         st.wo = get(10), st.throughput = get(13), st.L = get(16), st.pixel_sum = get(19);
-        surf.normal = get(22), surf.tangent = get(25), surf.bitangent = get(28);
-        surf.uv = V2{as_float(got[31]), as_float(got[32])};
+        surf.normal = get(22);
+        if (kLazyFrame)
+        {
+            surf.tangent = surf.bitangent = V3{0, 0, 0}, surf.uv = V2{0, 0};
+            if (st.alive && !st.in_medium)
+            {
+                HitRaw moved;
+                moved.inst = surf.inst, moved.inside = surf.inside, moved.prim = got[28];
+                moved.a = as_float(got[25]), moved.b = as_float(got[26]), moved.c = as_float(got[27]);
+                make_surface_part<C::kAnalytic, false, 2>(sc, moved, surf);
+            }
+        }
+        else
+        {
+            surf.tangent = get(25), surf.bitangent = get(28);
+            surf.uv = V2{as_float(got[31]), as_float(got[32])};
+        }
         slot = got[33], q = got[34];
 
         phase_mark(kPhaseSort, st.alive); // (the lanes counted are the paths that go on to connect and scatter)

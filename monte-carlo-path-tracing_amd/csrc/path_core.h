@@ -457,7 +457,9 @@ MCPT_HD bool path_extend(const DeviceScene &sc, PathState &st, LaneCounters *cnt
 // back face, light) and the roulette; afterwards either the sample is finished (st.alive == false) or the path stands at
 // its next vertex — a medium scattering event (st.in_medium, st.origin) or the surface point `surf` — and
 // path_connect_scatter does the rest of the step there.  path_shade = one after the other.
-template <class C>
+// (kPointOnly: `surf` gets the half of the record this function reads — instance, side, position, shading normal — and the caller
+//  completes it with make_surface_part<..., 2> for the lanes that go on from a surface vertex: instantiations without textures only)
+template <class C, bool kPointOnly = false>
 MCPT_HD void path_resolve(const DeviceScene &sc, PathState &st, LaneCounters *cnt, const Ray &ray, const HitRaw &raw, bool hit_valid,
                           Surface &surf)
 {
@@ -466,7 +468,13 @@ MCPT_HD void path_resolve(const DeviceScene &sc, PathState &st, LaneCounters *cn
     const LightTables LT = light_tables<C>(sc);
     if (hit_valid)
     {
-        surf = make_surface<C::kAnalytic, C::kTextures>(sc, ray, raw);
+        if (kPointOnly)
+        {
+            surf.uv = V2{0, 0}, surf.tangent = surf.bitangent = V3{0, 0, 0};
+            make_surface_part<C::kAnalytic, C::kTextures, kPointOnly ? 1 : 0>(sc, raw, surf);
+        }
+        else
+            surf = make_surface<C::kAnalytic, C::kTextures>(sc, ray, raw);
         if (cnt)
             ++cnt->shaded_hits;
     }

@@ -905,11 +905,19 @@ MCPT_HD bool walk_ordered_vote(const DeviceScene &sc, uint32_t *stack, Ray &ray,
 // Shading frame of the closest hit (second half of the reference's primitive
 // tests: triangle.cpp:122-144, sphere.cpp:48-83, disk.cpp:46-108,
 // cylinder.cpp:61-86), including bump mapping and the back-face flip.
-template <bool kAnalytic, bool kTextures>
-MCPT_HD Surface make_surface(const DeviceScene &sc, const Ray &ray, const HitRaw &h)
+// kPart: 0 = the whole record.  For instantiations WITHOUT textures (no bump map can turn the normal) the record can be built in two
+// halves, with the same operations on the same operands: 1 = what path_resolve needs (instance, side, position, shading normal),
+// 2 = the rest (uv, tangent, bitangent) of a record whose first half is in `s` — the class-sorted kernel builds it after its sort,
+// for the lanes that stand on a surface, where the lanes of one BSDF kind share a wavefront (hip/sorted_kernel.hip).
+template <bool kAnalytic, bool kTextures, int kPart>
+MCPT_HD void make_surface_part(const DeviceScene &sc, const HitRaw &h, Surface &s)
 {
-    Surface s;
-    s.inst = h.inst, s.inside = h.inside;
+    static_assert(kPart == 0 || !kTextures, "a bump map makes the normal depend on the tangent frame: one piece");
+    constexpr bool kPoint = kPart != 2, kFrame = kPart != 1;
+    if (kPoint)
+        s.inst = h.inst, s.inside = h.inside;
+    else if (h.inside)
+        s.normal = -s.normal; // (back to the geometric side the frame is built on; flipped again below)
     const InstanceRec &rec = sc.instances[h.inst];
     const uint32_t bsdf = rec.bsdf;
     auto bump = [&](V3 &normal, V3 &tangent, V3 &bitangent)
@@ -933,12 +941,18 @@ MCPT_HD Surface make_surface(const DeviceScene &sc, const Ray &ray, const HitRaw
         const float4 *p = sc.tri_pos + 3 * static_cast<size_t>(h.prim);
         const float4 *at = sc.tri_attr + 9 * static_cast<size_t>(h.prim);
         const float u = h.a, v = h.b, w = h.c;
-        s.uv = triangle_uv(at, u, v, w);
-        s.position = u * xyz(p[0]) + v * xyz(p[1]) + w * xyz(p[2]);
-        s.normal = normalize(u * xyz(at[0]) + v * xyz(at[1]) + w * xyz(at[2]));
-        s.tangent = normalize(u * xyz(at[3]) + v * xyz(at[4]) + w * xyz(at[5]));
-        s.bitangent = normalize(u * xyz(at[6]) + v * xyz(at[7]) + w * xyz(at[8]));
-        bump(s.normal, s.tangent, s.bitangent);
+        if (kPoint)
+        {
+            s.position = u * xyz(p[0]) + v * xyz(p[1]) + w * xyz(p[2]);
+            s.normal = normalize(u * xyz(at[0]) + v * xyz(at[1]) + w * xyz(at[2]));
+        }
+        if (kFrame)
+        {
+            s.uv = triangle_uv(at, u, v, w);
+            s.tangent = normalize(u * xyz(at[3]) + v * xyz(at[4]) + w * xyz(at[5]));
+            s.bitangent = normalize(u * xyz(at[6]) + v * xyz(at[7]) + w * xyz(at[8]));
+            bump(s.normal, s.tangent, s.bitangent);
+        }
         phase_mark(kPhaseTriangleFrame); // (diagnostic builds: phase_clock.h)
     }
     else
@@ -947,69 +961,95 @@ MCPT_HD Surface make_surface(const DeviceScene &sc, const Ray &ray, const HitRaw
         const V3 p_local = V3{h.a, h.b, h.c};
         if (rec.kind == kInstSphere)
         {
-            float theta, phi;
-            s.uv = sphere_uv(p_local, theta, phi);
-            s.position = transform_point(q.to_world, p_local + from(q.center));
-            s.normal = transform_dir(q.normal_to_world, normalize(p_local));
-            constexpr float jitter = 0.01f * kPi;
-            float theta_p = theta + jitter;
-            const bool flip = theta_p > kPi;
-            if (flip)
-                theta_p = theta - jitter;
-            s.bitangent = normalize(transform_point(q.to_world, from_spherical(theta_p, phi, 1.0f)) - s.position);
-            if (flip)
-                s.bitangent = -s.bitangent;
-            s.tangent = normalize(cross(s.bitangent, s.normal));
-            s.bitangent = normalize(cross(s.normal, s.tangent));
-            bump(s.normal, s.tangent, s.bitangent);
+            if (kPoint)
+            {
+                s.position = transform_point(q.to_world, p_local + from(q.center));
+                s.normal = transform_dir(q.normal_to_world, normalize(p_local));
+            }
+            if (kFrame)
+            {
+                float theta, phi;
+                s.uv = sphere_uv(p_local, theta, phi);
+                constexpr float jitter = 0.01f * kPi;
+                float theta_p = theta + jitter;
+                const bool flip = theta_p > kPi;
+                if (flip)
+                    theta_p = theta - jitter;
+                s.bitangent = normalize(transform_point(q.to_world, from_spherical(theta_p, phi, 1.0f)) - s.position);
+                if (flip)
+                    s.bitangent = -s.bitangent;
+                s.tangent = normalize(cross(s.bitangent, s.normal));
+                s.bitangent = normalize(cross(s.normal, s.tangent));
+                bump(s.normal, s.tangent, s.bitangent);
+            }
         }
         else if (rec.kind == kInstDisk)
         {
-            float theta, phi;
-            to_spherical(p_local, theta, phi);
-            const float r = length(p_local);
-            s.uv = V2{r, phi * k1Div2Pi};
-            s.position = transform_point(q.to_world, p_local);
-            constexpr float jitter = 0.01f * kPi;
-            float r_p = r + jitter;
-            const bool flip_b = r_p > r;
-            if (flip_b)
-                r_p = r - jitter;
-            float phi_p = phi + jitter;
-            const bool flip_t = phi_p > kPi;
-            if (flip_t)
-                phi_p = phi - jitter;
-            const V3 e1 = from_spherical(theta, phi, r_p) - p_local, e2 = from_spherical(theta, phi_p, r) - p_local;
-            const V2 duv1 = V2{r_p, s.uv.v} - s.uv, duv2 = V2{s.uv.u, phi_p * k1Div2Pi} - s.uv;
-            const float norm = 1.0f / (duv2.u * duv1.v - duv1.u * duv2.v);
-            V3 tangent = normalize((duv1.v * e2 - duv2.v * e1) * norm), normal = V3{0, 0, 1};
-            if (flip_t)
-                tangent = -tangent;
-            // the reference also derives a bitangent from the uv differentials
-            // (disk.cpp:76-79) but overwrites it before use (disk.cpp:85)
-            V3 bitangent = normalize(cross(normal, tangent));
-            tangent = normalize(cross(bitangent, normal));
-            bump(normal, tangent, bitangent);
-            s.normal = transform_dir(q.normal_to_world, normal);
-            s.tangent = transform_dir(q.to_world, tangent);
-            s.bitangent = transform_dir(q.to_world, bitangent);
+            V3 normal = V3{0, 0, 1};
+            if (kPoint)
+                s.position = transform_point(q.to_world, p_local);
+            if (kFrame)
+            {
+                float theta, phi;
+                to_spherical(p_local, theta, phi);
+                const float r = length(p_local);
+                s.uv = V2{r, phi * k1Div2Pi};
+                constexpr float jitter = 0.01f * kPi;
+                float r_p = r + jitter;
+                const bool flip_b = r_p > r;
+                if (flip_b)
+                    r_p = r - jitter;
+                float phi_p = phi + jitter;
+                const bool flip_t = phi_p > kPi;
+                if (flip_t)
+                    phi_p = phi - jitter;
+                const V3 e1 = from_spherical(theta, phi, r_p) - p_local, e2 = from_spherical(theta, phi_p, r) - p_local;
+                const V2 duv1 = V2{r_p, s.uv.v} - s.uv, duv2 = V2{s.uv.u, phi_p * k1Div2Pi} - s.uv;
+                const float norm = 1.0f / (duv2.u * duv1.v - duv1.u * duv2.v);
+                V3 tangent = normalize((duv1.v * e2 - duv2.v * e1) * norm);
+                if (flip_t)
+                    tangent = -tangent;
+                // the reference also derives a bitangent from the uv differentials
+                // (disk.cpp:76-79) but overwrites it before use (disk.cpp:85)
+                V3 bitangent = normalize(cross(normal, tangent));
+                tangent = normalize(cross(bitangent, normal));
+                bump(normal, tangent, bitangent);
+                s.tangent = transform_dir(q.to_world, tangent);
+                s.bitangent = transform_dir(q.to_world, bitangent);
+            }
+            if (kPoint) // (the local normal: (0, 0, 1) unless a bump map turned it — which only the one-piece form can have)
+                s.normal = transform_dir(q.normal_to_world, normal);
         }
         else
         {
-            s.uv = V2{gl::atan2f(p_local.y, p_local.x) * k1Div2Pi, p_local.z / q.length};
-            s.position = transform_point(q.to_world, p_local);
-            s.normal = transform_dir(q.normal_to_world, normalize(V3{p_local.x, p_local.y, 0.0f}));
-            s.tangent = transform_dir(q.normal_to_world, V3{0, 0, 1});
-            s.bitangent = normalize(cross(s.normal, s.tangent));
-            bump(s.normal, s.tangent, s.bitangent);
+            if (kPoint)
+            {
+                s.position = transform_point(q.to_world, p_local);
+                s.normal = transform_dir(q.normal_to_world, normalize(V3{p_local.x, p_local.y, 0.0f}));
+            }
+            if (kFrame)
+            {
+                s.uv = V2{gl::atan2f(p_local.y, p_local.x) * k1Div2Pi, p_local.z / q.length};
+                s.tangent = transform_dir(q.normal_to_world, V3{0, 0, 1});
+                s.bitangent = normalize(cross(s.normal, s.tangent));
+                bump(s.normal, s.tangent, s.bitangent);
+            }
         }
         phase_mark(kPhaseQuadricFrame);
     }
     if (h.inside)
     {
         s.normal = -s.normal;
-        s.bitangent = -s.bitangent;
+        if (kFrame)
+            s.bitangent = -s.bitangent;
     }
+}
+
+template <bool kAnalytic, bool kTextures>
+MCPT_HD Surface make_surface(const DeviceScene &sc, const Ray &ray, const HitRaw &h)
+{
+    Surface s;
+    make_surface_part<kAnalytic, kTextures, 0>(sc, h, s);
     return s;
 }
 
