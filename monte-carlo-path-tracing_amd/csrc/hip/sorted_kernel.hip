@@ -288,6 +288,7 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         st.origin = surf.position = get(7);
         st.wo = get(10), st.throughput = get(13), st.L = get(16), st.pixel_sum = get(19);
         surf.normal = get(22);
+        phase_mark(kPhaseSort, st.alive); // (the lanes counted are the paths that go on to connect and scatter)
         if (kLazyFrame)
         {
             surf.tangent = surf.bitangent = V3{0, 0, 0}, surf.uv = V2{0, 0};
@@ -306,7 +307,6 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         }
         slot = got[33], q = got[34];
 
-        phase_mark(kPhaseSort, st.alive); // (the lanes counted are the paths that go on to connect and scatter)
         // ---- connect, scatter ----
         if constexpr (C::kPool)
         {
