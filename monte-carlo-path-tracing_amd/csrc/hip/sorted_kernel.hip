@@ -34,7 +34,15 @@ namespace mcpt
 #ifndef MCPT_SORT_PASSES
 #define MCPT_SORT_PASSES 3
 #endif
-constexpr uint32_t kSortWords = 36, kSortPasses = MCPT_SORT_PASSES, kSortPassWords = kSortWords / kSortPasses;
+#ifndef MCPT_SORT_PASSES_LAZY
+#define MCPT_SORT_PASSES_LAZY 2
+#endif
+// The exchange: 36 words in MCPT_SORT_PASSES passes — or, where the surface frame is built behind the sort (instantiations without
+// textures: the raw hit travels instead of the frame), 32 words in two passes of 16: 8 KB per workgroup, four barriers a step instead of
+// six (with the lean instantiation's 6.6 KB of geometry, 4.5 KB of stacks: 19.4 KB, eight workgroups per CU).
+constexpr uint32_t sort_words(uint32_t features) { return (features & kFeatTextures) ? 36u : 32u; }
+constexpr uint32_t sort_passes(uint32_t features) { return (features & kFeatTextures) ? MCPT_SORT_PASSES : MCPT_SORT_PASSES_LAZY; }
+constexpr uint32_t sort_pass_words(uint32_t features) { return sort_words(features) / sort_passes(features); }
 constexpr uint32_t kSortClasses = 10; // medium vertex, surface without BSDF, 6 BSDF kinds, finished sample, exhausted lane
 constexpr uint32_t kClassIdle = 8, kClassExhausted = 9;
 
@@ -118,6 +126,7 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         n_staged = n_node_vec + n_tri_vec + n_walk_vec + n_slot_vec;
     }
     constexpr uint32_t kWaves = kBlockSize / 64u;
+    constexpr uint32_t kSortWords = sort_words(kFeatures), kSortPasses = sort_passes(kFeatures), kSortPassWords = sort_pass_words(kFeatures);
     uint32_t *lds_words = reinterpret_cast<uint32_t *>(lds_geometry + n_staged);
     // one walk per lane: the lanes' stack columns, then the exchange words.  Pool walk: one pool area per wavefront, and the
     // exchange words travel THROUGH the pool areas (no wavefront is inside a query between the count barrier and the barrier
@@ -261,11 +270,14 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         auto put = [&](uint32_t at, V3 v) { in[at] = as_uint(v.x), in[at + 1] = as_uint(v.y), in[at + 2] = as_uint(v.z); };
         put(7, vertex), put(10, st.wo), put(13, st.throughput), put(16, st.L), put(19, st.pixel_sum);
         put(22, surf.normal);
-        if (kLazyFrame)
-            in[25] = as_uint(hit.a), in[26] = as_uint(hit.b), in[27] = as_uint(hit.c), in[28] = hit.prim, in[29] = in[30] = in[31] = in[32] = 0;
+        if constexpr (kLazyFrame)
+            in[25] = as_uint(hit.a), in[26] = as_uint(hit.b), in[27] = as_uint(hit.c), in[28] = hit.prim;
         else
             put(25, surf.tangent), put(28, surf.bitangent), in[31] = as_uint(surf.uv.u), in[32] = as_uint(surf.uv.v);
-        in[33] = slot, in[34] = q, in[35] = 0;
+        if constexpr (kLazyFrame)
+            in[29] = slot, in[30] = q, in[31] = 0;
+        else
+            in[33] = slot, in[34] = q, in[35] = 0;
 #pragma unroll
         for (uint32_t pass = 0; pass < kSortPasses; ++pass)
         {
@@ -289,7 +301,7 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
         st.wo = get(10), st.throughput = get(13), st.L = get(16), st.pixel_sum = get(19);
         surf.normal = get(22);
         phase_mark(kPhaseSort, st.alive); // (the lanes counted are the paths that go on to connect and scatter)
-        if (kLazyFrame)
+        if constexpr (kLazyFrame)
         {
             surf.tangent = surf.bitangent = V3{0, 0, 0}, surf.uv = V2{0, 0};
             if (st.alive && !st.in_medium)
@@ -305,7 +317,7 @@ sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ 
             surf.tangent = get(25), surf.bitangent = get(28);
             surf.uv = V2{as_float(got[31]), as_float(got[32])};
         }
-        slot = got[33], q = got[34];
+        slot = got[kLazyFrame ? 29 : 33], q = got[kLazyFrame ? 30 : 34];
 
         // ---- connect, scatter ----
         if constexpr (C::kPool)
@@ -339,7 +351,7 @@ static hipError_t LaunchSorted(const DeviceScene &sc, const RenderJob &job, floa
     constexpr bool kPool = (kFeatures & kFeatPoolWalk) != 0;
     const size_t lds_bytes = kPool ? StagedBytes(sc, true, true) + (size_t(kBlockSize / 64u) * pool_wave_words((kFeatures & kFeatAnalytic) != 0) + 2u * (kBlockSize / 64u) * 16u) * sizeof(uint32_t)
                                    : StagedBytes(sc, true) + size_t(sc.integrator.walk_depth) * MCPT_WALK_STACK_STRIDE * sizeof(uint32_t) + // (the stacks: one column per lane of the workgroup)
-                                         (size_t(kSortPassWords) * kBlockSize + 2u * (kBlockSize / 64u) * 16u) * sizeof(uint32_t);
+                                         (size_t(sort_pass_words(kFeatures)) * kBlockSize + 2u * (kBlockSize / 64u) * 16u) * sizeof(uint32_t);
     int per_cu = 0;
     hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sorted_kernel<kFeatures>, kBlockSize, lds_bytes);
     if (err != hipSuccess)
