@@ -273,7 +273,10 @@ int mcpt_renderer_set_class_sort(mcpt_renderer *r, int mode);
  * hierarchy has at most 1024 nodes, on a 4-wide exact form of that hierarchy (DeviceScene::pool_nodes).  -1 (default): the
  * library's choice — on in the lean instantiations (cornell-box 512 x 512 spp 256: 55.2 -> 41.6 ms; a rank's 1/8 share of it
  * 42.0 -> 27.2 ms: lanes without a path of their own work on their wavefront's rays), off in the class-sorted full-feature
- * ones (volumetric-caustic: 231 -> 241 ms); environment MCPT_POOL_WALK = 0 / 1 / 2 overrides the default. */
+ * ones (volumetric-caustic: 231 -> 241 ms); environment MCPT_POOL_WALK = 0 / 1 / 2 overrides the default.
+ * 2: like 1, and the lean LDS-resident kernels (cornell-box's class) run with MERGED QUERIES as the kernels outside LDS do
+ * (csrc/path_core.h, path_step_merged: a vertex's last shadow ray travels with the next segment's closest query) — same frame;
+ * a full 512 x 512 frame is 27 % slower with it (three workgroups per CU instead of four), see EXPERIMENTS.md R6-1. */
 int mcpt_renderer_set_pool_walk(mcpt_renderer *r, int mode);
 
 /* Register budget of the stream kernel's instantiation on scenes outside LDS (surface materials): compiled for 4, 3 or 2

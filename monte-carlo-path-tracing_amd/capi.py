@@ -403,7 +403,7 @@ class Renderer:
 
     def set_pool_walk(self, mode: int):
         """Ray queries of the lanes kernel on LDS-resident scenes: -1 library's choice, 0 one walk per lane, 1 the
-        wavefront-cooperative pool walk (csrc/pool_walk.h).  Same frame."""
+        wavefront-cooperative pool walk (csrc/pool_walk.h), 2 the same with merged queries in the lean LDS kernels too.  Same frame."""
         _check(lib().mcpt_renderer_set_pool_walk(self._h, mode))
         return self
 

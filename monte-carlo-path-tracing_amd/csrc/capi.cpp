@@ -858,7 +858,9 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             const char *e = std::getenv("MCPT_SORT"); // (measurements: 0 = render_kernel instead of the class-sorted kernel)
             return e ? std::atoi(e) : 1;
         }();
-        job.sort_classes = sort_classes != 0 && r->class_sort_mode != 0 && r->rng_mode != 2 ? 1u : 0u;
+        // (1: where it is the measured choice — full-feature scenes in LDS; 2 = asked for: wherever an instantiation exists, also the
+        //  surface-material meshes outside LDS, hip/sorted_kernel.hip)
+        job.sort_classes = sort_classes != 0 && r->class_sort_mode != 0 && r->rng_mode != 2 ? (r->class_sort_mode == 1 ? 2u : 1u) : 0u;
         static const int pool_walk = []
         {
             const char *e = std::getenv("MCPT_POOL_WALK"); // (measurements: the library's choice when mcpt_renderer_set_pool_walk left it open)
@@ -867,7 +869,8 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         // 1: where it is the measured choice (the lean LDS instantiations, surface-material scenes outside LDS); 2: wherever an
         // instantiation exists (also the class-sorted full-feature kernels: volumetric-caustic 231.0 -> 241.3 ms with it, so not
         // by default)
-        job.pool_walk = r->pool_walk_mode < 0 ? (pool_walk != 0 ? static_cast<uint32_t>(pool_walk) : 0u) : r->pool_walk_mode != 0 ? 2u : 0u;
+        // (bit 2: the lean LDS-resident kernels in their merged-queries form, hip/render_kernel.hip)
+        job.pool_walk = r->pool_walk_mode < 0 ? (pool_walk != 0 ? static_cast<uint32_t>(pool_walk) : 0u) : r->pool_walk_mode == 2 ? 6u : r->pool_walk_mode != 0 ? 2u : 0u;
     }
     // The library's choices (kernel_mode -1): the first draw of a renderer calibrates — BEFORE this draw sizes any of its
     // own buffers, because the calibration's nested draws re-size the renderer's scratch allocations.
@@ -1262,13 +1265,15 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         // DIAGNOSTIC: MCPT_WAVE_CLOCK=<file> — start and end time (100 MHz clock) of every wavefront of the render launch, written
         // to <file> after a blocking draw (RenderJob::wave_clock; tools/experiments/wave_timeline.py reads it)
         static const char *wave_clock_file = std::getenv("MCPT_WAVE_CLOCK");
-        constexpr size_t kWaveClockWords = 4u * 8u * 4u; // per CU: at most 8 workgroups of 4 wavefronts, four words each
+        using mcpt::kWaveClockWords;
+        using mcpt::kPhaseSumWords;
+        const size_t clock_words = r->n_cus * kWaveClockWords + kPhaseSumWords;
         if (wave_clock_file && blocking)
         {
             if (!r->wave_clock_dev)
-                Check(hipMalloc(reinterpret_cast<void **>(&r->wave_clock_dev), r->n_cus * kWaveClockWords * sizeof(unsigned long long)), "allocate wave clocks");
-            Check(hipMemsetAsync(r->wave_clock_dev, 0, r->n_cus * kWaveClockWords * sizeof(unsigned long long), stream), "clear wave clocks");
-            job.wave_clock = r->wave_clock_dev;
+                Check(hipMalloc(reinterpret_cast<void **>(&r->wave_clock_dev), clock_words * sizeof(unsigned long long)), "allocate wave clocks");
+            Check(hipMemsetAsync(r->wave_clock_dev, 0, clock_words * sizeof(unsigned long long), stream), "clear wave clocks");
+            job.wave_clock = r->wave_clock_dev, job.phase_sums = r->wave_clock_dev + r->n_cus * kWaveClockWords;
         }
         hipError_t sorted = hipErrorNotSupported;
         if (job.sort_classes && counters == nullptr)
@@ -1328,7 +1333,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         Check(hipStreamSynchronize(stream), "draw");
     if (blocking && job.wave_clock)
     {
-        std::vector<unsigned long long> clocks(size_t(r->n_cus) * 128u);
+        std::vector<unsigned long long> clocks(size_t(r->n_cus) * mcpt::kWaveClockWords + mcpt::kPhaseSumWords); // (the file ends with the phase sums)
         Check(hipMemcpy(clocks.data(), r->wave_clock_dev, clocks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost), "read wave clocks");
         if (FILE *f = std::fopen(std::getenv("MCPT_WAVE_CLOCK"), "wb"))
         {
@@ -2031,8 +2036,8 @@ int mcpt_renderer_set_pool_walk(mcpt_renderer *r, int mode)
 {
     if (!r)
         return Fail("null argument");
-    if (mode < -1 || mode > 1)
-        return Fail("mcpt_renderer_set_pool_walk: mode is -1 (the library's choice), 0 (one walk per lane) or 1 (wavefront-cooperative pool walk where the scene allows it)");
+    if (mode < -1 || mode > 2)
+        return Fail("mcpt_renderer_set_pool_walk: mode is -1 (the library's choice), 0 (one walk per lane), 1 (wavefront-cooperative pool walk where the scene allows it) or 2 (... with merged queries in the lean LDS-resident kernels too)");
     r->pool_walk_mode = mode;
     r->InvalidateRangeCaches();
     return 0;

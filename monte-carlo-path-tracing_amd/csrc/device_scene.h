@@ -52,6 +52,8 @@
 
 #include <stdint.h>
 
+#include "wave_target.h"
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #else
@@ -282,6 +284,12 @@ enum SceneFeature : uint32_t
     // names the instantiations of the LOW-DISCREPANCY build (hip/render_variants_lowdisc.hip, compiled with MCPT_LOW_DISCREPANCY:
     // what a draw of the random stream returns is decided by that macro in vecmath.h, for the whole translation unit)
     kFeatLowDisc = 1u << 16,
+    // pool-walk kernels of the path integrator: MERGED QUERIES — a vertex's last shadow query travels with the next segment's
+    // closest query, two ray records per lane (path_core.h, path_step_merged; pool_walk.h, kDual)
+    kFeatPoolMerge = 1u << 17,
+    // the kernel's workgroups are 128 lanes (the class-sorted kernels, hip/sorted_body.h): the per-lane traversal stacks in LDS
+    // interleave at that stride instead of 256
+    kFeatGroup128 = 1u << 18,
 };
 constexpr uint32_t kLowDiscMaxSpp = 8192; // (a Sobol point's sample index has 13 bits: vecmath.h ld_pack)
 

@@ -2,7 +2,13 @@
 #ifndef MCPT_RENDER_KERNEL_H
 #define MCPT_RENDER_KERNEL_H
 
+#include "../wave_target.h"
+#if defined(MCPT_WAVE_EMU)
+typedef int hipError_t; // (the lockstep host build of the kernel bodies, tests/emu: declarations only)
+typedef void *hipStream_t;
+#else
 #include <hip/hip_runtime_api.h>
+#endif
 
 #include "../device_scene.h"
 
@@ -12,6 +18,7 @@ namespace mcpt
 constexpr int kBlockSize = 256;
 constexpr uint32_t kHitCounters = 32;
 constexpr uint32_t kScatterAuto = 0xFFFFFFFFu;
+constexpr size_t kWaveClockWords = 4u * 8u * 4u, kPhaseSumWords = 64; // RenderJob::wave_clock: words per CU (at most 8 workgroups of 4 wavefronts, four words each); phase_sums
 bool LastLaunchTransposed(); // what the calling thread's last LaunchRender chose (for the kernel description)
 // lane_spread from the job's EXPENSIVE pixels (camera ray hits something): the largest power of two with
 // spread <= kSpreadNum / kSpreadDen * launched lanes / expensive pixels.  Fitted to rank-share measurements
@@ -94,6 +101,9 @@ struct RenderJob
     // 100 MHz clock (s_memrealtime) when the wavefront starts, when it leaves the kernel and when it last took a pixel, and the
     // number of pixels it took.  What a frame's tail looks like.
     unsigned long long *wave_clock;
+    // ... and, in builds with -DMCPT_PHASE_CLOCK=1, 64 words of their own behind them for the per-phase sums of all wavefronts
+    // (phase_clock.h; round 5's advisor: they used to sit at a fixed offset that assumed 256 CUs)
+    unsigned long long *phase_sums;
 };
 
 // ---- stream kernel (stream_core.h, stream_kernel_impl.h) ------------------------------------------

@@ -202,9 +202,14 @@ static bool PoolSubsets()
     return on;
 }
 
+// The lean LDS-resident pool-walk kernels (cornell's class) exist in two forms: two queries per vertex (kP) and merged queries
+// (kPM: one ray record more per lane — 10.9 instead of 7.8 KB of LDS per wavefront, three workgroups per CU instead of four).
+// RenderJob::pool_walk bit 2 asks for the merged form (mcpt_renderer_set_pool_walk(r, 2); EXPERIMENTS R6-1 / R6-2: 27 % slower on a
+// full frame, which is bound by VALU issue at four wavefronts per SIMD — what merged queries shorten is a path's chain).
+
 // (the references an item of the production pool walks can hold: one bit less with merged queries, pool_walk.h)
 constexpr uint32_t kLdsPoolLimit = kPoolMaxRef;
-constexpr uint32_t kBigPoolLimit = MCPT_POOL_MERGE ? kPoolMaxRefBigDual : kPoolMaxRefBig;
+constexpr uint32_t kBigPoolLimit = kPoolMaxRefBigDual; // (the merged instantiations' 25 bits, for every kernel of the class)
 
 // Can the lane-owns-a-path kernel run this scene (outside LDS) with the pool walk?  No opacity masks (they draw random numbers
 // during a walk: the visiting order is part of the image), the 4-wide hierarchy within the items' 26 bits and the lists' head room.
@@ -276,12 +281,12 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
         if (!slivers && PoolSubsets() && !sc.integrator.has_non_conductor)
         {
             *variant = "surface-materials (diffuse + conductor only)+pool-walk";
-            return Launch<kSurface | kPB | kFeatConductorOnly, false>(sc, job, out, nullptr, stream, n_cus);
+            return Launch<kSurface | kPBU | kFeatConductorOnly, false>(sc, job, out, nullptr, stream, n_cus);
         }
         if (!slivers && PoolSubsets() && !sc.integrator.has_reflectors)
         {
             *variant = "surface-materials (diffuse + dielectric only)+pool-walk";
-            return Launch<kSurface | kPB | kFeatDielectricOnly, false>(sc, job, out, nullptr, stream, n_cus);
+            return Launch<kSurface | kPBU | kFeatDielectricOnly, false>(sc, job, out, nullptr, stream, n_cus);
         }
         *variant = slivers ? "surface-materials+slivers+pool-walk" : "surface-materials+pool-walk";
         return slivers ? Launch<kSurface | kPB | kS, false>(sc, job, out, nullptr, stream, n_cus) : Launch<kSurface | kPB, false>(sc, job, out, nullptr, stream, n_cus);
@@ -299,20 +304,26 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     }
     const bool lds = StagedBytes(sc, true) <= kLdsGeometryBytes;
     // the wavefront-cooperative pool walk (pool_walk.h): its items hold node and slot indices in 10 bits
-    const bool pool = lds && job.pool_walk != 0 && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kLdsPoolLimit + 1u &&
-                      sc.integrator.n_prims <= kLdsPoolLimit + 1u && sc.integrator.pool_depth <= kPoolMaxDepth &&
+#if defined(MCPT_FORCE_LEAN_MERGED) // (experiment builds: tools/experiments/bisect_lean_merge.sh)
+    const bool lean_merged = true;
+#else
+    const bool lean_merged = (job.pool_walk & 4u) != 0;
+#endif
+    const uint32_t lean_limit = lean_merged ? kPoolMaxRefDual : kPoolMaxRef; // (an item's reference bits: pool_walk.h)
+    const bool pool = lds && job.pool_walk != 0 && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= lean_limit + 1u &&
+                      sc.integrator.n_prims <= lean_limit + 1u && sc.integrator.pool_depth <= kPoolMaxDepth &&
                       StagedBytes(sc, true, true) <= kLdsGeometryBytes;
     if (f == 0)
     {
-        *variant = pool ? "diffuse-area+lds+pool-walk" : lds ? "diffuse-area+lds" : "diffuse-area";
-        return pool  ? Launch<kP, false, true>(sc, job, out, nullptr, stream, n_cus)
+        *variant = pool ? (lean_merged ? "diffuse-area+lds+pool-walk, merged queries" : "diffuse-area+lds+pool-walk") : lds ? "diffuse-area+lds" : "diffuse-area";
+        return pool  ? (lean_merged ? Launch<kPM, false, true>(sc, job, out, nullptr, stream, n_cus) : Launch<kP, false, true>(sc, job, out, nullptr, stream, n_cus))
                : lds ? Launch<kO, false, true>(sc, job, out, nullptr, stream, n_cus)
                      : Launch<kV, false>(sc, job, out, nullptr, stream, n_cus);
     }
     if ((f & ~kFeatEmitters) == 0)
     {
-        *variant = pool ? "diffuse-emitters+lds+pool-walk" : lds ? "diffuse-emitters+lds" : "diffuse-emitters";
-        return pool  ? Launch<kFeatEmitters | kP, false, true>(sc, job, out, nullptr, stream, n_cus)
+        *variant = pool ? (lean_merged ? "diffuse-emitters+lds+pool-walk, merged queries" : "diffuse-emitters+lds+pool-walk") : lds ? "diffuse-emitters+lds" : "diffuse-emitters";
+        return pool  ? (lean_merged ? Launch<kFeatEmitters | kPM, false, true>(sc, job, out, nullptr, stream, n_cus) : Launch<kFeatEmitters | kP, false, true>(sc, job, out, nullptr, stream, n_cus))
                : lds ? Launch<kFeatEmitters | kO, false, true>(sc, job, out, nullptr, stream, n_cus)
                      : Launch<kFeatEmitters | kV, false>(sc, job, out, nullptr, stream, n_cus);
     }

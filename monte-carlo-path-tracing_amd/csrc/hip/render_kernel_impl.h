@@ -26,7 +26,10 @@
 #ifndef MCPT_RENDER_KERNEL_IMPL_H
 #define MCPT_RENDER_KERNEL_IMPL_H
 
+#include "../wave_target.h"
+#if !defined(MCPT_WAVE_EMU)
 #include <hip/hip_runtime.h>
+#endif
 
 #include "../path_core.h"
 #include "render_kernel.h"
@@ -52,13 +55,18 @@ struct Budget
 #ifndef MCPT_FULL_LDS_WAVES
 #define MCPT_FULL_LDS_WAVES 3
 #endif
-#ifndef MCPT_POOL_BIG_WAVES
-#define MCPT_POOL_BIG_WAVES 3
-#endif
     // (pool walk outside LDS: a wavefront's pool area is 9.5 KB of LDS, 16 of them fit a CU.  Measured at 4 / 3 wavefronts per
     //  SIMD — 128 VGPRs with 49-140 spilled / 156-168 with none: dragon/scene.xml 239.5 / 230.8 ms, matpreview rough conductor
     //  652.0 / 613.6 ms, rough dielectric 902.8 / 905.9 ms)
-    static constexpr int kWavesPerSimd = (kFeatures & kFeatPoolBig) ? MCPT_POOL_BIG_WAVES
+    // (the one-BSDF units without merged queries — matpreview — need 129-131 VGPRs left alone and are throughput-bound: held to 128
+    //  = 4 wavefronts per SIMD they spill nothing, rough dielectric 849 -> 739 ms; merged queries' larger pool areas would cost them
+    //  that fourth wavefront, csrc/Makefile.  -DMCPT_POOL_BIG_WAVES=<n> overrides all of them in experiment builds)
+#ifdef MCPT_POOL_BIG_WAVES
+    static constexpr int kPoolBigWaves = MCPT_POOL_BIG_WAVES;
+#else
+    static constexpr int kPoolBigWaves = (kFeatures & (kFeatConductorOnly | kFeatDielectricOnly)) && !(kFeatures & kFeatPoolMerge) ? 4 : 3;
+#endif
+    static constexpr int kWavesPerSimd = (kFeatures & kFeatPoolBig) ? kPoolBigWaves
                                          : (kFeatures & (kFeatVolPath | kFeatAnalytic)) ? (kLdsGeometry ? MCPT_FULL_LDS_WAVES : 3)
 #ifdef MCPT_EXPERIMENT_MICROFACET_WAVES
                                          : (kFeatures & kFeatMicrofacet)              ? MCPT_EXPERIMENT_MICROFACET_WAVES
@@ -91,7 +99,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(((kFeatures & kFeatLowDisc) != 0) == (MCPT_LOW_DISCREPANCY_ACTIVE != 0), "low-discrepancy instantiations live in their own translation unit");
 #endif
-    extern __shared__ float4 lds_geometry[];
+    MCPT_DYNAMIC_LDS(float4, lds_geometry);
     if (job.wave_clock && (threadIdx.x & 63u) == 0)
         job.wave_clock[4u * (blockIdx.x * (kBlockSize / 64u) + (threadIdx.x >> 6))] = wall_clock64();
 #if MCPT_PHASE_CLOCK
@@ -196,6 +204,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
         q = kFetchNext;
     for (;;)
     {
+        MCPT_WAVE_CONVERGE();
         // WORK COUNTER: a lane that needs a new item takes the first one nobody has taken yet — NOW, when it is free, not ahead
         // of time.  (Rounds 2-4 reserved a lane's next item when it STARTED the current one, to hide the atomic's latency: every
         // lane then held one item hostage while it worked on another — at the end of a frame the items waiting behind the longest
@@ -217,7 +226,10 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
                 want = want && ((threadIdx.x & 63u) & ((1u << lg) - 1u)) == 0u;
             }
             if (want)
+            {
+                MCPT_WAVE_REGION();
                 q = counter_base + wave_reserve(job.work_counter, true);
+            }
         }
         // (pool walk: a lane without work of its own stays in the loop as a HELPER of its wavefront's ray queries)
         bool helper = false;
@@ -228,7 +240,9 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
                 retired = true;
                 atomicAdd(&compact_count[4], 1u);
             }
-            const uint32_t n_retired = *static_cast<volatile uint32_t *>(&compact_count[4]); // (one LDS word, the same for every lane)
+            // (one LDS word, read by every lane of the wavefront in the same instruction: uniform — and said so, the lockstep host build
+            //  of this body, tests/emu, runs a wavefront's lanes one after the other between cross-lane operations)
+            const uint32_t n_retired = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(*static_cast<volatile uint32_t *>(&compact_count[4]))));
             constexpr uint32_t kEvents = kBlockSize / 64u - 1u;
             // (every wavefront takes part in every event, also the ones that fall due together with the end: a
             //  wavefront that left early would leave the others waiting at the event's barriers)
@@ -371,11 +385,11 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     if (job.wave_clock && (threadIdx.x & 63u) == 0)
         job.wave_clock[4u * (blockIdx.x * (kBlockSize / 64u) + (threadIdx.x >> 6)) + 1u] = wall_clock64();
 #if MCPT_PHASE_CLOCK
-    if (job.wave_clock && (threadIdx.x & 63u) == 0)
+    if (job.phase_sums && (threadIdx.x & 63u) == 0)
     {
         const unsigned long long *a = phase_area();
         for (uint32_t k = 1; k < 1 + 3 * kPhaseCount; ++k)
-            atomicAdd(job.wave_clock + (256u * 128u - 64u) + k, a[k]);
+            atomicAdd(job.phase_sums + k, a[k]);
     }
 #endif
     if (kCount)
@@ -393,6 +407,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     }
 }
 
+#if !defined(MCPT_WAVE_EMU)
 template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
 __global__ void __launch_bounds__(kBlockSize, (Budget<kFeatures, kLdsGeometry>::kWavesPerSimd))
 render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ out, TraceCounters *__restrict__ counters)
@@ -408,6 +423,7 @@ cost_probe_kernel(const DeviceScene sc_in, const RenderJob job, float *__restric
 {
     render_body<kFeatures, false, true>(sc_in, job, out, nullptr);
 }
+#endif // !MCPT_WAVE_EMU
 
 constexpr uint32_t kAll = kFeatVolPath | kFeatEmitters | kFeatAnalytic | kFeatTextures | kFeatMicrofacet;
 constexpr uint32_t kSurface = kFeatEmitters | kFeatTextures | kFeatMicrofacet;
@@ -421,7 +437,9 @@ constexpr uint32_t kVolumeLean = kFeatVolPath | kFeatAnalytic | kFeatMicrofacet;
 #define MCPT_WIDE_WALK 0
 #endif
 constexpr uint32_t kP = kFeatOrderedWalk | kFeatPoolWalk; // the wavefront-cooperative pool walk (LDS-resident scenes)
-constexpr uint32_t kPB = kP | kFeatPoolBig;               // ... on scenes outside LDS
+constexpr uint32_t kPM = kP | kFeatPoolMerge;             // ... with merged queries (path_core.h: two ray records per lane)
+constexpr uint32_t kPBU = kP | kFeatPoolBig;              // ... on scenes outside LDS, two queries per vertex
+constexpr uint32_t kPB = kPBU | kFeatPoolMerge;           // ... with merged queries (the path integrator's kernels: not with kFeatVolPath)
 constexpr uint32_t kO = kFeatOrderedWalk, kV = kFeatOrderedWalk | kFeatVoteWalk | (MCPT_WIDE_WALK ? kFeatWideWalk : 0u), kS = kFeatSlivers;
 // stack entries per lane in LDS: the ring of the short stack, or one entry per level of the binary hierarchy
 inline size_t WalkStackEntries(const DeviceScene &sc, uint32_t features)
@@ -439,31 +457,34 @@ inline size_t StagedBytes(const DeviceScene &sc, bool ordered, bool pool = false
 
 void NoteTransposed(bool transposed);
 
-template <uint32_t kFeatures, bool kCount, bool kLdsGeometry = false>
-hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters, hipStream_t stream,
-                  uint32_t max_blocks)
+// The launch's dynamic LDS: the staged traversal data, the wavefronts' pool areas (or the lanes' stack columns) and the compaction's
+// words.  (One function for the launcher and for the lockstep host build of the kernel body, tests/emu: an area sized for another
+// instantiation than the one that runs is exactly the kind of error that build exists to find.)
+template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
+inline size_t LaunchLdsBytes(const DeviceScene &sc)
 {
     constexpr bool kOrdered = (kFeatures & kFeatOrderedWalk) != 0;
     constexpr bool kPool = (kFeatures & kFeatPoolWalk) != 0;
     static_assert(!kPool || (kOrdered && (kLdsGeometry != ((kFeatures & kFeatPoolBig) != 0))), "pool walk: 16-bit items with the hierarchy staged in LDS, 32-bit items outside");
     static_assert((kBlockSize / 64u) * pool_wave_words(false) >= kCompactWords * kBlockSize, "the compaction's words travel through the pool areas");
-    const size_t lds_bytes = (kLdsGeometry ? StagedBytes(sc, kOrdered, kPool) : 0) +
-                             (kPool      ? size_t(kBlockSize / 64u) * pool_wave_words((kFeatures & kFeatAnalytic) != 0, (kFeatures & kFeatPoolBig) != 0, Config<kFeatures>::kPoolDual) * sizeof(uint32_t) + 8 * sizeof(uint32_t)
-                              : kOrdered ? WalkStackEntries(sc, kFeatures) * kBlockSize * sizeof(uint32_t)
-                                         : 0) +
-                             (!kPool && kLdsGeometry && !kCount && kOrdered && !(kFeatures & (kFeatVolPath | kFeatAnalytic))
-                                  ? (size_t(kCompactWords) * kBlockSize + 8) * sizeof(uint32_t)
-                                  : 0);
-    int per_cu = 0;
-    hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &per_cu, render_kernel<kFeatures, kCount, kLdsGeometry>, kBlockSize, lds_bytes);
-    if (err != hipSuccess)
-        return err;
-    if (per_cu < 1)
-        per_cu = 1;
+    return (kLdsGeometry ? StagedBytes(sc, kOrdered, kPool) : 0) +
+           (kPool      ? size_t(kBlockSize / 64u) * pool_wave_words((kFeatures & kFeatAnalytic) != 0, (kFeatures & kFeatPoolBig) != 0, Config<kFeatures>::kPoolDual) * sizeof(uint32_t) + 8 * sizeof(uint32_t)
+            : kOrdered ? WalkStackEntries(sc, kFeatures) * kBlockSize * sizeof(uint32_t)
+                       : 0) +
+           (!kPool && kLdsGeometry && !kCount && kOrdered && !(kFeatures & (kFeatVolPath | kFeatAnalytic))
+                ? (size_t(kCompactWords) * kBlockSize + 8) * sizeof(uint32_t)
+                : 0);
+}
+
+// What a launch on `max_blocks` CUs with `per_cu` resident workgroups each does with a job: lanes per path, pixel order, the level
+// thresholds of its occupancy — and the number of workgroups (0: nothing to do).
+template <uint32_t kFeatures, bool kLdsGeometry>
+inline uint64_t ShapeLaunch(const RenderJob &job, int per_cu, uint32_t max_blocks, RenderJob &spread_job)
+{
+    constexpr bool kPool = (kFeatures & kFeatPoolWalk) != 0;
     const uint32_t n_work = job.n_items * (job.sample_split ? job.sample_split : 1u);
     const uint32_t resident = max_blocks * static_cast<uint32_t>(per_cu);
-    RenderJob spread_job = job;
+    spread_job = job;
     // (measured on rank shares of cornell-box and volumetric-caustic: this kernel's wavefronts execute nearly the same
     //  instructions with 8 paths as with 64 — dense is the default; cornell's 1/8 share gains 8 % at spread 2 - 4)
     //  — except the diffuse LDS instantiations on a quarter of the lanes or less: 1 path per 2 lanes, cornell's 1/4 and
@@ -500,10 +521,26 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
                                      uint64_t(n_work) <= uint64_t(resident) * kBlockSize
                                  ? 1u
                                  : 0u;
-    NoteTransposed(spread_job.scatter != 0);
     uint64_t blocks = (uint64_t(n_work) * spread_job.lane_spread + kBlockSize - 1) / kBlockSize;
-    if (blocks > resident)
-        blocks = resident;
+    return blocks > resident ? resident : blocks;
+}
+
+#if !defined(MCPT_WAVE_EMU)
+template <uint32_t kFeatures, bool kCount, bool kLdsGeometry = false>
+hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters, hipStream_t stream,
+                  uint32_t max_blocks)
+{
+    const size_t lds_bytes = LaunchLdsBytes<kFeatures, kCount, kLdsGeometry>(sc);
+    int per_cu = 0;
+    hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &per_cu, render_kernel<kFeatures, kCount, kLdsGeometry>, kBlockSize, lds_bytes);
+    if (err != hipSuccess)
+        return err;
+    if (per_cu < 1)
+        per_cu = 1;
+    RenderJob spread_job;
+    const uint64_t blocks = ShapeLaunch<kFeatures, kLdsGeometry>(job, per_cu, max_blocks, spread_job);
+    NoteTransposed(spread_job.scatter != 0);
     if (blocks == 0)
         return hipSuccess;
     if constexpr (kLdsGeometry && !kCount && (kFeatures & kAll & ~kFeatEmitters) == 0)
@@ -536,6 +573,14 @@ extern template hipError_t Launch<kAll | kP, true, true>(MCPT_LAUNCH_ARGS);
 extern template hipError_t Launch<kAll | kO, false, true>(MCPT_LAUNCH_ARGS);
 extern template hipError_t Launch<kVolumeLean | kO, false, true>(MCPT_LAUNCH_ARGS);
 #endif
+#if !defined(MCPT_UNIT_LEAN_POOL)
+extern template hipError_t Launch<kP, false, true>(MCPT_LAUNCH_ARGS);
+extern template hipError_t Launch<kFeatEmitters | kP, false, true>(MCPT_LAUNCH_ARGS);
+#endif
+#if !defined(MCPT_UNIT_LEAN_POOL_MERGED)
+extern template hipError_t Launch<kPM, false, true>(MCPT_LAUNCH_ARGS);
+extern template hipError_t Launch<kFeatEmitters | kPM, false, true>(MCPT_LAUNCH_ARGS);
+#endif
 #if !defined(MCPT_UNIT_POOL)
 extern template hipError_t Launch<kSurface | kPB, false, false>(MCPT_LAUNCH_ARGS);
 extern template hipError_t Launch<kSurface | kPB | kS, false, false>(MCPT_LAUNCH_ARGS);
@@ -549,13 +594,14 @@ extern template hipError_t Launch<kAll | kPB, false, false>(MCPT_LAUNCH_ARGS);
 extern template hipError_t Launch<kAll | kPB | kS, false, false>(MCPT_LAUNCH_ARGS);
 #endif
 #if !defined(MCPT_UNIT_POOL_3)
-extern template hipError_t Launch<kSurface | kPB | kFeatConductorOnly, false, false>(MCPT_LAUNCH_ARGS);
-extern template hipError_t Launch<kSurface | kPB | kFeatDielectricOnly, false, false>(MCPT_LAUNCH_ARGS);
+extern template hipError_t Launch<kSurface | kPBU | kFeatConductorOnly, false, false>(MCPT_LAUNCH_ARGS);
+extern template hipError_t Launch<kSurface | kPBU | kFeatDielectricOnly, false, false>(MCPT_LAUNCH_ARGS);
 #endif
 #if !defined(MCPT_UNIT_SURFACE)
 extern template hipError_t Launch<kSurface | kV, false, false>(MCPT_LAUNCH_ARGS);
 extern template hipError_t Launch<kSurface | kV | kS, false, false>(MCPT_LAUNCH_ARGS);
 #endif
+#endif // !MCPT_WAVE_EMU
 
 } // namespace mcpt
 

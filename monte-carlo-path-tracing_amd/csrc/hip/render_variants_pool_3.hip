@@ -6,7 +6,7 @@
 namespace mcpt
 {
 
-template hipError_t Launch<kSurface | kPB | kFeatConductorOnly, false, false>(MCPT_LAUNCH_ARGS);
-template hipError_t Launch<kSurface | kPB | kFeatDielectricOnly, false, false>(MCPT_LAUNCH_ARGS);
+template hipError_t Launch<kSurface | kPBU | kFeatConductorOnly, false, false>(MCPT_LAUNCH_ARGS);
+template hipError_t Launch<kSurface | kPBU | kFeatDielectricOnly, false, false>(MCPT_LAUNCH_ARGS);
 
 } // namespace mcpt

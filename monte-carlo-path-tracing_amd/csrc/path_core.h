@@ -30,10 +30,6 @@
 #include "traversal.h"
 #include "pool_walk.h"
 
-#ifndef MCPT_POOL_MERGE
-#define MCPT_POOL_MERGE 1
-#endif
-
 namespace mcpt
 {
 
@@ -59,11 +55,11 @@ struct Config
     static constexpr bool kPool = (kFeatures & kFeatPoolWalk) != 0;       // ... as the wavefront-cooperative pool walk (pool_walk.h; device only)
     static constexpr bool kPoolBig = (kFeatures & kFeatPoolBig) != 0;     // ... with 32-bit items, the hierarchy outside LDS
     // ... with MERGED queries: a vertex's last shadow query travels with the next segment's closest query (path_step_merged; the
-    // path integrator's pool-walk kernels; -DMCPT_POOL_MERGE=0 builds the two-queries-per-vertex form for A/B measurements)
-    // (scenes outside LDS only.  The LDS kernels keep two queries per vertex: with two ray records per lane their pool areas leave
-    //  room for 3 wavefronts per SIMD instead of 4 on a VALU-bound kernel — and the LDS form with an AREA light's pending ray gave
-    //  wrong visibility in round 5's tests for a reason that was not found, while every other combination is exact: EXPERIMENTS R5-6)
-    static constexpr bool kPoolDual = kPool && kPoolBig && !kVolPath && (MCPT_POOL_MERGE != 0);
+    // path integrator's pool-walk kernels).  A property of the INSTANTIATION (kFeatPoolMerge), not of a translation unit: which
+    // kernels are merged is written where they are instantiated (hip/render_kernel_impl.h: kPB / kPBU, kPM)
+    static constexpr bool kPoolDual = kPool && !kVolPath && (kFeatures & kFeatPoolMerge) != 0;
+    // distance between a lane's consecutive stack entries (walk_ordered; traversal.h): the workgroup's size on the device
+    static constexpr uint32_t kStackStride = (kFeatures & kFeatGroup128) != 0 && kWalkStackStride != 1u ? 128u : kWalkStackStride;
 };
 
 // What a vertex leaves behind for the NEXT step's merged query (path_step_merged): its last light's shadow ray and what the sample's
@@ -198,7 +194,7 @@ MCPT_HD bool trace(const DeviceScene &sc, uint32_t *stack, Ray &r, uint32_t &rng
 {
     if (C::kOrdered)
     {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if MCPT_WAVE_DEVICE
         if (C::kPool) // (`stack` = the wavefront's pool area)
             return count ? walk_pool<kAny, C::kAnalytic, true, C::kPoolBig, C::kSlivers>(sc, stack, true, r, hit, ts) : walk_pool<kAny, C::kAnalytic, false, C::kPoolBig, C::kSlivers>(sc, stack, true, r, hit, ts);
 #endif
@@ -208,8 +204,8 @@ MCPT_HD bool trace(const DeviceScene &sc, uint32_t *stack, Ray &r, uint32_t &rng
         if (C::kVote)
             return count ? walk_ordered_vote<kAny, C::kAnalytic, true, C::kSlivers>(sc, stack, r, hit, ts)
                          : walk_ordered_vote<kAny, C::kAnalytic, false, C::kSlivers>(sc, stack, r, hit, ts);
-        return count ? walk_ordered<kAny, C::kAnalytic, true, C::kSlivers>(sc, stack, r, hit, ts)
-                     : walk_ordered<kAny, C::kAnalytic, false, C::kSlivers>(sc, stack, r, hit, ts);
+        return count ? walk_ordered<kAny, C::kAnalytic, true, C::kSlivers, C::kStackStride>(sc, stack, r, hit, ts)
+                     : walk_ordered<kAny, C::kAnalytic, false, C::kSlivers, C::kStackStride>(sc, stack, r, hit, ts);
     }
     return count ? walk_scene<kAny, C::kAnalytic, C::kTextures, true>(sc, r, rng, hit, ts)
                  : walk_scene<kAny, C::kAnalytic, C::kTextures, false>(sc, r, rng, hit, ts);
@@ -667,7 +663,7 @@ MCPT_HD void path_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt)
     path_shade<C>(sc, st, cnt, ray, raw, hit_valid);
 }
 
-#if defined(__HIPCC__)
+#if MCPT_WAVE_CODE
 // ---- the step with UNIFORM ray queries (pool walk, pool_walk.h) -----------------------------------------------
 // path_step for the kernels whose ray queries are the wavefront-cooperative pool walk: every lane of the wavefront makes
 // every query call of the step, with a flag saying whether it brings a ray — a lane without a path (`has_path` false), or
@@ -1120,7 +1116,7 @@ __device__ __forceinline__ void path_step_merged(const DeviceScene &sc, PathStat
     }
     st.dir = -st.wi;
 }
-#endif // __HIPCC__
+#endif // MCPT_WAVE_CODE
 
 // Convenience for CPU-side emulation and unit tests: a whole pixel.
 template <class C>

@@ -127,13 +127,18 @@ MCPT_HD SlotHit probe_slot(const DeviceScene &sc, const float4 *p, const Ray &ra
     return h;
 }
 
-#if defined(__HIPCC__)
+#if MCPT_WAVE_CODE
 
 __device__ __forceinline__ void pool_sync()
 {
     // the lists and records are written and read by the lanes of ONE wavefront: LDS executes a wavefront's accesses in
     // order, what is needed is that the compiler keeps them in order
+#if defined(MCPT_POOL_SYNC_STRONG) // (A/B builds: every outstanding LDS access retired before the next one is issued)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+#else
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+#endif
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -168,6 +173,8 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
     if (sc.integrator.n_walk_nodes == 0)
         return false;
     constexpr uint32_t kRayVecs = pool_ray_words(kAnalytic) / 4u;
+    // (lockstep host build / experiment builds: the area holds nothing a query may rely on — wave_target.h)
+    MCPT_POOL_POISON(pool, pool_wave_words(kAnalytic, kBig, kDual));
     const uint32_t lane = __lane_id();
     const unsigned long long workers = __ballot(1);
     const uint32_t rank = pool_rank(workers), n_workers = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__popcll(workers))));
@@ -233,6 +240,7 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
         uint32_t next_nodes = 0, next_prims = 0;
         if (rank < k * G)
         {
+            MCPT_WAVE_REGION();
             const uint32_t sub = rank & (G - 1u), first = sub * kPer; // this lane's children: first ... first + kPer - 1 (G = 1: all four)
             if (kCount)
                 stats.node_tests += kPer;
@@ -458,6 +466,7 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
     {
         // more accepted hits than the list holds (many near-coincident surfaces: the apex of dragon/scene.xml's stand-in wings,
         // 20 sheets through one point): this lane walks its ray alone, the per-lane way, on a private stack
+        MCPT_WAVE_REGION();
         uint32_t own_stack[kWalkStackMax];
         return walk_ordered<false, kAnalytic, false, kSlivers, 1u>(sc, own_stack, ray, hit, stats);
     }
@@ -509,7 +518,7 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
     return true;
 }
 
-#endif // __HIPCC__
+#endif // MCPT_WAVE_CODE
 
 } // namespace mcpt
 

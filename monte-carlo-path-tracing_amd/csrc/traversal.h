@@ -387,12 +387,9 @@ MCPT_HD bool walk_scene(const DeviceScene &sc, Ray &ray, uint32_t &rng, HitRaw &
 // Stack: `stack[level * kWalkStackStride]`; on the GPU the lanes of a workgroup
 // interleave their stacks in LDS (stride = workgroup size, conflict free), the
 // host build uses a plain array.
-// (MCPT_WALK_STACK_STRIDE: a translation unit whose kernels all run smaller workgroups says so — hip/sorted_kernel.hip: 128)
-#ifndef MCPT_WALK_STACK_STRIDE
-#define MCPT_WALK_STACK_STRIDE 256
-#endif
-#if defined(__HIP_DEVICE_COMPILE__)
-constexpr uint32_t kWalkStackStride = MCPT_WALK_STACK_STRIDE;
+// (kernels with workgroups of 128 lanes — the class-sorted ones — say so with a feature bit: Config::kStackStride, path_core.h)
+#if MCPT_WAVE_DEVICE
+constexpr uint32_t kWalkStackStride = 256;
 #else
 constexpr uint32_t kWalkStackStride = 1;
 #endif
@@ -609,7 +606,7 @@ MCPT_HD void hit_from_record(const DeviceScene &sc, uint32_t inst, uint32_t prim
 // True for exactly one of the currently active lanes of the wavefront.
 MCPT_HD bool is_leading_lane()
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if MCPT_WAVE_DEVICE
     return static_cast<int>(__lane_id()) == __ffsll(static_cast<unsigned long long>(__ballot(1))) - 1;
 #else
     return true;
@@ -642,7 +639,7 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
     stack[0] = kWalkDone;
     uint32_t depth = 1; // entries on the stack
     uint32_t cur = 0;   // the top node
-#if MCPT_SIGN_ADDRESSED_NODES && defined(__HIP_DEVICE_COMPILE__)
+#if MCPT_SIGN_ADDRESSED_NODES && MCPT_WAVE_DEVICE
     const uint32_t near_x = ray.dir_rcp.x > 0 ? 0u : 4u, near_y = ray.dir_rcp.y > 0 ? 0u : 4u, near_z = ray.dir_rcp.z > 0 ? 0u : 4u;
 #if MCPT_FUSED_SLAB
     // FUSED SLAB TEST (culling only).  The reference's plane distance is fl(fl(p - o) r): a subtraction and a product per
@@ -676,7 +673,7 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
             float enter0, enter1;
             bool hit0, hit1;
             uint32_t ref0, ref1;
-#if MCPT_SIGN_ADDRESSED_NODES && defined(__HIP_DEVICE_COMPILE__)
+#if MCPT_SIGN_ADDRESSED_NODES && MCPT_WAVE_DEVICE
             {
                 // (this walk runs on hierarchies staged in LDS.)  The slab test needs, per axis, the box plane the
                 // ray enters through and the one it leaves through; which of lo / hi that is depends on the sign of
@@ -739,7 +736,7 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
             if (is_leading_lane())
                 ++stats.wave_prim_steps;
         }
-#if MCPT_SIGN_ADDRESSED_NODES && defined(__HIP_DEVICE_COMPILE__) && MCPT_FUSED_SLAB
+#if MCPT_SIGN_ADDRESSED_NODES && MCPT_WAVE_DEVICE && MCPT_FUSED_SLAB
         constexpr bool kLeafCheck = true; // the boxes on the way here were tested loosely: the primitive's own box decides
 #else
         constexpr bool kLeafCheck = false;
@@ -757,7 +754,7 @@ MCPT_HD bool walk_ordered(const DeviceScene &sc, uint32_t *stack, Ray &ray, HitR
 // Number of lanes of the wavefront for which `p` holds (1 or 0 on the host).
 MCPT_HD uint32_t lanes_where(bool p)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if MCPT_WAVE_DEVICE
     return static_cast<uint32_t>(__popcll(__ballot(p)));
 #else
     return p ? 1u : 0u;
@@ -767,7 +764,7 @@ MCPT_HD uint32_t lanes_where(bool p)
 // Sum of `v` over the lanes of the wavefront (the value itself on the host).
 MCPT_HD uint32_t lanes_sum(uint32_t v)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if MCPT_WAVE_DEVICE
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
         v += __shfl_xor(v, off, 64);
@@ -778,7 +775,7 @@ MCPT_HD uint32_t lanes_sum(uint32_t v)
 // Wavefront aggregation helpers (a "wavefront" of the host build is one lane).
 MCPT_HD uint32_t lane_rank_among(bool p, uint32_t &total) // index of this lane among the lanes where p holds
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if MCPT_WAVE_DEVICE
     const unsigned long long mask = __ballot(p);
     total = static_cast<uint32_t>(__popcll(mask));
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
@@ -794,7 +791,7 @@ MCPT_HD uint32_t wave_reserve(uint32_t *counter, bool p)
 {
     uint32_t n;
     const uint32_t rank = lane_rank_among(p, n);
-#if defined(__HIP_DEVICE_COMPILE__)
+#if MCPT_WAVE_DEVICE
     uint32_t base = 0;
     if (p && rank == 0)
         base = atomicAdd(counter, n);

@@ -378,7 +378,7 @@ MCPT_HD uint32_t cdf_search_rounds(uint32_t num, const float *cdf, float target)
 }
 MCPT_HD uint32_t cdf_search_long(uint32_t num, const float *cdf, float target)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if MCPT_WAVE_DEVICE
     return cdf_search_rounds(num, cdf, target);
 #else
     return cdf_search(num, cdf, target); // (host threads: the cache holds the table's top levels, the plain loop reads less)

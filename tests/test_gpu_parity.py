@@ -70,10 +70,12 @@ def test_golden_frames(name, pkg, scenes):
     assert_parity(frame, want, name, spp=scenes[name].camera.spp, has_medium=bool(scenes[name].media))
 
 
+@pytest.mark.formulations  # (a default build has no stream kernel: modes 1 / 2 would draw the lanes kernel three times)
 @pytest.mark.parametrize("name", CASE_NAMES)
 def test_stream_kernel_equals_lane_kernel(name, pkg, scenes):
     """The two kernel formulations (mcpt_renderer_set_kernel) give the same frame bit for bit, and — the golden
-    test above runs the default — the reference's.  Scenes the stream kernel does not cover fall back."""
+    test above runs the default — the reference's.  Scenes the stream kernel does not cover fall back.
+    (`make EXPERIMENTAL=1` builds only.)"""
     r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
     try:
         r.set_kernel(0)
@@ -746,6 +748,40 @@ def test_class_sort_does_not_change_the_image(name, pkg, scenes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["rough_conductor_envmap", "rough_dielectric_envmap", "plastic_spot", "bumpy_directional", "terrain_directional"])
+def test_class_sort_outside_lds_does_not_change_the_image(name, pkg, scenes):
+    """Round 6 (north_star's "sorts hit records by material in LDS", SURVEY g1, for scenes whose geometry is NOT in LDS): the class-sorted
+    kernel on the pool walk with 32-bit items — surface-material meshes, matpreview's class (BASELINE config 4, the "BSDF-sort path").
+    mcpt_renderer_set_class_sort(r, 1) asks for it (the library's own choice stays the unsorted kernel with lanes per path by tile cost:
+    EXPERIMENTS R6-4): the compiled reference's golden, bit for bit, fixed lists / work counter, and as three ranks' packed tile shares.
+    Scenes without a BSDF beyond diffuse (terrain, the bump-mapped diffuse object) are not of the class and take the unsorted kernel."""
+    golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
+    try:
+        expect_sorted = name not in ("terrain_directional", "bumpy_directional")
+        for work in (0, 1):
+            frame, _ = r.set_kernel(0).set_class_sort(1).set_work_distribution(work).set_prepass(0).draw()
+            assert ("class-sorted" in r.last_kernel()) == expect_sorted and ("lds" not in r.last_kernel()), r.last_kernel()
+            assert np.array_equal(frame, golden), (work, r.last_kernel())
+        frame, _ = r.set_class_sort(-1).draw()
+        assert "class-sorted" not in r.last_kernel() and np.array_equal(frame, golden)
+        if expect_sorted:
+            import torch
+            h, w = golden.shape[:2]
+            frame = np.zeros_like(golden)
+            r.set_class_sort(1).set_work_distribution(1)
+            for rank in range(3):
+                rng = pkg.capi.TileRange(rank, 3, 0)
+                buf = torch.zeros(r.tiles_in(rng) * 64 * 3, dtype=torch.float32, device="cuda:0")
+                r.draw_device(buf.data_ptr(), rng, packed=True)
+                assert "class-sorted" in r.last_kernel()
+                pkg.capi.unpack_tiles(buf.cpu().numpy(), rng, w, h, frame)
+            assert np.array_equal(frame, golden)
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["cornell_64_spp8", "cornell_96_spp32", "volumetric_96x54_spp16", "volumetric_iso_64x36_spp8", "conductor_aniso_mixed",
                                   "dielectric_area_sphere", "thin_dielectric_sun", "rough_plastic_constant_cyl", "rough_diffuse_point_disk"])
 def test_pool_walk_does_not_change_the_image(name, pkg, scenes):
@@ -855,6 +891,54 @@ def test_merged_queries_outside_lds_equal_the_oracle(lights, pkg, oracle, tmp_pa
             frame, _ = r.set_prepass(prepass).draw()
             assert "pool-walk" in r.last_kernel() and "lds" not in r.last_kernel(), r.last_kernel()
             assert np.array_equal(frame, want), (lights, prepass, r.last_kernel())
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lights", ["area", "area+directional", "directional"])
+def test_merged_queries_in_lds_equal_the_golden(lights, pkg, oracle, tmp_path):
+    """Round 6, EXPERIMENTS R6-1 — the regression test of round 5's unexplained wrong answer.  Merged queries in the lean LDS-RESIDENT
+    kernels (mcpt_renderer_set_pool_walk(r, 2): Launch<kPM, false, true> / <kFeatEmitters | kPM, false, true>): with a pending
+    AREA-light shadow ray this kernel rendered 80 % of cornell's pixels darker.  The source was right (tests/test_wave_emu.py: its
+    lockstep host build is exact under every lane order and with poisoned pool areas); ROCm 7.2's gfx950 back end generated wrong code
+    from the <2 x float> operations the SLP vectoriser formed, so the unit is compiled without that pass (csrc/Makefile).  A library
+    whose merged unit is compiled WITH it fails this test (profiles/r06_lds_merge_ab_session1.jsonl: `ldsmerge`, equal 0.09)."""
+    M = pkg.mcsd
+    golden = np.load(os.path.join(GOLDEN, "cornell_64_spp8.npz"))["frame"]
+    scene = pkg.scenes.cornell_box(64, 64, 8)
+    if lights == "directional":
+        scene.instances = scene.instances[:-1]
+    if "directional" in lights:
+        scene.emitters.append(M.Emitter(type=M.EMIT_DIRECTIONAL, direction=(0.2, -0.7, -0.68), radiance=(3, 3, 3)))
+    if lights == "area":
+        want = golden
+    else:
+        path = str(tmp_path / "scene.mcsd")
+        M.dump(scene, path)
+        want, _ = oracle.render(path)
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scene), device=0)
+    try:
+        r.set_pool_walk(2)
+        for prepass, spread in ((1, 0), (0, 0), (0, 64), (0, 4)):
+            frame, _ = r.set_prepass(prepass).set_lane_spread(spread).draw()
+            assert "lds+pool-walk, merged queries" in r.last_kernel(), r.last_kernel()
+            assert np.array_equal(frame, want), (lights, prepass, spread, r.last_kernel(), float((frame != want).any(axis=2).mean()))
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
+def test_merged_queries_in_lds_full_film(pkg):
+    """cornell-box 512 x 512 spp 64: the merged form's frame == the production kernel's (two queries per vertex), which the full-size
+    tests pin against the oracle."""
+    r = pkg.capi.Renderer(pkg.workloads.config("cornell", 512, 512, 64), device=0)
+    try:
+        want, _ = r.set_pool_walk(1).draw()
+        assert "merged" not in r.last_kernel()
+        frame, _ = r.set_pool_walk(2).draw()
+        assert "merged queries" in r.last_kernel(), r.last_kernel()
+        assert np.array_equal(frame, want)
     finally:
         r.close()
 

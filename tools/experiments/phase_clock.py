@@ -43,7 +43,7 @@ def main():
     r.draw()
     _, st = r.draw()
     words = np.fromfile(path, dtype=np.uint64)
-    tail = words[256 * 128 - 64:].astype(np.float64)
+    tail = words[-64:].astype(np.float64)  # (RenderJob::phase_sums: the last 64 words of the file)
     n = len(PHASES)
     cycles, visits, lanes = tail[1:1 + n], tail[1 + n:1 + 2 * n], tail[1 + 2 * n:1 + 3 * n]
     total = cycles.sum()
