@@ -73,6 +73,13 @@ PMC_GROUPS_MEMORY = [
     ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_GATE_EN1_sum"],
     ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_EA0_RDREQ_sum", "TCC_REQ_sum"],
 ]
+# LDS side, kernels whose traversal data and ray records live in LDS only (round 6; VERDICT round 5, task 4): how many of the
+# wave-cycles wait for an LDS instruction, and how much of the LDS's active time is bank conflicts (12-word ray records read with
+# ds_read_b128 at data-dependent record indices).  Two passes; a box whose rocprofv3 lacks a counter reports the pass under `failed`.
+PMC_GROUPS_LDS = [
+    ["SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"],
+    ["SQ_WAIT_INST_LDS", "SQ_INST_CYCLES_SALU", "SQ_LDS_ADDR_CONFLICT", "SQ_LDS_UNALIGNED_STALL"],
+]
 KERNEL_WORDS = ("render_kernel", "sorted_kernel", "stream_kernel", "primary_kernel", "queued_")
 # Issue cost per wave64 VALU instruction by class, from this repository's microbenchmark on MI355X
 # (tools/microbench/valu_rate.hip, profiles/r02_experiments/valu_issue_rate_microbench.jsonl): plain fp32
@@ -118,7 +125,7 @@ def stream_bandwidth(torch, device):
     return out
 
 
-def pmc_leg(workload, film, choice, timeout_s=300, memory_side=False):
+def pmc_leg(workload, film, choice, timeout_s=300, memory_side=False, lds_side=False):
     """Hardware counters of the render kernel for one full-size launch of the workload: rocprofv3 runs
     tools/render_scene.py (one draw) once per counter group.  Returns None when rocprofv3 is not there."""
     if shutil.which("rocprofv3") is None:
@@ -128,7 +135,7 @@ def pmc_leg(workload, film, choice, timeout_s=300, memory_side=False):
         env.pop(k, None)
     counters, kernels, failed, duration_ns = {}, set(), [], []
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
-        for gi, group in enumerate(PMC_GROUPS + (PMC_GROUPS_MEMORY if memory_side else [])):
+        for gi, group in enumerate(PMC_GROUPS + (PMC_GROUPS_MEMORY if memory_side else []) + (PMC_GROUPS_LDS if lds_side else [])):
             d = os.path.join(tmp, f"pass{gi}")
             target = [sys.executable, os.path.join(ROOT, "tools", "render_scene.py"), f"workload:{workload}",
                       "--film", *map(str, film), "--draws", "1", "--kernel-mode", str(choice[0]), "--work", str(choice[1]),
@@ -398,7 +405,7 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
                 "scene": {"walk_nodes": scene_info["walk_nodes"], "primitives": scene_info["primitives"],
                           "geometry_bytes": scene_info["geometry_bytes"]}}
         outside_lds = "+lds" not in kernel_name
-        pmc = None if (args.no_pmc or world > 1 or args.rng != "reference") else pmc_leg(name, (W, H, SPP), choice, memory_side=outside_lds)
+        pmc = None if (args.no_pmc or world > 1 or args.rng != "reference") else pmc_leg(name, (W, H, SPP), choice, memory_side=outside_lds, lds_side=not outside_lds)
         if pmc and pmc["counters"].get("SQ_INSTS_VALU") and pmc["kernel_ns"]:
             c = pmc["counters"]
             pmc_ms = pmc["kernel_ns"] * 1e-6
@@ -445,6 +452,20 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
                     "l2_fabric_read_gbs": c["TCC_EA0_RDREQ_sum"] * 128.0 / (pmc_ms * 1e-3) / 1e9,
                     "tcp_pending_stall_per_active_cycle": c["TCP_PENDING_STALL_CYCLES_sum"] / max(c.get("TCP_GATE_EN1_sum", 0.0), 1.0),
                     "note": "vector-cache hits include the 3 further 16-byte reads of a 64-byte node record already fetched"}
+            if c.get("SQ_INSTS_LDS") and c.get("SQ_LDS_IDX_ACTIVE"):
+                wave_cycles = max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0)
+                roof["lds"] = {
+                    "lds_insts_per_sample": c["SQ_INSTS_LDS"] / samples,
+                    "lds_insts_per_valu": c["SQ_INSTS_LDS"] / c["SQ_INSTS_VALU"],
+                    # of the cycles the LDS is busy with indexed accesses, the share it spends re-issuing conflicting banks
+                    "bank_conflict_per_active_cycle": c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"],
+                    # the LDS pipeline's busy share of the kernel (IDX_ACTIVE counts per CU-cycle; 256 CUs x cycles)
+                    "active_frac_of_cu_cycles": c["SQ_LDS_IDX_ACTIVE"] / max((n_simd / 4.0) * cycles, 1.0),
+                    "wave_cycles_waiting_for_lds": c.get("SQ_WAIT_INST_LDS", 0.0) / wave_cycles if "SQ_WAIT_INST_LDS" in c else None,
+                    "addr_conflict_per_active_cycle": c.get("SQ_LDS_ADDR_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"] if "SQ_LDS_ADDR_CONFLICT" in c else None,
+                    "unaligned_stall_per_active_cycle": c.get("SQ_LDS_UNALIGNED_STALL", 0.0) / c["SQ_LDS_IDX_ACTIVE"] if "SQ_LDS_UNALIGNED_STALL" in c else None,
+                    "salu_cycles_per_wave_cycle": c.get("SQ_INST_CYCLES_SALU", 0.0) / wave_cycles if "SQ_INST_CYCLES_SALU" in c else None,
+                }
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 # rocprofv3 reports KiB; FETCH_SIZE counts 64-byte requests where gfx950 moves 128 (guide's
                 # gfx950 note): doubled
@@ -480,9 +501,16 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
             wait = valu["wait_any_per_wave_cycle"]
             hbm_frac = hbm.get("measured_frac_of_stream_peak", 0.0)
             waves_resident = c.get("SQ_WAVE_CYCLES", 0.0) * 4.0 / max(n_simd * cycles, 1.0)
-            roof["limiter"] = {"kind": ("valu-issue" if issue >= 0.6 else "hbm" if hbm_frac >= 0.6 else "latency / occupancy"),
-                               "valu_issue_frac": issue, "hbm_frac_of_stream_peak": hbm_frac, "wave_cycles_waiting": wait,
+            lds_wait = (roof.get("lds") or {}).get("wave_cycles_waiting_for_lds") or 0.0
+            lds_conflict = (roof.get("lds") or {}).get("bank_conflict_per_active_cycle") or 0.0
+            kind = ("valu-issue" if issue >= 0.6 else "hbm" if hbm_frac >= 0.6 else
+                    "lds" if (lds_wait >= 0.5 * max(wait, 1e-9) and lds_conflict >= 0.10) else "latency / occupancy")
+            roof["limiter"] = {"kind": kind, "valu_issue_frac": issue, "hbm_frac_of_stream_peak": hbm_frac, "wave_cycles_waiting": wait,
                                "mean_wavefronts_per_simd": waves_resident}
+            # `bound` follows the limiter (dragon printed "valu" beside "latency / occupancy"): when neither roof the
+            # contract knows is what the kernel waits for, `bound` says so, and `nearest_roof` names the roof achieved / peak / frac price
+            roof["nearest_roof"] = roof["bound"]
+            roof["bound"] = {"valu-issue": "valu", "hbm": "hbm", "lds": "lds"}.get(kind, "latency")
             roof["pmc"] = {"kernels": pmc["kernels"], "failed": pmc["failed"],
                            "command": "rocprofv3 --kernel-trace --pmc <group> -- python tools/render_scene.py "
                                       f"workload:{name} --film {W} {H} {SPP} --draws 1 --kernel-mode {choice[0]} --work {choice[1]} "
@@ -545,6 +573,12 @@ def compact(full, detail_path):
             o["limiter"] = r["limiter"]["kind"]
             o["waiting"] = round(r["limiter"]["wave_cycles_waiting"], 2)
             o["waves_per_simd"] = round(r["limiter"]["mean_wavefronts_per_simd"], 2)
+        if "nearest_roof" in r:
+            o["nearest_roof"] = r["nearest_roof"]
+        if r.get("lds"):
+            o["lds_conflict"] = round(r["lds"]["bank_conflict_per_active_cycle"], 3)
+            if r["lds"].get("wave_cycles_waiting_for_lds") is not None:
+                o["lds_wait"] = round(r["lds"]["wave_cycles_waiting_for_lds"], 3)
         if "memory" in r:
             o["tcp_hit"] = round(r["memory"]["tcp_hit_rate"], 3)
             o["l2_hit"] = round(r["memory"]["l2_hit_rate"], 3)

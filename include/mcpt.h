@@ -251,7 +251,10 @@ int mcpt_renderer_set_work_distribution(mcpt_renderer *r, int mode);
  * measures the tiles with a 2-spp probe (steps per tile), a wavefront then renders one tile, and the tiles are laid over the
  * grid so that every SIMD holds a wavefront of each cost quarter and all SIMDs the same sum (csrc/capi.cpp,
  * CostOrderedTable): 60.8 -> 56.2 ms; an explicit mcpt_renderer_set_pixel_order wins.  With more pixels than lanes
- * (volumetric-caustic) the same probe orders the work counter's hand-out, most expensive first (+1 %).  No reference counterpart. */
+ * (volumetric-caustic) the same probe orders the work counter's hand-out, most expensive first (+1 %).  No reference counterpart.
+ * 2 (round 6): image order in EIGHT BANDS, one per XCD of an MI355X — the film's hand-out positions are cut into eight contiguous
+ * ranges with a counter each, and a workgroup takes from the band of the XCD it runs on while that has items, from the next bands
+ * after that: each XCD's private L2 then serves one region of the film (pool-walk kernels outside LDS; EXPERIMENTS.md R6-5). */
 int mcpt_renderer_set_tile_order(mcpt_renderer *r, int mode);
 
 /* Class sort of the lane-owns-a-path kernel (csrc/hip/sorted_kernel.hip); the image does not depend on it.  Scenes whose

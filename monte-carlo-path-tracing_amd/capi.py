@@ -413,7 +413,8 @@ class Renderer:
         return self
 
     def set_tile_order(self, mode: int):
-        """Hand-out order of the tiles: -1 library's choice, 0 image order, 1 most expensive first (from the pre-pass).  Same frame."""
+        """Hand-out order of the tiles: -1 library's choice, 0 image order, 1 most expensive first (from the pre-pass), 2 image order in
+        eight bands, one per XCD.  Same frame."""
         _check(lib().mcpt_renderer_set_tile_order(self._h, mode))
         return self
 

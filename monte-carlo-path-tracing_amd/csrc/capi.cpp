@@ -3,6 +3,7 @@
 // There is NO CPU rendering path in this library: without a HIP device every
 // renderer call fails with an error.
 #include "mcpt.h"
+#include "host/measurement_env.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -33,6 +34,7 @@
 #include "host/frontend.hpp"
 #include "host/standin_mesh.hpp"
 
+static constexpr size_t kWorkCounterBytes = size_t(mcpt::kBands) * mcpt::kBandStride * sizeof(uint32_t); // (RenderJob::work_counter / xcd_bands)
 #ifndef MCPT_POOL_WALK_DEFAULT
 #define MCPT_POOL_WALK_DEFAULT 1 // (what mcpt_renderer_set_pool_walk(r, -1) means: on where an instantiation exists)
 #endif
@@ -189,7 +191,7 @@ struct mcpt_renderer
     uint32_t tile_keys_capacity = 0;
     size_t tile_temp_bytes = 0;
     int last_tile_order = 0;
-    uint32_t *work_counter_dev = nullptr; // RenderJob::work_counter (dynamic work distribution), zeroed before every launch
+    uint32_t *work_counter_dev = nullptr; // RenderJob::work_counter (dynamic work distribution; one counter per XCD band: RenderJob::xcd_bands), zeroed before every launch
     int work_mode = -1;                   // mcpt_renderer_set_work_distribution: -1 library's choice, 0 fixed lists, 1 work counter
 
     ~mcpt_renderer()
@@ -690,7 +692,7 @@ uint32_t StreamWavesFor(const mcpt_renderer *r, bool counted)
 {
     static const int env = []
     {
-        const char *e = std::getenv("MCPT_STREAM_WAVES");
+        const char *e = mcpt::MeasurementEnv("MCPT_STREAM_WAVES");
         return e ? std::atoi(e) : -1;
     }();
     if (counted)
@@ -707,7 +709,7 @@ int CostOrderEnv()
 {
     static const int v = []
     {
-        const char *e = std::getenv("MCPT_COST_ORDER");
+        const char *e = mcpt::MeasurementEnv("MCPT_COST_ORDER");
         return e ? std::atoi(e) : 1;
     }();
     return v;
@@ -728,7 +730,7 @@ std::vector<unsigned long long> CostOrderedTable(const std::vector<uint32_t> &st
     for (uint32_t t = 0; t < n; ++t)
         order[t] = t;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return steps[a] > steps[b]; });
-    if (std::getenv("MCPT_COST_DEBUG"))
+    if (mcpt::MeasurementEnv("MCPT_COST_DEBUG"))
     {
         unsigned long long sum = 0;
         for (uint32_t t = 0; t < n; ++t)
@@ -795,12 +797,12 @@ void LevelThresholds(const std::vector<uint32_t> &steps, uint32_t resident_wavef
     out[0] = out[1] = out[2] = 0;
     static const bool on = []
     {
-        const char *e = std::getenv("MCPT_LEVELS");
+        const char *e = mcpt::MeasurementEnv("MCPT_LEVELS");
         return !e || std::atoi(e) != 0;
     }();
     static const double kappa = []
     {
-        const char *e = std::getenv("MCPT_LEVEL_KAPPA");
+        const char *e = mcpt::MeasurementEnv("MCPT_LEVEL_KAPPA");
         return e ? std::atof(e) : 0.6;
     }();
     if (!on || steps.empty())
@@ -824,7 +826,7 @@ void LevelThresholds(const std::vector<uint32_t> &steps, uint32_t resident_wavef
     // (never the whole job: what is handed out last runs among lanes that are running out of work anyway)
     for (int level = 0; level < 3; ++level)
         out[level] = std::min<uint32_t>(out[level], static_cast<uint32_t>(sorted.size() / 2u) * 64u);
-    if (std::getenv("MCPT_COST_DEBUG"))
+    if (mcpt::MeasurementEnv("MCPT_COST_DEBUG"))
         std::fprintf(stderr, "lanes per path by tile cost: %u resident wavefronts, most expensive tile %.2f of a wavefront's share; 8 / 4 / 2 lanes per path until item %u / %u / %u of %zu\n",
                      resident_wavefronts, sorted[0] / share, out[0], out[1], out[2], sorted.size() * 64u);
 }
@@ -849,13 +851,13 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     {
         static const int compact = []
         {
-            const char *e = std::getenv("MCPT_COMPACT"); // (measurements: 0 switches the compaction of thinning workgroups off)
+            const char *e = mcpt::MeasurementEnv("MCPT_COMPACT"); // (measurements: 0 switches the compaction of thinning workgroups off)
             return e ? std::atoi(e) : 1;
         }();
         job.compact = compact != 0 ? 1u : 0u;
         static const int sort_classes = []
         {
-            const char *e = std::getenv("MCPT_SORT"); // (measurements: 0 = render_kernel instead of the class-sorted kernel)
+            const char *e = mcpt::MeasurementEnv("MCPT_SORT"); // (measurements: 0 = render_kernel instead of the class-sorted kernel)
             return e ? std::atoi(e) : 1;
         }();
         // (1: where it is the measured choice — full-feature scenes in LDS; 2 = asked for: wherever an instantiation exists, also the
@@ -863,7 +865,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         job.sort_classes = sort_classes != 0 && r->class_sort_mode != 0 && r->rng_mode != 2 ? (r->class_sort_mode == 1 ? 2u : 1u) : 0u;
         static const int pool_walk = []
         {
-            const char *e = std::getenv("MCPT_POOL_WALK"); // (measurements: the library's choice when mcpt_renderer_set_pool_walk left it open)
+            const char *e = mcpt::MeasurementEnv("MCPT_POOL_WALK"); // (measurements: the library's choice when mcpt_renderer_set_pool_walk left it open)
             return e ? std::atoi(e) : MCPT_POOL_WALK_DEFAULT;
         }();
         // 1: where it is the measured choice (the lean LDS instantiations, surface-material scenes outside LDS); 2: wherever an
@@ -1014,9 +1016,13 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     if (dynamic_work)
     {
         if (!r->work_counter_dev)
-            Check(hipMalloc(reinterpret_cast<void **>(&r->work_counter_dev), sizeof(uint32_t)), "allocate work counter");
-        Check(hipMemsetAsync(r->work_counter_dev, 0, sizeof(uint32_t), stream), "clear work counter");
+            Check(hipMalloc(reinterpret_cast<void **>(&r->work_counter_dev), kWorkCounterBytes), "allocate work counter");
+        Check(hipMemsetAsync(r->work_counter_dev, 0, kWorkCounterBytes, stream), "clear work counter");
         job.work_counter = r->work_counter_dev;
+        // XCD bands (RenderJob::xcd_bands; mcpt_renderer_set_tile_order(r, 2)): image order, whole film or tile range, one item per pixel
+        job.xcd_bands = r->tile_order_mode == 2 && job.tile_order == nullptr && job.sample_split <= 1 && job.scatter != 1u ? 1u : 0u;
+        if (job.xcd_bands)
+            job.scatter = 0;
     }
     if (timed)
         Check(hipEventRecord(r->ev_begin, stream), "record event");
@@ -1070,7 +1076,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                 }
             }
             // tiles most expensive first (by what their camera rays hit), for the work counter to hand out
-            if (dynamic_work && r->tile_order_mode != 0 && job.sample_split <= 1 && n_tiles > 1)
+            if (dynamic_work && r->tile_order_mode != 0 && r->tile_order_mode != 2 && job.sample_split <= 1 && n_tiles > 1)
             {
                 if (n_tiles > r->tile_keys_capacity)
                 {
@@ -1131,7 +1137,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                             LevelThresholds(steps, r->n_cus * 16u, r->mesh_level_until[1]);
                             Check(hipMemcpyAsync(r->mesh_table_dev, table.data(), n_tiles * sizeof(unsigned long long), hipMemcpyHostToDevice, stream), "upload the tile table");
                             Check(hipStreamSynchronize(stream), "wait for the tile table");
-                            Check(hipMemsetAsync(r->work_counter_dev, 0, sizeof(uint32_t), stream), "clear work counter");
+                            Check(hipMemsetAsync(r->work_counter_dev, 0, kWorkCounterBytes, stream), "clear work counter");
                         }
                     }
                     probed = r->mesh_table_ready;
@@ -1183,7 +1189,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         const int cost_order = CostOrderEnv();
         static const int cost_layout = []
         {
-            const char *e = std::getenv("MCPT_COST_LAYOUT");
+            const char *e = mcpt::MeasurementEnv("MCPT_COST_LAYOUT");
             return e ? std::atoi(e) : 1;
         }();
         // (jobs that fill at least half of the lanes: below that the launch spreads the paths over the lanes instead, and the
@@ -1218,7 +1224,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                 Check(hipMemsetAsync(r->tile_steps_dev, 0, n_tiles * sizeof(uint32_t), stream), "clear tile step counts");
                 static const uint32_t probe_spp = []
                 {
-                    const char *e = std::getenv("MCPT_COST_PROBE_SPP");
+                    const char *e = mcpt::MeasurementEnv("MCPT_COST_PROBE_SPP");
                     return e ? static_cast<uint32_t>(std::max(1, std::atoi(e))) : 2u;
                 }();
                 mcpt::DeviceScene probe = r->dev;
@@ -1238,7 +1244,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                       "upload the tile table");
                 Check(hipStreamSynchronize(stream), "wait for the tile table");
                 if (job.work_counter)
-                    Check(hipMemsetAsync(r->work_counter_dev, 0, sizeof(uint32_t), stream), "clear work counter");
+                    Check(hipMemsetAsync(r->work_counter_dev, 0, kWorkCounterBytes, stream), "clear work counter");
                 r->lds_table_tiles = n_tiles, r->lds_table_first = range.tile_first, r->lds_table_stride = range.tile_stride;
             }
             job.tile_order = r->tile_keys_dev + r->tile_keys_capacity;
@@ -1264,7 +1270,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         }
         // DIAGNOSTIC: MCPT_WAVE_CLOCK=<file> — start and end time (100 MHz clock) of every wavefront of the render launch, written
         // to <file> after a blocking draw (RenderJob::wave_clock; tools/experiments/wave_timeline.py reads it)
-        static const char *wave_clock_file = std::getenv("MCPT_WAVE_CLOCK");
+        static const char *wave_clock_file = mcpt::MeasurementEnv("MCPT_WAVE_CLOCK");
         using mcpt::kWaveClockWords;
         using mcpt::kPhaseSumWords;
         const size_t clock_words = r->n_cus * kWaveClockWords + kPhaseSumWords;
@@ -1309,7 +1315,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     if (r->dev.prehit)
         r->variant += " + camera-ray pre-pass";
     if (dynamic_work)
-        r->variant += job.tile_order && r->dev.prehit ? ", work counter (tiles most expensive first)" : ", work counter";
+        r->variant += job.tile_order && r->dev.prehit ? ", work counter (tiles most expensive first)" : job.xcd_bands ? ", work counter (image order in XCD bands)" : ", work counter";
     if (!streamed && !wavefront && !queued && (job.level_until[2] != 0 || job.level_until_4[2] != 0))
         r->variant += ", 2-8 lanes per path on the most expensive tiles";
     if (job.tile_order && !r->dev.prehit)
@@ -1335,7 +1341,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
     {
         std::vector<unsigned long long> clocks(size_t(r->n_cus) * mcpt::kWaveClockWords + mcpt::kPhaseSumWords); // (the file ends with the phase sums)
         Check(hipMemcpy(clocks.data(), r->wave_clock_dev, clocks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost), "read wave clocks");
-        if (FILE *f = std::fopen(std::getenv("MCPT_WAVE_CLOCK"), "wb"))
+        if (FILE *f = std::fopen(mcpt::MeasurementEnv("MCPT_WAVE_CLOCK"), "wb"))
         {
             std::fwrite(clocks.data(), sizeof(unsigned long long), clocks.size(), f);
             std::fclose(f);
@@ -2004,8 +2010,8 @@ int mcpt_renderer_set_tile_order(mcpt_renderer *r, int mode)
 {
     if (!r)
         return Fail("null argument");
-    if (mode < -1 || mode > 1)
-        return Fail("mcpt_renderer_set_tile_order: mode is -1 (the library's choice), 0 (image order) or 1 (most expensive tiles first)");
+    if (mode < -1 || mode > 2)
+        return Fail("mcpt_renderer_set_tile_order: mode is -1 (the library's choice), 0 (image order), 1 (most expensive tiles first) or 2 (image order in eight bands, one per XCD)");
     r->tile_order_mode = mode;
     r->InvalidateRangeCaches();
     return 0;

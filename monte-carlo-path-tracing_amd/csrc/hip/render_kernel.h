@@ -18,6 +18,7 @@ namespace mcpt
 constexpr int kBlockSize = 256;
 constexpr uint32_t kHitCounters = 32;
 constexpr uint32_t kScatterAuto = 0xFFFFFFFFu;
+constexpr uint32_t kBands = 8, kBandStride = 32; // RenderJob::xcd_bands: one counter per XCD, 128 bytes apart
 constexpr size_t kWaveClockWords = 4u * 8u * 4u, kPhaseSumWords = 64; // RenderJob::wave_clock: words per CU (at most 8 workgroups of 4 wavefronts, four words each); phase_sums
 bool LastLaunchTransposed(); // what the calling thread's last LaunchRender chose (for the kernel description)
 // lane_spread from the job's EXPENSIVE pixels (camera ray hits something): the largest power of two with
@@ -70,6 +71,12 @@ struct RenderJob
     // expensive part of the job is.  The stream kernel sizes lane_spread from it (lane_spread 0 only).
     uint32_t *hit_counters;
     uint32_t *work_counter;
+    // XCD BANDS (round 6; image order only: no tile_order, no scatter, no sample split).  1: the hand-out positions are cut into eight
+    // contiguous bands (horizontal stripes of the film), band b has its own counter (work_counter[kBandStride * b], all zeroed), and a
+    // workgroup takes from the band of the XCD it runs on (HW_REG_XCC_ID) while that has items, from the next bands after that.  Each
+    // of MI355X's eight XCDs has its own 4 MB L2: the wavefronts of one XCD then work on one region of the film — camera rays, first
+    // bounces and shadow rays that touch one region of the scene — instead of all eight L2s each caching all of it.
+    uint32_t xcd_bands;
     // Hand-out order of the tiles (null: image order).  The work counter hands out items 0, 1, 2, ...; with a table,
     // hand-out position p stands for local tile (uint32_t)tile_order[p >> 6] — the tiles sorted MOST EXPENSIVE FIRST
     // (hip/tile_order.hip: a cost from the pre-pass's camera-ray hits).  The reference's one random stream per pixel makes

@@ -3,6 +3,7 @@
 #include <cstdlib>
 
 #include "render_kernel_impl.h"
+#include "../host/measurement_env.hpp"
 
 namespace mcpt
 {
@@ -196,7 +197,7 @@ static bool PoolSubsets()
 {
     static const bool on = []
     {
-        const char *e = std::getenv("MCPT_POOL_SUBSETS");
+        const char *e = mcpt::MeasurementEnv("MCPT_POOL_SUBSETS");
         return !e || std::atoi(e) != 0;
     }();
     return on;

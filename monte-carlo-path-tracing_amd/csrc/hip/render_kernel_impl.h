@@ -92,6 +92,37 @@ constexpr uint32_t kCompactWords = 8, kCompactPasses = 4; // a path's 30 state w
 // latency shortens every step.  Large scenes stream from HBM / L2.
 // The ordered walk's stacks always live in LDS: lane t of the workgroup owns the
 // words t, t + 256, t + 512, ... of the stack area.
+// The XCD this wavefront runs on (0-7; observed: workgroup b runs on XCD b % 8, MI355X_MICROARCH guide — a performance hint only).
+__device__ __forceinline__ uint32_t xcd_id()
+{
+    // s_getreg_b32 hwreg(HW_REG_XCC_ID = 20, offset 0, size 4)
+    return static_cast<uint32_t>(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20)) & (kBands - 1u);
+}
+
+// RenderJob::xcd_bands: the next hand-out position for every calling lane — from band `first` while it has items, then from the bands
+// behind it (a band that ran dry is skipped with one load).  n_work: when nothing is left anywhere.  Bands are whole tiles.
+__device__ __forceinline__ uint32_t band_reserve(uint32_t *counters, uint32_t first, uint32_t n_work)
+{
+    const uint32_t tiles = n_work >> 6;
+    uint32_t got = n_work;
+    bool want = true;
+    for (uint32_t k = 0; k < kBands; ++k) // (uniform: the calling lanes of a wavefront go through the bands together)
+    {
+        if (__ballot(want) == 0)
+            break;
+        const uint32_t b = (first + k) & (kBands - 1u);
+        const uint32_t begin = (static_cast<uint64_t>(tiles) * b / kBands) << 6, end = (static_cast<uint64_t>(tiles) * (b + 1u) / kBands) << 6;
+        uint32_t *counter = counters + kBandStride * b;
+        const uint32_t taken = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))));
+        if (taken >= end - begin)
+            continue; // (dry: a stale value says "not yet" at worst, and the reservation below finds out)
+        const uint32_t r = wave_reserve(counter, want);
+        if (want && r < end - begin)
+            got = begin + r, want = false;
+    }
+    return got;
+}
+
 template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
 __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const RenderJob &job, float *__restrict__ out, TraceCounters *__restrict__ counters)
 {
@@ -198,9 +229,12 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     // may take one depends on what is being handed out
     // (kernels outside LDS only: the LDS kernels' compaction retires a lane that waits for its turn, and moves paths to other lanes)
     const bool levels = C::kPoolBig && job.work_counter != nullptr && job.level_until[2] != 0;
+    // XCD bands (RenderJob::xcd_bands): every item comes from the counters too, the band of this workgroup's XCD first
+    const bool bands = C::kPoolBig && job.work_counter != nullptr && job.xcd_bands != 0;
+    const uint32_t my_band = bands ? xcd_id() : 0u;
     const uint32_t counter_base = levels ? 0u : stride;
     uint32_t my_lg = 0; // log2 of the lanes per path this lane's pixel was handed out with
-    if (levels && q < n_work)
+    if ((levels || bands) && q < n_work)
         q = kFetchNext;
     for (;;)
     {
@@ -228,7 +262,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
             if (want)
             {
                 MCPT_WAVE_REGION();
-                q = counter_base + wave_reserve(job.work_counter, true);
+                q = bands ? band_reserve(job.work_counter, my_band, n_work) : counter_base + wave_reserve(job.work_counter, true);
             }
         }
         // (pool walk: a lane without work of its own stays in the loop as a HELPER of its wavefront's ray queries)

@@ -13,6 +13,7 @@
 // (src/renderer/emitters/emitter.cpp:122-175, envmap.cpp:20-68,
 // renderer.cpp:597-606), the Kulla-Conty LUT (kulla_conty.cpp:12-80).
 #include "commit.hpp"
+#include "measurement_env.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -251,7 +252,7 @@ void BuildPoolNodes(FlatScene &fs)
     };
     static const int order_env = []
     {
-        const char *e = std::getenv("MCPT_POOL_ORDER");
+        const char *e = mcpt::MeasurementEnv("MCPT_POOL_ORDER");
         return e == nullptr ? -1 : std::string(e) == "sorted" ? 1 : 0;
     }();
     const bool sorted_children = order_env >= 0 ? order_env == 1 : (n_binary <= 1024u && ig.n_prims <= 1024u);
@@ -328,6 +329,11 @@ void BuildPoolNodes(FlatScene &fs)
 // it does.  The slab test is monotone in the box, so every primitive the exact hierarchy reaches is reached here too;
 // what a larger box lets through in addition is stopped at the primitive by the exact leaf-box test
 // (traversal.h, test_slot: kLeafCheck), as it already is for slivers' grown boxes.  Answers unchanged.
+#ifndef MCPT_WIDE_TREELET
+#define MCPT_WIDE_TREELET 0
+#endif
+constexpr uint32_t kWideTreelet = MCPT_WIDE_TREELET; // records per treelet of wide_nodes (0: breadth-first numbering)
+
 void BuildWideNodes(FlatScene &fs)
 {
     IntegratorRec &ig = fs.integrator;
@@ -381,7 +387,7 @@ void BuildWideNodes(FlatScene &fs)
     // spread, matpreview 1.2-1.6 % slower (more records under the same caches) — so it is off unless asked for.
     static const bool align_pairs = []
     {
-        const char *e = std::getenv("MCPT_WIDE_ALIGN");
+        const char *e = mcpt::MeasurementEnv("MCPT_WIDE_ALIGN");
         return e != nullptr && std::atoi(e) != 0;
     }();
     constexpr uint32_t kPadding = 0xFFFFFFFFu;
@@ -484,6 +490,77 @@ void BuildWideNodes(FlatScene &fs)
     }
     ig.n_wide_nodes = static_cast<uint32_t>(todo.size());
     ig.wide_stack = worst_stack + 1;
+    // TREELET ORDER (round 6; VERDICT round 4 / 5: "lay wide_nodes out in depth-first treelet order").  Breadth-first numbering puts
+    // siblings side by side — which the pool walk's node steps like — and a node's children a whole level away from it: a ray's path
+    // from the top touches one record per level, each in another part of a 20-50 MB array.  Here the records are renumbered in
+    // TREELETS: a treelet is a subtree's top `kTreelet` records in breadth-first order (siblings stay adjacent), the subtrees hanging
+    // below it follow as treelets of their own, depth first — so the levels a walk descends through next lie within 2-4 KB of the
+    // record it stands at.  A pure renumbering: the same records and references, the same walk, the same answers.
+    // Measured (EXPERIMENTS R6-5); MCPT_TREELET=<records per treelet, 0 = breadth-first> overrides in experiment builds.
+    static const uint32_t treelet = []
+    {
+        const char *e = MeasurementEnv("MCPT_TREELET");
+        return e != nullptr ? static_cast<uint32_t>(std::atoi(e)) : kWideTreelet;
+    }();
+    const uint32_t n_nodes = ig.n_wide_nodes;
+    if (treelet > 1 && n_nodes > treelet)
+    {
+        auto inner_children = [&](uint32_t node, uint32_t kids[4]) -> int
+        {
+            const uint4 refs = out[4 * size_t(node) + 1];
+            const uint32_t r[4] = {refs.x, refs.y, refs.z, refs.w};
+            int n = 0;
+            for (uint32_t v : r)
+                if (v != kWalkDone && !(v & kWalkLeaf))
+                    kids[n++] = v;
+            return n;
+        };
+        std::vector<uint32_t> order, roots{0u}, queue, frontier; // order[new] = old
+        order.reserve(n_nodes);
+        std::vector<uint8_t> placed(n_nodes, 0);
+        while (!roots.empty())
+        {
+            const uint32_t root = roots.back();
+            roots.pop_back();
+            queue.assign(1, root), frontier.clear();
+            uint32_t count = 0;
+            for (size_t head = 0; head < queue.size(); ++head)
+            {
+                const uint32_t node = queue[head];
+                if (count >= treelet)
+                {
+                    frontier.push_back(node);
+                    continue;
+                }
+                order.push_back(node), placed[node] = 1, ++count;
+                uint32_t kids[4];
+                const int n = inner_children(node, kids);
+                for (int i = 0; i < n; ++i)
+                    queue.push_back(kids[i]);
+            }
+            for (size_t i = frontier.size(); i-- > 0;) // (depth first: the first subtree below the treelet comes right behind it)
+                roots.push_back(frontier[i]);
+        }
+        // (padding records of MCPT_WIDE_ALIGN are referenced by nobody: they go to the end)
+        for (uint32_t node = 0; node < n_nodes; ++node)
+            if (!placed[node])
+                order.push_back(node);
+        std::vector<uint32_t> renumbered(n_nodes);
+        for (uint32_t k = 0; k < n_nodes; ++k)
+            renumbered[order[k]] = k;
+        std::vector<uint4> moved(out.size());
+        for (uint32_t k = 0; k < n_nodes; ++k)
+        {
+            for (int v = 0; v < 4; ++v)
+                moved[4 * size_t(k) + v] = out[4 * size_t(order[k]) + v];
+            uint4 &refs = moved[4 * size_t(k) + 1];
+            uint32_t *r[4] = {&refs.x, &refs.y, &refs.z, &refs.w};
+            for (uint32_t *v : r)
+                if (*v != kWalkDone && !(*v & kWalkLeaf))
+                    *v = renumbered[*v];
+        }
+        out.swap(moved);
+    }
 }
 
 class WalkTreeBuilder

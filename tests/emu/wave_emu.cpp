@@ -421,6 +421,7 @@ struct Options
     uint32_t compact;     // RenderJob::compact
     uint32_t scatter;     // RenderJob::scatter (0xFFFFFFFF: the launcher's rule)
     uint32_t threads;     // host threads, one workgroup each at a time (0: all cores)
+    uint32_t xcd_bands;     // RenderJob::xcd_bands: the hand-out in eight bands, one counter each
     uint32_t lds_shortfall; // bytes the LDS array is SHORTER than the launch asks for (the sanitizer build's self-test: it must notice)
 };
 
@@ -446,12 +447,15 @@ struct BodyArgs
 
 RenderJob FilmJob(const DeviceScene &sc, const Options &opt, uint32_t *work_counter)
 {
+    for (uint32_t i = 0; i < kBands * kBandStride; ++i)
+        work_counter[i] = 0;
     const uint32_t width = static_cast<uint32_t>(sc.camera.width), height = static_cast<uint32_t>(sc.camera.height);
     const uint32_t tiles_x = (width + 7u) / 8u, tiles_y = (height + 7u) / 8u;
     RenderJob job{};
     job.n_items = tiles_x * tiles_y * 64u, job.tile_first = 0, job.tile_stride = 1, job.tiles_x = tiles_x;
     job.work_counter = work_counter;
-    job.lane_spread = opt.lane_spread, job.compact = opt.compact, job.scatter = opt.scatter, job.pool_walk = 1;
+    job.lane_spread = opt.lane_spread, job.compact = opt.compact, job.scatter = opt.xcd_bands ? 0u : opt.scatter, job.pool_walk = 1;
+    job.xcd_bands = opt.xcd_bands;
     return job;
 }
 
@@ -460,8 +464,8 @@ void RunGrid(void (*body)(void *), void *body_arg, uint32_t n_lanes, uint64_t bl
 template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
 void RenderGrid(const DeviceScene &sc, const Options &opt, float *frame, TraceCounters *counters, Report *report)
 {
-    uint32_t work_counter = 0;
-    const RenderJob job = FilmJob(sc, opt, &work_counter);
+    uint32_t work_counter[kBands * kBandStride];
+    const RenderJob job = FilmJob(sc, opt, work_counter);
     RenderJob shaped;
     const uint64_t blocks = ShapeLaunch<kFeatures, kLdsGeometry>(job, opt.per_cu ? static_cast<int>(opt.per_cu) : 1, opt.max_blocks ? opt.max_blocks : 4u, shaped);
     BodyArgs<kFeatures, kCount, kLdsGeometry> args{&sc, &shaped, frame, counters};
@@ -485,8 +489,8 @@ struct SortedArgs
 template <uint32_t kFeatures, bool kLdsGeometry>
 void RenderGridSorted(const DeviceScene &sc, const Options &opt, float *frame, Report *report)
 {
-    uint32_t work_counter = 0;
-    RenderJob shaped = FilmJob(sc, opt, &work_counter);
+    uint32_t work_counter[kBands * kBandStride];
+    RenderJob shaped = FilmJob(sc, opt, work_counter);
     shaped.lane_spread = 1, shaped.scatter = 0, shaped.sort_classes = 1;
     const uint64_t resident = uint64_t(opt.max_blocks ? opt.max_blocks : 4u) * (opt.per_cu ? opt.per_cu : 1u);
     uint64_t blocks = (uint64_t(shaped.n_items) + kSortLanes - 1) / kSortLanes;
@@ -651,7 +655,7 @@ int mcpt_wave_emu_render(const char *mcsd_path, uint32_t features, int lds_geome
     {
         const FlatScene flat = CommitScene(mcsd::Load(mcsd_path));
         const DeviceScene sc = flat.HostView();
-        const Options opt = options ? *options : Options{0, 0, 0, 0, 4, 1, 0, 0, 0xFFFFFFFFu, 0, 0};
+        const Options opt = options ? *options : Options{0, 0, 0, 0, 4, 1, 0, 0, 0xFFFFFFFFu, 0, 0, 0};
         if (report)
             *report = Report{};
         constexpr uint32_t kScene = kAll | kFeatSlivers; // what a scene can ask of an instantiation
@@ -694,7 +698,7 @@ int mcpt_wave_emu_render_sorted(const char *mcsd_path, uint32_t features, int ld
     {
         const FlatScene flat = CommitScene(mcsd::Load(mcsd_path));
         const DeviceScene sc = flat.HostView();
-        const Options opt = options ? *options : Options{0, 0, 0, 0, 4, 1, 0, 0, 0xFFFFFFFFu, 0, 0};
+        const Options opt = options ? *options : Options{0, 0, 0, 0, 4, 1, 0, 0, 0xFFFFFFFFu, 0, 0, 0};
         if (report)
             *report = Report{};
         if ((flat.features & kAll & ~features) != 0 || flat.integrator.walk_sliver_reach > 0.0f || flat.integrator.has_masks)

@@ -27,7 +27,7 @@ VOLUME_LEAN = VOLPATH | ANALYTIC | MICROFACET
 
 class Options(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in ("order", "seed", "poison", "poison_word", "max_blocks", "per_cu", "lane_spread",
-                                               "compact", "scatter", "threads", "lds_shortfall")]
+                                               "compact", "scatter", "threads", "xcd_bands", "lds_shortfall")]
 
 
 class Report(ctypes.Structure):
@@ -50,7 +50,7 @@ class WaveEmulator:
 
     def render_sorted(self, mcsd_path, width, height, features, lds, order=0, seed=0, poison=None, max_blocks=4, per_cu=1, threads=0):
         """The class-sorted kernel's body (csrc/hip/sorted_body.h), workgroups of 128 lanes.  -> (frame, report dict)"""
-        opt = Options(order, seed, 0 if poison is None else 1, poison or 0, max_blocks, per_cu, 1, 0, 0, threads, 0)
+        opt = Options(order, seed, 0 if poison is None else 1, poison or 0, max_blocks, per_cu, 1, 0, 0, threads, 0, 0)
         frame = np.zeros((height, width, 3), dtype=np.float32)
         rep = Report()
         rc = self.lib.mcpt_wave_emu_render_sorted(str(mcsd_path).encode(), features, 1 if lds else 0, ctypes.byref(opt), frame, ctypes.byref(rep))
@@ -59,10 +59,10 @@ class WaveEmulator:
         return frame, {n: getattr(rep, n) for n, _ in Report._fields_}
 
     def render(self, mcsd_path, width, height, features, lds, order=0, seed=0, poison=None, max_blocks=4, per_cu=1,
-               lane_spread=0, compact=0, scatter=0xFFFFFFFF, threads=0, counted=False):
+               lane_spread=0, compact=0, scatter=0xFFFFFFFF, threads=0, counted=False, xcd_bands=0):
         """-> (frame, report dict).  order: 0 ascending / 1 descending / 2 shuffled lanes between collectives; poison: None or
         the 32-bit word a wavefront's pool area is filled with before every ray query."""
-        opt = Options(order, seed, 0 if poison is None else 1, poison or 0, max_blocks, per_cu, lane_spread, compact, scatter, threads, 0)
+        opt = Options(order, seed, 0 if poison is None else 1, poison or 0, max_blocks, per_cu, lane_spread, compact, scatter, threads, xcd_bands, 0)
         frame = np.zeros((height, width, 3), dtype=np.float32)
         counters = np.zeros(8, dtype=np.uint64)
         rep = Report()

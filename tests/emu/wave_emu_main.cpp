@@ -8,7 +8,7 @@
 
 struct Options
 {
-    uint32_t order, seed, poison, poison_word, max_blocks, per_cu, lane_spread, compact, scatter, threads, lds_shortfall;
+    uint32_t order, seed, poison, poison_word, max_blocks, per_cu, lane_spread, compact, scatter, threads, xcd_bands, lds_shortfall;
 };
 struct Report
 {
@@ -33,7 +33,7 @@ int main(int argc, char **argv)
         return 1;
     }
     const Options opt{static_cast<uint32_t>(strtoul(argv[4], nullptr, 0)), 1u, static_cast<uint32_t>(strtoul(argv[5], nullptr, 0)), static_cast<uint32_t>(strtoul(argv[6], nullptr, 0)), 2u, 1u,
-                      static_cast<uint32_t>(strtoul(argv[7], nullptr, 0)), static_cast<uint32_t>(strtoul(argv[8], nullptr, 0)), 0xFFFFFFFFu, 2u, argc == 11 ? static_cast<uint32_t>(strtoul(argv[10], nullptr, 0)) : 0u};
+                      static_cast<uint32_t>(strtoul(argv[7], nullptr, 0)), static_cast<uint32_t>(strtoul(argv[8], nullptr, 0)), 0xFFFFFFFFu, 2u, 0u, argc == 11 ? static_cast<uint32_t>(strtoul(argv[10], nullptr, 0)) : 0u};
     std::vector<float> frame(size_t(width) * height * 3);
     Report rep{};
     if (mcpt_wave_emu_render(argv[1], static_cast<uint32_t>(strtoul(argv[2], nullptr, 0)), atoi(argv[3]), &opt, frame.data(), nullptr, &rep) != 0)

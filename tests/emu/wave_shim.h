@@ -130,6 +130,7 @@ static const ::wave_emu::Index3 gridDim{{::wave_emu::grid_blocks}};
 #define __builtin_amdgcn_s_sleep(n) static_cast<void>(::wave_emu::collective(::wave_emu::kSleep, 0xFFFFFFF8u, 0))
 #define __syncthreads() static_cast<void>(::wave_emu::collective(::wave_emu::kSyncThreads, MCPT_WAVE_SITE, 0))
 #define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_RELAXED)
+#define __builtin_amdgcn_s_getreg(immediate) (::wave_emu::block_index() & 7u) /* HW_REG_XCC_ID: workgroup b runs on XCD b % 8 */
 #define __HIP_MEMORY_SCOPE_AGENT 0
 
 inline uint32_t __float_as_uint(float f)

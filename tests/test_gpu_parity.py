@@ -748,6 +748,34 @@ def test_class_sort_does_not_change_the_image(name, pkg, scenes):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["terrain_directional", "rough_conductor_envmap", "bumpy_directional"])
+def test_xcd_bands_do_not_change_the_image(name, pkg, scenes):
+    """Round 6: mcpt_renderer_set_tile_order(r, 2) — the work counter hands out the film in eight bands, a workgroup takes from the band
+    of the XCD it runs on first (RenderJob::xcd_bands, hip/render_kernel_impl.h band_reserve) and from the others when that is dry.  Which
+    lane renders a pixel is irrelevant to it: the golden, bit for bit, whole film and as three ranks' packed tile shares, dense and with
+    lanes between the paths."""
+    golden = np.load(os.path.join(GOLDEN, name + ".npz"))["frame"]
+    r = pkg.capi.Renderer(pkg.capi.Config.from_scene(scenes[name]), device=0)
+    try:
+        r.set_kernel(0).set_work_distribution(1).set_tile_order(2)
+        for spread in (0, 1, 4):
+            frame, _ = r.set_lane_spread(spread).draw()
+            assert "XCD bands" in r.last_kernel(), r.last_kernel()
+            assert np.array_equal(frame, golden), (spread, r.last_kernel())
+        import torch
+        h, w = golden.shape[:2]
+        frame = np.zeros_like(golden)
+        for rank in range(3):
+            rng = pkg.capi.TileRange(rank, 3, 0)
+            buf = torch.zeros(r.tiles_in(rng) * 64 * 3, dtype=torch.float32, device="cuda:0")
+            r.draw_device(buf.data_ptr(), rng, packed=True)
+            pkg.capi.unpack_tiles(buf.cpu().numpy(), rng, w, h, frame)
+        assert np.array_equal(frame, golden)
+    finally:
+        r.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["rough_conductor_envmap", "rough_dielectric_envmap", "plastic_spot", "bumpy_directional", "terrain_directional"])
 def test_class_sort_outside_lds_does_not_change_the_image(name, pkg, scenes):
     """Round 6 (north_star's "sorts hit records by material in LDS", SURVEY g1, for scenes whose geometry is NOT in LDS): the class-sorted

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--work", type=int, default=-1, help="work distribution: -1 library's choice, 0 fixed lists, 1 work counter")
     ap.add_argument("--prepass", type=int, default=-1, help="camera-ray pre-pass: -1 library's choice, 0 off, 1 on")
     ap.add_argument("--kernel-mode", type=int, default=None, help="numeric kernel mode (overrides --kernel)")
+    ap.add_argument("--tile-order", type=int, default=-1, help="hand-out order of the tiles: -1 library's choice, 0 image order, 1 most expensive first, 2 image order in XCD bands")
     a = ap.parse_args()
     from _pkg import load_package
     pkg = load_package()
@@ -47,7 +48,7 @@ def main():
     w, h, spp = cfg.film()
     r = capi.Renderer(cfg)
     r.set_kernel({"auto": -1, "stream": 1, "lanes": 0}[a.kernel] if a.kernel_mode is None else a.kernel_mode)
-    r.set_work_distribution(a.work).set_prepass(a.prepass)
+    r.set_work_distribution(a.work).set_prepass(a.prepass).set_tile_order(a.tile_order)
     out = {"scene": a.scene, "film": [w, h, spp], "info": r.info()}
     for _ in range(a.draws):
         _, st = r.draw()
