@@ -394,7 +394,12 @@ def measure(pkg, torch, dist, args, name, film, world, rank, local_rank, device,
         walk = {"rays_per_s": rays / counts["samples"] * rank_samples / (kernel_ms * 1e-3),
                 "node_phase_lane_util": (counts["node_tests"] / boxes_per_node_step) / (64.0 * max(counts["wave_node_steps"], 1)),
                 "counting_kernel": counting_kernel,
-                "prim_phase_lane_util": counts["prim_tests"] / (64.0 * max(counts["wave_prim_steps"], 1))}
+                "prim_phase_lane_util": counts["prim_tests"] / (64.0 * max(counts["wave_prim_steps"], 1)),
+                # (round 5's advisor) what the counts describe: the counting instantiations walk two queries per vertex (they carry the
+                # volume-path code, so they are never merged), the production kernels outside LDS merge a vertex's last shadow query with
+                # the next segment's closest query — the same rays, boxes and primitives, half the query rounds — and a node step with
+                # few items is worked off by 2 / 4 lanes per item: node_phase_lane_util counts ITEMS per step, not busy lanes
+                "note": "counted on the two-queries-per-vertex form; node_phase_lane_util = node items per node step / 64"}
         hbm = {"algorithmic_gbs": algorithmic_gbs, "bytes_per_sample": b_per_sample,
                "stream_peak_gbs": hbm_peak, "stream_copy_gbs": bw["copy_gbs"], "stream_read_gbs": bw["read_gbs"],
                "spec_peak_gbs": HBM_SPEC_GBS, "frac_algorithmic_of_stream_peak": algorithmic_gbs / hbm_peak,

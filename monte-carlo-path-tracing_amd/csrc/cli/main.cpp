@@ -182,6 +182,13 @@ int main(int argc, char **argv)
         std::fprintf(stderr, "[error] --rng pcg | sobol are modes of the single-GPU renderer (the host path and the tiled renderer keep the reference's stream).\n");
         return 2;
     }
+    if (check_walks && (on_cpu || gpus > 1))
+    {
+        // (round 5's advisor: the flag used to be accepted and ignored here — a user would believe the scene was verified)
+        std::fprintf(stderr, "[error] --check-walks compares the single-GPU renderer's ray query with the reference-order walk: not with --cpu (which IS the reference-order "
+                             "walk) or --gpus N (check the scene once on one GPU).\n");
+        return 2;
+    }
     if (on_cpu)
     {
         // the reference's `--cpu` (apps/main.cpp:130-137): the kernel body on host threads, from the optional

@@ -235,6 +235,10 @@ hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out,
     return job.pool_walk ? Launch<kP, false, true>(sc, job, out, nullptr, stream, n_cus) : Launch<kO, false, true>(sc, job, out, nullptr, stream, n_cus);
 #endif
     const bool slivers = sc.integrator.walk_sliver_reach > 0.0f;
+    // (Round 5's advisor: "follows" means the KIND of ray query — pool walk or per-lane walk.  The counting instantiations carry the
+    //  volume-path code, so they are never merged (Config::kPoolDual needs !kVolPath): they walk two queries per vertex where the
+    //  production kernels outside LDS walk one merged query — the same rays, box and primitive tests, twice the query rounds — and
+    //  bench.py says so next to the counts.)
     // The counting instantiation follows the PRODUCTION launch's ray query (round 4's advisor: it used to count a pool walk for every
     // scene the big form supports, also where the timed kernel walks per lane — volumetric-caustic's class-sorted kernel): the pool
     // walk's per-item counts (4 box tests per node item) where the uncounted launch below uses the pool walk — its LDS form

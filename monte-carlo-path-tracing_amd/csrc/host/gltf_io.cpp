@@ -405,7 +405,13 @@ std::vector<float> ReadFloats(Document &doc, long accessor, int components, size
         throw std::runtime_error("'" + doc.path + "': accessor of an unsupported kind.");
     *count_out = count;
     if (view_index < 0 || count == 0)
-        return std::vector<float>(count * static_cast<size_t>(components), 0.0f); // (an accessor without a buffer view is all zeros)
+    {
+        // an accessor without a buffer view is all zeros (specification) — of a size the FILE did not have to back with bytes: bounded
+        // (round 5's advisor: `count` alone could ask for a 64 GB allocation), 2^26 elements are 1 GB of float4 already
+        if (count > (size_t(1) << 26))
+            throw std::runtime_error("'" + doc.path + "': an accessor without a buffer view names more than 2^26 elements.");
+        return std::vector<float>(count * static_cast<size_t>(components), 0.0f);
+    }
     const Json &view = doc.Entry("bufferViews", view_index);
     const size_t element = static_cast<size_t>(cbytes) * static_cast<size_t>(n);
     const AccessorSpan span = SpanOf(doc, a, view, count, element); // (throws before anything of `count` elements is allocated)

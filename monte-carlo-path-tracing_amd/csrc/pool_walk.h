@@ -76,6 +76,21 @@ constexpr uint32_t kPoolMaxRefDual = 511, kPoolMaxRefBigDual = (1u << 25) - 1u; 
 #ifndef MCPT_POOL_QUANT
 #define MCPT_POOL_QUANT 1
 #endif
+// PACKED SLAB TESTS (round 6; measured, OFF).  A node step tests the boxes of kPer = 4 / 2 children against one ray: per child and
+// axis the same `(plane - origin) * reciprocal` with the ray's two scalars.  gfx950 has packed FP32 instructions (v_pk_add_f32,
+// v_pk_mul_f32, v_pk_fma_f32: two IEEE single-precision operations per lane and instruction, each rounded like its scalar twin —
+// tools/microbench/gen_pk_f32_modifiers.py checks every operand-select / negate combination against the scalar instructions);
+// written on pairs of children the 48 subtractions and products of a four-child step are 24 instructions, the frames stay bit for
+// bit — and the kernels get SLOWER: cornell 37.5 -> 39.1 ms, matpreview 413 -> 444 / 672 -> 716 ms
+// (profiles/r06_ab_packed_slab_and_aligned_planes.jsonl): a packed instruction costs a wave64 the issue time of its two scalar
+// halves, and the halves' results need a canonicalising v_max each before the max3 / min3 chains.  -DMCPT_POOL_PACKED=1 builds it.
+// (What did pay in the same experiment: the plane sets of the exact records read as ONE aligned ds_read_b128 each — `Planes` below —
+//  instead of two ds_read2_b32: cornell 38.9 -> 37.5 ms.)
+#ifndef MCPT_POOL_PACKED
+#define MCPT_POOL_PACKED 0
+#endif
+typedef float pool_float2 __attribute__((ext_vector_type(2)));
+
 #ifndef MCPT_POOL_CHILD_PARALLEL
 #define MCPT_POOL_CHILD_PARALLEL 1 // node steps with 4 / 2 lanes per item when the items are few (walk_pool); 0: always one lane per item
 #endif
@@ -276,13 +291,36 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
                 const uint32_t near_x = px ? n2.x : n2.w, far_x = px ? n2.w : n2.x;
                 const uint32_t near_y = py ? n2.y : n3.x, far_y = py ? n3.x : n2.y;
                 const uint32_t near_z = pz ? n2.z : n3.y, far_z = pz ? n3.y : n2.z;
-#pragma unroll
-                for (uint32_t j = 0; j < kPer; ++j)
+                if constexpr (MCPT_POOL_PACKED != 0 && kPer >= 2)
                 {
-                    const uint32_t shift = 8u * (first + j); // (a constant when G = 1)
-                    auto plane = [shift](uint32_t word, float scale, float origin) { return __builtin_fmaf(scale, static_cast<float>((word >> shift) & 0xFFu), origin); };
-                    enter[j] = fmaxf(fmaxf(fmaxf(kEpsDistance, (plane(near_x, sx, gx) - a.x) * b.x), (plane(near_y, sy, gy) - a.y) * b.y), (plane(near_z, sz, gz) - a.z) * b.z);
-                    leave[j] = fminf(fminf(fminf(a.w, (plane(far_x, sx, gx) - a.x) * b.x), (plane(far_y, sy, gy) - a.y) * b.y), (plane(far_z, sz, gz) - a.z) * b.z);
+                    // (pairs of children through the packed FP32 instructions: decode — one fused multiply-add per plane, as the
+                    //  quantiser verified it — subtraction and product for two children at a time)
+#pragma unroll
+                    for (uint32_t j = 0; j < kPer; j += 2)
+                    {
+                        const uint32_t shift = 8u * (first + j);
+                        auto slab = [shift](uint32_t word, float scale, float grid, float origin, float rcp)
+                        {
+                            const pool_float2 q = {static_cast<float>((word >> shift) & 0xFFu), static_cast<float>((word >> (shift + 8u)) & 0xFFu)};
+                            const pool_float2 plane = __builtin_elementwise_fma(pool_float2{scale, scale}, q, pool_float2{grid, grid});
+                            return (plane - pool_float2{origin, origin}) * pool_float2{rcp, rcp};
+                        };
+                        const pool_float2 ex = slab(near_x, sx, gx, a.x, b.x), ey = slab(near_y, sy, gy, a.y, b.y), ez = slab(near_z, sz, gz, a.z, b.z);
+                        const pool_float2 lx = slab(far_x, sx, gx, a.x, b.x), ly = slab(far_y, sy, gy, a.y, b.y), lz = slab(far_z, sz, gz, a.z, b.z);
+                        enter[j] = fmaxf(fmaxf(fmaxf(kEpsDistance, ex.x), ey.x), ez.x), enter[j + 1] = fmaxf(fmaxf(fmaxf(kEpsDistance, ex.y), ey.y), ez.y);
+                        leave[j] = fminf(fminf(fminf(a.w, lx.x), ly.x), lz.x), leave[j + 1] = fminf(fminf(fminf(a.w, lx.y), ly.y), lz.y);
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (uint32_t j = 0; j < kPer; ++j)
+                    {
+                        const uint32_t shift = 8u * (first + j); // (a constant when G = 1)
+                        auto plane = [shift](uint32_t word, float scale, float origin) { return __builtin_fmaf(scale, static_cast<float>((word >> shift) & 0xFFu), origin); };
+                        enter[j] = fmaxf(fmaxf(fmaxf(kEpsDistance, (plane(near_x, sx, gx) - a.x) * b.x), (plane(near_y, sy, gy) - a.y) * b.y), (plane(near_z, sz, gz) - a.z) * b.z);
+                        leave[j] = fminf(fminf(fminf(a.w, (plane(far_x, sx, gx) - a.x) * b.x), (plane(far_y, sy, gy) - a.y) * b.y), (plane(far_z, sz, gz) - a.z) * b.z);
+                    }
                 }
             }
             else
@@ -291,21 +329,41 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
                 // hi.z 80 of the 128-byte record, four children each; the references at 96
                 const char *w = reinterpret_cast<const char *>(sc.pool_nodes) + 128u * node + 4u * first;
                 const uint32_t ox = pack & 0xffu, oy = (pack >> 8) & 0xffu, oz = (pack >> 16) & 0xffu;
-                struct Planes
+                struct alignas(4u * kPer) Planes // (the planes of this lane's children: one 16- / 8- / 4-byte LDS read each)
                 {
                     float v[kPer];
                 };
-                const Planes nx = *reinterpret_cast<const Planes *>(w + ox), fx = *reinterpret_cast<const Planes *>(w + (48u - ox));
-                const Planes ny = *reinterpret_cast<const Planes *>(w + oy), fy = *reinterpret_cast<const Planes *>(w + (80u - oy));
-                const Planes nz = *reinterpret_cast<const Planes *>(w + oz), fz = *reinterpret_cast<const Planes *>(w + (112u - oz));
-                const Planes rf = *reinterpret_cast<const Planes *>(w + 96u);
+                // (every offset is a multiple of 4 kPer bytes inside a 128-byte record: one ds_read_b128 / _b64 per plane set)
+                auto planes_at = [&](uint32_t offset) { return *reinterpret_cast<const Planes *>(w + offset); };
+                const Planes nx = planes_at(ox), fx = planes_at(48u - ox);
+                const Planes ny = planes_at(oy), fy = planes_at(80u - oy);
+                const Planes nz = planes_at(oz), fz = planes_at(112u - oz);
+                const Planes rf = planes_at(96u);
+                if constexpr (MCPT_POOL_PACKED != 0 && kPer >= 2)
+                {
+#pragma unroll
+                    for (uint32_t j = 0; j < kPer; j += 2)
+                    {
+                        auto slab = [](const Planes &p, uint32_t at, float origin, float rcp)
+                        { return (pool_float2{p.v[at], p.v[at + 1]} - pool_float2{origin, origin}) * pool_float2{rcp, rcp}; };
+                        const pool_float2 ex = slab(nx, j, a.x, b.x), ey = slab(ny, j, a.y, b.y), ez = slab(nz, j, a.z, b.z);
+                        const pool_float2 lx = slab(fx, j, a.x, b.x), ly = slab(fy, j, a.y, b.y), lz = slab(fz, j, a.z, b.z);
+                        enter[j] = fmaxf(fmaxf(fmaxf(kEpsDistance, ex.x), ey.x), ez.x), enter[j + 1] = fmaxf(fmaxf(fmaxf(kEpsDistance, ex.y), ey.y), ez.y);
+                        leave[j] = fminf(fminf(fminf(a.w, lx.x), ly.x), lz.x), leave[j + 1] = fminf(fminf(fminf(a.w, lx.y), ly.y), lz.y);
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (uint32_t j = 0; j < kPer; ++j)
+                    {
+                        enter[j] = fmaxf(fmaxf(fmaxf(kEpsDistance, (nx.v[j] - a.x) * b.x), (ny.v[j] - a.y) * b.y), (nz.v[j] - a.z) * b.z);
+                        leave[j] = fminf(fminf(fminf(a.w, (fx.v[j] - a.x) * b.x), (fy.v[j] - a.y) * b.y), (fz.v[j] - a.z) * b.z);
+                    }
+                }
 #pragma unroll
                 for (uint32_t j = 0; j < kPer; ++j)
-                {
-                    enter[j] = fmaxf(fmaxf(fmaxf(kEpsDistance, (nx.v[j] - a.x) * b.x), (ny.v[j] - a.y) * b.y), (nz.v[j] - a.z) * b.z);
-                    leave[j] = fminf(fminf(fminf(a.w, (fx.v[j] - a.x) * b.x), (fy.v[j] - a.y) * b.y), (fz.v[j] - a.z) * b.z);
                     ref[j] = __float_as_uint(rf.v[j]);
-                }
             }
             uint32_t at_nodes = n_nodes - k, at_prims = n_prims;
 #pragma unroll
