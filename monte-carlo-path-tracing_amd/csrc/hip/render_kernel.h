@@ -113,6 +113,25 @@ struct RenderJob
     unsigned long long *phase_sums;
 };
 
+// ---- the records of one launch, behind a pointer (round 6) -----------------------------------------
+// The render kernels used to take the scene's and the job's records by value: ~1.3 KB of kernel arguments, which the compiler loads
+// once, keeps in scalar registers across the persistent loop and — 106 SGPRs — spills into lanes of vector registers (116-210 spilled
+// scalars per kernel, v_readlane / v_writelane around their uses).  The reference's kernel takes two pointers (renderer.cpp:88).  The
+// kernels of the instantiations named by records_behind_pointer() (render_kernel_impl.h) take ONE pointer to {scene, job} in device
+// memory and read the fields through the constant address space: scalar loads that the compiler may repeat at a use instead of keeping
+// the value — 67-131 spilled scalars, cornell -1.6 %, volumetric-caustic -1.8 %, matpreview -0.6 ... -0.9 % (EXPERIMENTS R6-8).
+struct LaunchRecords
+{
+    DeviceScene sc;
+    RenderJob job;
+};
+// Copies the records into the next slot of the current device's ring (16 slots: device memory + a pinned mirror + an event each) in
+// stream order and returns the device address; a slot is taken again when the launch that used it has finished (its event).  Thread
+// safe.  Null (and *error) when a HIP call fails.  The caller launches ONE kernel that reads the records on `stream` and then calls
+// LaunchRecordsInFlight(stream) from the same thread.
+const LaunchRecords *StageLaunchRecords(const DeviceScene &sc, const RenderJob &job, hipStream_t stream, hipError_t *error);
+void LaunchRecordsInFlight(hipStream_t stream);
+
 // ---- stream kernel (stream_core.h, stream_kernel_impl.h) ------------------------------------------
 // Launch parameters of the stream kernel.  `slots` and `refill_at` are inputs of PlanRenderStream (0 = the
 // built-in choice for the scene), the rest is filled in by it.

@@ -1,12 +1,82 @@
 // The lean render-kernel instantiations, the unit kernels and the dispatcher; the kernel template
 // itself is in render_kernel_impl.h.
 #include <cstdlib>
+#include <mutex>
 
 #include "render_kernel_impl.h"
 #include "../host/measurement_env.hpp"
 
 namespace mcpt
 {
+
+// ---- the records of a launch in device memory (render_kernel.h, LaunchRecords) ----------
+namespace
+{
+constexpr int kRecordSlots = 16, kRecordDevices = 64;
+struct RecordRing
+{
+    LaunchRecords *device = nullptr, *host = nullptr; // kRecordSlots records each (device memory; its pinned mirror)
+    hipEvent_t done[kRecordSlots] = {};               // the launch that read slot k has finished
+    bool used[kRecordSlots] = {};
+    unsigned next = 0;
+};
+std::mutex g_record_mutex;
+RecordRing g_record_rings[kRecordDevices]; // (one per device, made at the first launch there; they live as long as the process)
+thread_local hipEvent_t t_record_event = nullptr;
+} // namespace
+
+const LaunchRecords *StageLaunchRecords(const DeviceScene &sc, const RenderJob &job, hipStream_t stream, hipError_t *error)
+{
+    int dev = 0;
+    hipError_t err = hipGetDevice(&dev);
+    if (err == hipSuccess && (dev < 0 || dev >= kRecordDevices))
+        err = hipErrorInvalidDevice;
+    LaunchRecords *where = nullptr;
+    if (err == hipSuccess)
+    {
+        std::lock_guard<std::mutex> lock(g_record_mutex);
+        RecordRing &ring = g_record_rings[dev];
+        if (!ring.device)
+        {
+            LaunchRecords *d = nullptr, *h = nullptr;
+            err = hipMalloc(reinterpret_cast<void **>(&d), kRecordSlots * sizeof(LaunchRecords));
+            if (err == hipSuccess)
+                err = hipHostMalloc(reinterpret_cast<void **>(&h), kRecordSlots * sizeof(LaunchRecords), hipHostMallocDefault);
+            for (int k = 0; k < kRecordSlots && err == hipSuccess; ++k)
+                err = hipEventCreateWithFlags(&ring.done[k], hipEventDisableTiming);
+            if (err == hipSuccess)
+                ring.device = d, ring.host = h;
+            else
+                (void)hipFree(d), (void)hipHostFree(h);
+        }
+        if (err == hipSuccess)
+        {
+            const unsigned k = ring.next++ % kRecordSlots;
+            if (ring.used[k])
+                err = hipEventSynchronize(ring.done[k]); // (the launch that read this slot sixteen launches ago)
+            if (err == hipSuccess)
+            {
+                ring.host[k].sc = sc, ring.host[k].job = job;
+                err = hipMemcpyAsync(ring.device + k, ring.host + k, sizeof(LaunchRecords), hipMemcpyHostToDevice, stream);
+                // (the slot counts as taken from here on, whatever happens next: its event is recorded behind the launch, or — when
+                //  the caller gives up — behind the copy, by the next LaunchRecordsInFlight of this thread)
+                ring.used[k] = true;
+                t_record_event = ring.done[k];
+                where = ring.device + k;
+            }
+        }
+    }
+    if (error)
+        *error = err;
+    return err == hipSuccess ? where : nullptr;
+}
+
+void LaunchRecordsInFlight(hipStream_t stream)
+{
+    if (t_record_event)
+        (void)hipEventRecord(t_record_event, stream);
+    t_record_event = nullptr;
+}
 
 // ---- unit kernels (diagnostics / parity tests): one query per lane ----------
 

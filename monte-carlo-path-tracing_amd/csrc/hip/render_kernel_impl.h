@@ -148,14 +148,15 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     {
         const uint32_t n_node_vec = 2u * sc_in.integrator.n_nodes, n_tri_vec = 3u * sc_in.integrator.n_prims;
         // (pool walk: the 4-wide exact form of the hierarchy instead of the binary one)
-        const uint32_t n_walk_vec = C::kPool ? 8u * sc_in.integrator.n_pool_nodes : C::kOrdered ? 4u * sc_in.integrator.n_walk_nodes : 0u;
+        const uint32_t n_walk_vec = C::kPool ? kPoolLdsNodeVecs * sc_in.integrator.n_pool_nodes : C::kOrdered ? 4u * sc_in.integrator.n_walk_nodes : 0u;
         const uint32_t n_slot_vec = C::kOrdered ? n_tri_vec : 0u;
         for (uint32_t i = threadIdx.x; i < n_node_vec; i += blockDim.x)
             lds_geometry[i] = sc_in.nodes[i];
         for (uint32_t i = threadIdx.x; i < n_tri_vec; i += blockDim.x)
             lds_geometry[n_node_vec + i] = sc_in.tri_pos[i];
-        for (uint32_t i = threadIdx.x; i < n_walk_vec; i += blockDim.x)
-            lds_geometry[n_node_vec + n_tri_vec + i] = C::kPool ? sc_in.pool_nodes[i] : sc_in.walk_nodes[i];
+        // (pool walk: the staged node records lie kPoolLdsNodeVecs vectors apart — LDS banks, pool_walk.h)
+        for (uint32_t i = threadIdx.x; i < (C::kPool ? 8u * sc_in.integrator.n_pool_nodes : n_walk_vec); i += blockDim.x)
+            lds_geometry[n_node_vec + n_tri_vec + (C::kPool ? (i >> 3) * kPoolLdsNodeVecs + (i & 7u) : i)] = C::kPool ? sc_in.pool_nodes[i] : sc_in.walk_nodes[i];
         for (uint32_t i = threadIdx.x; i < n_slot_vec; i += blockDim.x)
             lds_geometry[n_node_vec + n_tri_vec + n_walk_vec + i] = sc_in.walk_prims[i];
         __syncthreads();
@@ -442,11 +443,37 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
 }
 
 #if !defined(MCPT_WAVE_EMU)
+// THE RECORDS BEHIND A POINTER (render_kernel.h, LaunchRecords; EXPERIMENTS R6-8): which instantiations read the scene and the job
+// through a pointer to device memory instead of taking them by value.  Measured per unit (same box, frames identical): the lean
+// LDS-resident pool-walk kernels (cornell 37.6 -> 37.0 ms), the one-BSDF surface units (matpreview 415 -> 412, 672 -> 668) and the
+// class-sorted kernels (volumetric-caustic 649 -> 637); dragon's unit moves inside its own +-13 % in both directions and keeps the
+// arguments.  -DMCPT_SCENE_POINTER=0 / 1 (on every unit) builds all of them one way for A/B measurements.
+template <uint32_t kFeatures, bool kLdsGeometry>
+constexpr bool records_behind_pointer()
+{
+#if defined(MCPT_SCENE_POINTER)
+    return MCPT_SCENE_POINTER != 0;
+#else
+    return (kLdsGeometry && (kFeatures & kFeatPoolWalk) != 0 && (kFeatures & (kFeatVolPath | kFeatAnalytic | kFeatMicrofacet | kFeatTextures)) == 0) ||
+           (kFeatures & (kFeatConductorOnly | kFeatDielectricOnly)) != 0;
+#endif
+}
+// (the constant address space: the loads are scalar loads, like the ones from the kernel-argument segment)
+typedef const LaunchRecords __attribute__((address_space(4))) *LaunchRecordsPtr;
+#define MCPT_RECORDS_SCENE(records) (*(const DeviceScene *)(&(records)->sc))
+#define MCPT_RECORDS_JOB(records) (*(const RenderJob *)(&(records)->job))
+
 template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
 __global__ void __launch_bounds__(kBlockSize, (Budget<kFeatures, kLdsGeometry>::kWavesPerSimd))
 render_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ out, TraceCounters *__restrict__ counters)
 {
     render_body<kFeatures, kCount, kLdsGeometry>(sc_in, job, out, counters);
+}
+template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
+__global__ void __launch_bounds__(kBlockSize, (Budget<kFeatures, kLdsGeometry>::kWavesPerSimd))
+render_kernel(LaunchRecordsPtr records, float *__restrict__ out, TraceCounters *__restrict__ counters)
+{
+    render_body<kFeatures, kCount, kLdsGeometry>(MCPT_RECORDS_SCENE(records), MCPT_RECORDS_JOB(records), out, counters);
 }
 
 // The same kernel under its own name for the low-spp COST PROBE (RenderJob::tile_steps; capi.cpp, CostOrderedTable), so that a
@@ -456,6 +483,12 @@ __global__ void __launch_bounds__(kBlockSize, (Budget<kFeatures, true>::kWavesPe
 cost_probe_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ out)
 {
     render_body<kFeatures, false, true>(sc_in, job, out, nullptr);
+}
+template <uint32_t kFeatures>
+__global__ void __launch_bounds__(kBlockSize, (Budget<kFeatures, true>::kWavesPerSimd))
+cost_probe_kernel(LaunchRecordsPtr records, float *__restrict__ out)
+{
+    render_body<kFeatures, false, true>(MCPT_RECORDS_SCENE(records), MCPT_RECORDS_JOB(records), out, nullptr);
 }
 #endif // !MCPT_WAVE_EMU
 
@@ -485,7 +518,7 @@ inline size_t StagedBytes(const DeviceScene &sc, bool ordered, bool pool = false
 {
     size_t vecs = 2ull * sc.integrator.n_nodes + 3ull * sc.integrator.n_prims;
     if (ordered)
-        vecs += (pool ? 8ull * sc.integrator.n_pool_nodes : 4ull * sc.integrator.n_walk_nodes) + 3ull * sc.integrator.n_prims;
+        vecs += (pool ? static_cast<unsigned long long>(kPoolLdsNodeVecs) * sc.integrator.n_pool_nodes : 4ull * sc.integrator.n_walk_nodes) + 3ull * sc.integrator.n_prims;
     return vecs * sizeof(float4);
 }
 
@@ -564,10 +597,17 @@ template <uint32_t kFeatures, bool kCount, bool kLdsGeometry = false>
 hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters, hipStream_t stream,
                   uint32_t max_blocks)
 {
+    constexpr bool kByPointer = records_behind_pointer<kFeatures, kLdsGeometry>();
+    constexpr bool kProbed = kLdsGeometry && !kCount && (kFeatures & kAll & ~kFeatEmitters) == 0; // (only the diffuse LDS instantiations are probed)
+    // (the two forms of a kernel are overloads of one name: a kernel trace shows `render_kernel<...>` either way)
+    using ByValue = void (*)(const DeviceScene, const RenderJob, float *, TraceCounters *);
+    using ByPointer = void (*)(LaunchRecordsPtr, float *, TraceCounters *);
+    using ProbeByValue = void (*)(const DeviceScene, const RenderJob, float *);
+    using ProbeByPointer = void (*)(LaunchRecordsPtr, float *);
+    const typename std::conditional<kByPointer, ByPointer, ByValue>::type kernel = render_kernel<kFeatures, kCount, kLdsGeometry>;
     const size_t lds_bytes = LaunchLdsBytes<kFeatures, kCount, kLdsGeometry>(sc);
     int per_cu = 0;
-    hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &per_cu, render_kernel<kFeatures, kCount, kLdsGeometry>, kBlockSize, lds_bytes);
+    hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlockSize, lds_bytes);
     if (err != hipSuccess)
         return err;
     if (per_cu < 1)
@@ -577,17 +617,43 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
     NoteTransposed(spread_job.scatter != 0);
     if (blocks == 0)
         return hipSuccess;
-    if constexpr (kLdsGeometry && !kCount && (kFeatures & kAll & ~kFeatEmitters) == 0)
+    const dim3 grid(static_cast<uint32_t>(blocks)), block(kBlockSize);
+    if constexpr (kByPointer)
     {
-        if (job.tile_steps)
+        const LaunchRecords *records = StageLaunchRecords(sc, spread_job, stream, &err);
+        if (!records)
+            return err;
+        bool probe = false;
+        if constexpr (kProbed)
+            probe = job.tile_steps != nullptr;
+        if constexpr (kProbed)
         {
-            hipLaunchKernelGGL((cost_probe_kernel<kFeatures>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlockSize), lds_bytes, stream, sc, spread_job, out);
-            return hipGetLastError();
+            if (probe)
+            {
+                const ProbeByPointer probe_kernel = cost_probe_kernel<kFeatures>;
+                hipLaunchKernelGGL(probe_kernel, grid, block, lds_bytes, stream, (LaunchRecordsPtr)(records), out);
+            }
         }
+        if (!probe)
+            hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, (LaunchRecordsPtr)(records), out, counters);
+        err = hipGetLastError();
+        LaunchRecordsInFlight(stream);
+        return err;
     }
-    hipLaunchKernelGGL((render_kernel<kFeatures, kCount, kLdsGeometry>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlockSize),
-                       lds_bytes, stream, sc, spread_job, out, counters);
-    return hipGetLastError();
+    else
+    {
+        if constexpr (kProbed)
+        {
+            if (job.tile_steps)
+            {
+                const ProbeByValue probe_kernel = cost_probe_kernel<kFeatures>;
+                hipLaunchKernelGGL(probe_kernel, grid, block, lds_bytes, stream, sc, spread_job, out);
+                return hipGetLastError();
+            }
+        }
+        hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, sc, spread_job, out, counters);
+        return hipGetLastError();
+    }
 }
 
 // who instantiates what

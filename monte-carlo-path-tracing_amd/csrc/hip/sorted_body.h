@@ -127,13 +127,14 @@ __device__ __forceinline__ void sorted_body(const DeviceScene &sc_in, const Rend
     {
         const uint32_t n_node_vec = 2u * sc_in.integrator.n_nodes, n_tri_vec = 3u * sc_in.integrator.n_prims;
         // (pool walk, pool_walk.h: the 4-wide exact form of the hierarchy instead of the binary one)
-        const uint32_t n_walk_vec = C::kPool ? 8u * sc_in.integrator.n_pool_nodes : 4u * sc_in.integrator.n_walk_nodes, n_slot_vec = n_tri_vec;
+        const uint32_t n_walk_vec = C::kPool ? kPoolLdsNodeVecs * sc_in.integrator.n_pool_nodes : 4u * sc_in.integrator.n_walk_nodes, n_slot_vec = n_tri_vec;
         for (uint32_t i = threadIdx.x; i < n_node_vec; i += blockDim.x)
             lds_geometry[i] = sc_in.nodes[i];
         for (uint32_t i = threadIdx.x; i < n_tri_vec; i += blockDim.x)
             lds_geometry[n_node_vec + i] = sc_in.tri_pos[i];
-        for (uint32_t i = threadIdx.x; i < n_walk_vec; i += blockDim.x)
-            lds_geometry[n_node_vec + n_tri_vec + i] = C::kPool ? sc_in.pool_nodes[i] : sc_in.walk_nodes[i];
+        // (pool walk: the staged node records lie kPoolLdsNodeVecs vectors apart — LDS banks, pool_walk.h)
+        for (uint32_t i = threadIdx.x; i < (C::kPool ? 8u * sc_in.integrator.n_pool_nodes : n_walk_vec); i += blockDim.x)
+            lds_geometry[n_node_vec + n_tri_vec + (C::kPool ? (i >> 3) * kPoolLdsNodeVecs + (i & 7u) : i)] = C::kPool ? sc_in.pool_nodes[i] : sc_in.walk_nodes[i];
         for (uint32_t i = threadIdx.x; i < n_slot_vec; i += blockDim.x)
             lds_geometry[n_node_vec + n_tri_vec + n_walk_vec + i] = sc_in.walk_prims[i];
         sc.nodes = lds_geometry;

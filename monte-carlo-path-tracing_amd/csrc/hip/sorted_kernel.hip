@@ -4,11 +4,28 @@
 namespace mcpt
 {
 
+// (two forms, overloads of one name: the records by value, or behind a pointer to device memory — render_kernel.h LaunchRecords,
+//  render_kernel_impl.h records_behind_pointer; every class-sorted instantiation takes the pointer: volumetric-caustic 649 -> 637 ms)
 template <uint32_t kFeatures, bool kLdsGeometry>
 __global__ void __launch_bounds__(kSortLanes, sorted_waves(kFeatures))
 sorted_kernel(const DeviceScene sc_in, const RenderJob job, float *__restrict__ out)
 {
     sorted_body<kFeatures, kLdsGeometry>(sc_in, job, out);
+}
+template <uint32_t kFeatures, bool kLdsGeometry>
+__global__ void __launch_bounds__(kSortLanes, sorted_waves(kFeatures))
+sorted_kernel(LaunchRecordsPtr records, float *__restrict__ out)
+{
+    sorted_body<kFeatures, kLdsGeometry>(MCPT_RECORDS_SCENE(records), MCPT_RECORDS_JOB(records), out);
+}
+template <uint32_t kFeatures>
+constexpr bool sorted_behind_pointer()
+{
+#if defined(MCPT_SCENE_POINTER)
+    return MCPT_SCENE_POINTER != 0;
+#else
+    return true;
+#endif
 }
 
 template <uint32_t kFeatures, bool kLdsGeometry = true>
@@ -17,7 +34,11 @@ static hipError_t LaunchSorted(const DeviceScene &sc, const RenderJob &job, floa
     constexpr uint32_t kBlockSize = kSortLanes;
     const size_t lds_bytes = SortedLdsBytes<kFeatures, kLdsGeometry>(sc);
     int per_cu = 0;
-    hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sorted_kernel<kFeatures, kLdsGeometry>, kBlockSize, lds_bytes);
+    constexpr bool kSortedByPointer = sorted_behind_pointer<kFeatures>();
+    using ByValue = void (*)(const DeviceScene, const RenderJob, float *);
+    using ByPointer = void (*)(LaunchRecordsPtr, float *);
+    const typename std::conditional<kSortedByPointer, ByPointer, ByValue>::type kernel = sorted_kernel<kFeatures, kLdsGeometry>;
+    hipError_t err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlockSize, lds_bytes);
     if (err != hipSuccess)
         return err;
     if (per_cu < 1)
@@ -34,8 +55,22 @@ static hipError_t LaunchSorted(const DeviceScene &sc, const RenderJob &job, floa
         blocks = resident;
     if (blocks == 0)
         return hipSuccess;
-    hipLaunchKernelGGL((sorted_kernel<kFeatures, kLdsGeometry>), dim3(static_cast<uint32_t>(blocks)), dim3(kBlockSize), lds_bytes, stream, sc, j, out);
-    return hipGetLastError();
+    const dim3 grid(static_cast<uint32_t>(blocks)), block(kBlockSize);
+    if constexpr (kSortedByPointer)
+    {
+        const LaunchRecords *records = StageLaunchRecords(sc, j, stream, &err);
+        if (!records)
+            return err;
+        hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, (LaunchRecordsPtr)(records), out);
+        err = hipGetLastError();
+        LaunchRecordsInFlight(stream);
+        return err;
+    }
+    else
+    {
+        hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, sc, j, out);
+        return hipGetLastError();
+    }
 }
 
 // The class-sorted kernel for the job's scene, or hipErrorNotSupported when the scene is not one of its classes (the

@@ -91,6 +91,17 @@ constexpr uint32_t kPoolMaxRefDual = 511, kPoolMaxRefBigDual = (1u << 25) - 1u; 
 #endif
 typedef float pool_float2 __attribute__((ext_vector_type(2)));
 
+// NODE RECORDS IN LDS: 144 bytes apart (round 6).  A node step reads seven 16-byte plane sets of its item's node with ds_read_b128,
+// whose bank is (address / 4) mod 64: records 128 bytes = 32 banks apart put every even node's planes on one set of banks and every
+// odd node's on the other, so the 16 lanes of a read group, on ~8 different nodes, queued 4 deep behind each other (cornell:
+// SQ_LDS_BANK_CONFLICT = 0.47 of the LDS's active cycles).  36 banks apart, nodes n and n + 16 are the first to share banks.
+// 8: the records as they are stored in memory (A/B builds).
+#ifndef MCPT_POOL_LDS_NODE_VECS
+#define MCPT_POOL_LDS_NODE_VECS 9
+#endif
+constexpr uint32_t kPoolLdsNodeVecs = MCPT_POOL_LDS_NODE_VECS; // 16-byte vectors from one staged node record to the next (8 hold it)
+static_assert(kPoolLdsNodeVecs >= 8, "a node record is 8 vectors");
+
 #ifndef MCPT_POOL_CHILD_PARALLEL
 #define MCPT_POOL_CHILD_PARALLEL 1 // node steps with 4 / 2 lanes per item when the items are few (walk_pool); 0: always one lane per item
 #endif
@@ -327,7 +338,8 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
             {
                 // the planes the ray enters / leaves through, of this lane's children: lo.x at 0, lo.y 16, lo.z 32, hi.x 48, hi.y 64,
                 // hi.z 80 of the 128-byte record, four children each; the references at 96
-                const char *w = reinterpret_cast<const char *>(sc.pool_nodes) + 128u * node + 4u * first;
+                // (the exact form outside LDS exists in A/B builds only, MCPT_POOL_QUANT=0: records as stored, 128 bytes apart)
+                const char *w = reinterpret_cast<const char *>(sc.pool_nodes) + (kBig ? 128u : 16u * kPoolLdsNodeVecs) * node + 4u * first;
                 const uint32_t ox = pack & 0xffu, oy = (pack >> 8) & 0xffu, oz = (pack >> 16) & 0xffu;
                 struct alignas(4u * kPer) Planes // (the planes of this lane's children: one 16- / 8- / 4-byte LDS read each)
                 {

@@ -75,7 +75,7 @@ def test_the_scheduler_models_a_diverged_block_and_refuses_an_unmarked_one(locks
 @pytest.mark.parametrize("order", [0, 1, 2], ids=["ascending", "descending", "shuffled"])
 def test_lds_resident_pool_walk_kernel_equals_the_golden_under_every_lane_order(lockstep, scenes, form, order):
     frame, golden, info = render(lockstep, scenes, "cornell_64_spp8", LEAN[form], True, order=order, seed=11 + order)
-    assert info["queries"] > 1000 and info["lds_bytes"] in (40320, 53120)
+    assert info["queries"] > 1000 and info["lds_bytes"] in (40640, 53440)
     assert np.array_equal(frame, golden), f"{(frame != golden).any(axis=2).mean():.3f} of the pixels differ"
 
 
