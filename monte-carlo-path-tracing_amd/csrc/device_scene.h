@@ -218,6 +218,12 @@ struct CameraRec // reference camera.cpp:26-37
     Vec3f eye, front, dx, dy;
 };
 
+// (experiment builds: DeviceScene::wide_nodes holds PAIRS of quantised records, 128 bytes per node item — host/commit.cpp BuildWidePairs,
+//  pool_walk.h; a property of the whole library, host and device side)
+#ifndef MCPT_POOL_PAIRS
+#define MCPT_POOL_PAIRS 0
+#endif
+
 struct IntegratorRec // reference integrator.hpp:31-69 (the scalar part)
 {
     uint32_t volpath, hide_emitters;

@@ -334,6 +334,64 @@ void BuildPoolNodes(FlatScene &fs)
 #endif
 constexpr uint32_t kWideTreelet = MCPT_WIDE_TREELET; // records per treelet of wide_nodes (0: breadth-first numbering)
 
+// One 64-byte record of the quantised form: the boxes of `n` <= 4 children on the record's own grid (origin = their common lower corner,
+// scale = the power of two per axis that spans the extent in 255 steps), decoded planes verified with the device's own operations.
+struct WideChild
+{
+    uint32_t ref; // binary node index, or kWalkLeaf | slot
+    Bounds box;
+};
+void EmitWideRecord(const WideChild *kids, int n, const uint32_t refs[4], std::vector<uint4> &out)
+{
+    Bounds all;
+    for (int i = 0; i < n; ++i)
+        all.Add(kids[i].box);
+    const float origin[3] = {n ? all.lo.x : 0.0f, n ? all.lo.y : 0.0f, n ? all.lo.z : 0.0f}, top[3] = {n ? all.hi.x : 0.0f, n ? all.hi.y : 0.0f, n ? all.hi.z : 0.0f};
+    uint32_t expo[3];
+    uint8_t qlo[4][3] = {}, qhi[4][3] = {};
+    for (int a = 0; a < 3; ++a)
+    {
+        const float extent = top[a] - origin[a];
+        int e = extent > 0.0f ? std::max(-126, std::ilogb(extent) - 9) : -126;
+        for (;; ++e)
+        {
+            const float scale = std::ldexp(1.0f, e);
+            bool fits = origin[a] + scale * 255.0f >= top[a];
+            for (int i = 0; i < n && fits; ++i)
+            {
+                const float lo = comp(kids[i].box.lo, a), hi = comp(kids[i].box.hi, a);
+                int ql = static_cast<int>(std::floor((double(lo) - origin[a]) / scale)), qh = static_cast<int>(std::ceil((double(hi) - origin[a]) / scale));
+                ql = std::min(std::max(ql, 0), 255), qh = std::min(std::max(qh, 0), 255);
+                while (ql > 0 && !(origin[a] + scale * static_cast<float>(ql) <= lo))
+                    --ql;
+                while (qh < 255 && !(origin[a] + scale * static_cast<float>(qh) >= hi))
+                    ++qh;
+                fits = origin[a] + scale * static_cast<float>(ql) <= lo && origin[a] + scale * static_cast<float>(qh) >= hi;
+                qlo[i][a] = static_cast<uint8_t>(ql), qhi[i][a] = static_cast<uint8_t>(qh);
+            }
+            if (fits || e >= 127)
+                break;
+        }
+        expo[a] = static_cast<uint32_t>(e + 127);
+    }
+    auto bits = [](float f)
+    {
+        uint32_t u;
+        std::memcpy(&u, &f, 4);
+        return u;
+    };
+    auto plane_word = [&](const uint8_t q[4][3], int a)
+    { return uint32_t(q[0][a]) | (uint32_t(q[1][a]) << 8) | (uint32_t(q[2][a]) << 16) | (uint32_t(q[3][a]) << 24); };
+    // unused child slots: an inverted box (255 .. 0) and the "done" reference; `n` in the top byte of word 3
+    for (int i = n; i < 4; ++i)
+        for (int a = 0; a < 3; ++a)
+            qlo[i][a] = 255, qhi[i][a] = 0;
+    out.push_back(uint4{bits(origin[0]), bits(origin[1]), bits(origin[2]), expo[0] | (expo[1] << 8) | (expo[2] << 16) | (uint32_t(n) << 24)});
+    out.push_back(uint4{refs[0], refs[1], refs[2], refs[3]});
+    out.push_back(uint4{plane_word(qlo, 0), plane_word(qlo, 1), plane_word(qlo, 2), plane_word(qhi, 0)});
+    out.push_back(uint4{plane_word(qhi, 1), plane_word(qhi, 2), 0u, 0u});
+}
+
 void BuildWideNodes(FlatScene &fs)
 {
     IntegratorRec &ig = fs.integrator;
@@ -561,6 +619,96 @@ void BuildWideNodes(FlatScene &fs)
         }
         out.swap(moved);
     }
+}
+
+// ---- PAIRS of quantised records (experiment builds, -DMCPT_POOL_PAIRS=1; EXPERIMENTS R6-10) ------------------------------------
+// A path of dragon/scene.xml's slowest tiles is a chain of dependent steps — item, ray record, node record through L2, pushes — and
+// the frame ends with such chains.  What shortens a chain is fewer steps per ray query: here a node item names a PAIR of 64-byte
+// records in one 128-byte line — the collapse (to at most four children each, as above) of the two children of a binary node —, so
+// that one step looks at up to EIGHT descendants three binary levels down, two to eight lanes per item (pool_walk.h).  A half whose
+// binary child is a leaf holds that leaf alone.  Inner references name pairs.  Same boxes, same reachability, same answers.
+void BuildWidePairs(FlatScene &fs)
+{
+    IntegratorRec &ig = fs.integrator;
+    fs.wide_nodes.clear();
+    ig.n_wide_nodes = 0, ig.wide_stack = 1;
+    const uint32_t n_binary = ig.n_walk_nodes;
+    if (n_binary == 0)
+    {
+        fs.wide_nodes.assign(8, uint4{0, 0, 0, 0});
+        return;
+    }
+    auto children_of = [&](uint32_t node, WideChild out[2]) -> int
+    {
+        const float4 *n = &fs.walk_nodes[4 * size_t(node)];
+        int k = 0;
+        uint32_t ref0, ref1;
+        std::memcpy(&ref0, &n[0].w, 4), std::memcpy(&ref1, &n[1].w, 4);
+        Bounds b0, b1;
+        b0.lo = V3{n[0].x, n[0].y, n[0].z}, b0.hi = V3{n[1].x, n[1].y, n[1].z};
+        b1.lo = V3{n[2].x, n[2].y, n[2].z}, b1.hi = V3{n[3].x, n[3].y, n[3].z};
+        if (!(b0.lo.x > b0.hi.x)) // (not the "never entered" box of the top node's second child)
+            out[k++] = WideChild{ref0, b0};
+        if (!(b1.lo.x > b1.hi.x))
+            out[k++] = WideChild{ref1, b1};
+        return k;
+    };
+    auto area = [](const Bounds &b)
+    {
+        const double dx = double(b.hi.x) - b.lo.x, dy = double(b.hi.y) - b.lo.y, dz = double(b.hi.z) - b.lo.z;
+        return dx * dy + dy * dz + dz * dx;
+    };
+    std::vector<uint32_t> todo{0u}; // pair k covers the two children of binary node todo[k]
+    std::vector<uint4> &out = fs.wide_nodes;
+    for (size_t k = 0; k < todo.size(); ++k)
+    {
+        WideChild top[2];
+        const int n_top = children_of(todo[k], top);
+        for (int h = 0; h < 2; ++h)
+        {
+            WideChild kids[4];
+            int n = 0;
+            if (h < n_top)
+            {
+                if (top[h].ref & kWalkLeaf)
+                    kids[n++] = top[h];
+                else
+                {
+                    n = children_of(top[h].ref, kids);
+                    for (;;) // take grandchildren, largest surface first, while there is room
+                    {
+                        int pick = -1;
+                        double best = -1.0;
+                        for (int i = 0; i < n; ++i)
+                            if (!(kids[i].ref & kWalkLeaf) && area(kids[i].box) > best)
+                                best = area(kids[i].box), pick = i;
+                        if (pick < 0 || n >= 4)
+                            break;
+                        WideChild grand[2];
+                        const int g = children_of(kids[pick].ref, grand);
+                        if (n - 1 + g > 4)
+                            break;
+                        kids[pick] = kids[n - 1], --n;
+                        for (int i = 0; i < g; ++i)
+                            kids[n++] = grand[i];
+                    }
+                }
+            }
+            uint32_t refs[4] = {kWalkDone, kWalkDone, kWalkDone, kWalkDone};
+            for (int i = 0; i < n; ++i)
+            {
+                if (kids[i].ref & kWalkLeaf)
+                    refs[i] = kids[i].ref;
+                else
+                {
+                    refs[i] = static_cast<uint32_t>(todo.size());
+                    todo.push_back(kids[i].ref);
+                }
+            }
+            EmitWideRecord(kids, n, refs, out);
+        }
+    }
+    ig.n_wide_nodes = static_cast<uint32_t>(todo.size());
 }
 
 class WalkTreeBuilder
@@ -1439,7 +1587,11 @@ FlatScene CommitScene(const mcsd::Scene &in, LbvhAccelerator *lbvh)
             fs.walk_prims.push_back(float4{p[1].x, p[1].y, p[1].z, Bits(prim_inst[prim])});
             fs.walk_prims.push_back(float4{p[2].x, p[2].y, p[2].z, Bits(rank[prim] | (sliver[prim] ? kWalkSliver : 0u))});
         }
+#if MCPT_POOL_PAIRS
+        BuildWidePairs(fs);
+#else
         BuildWideNodes(fs);
+#endif
         BuildPoolNodes(fs);
         fs.seconds_walk = seconds_since(t_walk);
     }

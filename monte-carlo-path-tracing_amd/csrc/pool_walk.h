@@ -196,6 +196,7 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
     constexpr uint32_t kPoolCands = pool_cands(kDual);
     constexpr uint32_t kRecords = kDual ? 128u : 64u, kNodeItems = kDual ? kPoolNodeItemsDual : kPoolNodeItems, kNodeFull = kDual ? kPoolNodeFullDual : kPoolNodeFull;
     constexpr bool kQuant = kBig && (MCPT_POOL_QUANT != 0); // the quantised node records + the leaf-box test at the primitive
+    constexpr bool kPairs = kQuant && (MCPT_POOL_PAIRS != 0); // (experiment builds) node items name pairs of records: device_scene.h
     if (sc.integrator.n_walk_nodes == 0)
         return false;
     constexpr uint32_t kRayVecs = pool_ray_words(kAnalytic) / 4u;
@@ -204,6 +205,8 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
     const uint32_t lane = __lane_id();
     const unsigned long long workers = __ballot(1);
     const uint32_t rank = pool_rank(workers), n_workers = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(__popcll(workers))));
+    if (kPairs && n_workers < 2u)
+        __builtin_trap(); // (a pair of records takes two lanes: every caller brings whole wavefronts)
     float4 *rays = reinterpret_cast<float4 *>(pool);
     uint32_t *counts = pool + kRecords * pool_ray_words(kAnalytic);
     uint2 *cands = reinterpret_cast<uint2 *>(counts + kRecords);
@@ -262,12 +265,15 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
     // that leave the region would travel as 0 / 1 words through vector registers.
     auto node_step = [&](auto g_tag, const uint32_t k)
     {
-        constexpr uint32_t G = decltype(g_tag)::value, kPer = 4u / G;
+        // (kPairs, experiment builds: an item names a PAIR of records, G = 2 / 4 / 8 lanes per item, G / 2 of them on each record)
+        constexpr uint32_t G = decltype(g_tag)::value, Gh = kPairs ? G / 2u : G, kPer = 4u / Gh;
+        static_assert(!kPairs || G >= 2u, "a pair of records takes at least two lanes");
         uint32_t next_nodes = 0, next_prims = 0;
         if (rank < k * G)
         {
             MCPT_WAVE_REGION();
-            const uint32_t sub = rank & (G - 1u), first = sub * kPer; // this lane's children: first ... first + kPer - 1 (G = 1: all four)
+            const uint32_t half = kPairs ? (rank & (G - 1u)) / Gh : 0u;
+            const uint32_t sub = rank & (Gh - 1u), first = sub * kPer; // this lane's children: first ... first + kPer - 1 of its record (Gh = 1: all four)
             if (kCount)
                 stats.node_tests += kPer;
             const uint32_t item = node_items[n_nodes - 1u - rank / G];
@@ -282,14 +288,14 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
                 // lo.x lo.y lo.z hi.x | hi.y hi.z, one byte per child.  Planes are decoded to world space — origin + 2^e * q, the
                 // operations the quantiser verified (the product is exact, so the fused form rounds once, to the same value) — and
                 // go through the same slab test as the exact boxes they contain.
-                const uint4 *wq = sc.wide_nodes + 4u * static_cast<size_t>(node);
+                const uint4 *wq = sc.wide_nodes + (kPairs ? 8u : 4u) * static_cast<size_t>(node) + 4u * half;
                 const uint4 n0 = wq[0], n2 = wq[2], n3 = wq[3];
-                if constexpr (G == 1)
+                if constexpr (Gh == 1)
                 {
                     const uint4 refs = wq[1];
                     ref[0] = refs.x, ref[1] = refs.y, ref[2] = refs.z, ref[3] = refs.w;
                 }
-                else if constexpr (G == 2)
+                else if constexpr (Gh == 2)
                 {
                     const uint2 refs = reinterpret_cast<const uint2 *>(wq + 1)[sub];
                     ref[0] = refs.x, ref[1] = refs.y;
@@ -498,8 +504,11 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
             //      ones gave 11.9 instead of 12.4 steps per round on cornell — not worth a sort per item) ----
             // (head room: a step with k items grows the list by at most 3 k.  Below kPoolNodeFull every worker takes an item
             //  if that fits; above, ONE does — a depth-first walk, which adds at most 3 x the tree's depth to the list)
-            uint32_t k = uni(n_nodes < n_workers ? n_nodes : n_workers);
-            const uint32_t room = uni(n_nodes < kNodeFull ? (kNodeFull - n_nodes + 2u) / 3u : 1u);
+            // (pairs: two lanes per item at least, an item lists up to eight children — seven more than it took away)
+            constexpr uint32_t kGrowth = kPairs ? 7u : 3u, kLanesAtLeast = kPairs ? 2u : 1u, kFull = kPairs ? kNodeItems - kGrowth * kPoolMaxDepth : kNodeFull;
+            const uint32_t takers = uni(n_workers / kLanesAtLeast);
+            uint32_t k = uni(n_nodes < takers ? n_nodes : takers);
+            const uint32_t room = uni(n_nodes < kFull ? (kFull - n_nodes + kGrowth - 1u) / kGrowth : 1u);
             k = uni(k < room ? k : room);
             if (kCount && rank == 0)
                 ++stats.wave_node_steps;
@@ -510,14 +519,26 @@ __device__ __forceinline__ bool walk_pool(const DeviceScene &sc, uint32_t *pool,
             // quarter / half of the instructions, which is what a near-empty wavefront's step costs (its chain of dependent
             // instructions), and what a VALU-bound kernel pays per item.  Which lane tests which child changes the ORDER of the pushed
             // items only; the walk's answers do not depend on it.
-#if MCPT_POOL_CHILD_PARALLEL
-            if (k * 4u <= n_workers)
-                node_step(std::integral_constant<uint32_t, 4u>{}, k);
-            else if (k * 2u <= n_workers)
-                node_step(std::integral_constant<uint32_t, 2u>{}, k);
+            if constexpr (kPairs)
+            {
+                if (k * 8u <= n_workers)
+                    node_step(std::integral_constant<uint32_t, 8u>{}, k);
+                else if (k * 4u <= n_workers)
+                    node_step(std::integral_constant<uint32_t, 4u>{}, k);
+                else
+                    node_step(std::integral_constant<uint32_t, 2u>{}, k);
+            }
             else
+            {
+#if MCPT_POOL_CHILD_PARALLEL
+                if (k * 4u <= n_workers)
+                    node_step(std::integral_constant<uint32_t, 4u>{}, k);
+                else if (k * 2u <= n_workers)
+                    node_step(std::integral_constant<uint32_t, 2u>{}, k);
+                else
 #endif
-                node_step(std::integral_constant<uint32_t, 1u>{}, k);
+                    node_step(std::integral_constant<uint32_t, 1u>{}, k);
+            }
             pool_sync();
         }
     }
