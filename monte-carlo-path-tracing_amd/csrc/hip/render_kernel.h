@@ -87,6 +87,11 @@ struct RenderJob
     // moved into the first wavefronts of their workgroup whenever another 64 of its lanes have retired
     // (render_kernel_impl.h, "COMPACTION").  The image does not depend on it.
     uint32_t compact;
+    // Pool-walk kernels OUTSIDE LDS with the work counter (round 6): 1 = once the counter is dry, the paths a workgroup still holds are
+    // dealt out evenly over its four wavefronts whenever few enough of them are left (render_kernel_impl.h, "TAIL SPREAD"): a frame
+    // of dragon/scene.xml ends on wavefronts that hold 32 long pixel chains each while their three neighbours have nothing left, and
+    // a chain runs faster the more helper lanes its wavefront has.  The image does not depend on it.
+    uint32_t tail_spread;
     // Full-feature scenes with the traversal data in LDS: 1 = the class-sorted kernel (hip/sorted_kernel.hip: the paths of a
     // workgroup are regrouped by what their ray found, between the ray query and the shading).  The image does not depend on it.
     uint32_t sort_classes;

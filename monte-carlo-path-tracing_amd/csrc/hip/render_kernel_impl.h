@@ -83,6 +83,10 @@ struct Budget
 constexpr uint32_t kPoolMaxSpread = MCPT_POOL_MAX_SPREAD; // lanes per path at most, when a launch has fewer pixels than lanes (pool walk)
 constexpr uint32_t kFetchNext = 0xFFFFFFFFu; // a lane's item variable: "ask the work counter when the current pixel is done"
 constexpr uint32_t kCompactWords = 8, kCompactPasses = 4; // a path's 30 state words travel through LDS in four passes of eight
+constexpr uint32_t kSpreadPasses = 6; // ... with a pending shadow ray (merged queries: 17 words more) in six
+#ifndef MCPT_TAIL_SPREAD
+#define MCPT_TAIL_SPREAD 1
+#endif
 
 // kLdsGeometry: the arrays the ray queries and the light sampler read (both
 // hierarchies, walk primitives, triangle positions) are copied into LDS by each
@@ -206,15 +210,34 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     // (measured: cornell 1074 -> 1098 Msamples/s; the full-feature instantiation — volumetric-caustic, 3 wavefronts per
     //  SIMD, 3.5 pixels per lane from the work counter — 1012 -> 1007, so not there)
     constexpr bool kCompact = kLdsGeometry && !kCount && C::kOrdered && !(C::kVolPath || C::kAnalytic) && !C::kPoolDual; // (the compaction carries no pending shadow ray)
+    // TAIL SPREAD (round 6; pool-walk kernels outside LDS with the work counter: RenderJob::tail_spread).  The same events, the other
+    // way round.  dragon/scene.xml's frame ends on a few dozen wavefronts that hold 32 paths of its most expensive tiles each — a tile
+    // alone takes 95 ms at 1 path per 2 lanes, 52 at 1 per 8 (EXPERIMENTS R6-10) — while the other wavefronts of their workgroups
+    // have nothing left and wait.  Once a wavefront of the workgroup has been refused by the work counter (dry: nothing will ever be
+    // handed out again), lanes without a pixel retire, and whenever the workgroup is down to 96 / 64 / 32 / 16 / 8 paths these are
+    // DEALT OUT over its four wavefronts — path j of the workgroup's order to wavefront j mod 4 —, pending shadow rays included: every
+    // wavefront then holds a quarter of the paths and three quarters more helper lanes.  A path's state is all that makes its pixel:
+    // the frame is unchanged.
+    // Built into the diffuse (+ emitters, slivers) kernels outside LDS — dragon/scene.xml's class: 119.4 -> 107.1 ms (108.9-131.6 ->
+    // 101.5-115.1 over 24 draws), its 1/8 share 44.5 -> 40.1.  The one-BSDF surface units lose 1.5-1.9 % with the code compiled in
+    // (they sit at their 128-register limit, and their tails are what lanes per path by tile cost is for): not there (EXPERIMENTS R6-13).
+    constexpr bool kTailSpread = MCPT_TAIL_SPREAD != 0 && C::kPool && C::kPoolBig && !kLdsGeometry && !kCount &&
+                                 (kFeatures & (kFeatVolPath | kFeatAnalytic | kFeatMicrofacet | kFeatTextures)) == 0;
+    constexpr bool kEventsBuilt = kCompact || kTailSpread;
+    constexpr uint32_t kEvents = kTailSpread ? 5u : kBlockSize / 64u - 1u;
+    // (event k falls due when this many lanes of the workgroup have retired)
+    auto event_at = [](uint32_t k) { return kTailSpread ? (k == 0 ? 160u : k == 1 ? 192u : k == 2 ? 224u : k == 3 ? 240u : 248u) : 64u * (k + 1u); };
+    constexpr uint32_t kEventPasses = kTailSpread && C::kPoolDual ? kSpreadPasses : kCompactPasses;
+    const bool events_on = kEventsBuilt && (kTailSpread ? job.tail_spread != 0 && job.work_counter != nullptr && job.tile_steps == nullptr && job.xcd_bands == 0 : job.compact != 0);
     // (pool walk: the words travel through the pool areas — no wavefront is inside a query during an event — and the
     //  counters, which are read at every step, have their own words behind them)
     uint32_t *compact_words = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged)
                                        : reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + static_cast<size_t>(sc_in.integrator.walk_depth) * kBlockSize;
     uint32_t *compact_count = C::kPool ? reinterpret_cast<uint32_t *>(lds_geometry + n_staged) + (kBlockSize / 64u) * pool_wave_words(C::kAnalytic, C::kPoolBig, C::kPoolDual)
-                                       : compact_words + kCompactWords * kBlockSize; // [0..3]: live lanes per wavefront, [4]: retired lanes of the workgroup
+                                       : compact_words + kCompactWords * kBlockSize; // [0..3]: live lanes per wavefront, [4]: retired lanes of the workgroup, [5]: the work counter is dry
     bool retired = false;
-    uint32_t compact_events = 0; // events this wavefront has taken part in (event k: 64 (k + 1) lanes retired)
-    if (kCompact)
+    uint32_t compact_events = 0; // events this wavefront has taken part in
+    if (kEventsBuilt)
     {
         if (threadIdx.x < 8)
             compact_count[threadIdx.x] = 0;
@@ -264,28 +287,33 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
             {
                 MCPT_WAVE_REGION();
                 q = bands ? band_reserve(job.work_counter, my_band, n_work) : counter_base + wave_reserve(job.work_counter, true);
+                // (tail spread: a lane that ASKED and got nothing has seen the counter dry — nothing will be handed out any more)
+                if (kTailSpread && events_on && q >= n_work)
+                    compact_count[5] = 1u;
             }
         }
         // (pool walk: a lane without work of its own stays in the loop as a HELPER of its wavefront's ray queries)
         bool helper = false;
-        if (kCompact && job.compact)
+        if (kEventsBuilt && events_on)
         {
-            if (!has_pixel && !retired && q >= n_work)
+            // (one LDS word each, read by every lane of the wavefront in the same instruction: uniform — and said so, the lockstep host
+            //  build of this body, tests/emu, runs a wavefront's lanes one after the other between cross-lane operations)
+            // tail spread: lanes retire only once the work counter is known to be dry (a lane that waits for its turn — lanes per path
+            // by tile cost — may still be given a pixel before that); the compaction's lanes all asked, one pixel per lane
+            const bool dry = !kTailSpread || __builtin_amdgcn_readfirstlane(static_cast<int>(*static_cast<volatile uint32_t *>(&compact_count[5]))) != 0;
+            if (!has_pixel && !retired && q >= n_work && dry)
             {
                 retired = true;
                 atomicAdd(&compact_count[4], 1u);
             }
-            // (one LDS word, read by every lane of the wavefront in the same instruction: uniform — and said so, the lockstep host build
-            //  of this body, tests/emu, runs a wavefront's lanes one after the other between cross-lane operations)
             const uint32_t n_retired = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(*static_cast<volatile uint32_t *>(&compact_count[4]))));
-            constexpr uint32_t kEvents = kBlockSize / 64u - 1u;
             // (every wavefront takes part in every event, also the ones that fall due together with the end: a
             //  wavefront that left early would leave the others waiting at the event's barriers)
             if (n_retired >= kBlockSize && compact_events == kEvents)
                 break; // the workgroup is done
-            if (compact_events < kEvents && n_retired >= 64u * (compact_events + 1u))
+            if (compact_events < kEvents && n_retired >= event_at(compact_events))
             {
-                // ---- event: every wavefront of the workgroup comes here once per 64 retired lanes, in the same order ----
+                // ---- event: every wavefront of the workgroup comes here once per threshold, in the same order ----
                 ++compact_events;
                 uint32_t n_live;
                 // (live = holds a pixel in flight, or an item it has reserved and not started yet)
@@ -302,17 +330,30 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
                     before += w < (threadIdx.x >> 6) ? c : 0u;
                     total += c;
                 }
-                const uint32_t dst = before + rank_in_wave;
-                uint32_t in[kCompactWords * kCompactPasses], got[kCompactWords * kCompactPasses];
+                // compaction: the paths in the workgroup's order fill its first lanes (the first wavefronts are full again); tail
+                // spread: path j goes to wavefront j mod 4, lane j / 4 — which lane of a wavefront carries a path is irrelevant to the
+                // pool walk, every lane is a worker
+                const uint32_t place = before + rank_in_wave;
+                const uint32_t dst = kTailSpread ? (place & 3u) * 64u + (place >> 2) : place;
+                const uint32_t mine = kTailSpread ? (threadIdx.x & 63u) * 4u + (threadIdx.x >> 6) : threadIdx.x; // the place whose path this lane receives
+                uint32_t in[kCompactWords * kEventPasses], got[kCompactWords * kEventPasses];
                 in[0] = st.rng, in[1] = st.pixel, in[2] = st.sample, in[3] = st.depth;
-                in[4] = (st.alive ? 1u : 0u) | (st.primary ? 2u : 0u) | (st.in_medium ? 4u : 0u) | (has_pixel ? 8u : 0u), in[5] = st.medium;
+                in[4] = (st.alive ? 1u : 0u) | (st.primary ? 2u : 0u) | (st.in_medium ? 4u : 0u) | (has_pixel ? 8u : 0u) | (pend.shadow ? 16u : 0u) | (pend.finish ? 32u : 0u) | (my_lg << 8);
+                in[5] = st.medium;
                 in[6] = as_uint(st.pdf_sample);
                 auto put = [&](uint32_t at, V3 v) { in[at] = as_uint(v.x), in[at + 1] = as_uint(v.y), in[at + 2] = as_uint(v.z); };
                 put(7, st.origin), put(10, st.dir), put(13, st.wo), put(16, st.wi), put(19, st.throughput), put(22, st.L), put(25, st.pixel_sum);
-                in[28] = slot, in[29] = q, in[30] = 0, in[31] = 0; // (no pending shadow ray travels: merged queries run outside LDS, the compaction inside)
+                in[28] = slot, in[29] = q, in[30] = 0, in[31] = 0;
                 static_assert(!(kCompact && C::kPoolDual), "the compaction does not carry a pending shadow ray");
+                if constexpr (kEventPasses > kCompactPasses)
+                {
+                    // (merged queries: the vertex's pending shadow ray and what the sample gains with either answer travel with the path)
+                    put(30, pend.origin), put(33, pend.dir), in[36] = as_uint(pend.t_max);
+                    put(37, pend.add_visible), put(40, pend.add_occluded), put(43, pend.old_L);
+                    in[46] = 0, in[47] = 0;
+                }
 #pragma unroll
-                for (uint32_t pass = 0; pass < kCompactPasses; ++pass)
+                for (uint32_t pass = 0; pass < kEventPasses; ++pass)
                 {
                     if (live)
 #pragma unroll
@@ -324,7 +365,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
                         got[pass * kCompactWords + k] = compact_words[k * kBlockSize + threadIdx.x];
                     __syncthreads();
                 }
-                retired = threadIdx.x >= total;
+                retired = mine >= total;
                 has_pixel = !retired && (got[4] & 8u) != 0;
                 if (!retired)
                 {
@@ -335,9 +376,19 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
                     st.origin = get(7), st.dir = get(10), st.wo = get(13), st.wi = get(16), st.throughput = get(19), st.L = get(22);
                     st.pixel_sum = get(25);
                     slot = got[28], q = got[29];
+                    if constexpr (kEventPasses > kCompactPasses)
+                    {
+                        pend.shadow = (got[4] & 16u) != 0, pend.finish = (got[4] & 32u) != 0;
+                        pend.origin = get(30), pend.dir = get(33), pend.t_max = as_float(got[36]);
+                        pend.add_visible = get(37), pend.add_occluded = get(40), pend.old_L = get(43);
+                    }
+                    my_lg = (got[4] >> 8) & 3u;
                 }
                 else
+                {
                     q = n_work;
+                    pend.shadow = pend.finish = false;
+                }
                 continue;
             }
             if (lanes_where(!retired) == 0)
@@ -358,7 +409,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
                 break;
             helper = true;
         }
-        if (C::kPool && !(kCompact && job.compact) && __ballot(!helper) == 0)
+        if (C::kPool && !(kEventsBuilt && events_on) && __ballot(!helper) == 0)
             break; // every lane of the wavefront that is here is out of work
         if (!helper && !has_pixel)
         {

@@ -454,7 +454,7 @@ RenderJob FilmJob(const DeviceScene &sc, const Options &opt, uint32_t *work_coun
     RenderJob job{};
     job.n_items = tiles_x * tiles_y * 64u, job.tile_first = 0, job.tile_stride = 1, job.tiles_x = tiles_x;
     job.work_counter = work_counter;
-    job.lane_spread = opt.lane_spread, job.compact = opt.compact, job.scatter = opt.xcd_bands ? 0u : opt.scatter, job.pool_walk = 1;
+    job.lane_spread = opt.lane_spread, job.compact = opt.compact, job.tail_spread = opt.compact /* (one switch for both kinds of event) */, job.scatter = opt.xcd_bands ? 0u : opt.scatter, job.pool_walk = 1;
     job.xcd_bands = opt.xcd_bands;
     return job;
 }

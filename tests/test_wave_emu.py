@@ -116,6 +116,23 @@ BIG = [("terrain_directional", W.EMITTERS | W.PB), ("terrain_directional", W.EMI
        ("bumpy_directional", W.SURFACE | W.PB | W.SLIVERS), ("depth_limited", W.SURFACE | W.PB | W.SLIVERS)]
 
 
+# (the diffuse + emitters kernels outside LDS — dragon/scene.xml's class — are the ones the tail spread is built into)
+SPREAD = [("terrain_directional", W.EMITTERS | W.PB, 1, 0, 0), ("terrain_directional", W.EMITTERS | W.PBU, 1, 2, 2), ("cornell_64_spp8", W.EMITTERS | W.PB, 2, 0, 2),
+          ("cornell_64_spp8", W.EMITTERS | W.PB, 1, 2, 1), ("cornell_64_spp8", W.EMITTERS | W.PBU, 1, 4, 2)]
+
+
+@pytest.mark.parametrize("name,features,blocks,spread,order", SPREAD, ids=[f"{n}-{f:#x}-{b}-{s}" for n, f, b, s, _ in SPREAD])
+def test_tail_spread_deals_the_last_paths_out_and_changes_nothing(lockstep, scenes, name, features, blocks, spread, order):
+    """RenderJob::tail_spread (render_kernel_impl.h, round 6): once the work counter is dry, the paths a workgroup still holds are dealt
+    out over its four wavefronts at five thresholds — barriers of all four wavefronts, path state AND the pending shadow ray of merged
+    queries travelling through the pool areas.  One / two workgroups for the whole film, so that the counter runs dry with paths in
+    flight and every event happens; 1 path per 1 / 2 / 4 lanes.  (That paths do move: a build that flips a bit of the random state of
+    every path an event delivers renders 0.03-4 % of these films' pixels differently — EXPERIMENTS R6-13.)"""
+    frame, golden, info = render(lockstep, scenes, name, features, False, order=order, seed=7, poison=0xFFFFFFFF, compact=1, max_blocks=blocks, lane_spread=spread)
+    assert info["blocks"] == blocks
+    assert np.array_equal(frame, golden)
+
+
 @pytest.mark.parametrize("name,features", BIG, ids=[f"{n}-{f:#x}" for n, f in BIG])
 def test_pool_walk_kernels_outside_lds_equal_the_golden(lockstep, scenes, name, features):
     """32-bit items, the quantised 4-wide hierarchy, the leaf-box test at the primitive, merged (kPB) and unmerged (kPBU) queries,
