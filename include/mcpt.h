@@ -134,8 +134,11 @@ int mcpt_unpack_tiles(const float *packed, const mcpt_tile_range *range, int wid
 /* Committed-table inspection (tests, tools).  `what`: "nodes" (float, 8 per
  * node), "node_area", "walk_nodes" (16 per node), "walk_prims" (12 per slot),
  * "tri_pos" (float, 12 per primitive), "tri_attr" (36 per primitive),
- * "lut_brdf", "lut_albedo", "light_cdf", "env_tables".  Returns a
- * pointer into renderer-owned HOST memory, valid until the renderer dies. */
+ * "lut_brdf", "lut_albedo", "light_cdf", "env_tables", "camera" (12).  Returns a
+ * pointer into renderer-owned HOST memory, valid until the renderer dies.
+ * "market": 3 floats read back from the device after the last draw has finished (the call waits for it) — tickets taken by
+ * waiting wavefronts, path records given away, items of the job finished: what the kernels outside LDS did with the frame's last
+ * paths (csrc/hip/render_kernel_impl.h, "PATH MARKET"); zeros for a renderer whose kernels have none.  Thread-local storage. */
 int mcpt_renderer_table(const mcpt_renderer *r, const char *what, const void **data, size_t *count);
 
 /* Scene statistics (9 x uint64): nodes and TLAS nodes of the reference-topology

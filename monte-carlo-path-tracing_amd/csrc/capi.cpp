@@ -170,7 +170,7 @@ struct mcpt_renderer
     unsigned long long *wave_clock_dev = nullptr; // diagnostic: MCPT_WAVE_CLOCK
     unsigned long long *mesh_table_dev = nullptr; // probed hand-out table of a scene outside LDS (cost_order_* say for which range)
     uint32_t mesh_table_capacity = 0;
-    bool mesh_table_ready = false;
+    bool mesh_table_ready = false, mesh_levels_ready = false;
     uint32_t mesh_level_until[2][3] = {{0, 0, 0}, {0, 0, 0}}; // RenderJob::level_until of the probed table, for 3 / 4 wavefronts per SIMD
     bool range_fresh = false;             // the range's statistics were just (re)read: tables made from them are stale
     unsigned long long range_hits = 0;    // camera rays of the range that hit something (pre-pass)
@@ -193,9 +193,15 @@ struct mcpt_renderer
     int last_tile_order = 0;
     uint32_t *work_counter_dev = nullptr; // RenderJob::work_counter (dynamic work distribution; one counter per XCD band: RenderJob::xcd_bands), zeroed before every launch
     int work_mode = -1;                   // mcpt_renderer_set_work_distribution: -1 library's choice, 0 fixed lists, 1 work counter
+    mcpt::LaunchRecords *records_dev = nullptr; // RenderJob::launch_records: the scene's and the job's records of the launch in flight (kernels that read them through a pointer)
+    uint32_t *market_dev = nullptr;             // RenderJob::market: the path market of the kernels with the tail spread, header zeroed before every launch
 
     ~mcpt_renderer()
     {
+        if (records_dev)
+            (void)hipFree(records_dev);
+        if (market_dev)
+            (void)hipFree(market_dev);
         if (scratch_dev)
             (void)hipFree(scratch_dev);
         if (planes_dev)
@@ -1014,12 +1020,23 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         else if (planned != hipErrorNotSupported && planned != hipErrorOutOfMemory)
             Check(planned, "plan the stream kernel");
     }
+    if (!r->records_dev)
+        Check(hipMalloc(reinterpret_cast<void **>(&r->records_dev), sizeof(mcpt::LaunchRecords)), "allocate launch records");
+    job.launch_records = r->records_dev;
     if (dynamic_work)
     {
         if (!r->work_counter_dev)
             Check(hipMalloc(reinterpret_cast<void **>(&r->work_counter_dev), kWorkCounterBytes), "allocate work counter");
         Check(hipMemsetAsync(r->work_counter_dev, 0, kWorkCounterBytes, stream), "clear work counter");
         job.work_counter = r->work_counter_dev;
+        // the path market of the tail spread (RenderJob::market; kernels outside LDS, reference and throughput streams alike)
+        if (job.tail_spread != 0 && !small_scene && !counted)
+        {
+            if (!r->market_dev)
+                Check(hipMalloc(reinterpret_cast<void **>(&r->market_dev), mcpt::kMarketWords * sizeof(uint32_t)), "allocate path market");
+            Check(hipMemsetAsync(r->market_dev, 0, mcpt::kMarketRecordsAt * sizeof(uint32_t), stream), "clear path market");
+            job.market = r->market_dev;
+        }
         // XCD bands (RenderJob::xcd_bands; mcpt_renderer_set_tile_order(r, 2)): image order, whole film or tile range, one item per pixel
         job.xcd_bands = r->tile_order_mode == 2 && job.tile_order == nullptr && job.sample_split <= 1 && job.scatter != 1u ? 1u : 0u;
         if (job.xcd_bands)
@@ -1118,7 +1135,15 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                     {
                         r->range_fresh = false;
                         // (MCPT_COST_ORDER=4, measurements: every mesh job is ordered by probed cost, whatever its hit count)
-                        r->mesh_table_ready = CostOrderEnv() >= 4 || 2ull * r->range_hits >= static_cast<unsigned long long>(job.n_items) * r->dev.camera.spp;
+                        // ... and jobs whose kernel has the tail spread and the path market (round 6: dragon/scene.xml's class).  Their frames end
+                        // on the chains that started last; with the market those chains run one path per wavefront, so what is left to decide
+                        // is WHEN the long ones start: first.  dragon, 16 draws each (EXPERIMENTS R6-14): image order 110-112 ms, most
+                        // expensive first 101.0 (100.4-102.7) — without the market that order is 123 ms (the long chains ARE the frame).
+                        // Lanes per path by tile cost stays with the class whose camera rays mostly hit: thresholds zero here.
+                        const bool hits_class = 2ull * r->range_hits >= static_cast<unsigned long long>(job.n_items) * r->dev.camera.spp;
+                        const bool market_class = job.market != nullptr && mcpt::TailSpreadRuns(r->dev, job);
+                        r->mesh_table_ready = CostOrderEnv() >= 4 || hits_class || market_class;
+                        r->mesh_levels_ready = hits_class || (CostOrderEnv() >= 4 && !market_class);
                         if (r->mesh_table_ready)
                         {
                             Check(hipMemsetAsync(r->tile_steps_dev, 0, n_tiles * sizeof(uint32_t), stream), "clear tile step counts");
@@ -1134,8 +1159,14 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                             Check(hipMemcpyAsync(steps.data(), r->tile_steps_dev, n_tiles * sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "read tile step counts");
                             Check(hipStreamSynchronize(stream), "wait for the cost probe");
                             const std::vector<unsigned long long> table = CostOrderedTable(steps, r->n_cus, 0);
-                            LevelThresholds(steps, r->n_cus * 12u, r->mesh_level_until[0]);
-                            LevelThresholds(steps, r->n_cus * 16u, r->mesh_level_until[1]);
+                            for (int k = 0; k < 2; ++k)
+                                for (int i = 0; i < 3; ++i)
+                                    r->mesh_level_until[k][i] = 0;
+                            if (r->mesh_levels_ready)
+                            {
+                                LevelThresholds(steps, r->n_cus * 12u, r->mesh_level_until[0]);
+                                LevelThresholds(steps, r->n_cus * 16u, r->mesh_level_until[1]);
+                            }
                             Check(hipMemcpyAsync(r->mesh_table_dev, table.data(), n_tiles * sizeof(unsigned long long), hipMemcpyHostToDevice, stream), "upload the tile table");
                             Check(hipStreamSynchronize(stream), "wait for the tile table");
                             Check(hipMemsetAsync(r->work_counter_dev, 0, kWorkCounterBytes, stream), "clear work counter");
@@ -1830,6 +1861,22 @@ int mcpt_renderer_table(const mcpt_renderer *r, const char *what, const void **d
         return set(f.env_tables.data(), f.env_tables.size());
     if (w == "camera") // eye, front, dx, dy (camera.cpp:26-37): 12 floats
         return set(&f.camera.eye, 12);
+    if (w == "market") // what the last draw's path market saw (RenderJob::market): tickets taken, records given, items finished — 3 floats
+    {
+        static thread_local float seen[3];
+        seen[0] = seen[1] = seen[2] = 0.0f;
+        if (r->market_dev)
+        {
+            uint32_t head[3] = {0, 0, 0};
+            if (hipSetDevice(r->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+                hipMemcpy(&head[0], r->market_dev, 4, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&head[1], r->market_dev + 32, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemcpy(&head[2], r->market_dev + 64, 4, hipMemcpyDeviceToHost) != hipSuccess)
+                return Fail("read the path market's counters");
+            for (int i = 0; i < 3; ++i)
+                seen[i] = static_cast<float>(head[i]);
+        }
+        return set(seen, 3);
+    }
     return Fail("unknown table '" + w + "'");
 }
 

@@ -18,6 +18,8 @@ namespace mcpt
 constexpr int kBlockSize = 256;
 constexpr uint32_t kHitCounters = 32;
 constexpr uint32_t kScatterAuto = 0xFFFFFFFFu;
+constexpr uint32_t kMarketSlots = 16384, kMarketRecord = 48, kMarketReadyAt = 128, kMarketRecordsAt = kMarketReadyAt + kMarketSlots;
+constexpr size_t kMarketWords = kMarketRecordsAt + size_t(kMarketSlots) * kMarketRecord; // RenderJob::market (3.2 MB); the launch's caller zeroes the first kMarketRecordsAt
 constexpr uint32_t kBands = 8, kBandStride = 32; // RenderJob::xcd_bands: one counter per XCD, 128 bytes apart
 constexpr size_t kWaveClockWords = 4u * 8u * 4u, kPhaseSumWords = 64; // RenderJob::wave_clock: words per CU (at most 8 workgroups of 4 wavefronts, four words each); phase_sums
 bool LastLaunchTransposed(); // what the calling thread's last LaunchRender chose (for the kernel description)
@@ -92,6 +94,17 @@ struct RenderJob
     // of dragon/scene.xml ends on wavefronts that hold 32 long pixel chains each while their three neighbours have nothing left, and
     // a chain runs faster the more helper lanes its wavefront has.  The image does not depend on it.
     uint32_t tail_spread;
+    // ... and BETWEEN workgroups (null: off): the path market, kMarketWords words of device memory, header and ready words zeroed
+    // before the launch.  A wavefront whose workgroup is done does not leave: it takes a ticket and waits for a path; a wavefront
+    // that still holds two or more paths after the counter ran dry gives half of them (at most one per waiting ticket) away — state
+    // and pending shadow ray through device memory — so that the frame's last paths run one per wavefront, with 63 helper lanes each,
+    // on ALL wavefronts of the GPU instead of 32 per wavefront on a few dozen (render_kernel_impl.h, "PATH MARKET").  Words: [0] tickets
+    // taken, [32] records given, [64] items of the job finished (a waiting wavefront leaves when that reaches the job's items),
+    // [128 + s] generation of slot s, records of 48 words behind them.  The image does not depend on it.
+    uint32_t *market;
+    // Device memory for the records of a launch (the kernels that read the scene and the job through a pointer: LaunchRecords below,
+    // render_kernel_impl.h records_behind_pointer); the renderer's own.  Host-side meaning only.
+    struct LaunchRecords *launch_records;
     // Full-feature scenes with the traversal data in LDS: 1 = the class-sorted kernel (hip/sorted_kernel.hip: the paths of a
     // workgroup are regrouped by what their ray found, between the ray query and the shading).  The image does not depend on it.
     uint32_t sort_classes;
@@ -123,19 +136,22 @@ struct RenderJob
 // once, keeps in scalar registers across the persistent loop and — 106 SGPRs — spills into lanes of vector registers (116-210 spilled
 // scalars per kernel, v_readlane / v_writelane around their uses).  The reference's kernel takes two pointers (renderer.cpp:88).  The
 // kernels of the instantiations named by records_behind_pointer() (render_kernel_impl.h) take ONE pointer to {scene, job} in device
-// memory and read the fields through the constant address space: scalar loads that the compiler may repeat at a use instead of keeping
-// the value — 67-131 spilled scalars, cornell -1.6 %, volumetric-caustic -1.8 %, matpreview -0.6 ... -0.9 % (EXPERIMENTS R6-8).
+// memory (RenderJob::launch_records) and read the fields through the constant address space: scalar loads that the compiler may repeat at
+// a use instead of keeping the value — 67-131 spilled scalars, cornell -1.6 %, volumetric-caustic -1.8 %, matpreview -0.6 ... -0.9 %
+// (EXPERIMENTS R6-8).
 struct LaunchRecords
 {
     DeviceScene sc;
     RenderJob job;
 };
-// Copies the records into the next slot of the current device's ring (16 slots: device memory + a pinned mirror + an event each) in
-// stream order and returns the device address; a slot is taken again when the launch that used it has finished (its event).  Thread
-// safe.  Null (and *error) when a HIP call fails.  The caller launches ONE kernel that reads the records on `stream` and then calls
-// LaunchRecordsInFlight(stream) from the same thread.
-const LaunchRecords *StageLaunchRecords(const DeviceScene &sc, const RenderJob &job, hipStream_t stream, hipError_t *error);
-void LaunchRecordsInFlight(hipStream_t stream);
+// Writes the records to `job.launch_records` (device memory of sizeof(LaunchRecords) bytes that belongs to the caller — a renderer owns
+// one, like its work counter: its draws are ordered on one stream at a time) in stream order: a one-wavefront kernel that takes the two
+// records by value and copies its own argument segment.  No host buffer outlives the call, nothing waits.  The kernel that reads the
+// records is launched behind it on the same stream.
+hipError_t StageLaunchRecords(const DeviceScene &sc, const RenderJob &job, hipStream_t stream);
+// Whether LaunchRender (no counters) runs an instantiation with the tail spread and the path market for this job: the diffuse
+// (+ emitters, slivers) pool-walk kernels outside LDS.
+bool TailSpreadRuns(const DeviceScene &sc, const RenderJob &job);
 
 // ---- stream kernel (stream_core.h, stream_kernel_impl.h) ------------------------------------------
 // Launch parameters of the stream kernel.  `slots` and `refill_at` are inputs of PlanRenderStream (0 = the

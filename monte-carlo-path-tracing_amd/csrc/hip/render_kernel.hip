@@ -1,7 +1,7 @@
 // The lean render-kernel instantiations, the unit kernels and the dispatcher; the kernel template
 // itself is in render_kernel_impl.h.
+#include <cstddef>
 #include <cstdlib>
-#include <mutex>
 
 #include "render_kernel_impl.h"
 #include "../host/measurement_env.hpp"
@@ -10,72 +10,21 @@ namespace mcpt
 {
 
 // ---- the records of a launch in device memory (render_kernel.h, LaunchRecords) ----------
-namespace
+// The argument segment of this kernel IS a LaunchRecords (the two records by value, each at its natural alignment): its 64 lanes copy it.
+__global__ void stage_records_kernel(const DeviceScene, const RenderJob, uint32_t *__restrict__ dst)
 {
-constexpr int kRecordSlots = 16, kRecordDevices = 64;
-struct RecordRing
-{
-    LaunchRecords *device = nullptr, *host = nullptr; // kRecordSlots records each (device memory; its pinned mirror)
-    hipEvent_t done[kRecordSlots] = {};               // the launch that read slot k has finished
-    bool used[kRecordSlots] = {};
-    unsigned next = 0;
-};
-std::mutex g_record_mutex;
-RecordRing g_record_rings[kRecordDevices]; // (one per device, made at the first launch there; they live as long as the process)
-thread_local hipEvent_t t_record_event = nullptr;
-} // namespace
-
-const LaunchRecords *StageLaunchRecords(const DeviceScene &sc, const RenderJob &job, hipStream_t stream, hipError_t *error)
-{
-    int dev = 0;
-    hipError_t err = hipGetDevice(&dev);
-    if (err == hipSuccess && (dev < 0 || dev >= kRecordDevices))
-        err = hipErrorInvalidDevice;
-    LaunchRecords *where = nullptr;
-    if (err == hipSuccess)
-    {
-        std::lock_guard<std::mutex> lock(g_record_mutex);
-        RecordRing &ring = g_record_rings[dev];
-        if (!ring.device)
-        {
-            LaunchRecords *d = nullptr, *h = nullptr;
-            err = hipMalloc(reinterpret_cast<void **>(&d), kRecordSlots * sizeof(LaunchRecords));
-            if (err == hipSuccess)
-                err = hipHostMalloc(reinterpret_cast<void **>(&h), kRecordSlots * sizeof(LaunchRecords), hipHostMallocDefault);
-            for (int k = 0; k < kRecordSlots && err == hipSuccess; ++k)
-                err = hipEventCreateWithFlags(&ring.done[k], hipEventDisableTiming);
-            if (err == hipSuccess)
-                ring.device = d, ring.host = h;
-            else
-                (void)hipFree(d), (void)hipHostFree(h);
-        }
-        if (err == hipSuccess)
-        {
-            const unsigned k = ring.next++ % kRecordSlots;
-            if (ring.used[k])
-                err = hipEventSynchronize(ring.done[k]); // (the launch that read this slot sixteen launches ago)
-            if (err == hipSuccess)
-            {
-                ring.host[k].sc = sc, ring.host[k].job = job;
-                err = hipMemcpyAsync(ring.device + k, ring.host + k, sizeof(LaunchRecords), hipMemcpyHostToDevice, stream);
-                // (the slot counts as taken from here on, whatever happens next: its event is recorded behind the launch, or — when
-                //  the caller gives up — behind the copy, by the next LaunchRecordsInFlight of this thread)
-                ring.used[k] = true;
-                t_record_event = ring.done[k];
-                where = ring.device + k;
-            }
-        }
-    }
-    if (error)
-        *error = err;
-    return err == hipSuccess ? where : nullptr;
+    static_assert(offsetof(LaunchRecords, job) == (sizeof(DeviceScene) + alignof(RenderJob) - 1) / alignof(RenderJob) * alignof(RenderJob), "two kernel arguments lie like the struct's two members");
+    const uint32_t __attribute__((address_space(4))) *src = (const uint32_t __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+    for (uint32_t i = threadIdx.x; i < sizeof(LaunchRecords) / sizeof(uint32_t); i += blockDim.x)
+        dst[i] = src[i];
 }
 
-void LaunchRecordsInFlight(hipStream_t stream)
+hipError_t StageLaunchRecords(const DeviceScene &sc, const RenderJob &job, hipStream_t stream)
 {
-    if (t_record_event)
-        (void)hipEventRecord(t_record_event, stream);
-    t_record_event = nullptr;
+    if (!job.launch_records)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(stage_records_kernel, dim3(1), dim3(64), 0, stream, sc, job, reinterpret_cast<uint32_t *>(job.launch_records));
+    return hipGetLastError();
 }
 
 // ---- unit kernels (diagnostics / parity tests): one query per lane ----------
@@ -290,6 +239,13 @@ bool PoolBigSupports(const DeviceScene &sc)
     return !sc.integrator.has_masks && sc.integrator.n_pool_nodes != 0 && sc.integrator.n_pool_nodes <= kBigPoolLimit &&
            (MCPT_POOL_QUANT == 0 || (sc.integrator.n_wide_nodes != 0 && sc.integrator.n_wide_nodes <= kBigPoolLimit)) &&
            sc.integrator.n_prims <= kBigPoolLimit && sc.integrator.pool_depth <= kPoolMaxDepth;
+}
+
+// (LaunchRender's own conditions for Launch<kFeatEmitters | kPB [| kS]>, below)
+bool TailSpreadRuns(const DeviceScene &sc, const RenderJob &job)
+{
+    return MCPT_TAIL_SPREAD != 0 && !job.reference_walk && !sc.integrator.has_masks && job.pool_walk >= 1 && StagedBytes(sc, true) > kLdsGeometryBytes && PoolBigSupports(sc) &&
+           (sc.features & ~uint32_t(kFeatEmitters)) == 0;
 }
 
 hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,

@@ -260,9 +260,59 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     uint32_t my_lg = 0; // log2 of the lanes per path this lane's pixel was handed out with
     if ((levels || bands) && q < n_work)
         q = kFetchNext;
+    // a path's state as words (the events' exchange through LDS, the market's records in device memory): 32 words, 48 with the pending
+    // shadow ray of merged queries
+    constexpr uint32_t kStateWords = kCompactWords * kEventPasses;
+    auto pack_path = [&](uint32_t *in) __attribute__((always_inline))
+    {
+        in[0] = st.rng, in[1] = st.pixel, in[2] = st.sample, in[3] = st.depth;
+        in[4] = (st.alive ? 1u : 0u) | (st.primary ? 2u : 0u) | (st.in_medium ? 4u : 0u) | (has_pixel ? 8u : 0u) | (pend.shadow ? 16u : 0u) | (pend.finish ? 32u : 0u) | (my_lg << 8);
+        in[5] = st.medium;
+        in[6] = as_uint(st.pdf_sample);
+        auto put = [&](uint32_t at, V3 v) { in[at] = as_uint(v.x), in[at + 1] = as_uint(v.y), in[at + 2] = as_uint(v.z); };
+        put(7, st.origin), put(10, st.dir), put(13, st.wo), put(16, st.wi), put(19, st.throughput), put(22, st.L), put(25, st.pixel_sum);
+        in[28] = slot, in[29] = q, in[30] = 0, in[31] = 0;
+        if constexpr (kEventPasses > kCompactPasses)
+        {
+            // (merged queries: the vertex's pending shadow ray and what the sample gains with either answer travel with the path)
+            put(30, pend.origin), put(33, pend.dir), in[36] = as_uint(pend.t_max);
+            put(37, pend.add_visible), put(40, pend.add_occluded), put(43, pend.old_L);
+            in[46] = 0, in[47] = 0;
+        }
+    };
+    auto unpack_path = [&](const uint32_t *got) __attribute__((always_inline))
+    {
+        st.rng = got[0], st.pixel = got[1], st.sample = got[2], st.depth = got[3];
+        st.alive = (got[4] & 1u) != 0, st.primary = (got[4] & 2u) != 0, st.in_medium = (got[4] & 4u) != 0;
+        has_pixel = (got[4] & 8u) != 0;
+        st.medium = got[5], st.pdf_sample = as_float(got[6]);
+        auto get = [&](uint32_t at) { return V3{as_float(got[at]), as_float(got[at + 1]), as_float(got[at + 2])}; };
+        st.origin = get(7), st.dir = get(10), st.wo = get(13), st.wi = get(16), st.throughput = get(19), st.L = get(22);
+        st.pixel_sum = get(25);
+        slot = got[28], q = got[29];
+        if constexpr (kEventPasses > kCompactPasses)
+        {
+            pend.shadow = (got[4] & 16u) != 0, pend.finish = (got[4] & 32u) != 0;
+            pend.origin = get(30), pend.dir = get(33), pend.t_max = as_float(got[36]);
+            pend.add_visible = get(37), pend.add_occluded = get(40), pend.old_L = get(43);
+        }
+        my_lg = (got[4] >> 8) & 3u;
+    };
+    // PATH MARKET (RenderJob::market; kernels with the tail spread): what the tail spread does inside a workgroup, between workgroups.
+    uint32_t *const market = kTailSpread && events_on ? job.market : nullptr;
+    bool market_mode = false, have_ticket = false, finished_item = false; // (this wavefront's workgroup is done: it waits for paths; its ticket; an item ended on this lane)
+    uint32_t ticket = 0, rounds = 0, backoff = 1;
     for (;;)
     {
         MCPT_WAVE_CONVERGE();
+        if (kTailSpread && market != nullptr)
+        {
+            // (items finished since the last time here: the count a waiting wavefront leaves by)
+            const unsigned long long fin = __ballot(finished_item);
+            finished_item = false;
+            if (fin != 0 && pool_rank(fin) == 0 && (fin >> (threadIdx.x & 63u)) & 1ull)
+                atomicAdd(&market[64], static_cast<uint32_t>(__popcll(fin)));
+        }
         // WORK COUNTER: a lane that needs a new item takes the first one nobody has taken yet — NOW, when it is free, not ahead
         // of time.  (Rounds 2-4 reserved a lane's next item when it STARTED the current one, to hide the atomic's latency: every
         // lane then held one item hostage while it worked on another — at the end of a frame the items waiting behind the longest
@@ -294,7 +344,55 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
         }
         // (pool walk: a lane without work of its own stays in the loop as a HELPER of its wavefront's ray queries)
         bool helper = false;
-        if (kEventsBuilt && events_on)
+        if (kTailSpread && market_mode)
+        {
+            // ---- this wavefront's workgroup is done: it runs paths other wavefronts give away, one at a time, on its first lane ----
+            if (__ballot(has_pixel) == 0)
+            {
+                if (!have_ticket)
+                {
+                    uint32_t t = 0;
+                    if ((threadIdx.x & 63u) == 0)
+                        t = atomicAdd(&market[0], 1u);
+                    ticket = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(t))), have_ticket = true;
+                }
+                const uint32_t at = ticket & (kMarketSlots - 1u), generation = ticket / kMarketSlots + 1u;
+                // (wavefront-uniform decisions from ONE lane's loads: the lanes' own loads may see different moments)
+                auto uniform_load = [&](uint32_t *word, int order) __attribute__((always_inline))
+                {
+                    uint32_t v = 0;
+                    if ((threadIdx.x & 63u) == 0)
+                        v = order == __ATOMIC_ACQUIRE ? __hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v)));
+                };
+                if (uniform_load(&market[kMarketReadyAt + at], __ATOMIC_ACQUIRE) == generation)
+                {
+                    have_ticket = false, backoff = 1;
+                    if ((threadIdx.x & 63u) == 0)
+                    {
+                        uint32_t got[kStateWords];
+#pragma unroll
+                        for (uint32_t k = 0; k < kStateWords; ++k) // (through L2: the vector cache may hold an older record of this slot)
+                            got[k] = __hip_atomic_load(&market[kMarketRecordsAt + kMarketRecord * at + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        unpack_path(got);
+                        retired = false;
+                    }
+                }
+                else
+                {
+                    if (uniform_load(&market[64], __ATOMIC_RELAXED) >= n_work)
+                        break; // every item of the job is finished: nothing will be given away any more
+                    // (3 000 waiting wavefronts that ask every 3 us keep one L2 channel busy with nothing else — measured: the frame
+                    //  THREE times as long; a path that waits 100 us for its wavefront loses nothing against a tail of 20 ms)
+                    for (uint32_t i = 0; i < backoff; ++i)
+                        __builtin_amdgcn_s_sleep(127);
+                    backoff = backoff < 32u ? backoff * 2u : 32u;
+                    continue;
+                }
+            }
+            helper = !has_pixel;
+        }
+        else if (kEventsBuilt && events_on)
         {
             // (one LDS word each, read by every lane of the wavefront in the same instruction: uniform — and said so, the lockstep host
             //  build of this body, tests/emu, runs a wavefront's lanes one after the other between cross-lane operations)
@@ -310,7 +408,14 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
             // (every wavefront takes part in every event, also the ones that fall due together with the end: a
             //  wavefront that left early would leave the others waiting at the event's barriers)
             if (n_retired >= kBlockSize && compact_events == kEvents)
+            {
+                if (kTailSpread && market != nullptr)
+                {
+                    market_mode = true; // the workgroup is done: its wavefronts wait for other workgroups' paths
+                    continue;
+                }
                 break; // the workgroup is done
+            }
             if (compact_events < kEvents && n_retired >= event_at(compact_events))
             {
                 // ---- event: every wavefront of the workgroup comes here once per threshold, in the same order ----
@@ -336,22 +441,9 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
                 const uint32_t place = before + rank_in_wave;
                 const uint32_t dst = kTailSpread ? (place & 3u) * 64u + (place >> 2) : place;
                 const uint32_t mine = kTailSpread ? (threadIdx.x & 63u) * 4u + (threadIdx.x >> 6) : threadIdx.x; // the place whose path this lane receives
-                uint32_t in[kCompactWords * kEventPasses], got[kCompactWords * kEventPasses];
-                in[0] = st.rng, in[1] = st.pixel, in[2] = st.sample, in[3] = st.depth;
-                in[4] = (st.alive ? 1u : 0u) | (st.primary ? 2u : 0u) | (st.in_medium ? 4u : 0u) | (has_pixel ? 8u : 0u) | (pend.shadow ? 16u : 0u) | (pend.finish ? 32u : 0u) | (my_lg << 8);
-                in[5] = st.medium;
-                in[6] = as_uint(st.pdf_sample);
-                auto put = [&](uint32_t at, V3 v) { in[at] = as_uint(v.x), in[at + 1] = as_uint(v.y), in[at + 2] = as_uint(v.z); };
-                put(7, st.origin), put(10, st.dir), put(13, st.wo), put(16, st.wi), put(19, st.throughput), put(22, st.L), put(25, st.pixel_sum);
-                in[28] = slot, in[29] = q, in[30] = 0, in[31] = 0;
+                uint32_t in[kStateWords], got[kStateWords];
+                pack_path(in);
                 static_assert(!(kCompact && C::kPoolDual), "the compaction does not carry a pending shadow ray");
-                if constexpr (kEventPasses > kCompactPasses)
-                {
-                    // (merged queries: the vertex's pending shadow ray and what the sample gains with either answer travel with the path)
-                    put(30, pend.origin), put(33, pend.dir), in[36] = as_uint(pend.t_max);
-                    put(37, pend.add_visible), put(40, pend.add_occluded), put(43, pend.old_L);
-                    in[46] = 0, in[47] = 0;
-                }
 #pragma unroll
                 for (uint32_t pass = 0; pass < kEventPasses; ++pass)
                 {
@@ -366,30 +458,73 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
                     __syncthreads();
                 }
                 retired = mine >= total;
-                has_pixel = !retired && (got[4] & 8u) != 0;
                 if (!retired)
-                {
-                    st.rng = got[0], st.pixel = got[1], st.sample = got[2], st.depth = got[3];
-                    st.alive = (got[4] & 1u) != 0, st.primary = (got[4] & 2u) != 0, st.in_medium = (got[4] & 4u) != 0;
-                    st.medium = got[5], st.pdf_sample = as_float(got[6]);
-                    auto get = [&](uint32_t at) { return V3{as_float(got[at]), as_float(got[at + 1]), as_float(got[at + 2])}; };
-                    st.origin = get(7), st.dir = get(10), st.wo = get(13), st.wi = get(16), st.throughput = get(19), st.L = get(22);
-                    st.pixel_sum = get(25);
-                    slot = got[28], q = got[29];
-                    if constexpr (kEventPasses > kCompactPasses)
-                    {
-                        pend.shadow = (got[4] & 16u) != 0, pend.finish = (got[4] & 32u) != 0;
-                        pend.origin = get(30), pend.dir = get(33), pend.t_max = as_float(got[36]);
-                        pend.add_visible = get(37), pend.add_occluded = get(40), pend.old_L = get(43);
-                    }
-                    my_lg = (got[4] >> 8) & 3u;
-                }
+                    unpack_path(got);
                 else
                 {
+                    has_pixel = false;
                     q = n_work;
                     pend.shadow = pend.finish = false;
                 }
                 continue;
+            }
+            // ---- path market, the giving side: a wavefront with two or more paths, while tickets wait ----
+            if (kTailSpread && market != nullptr && (rounds++ & 3u) == 0u)
+            {
+                uint32_t tickets = 0, given = 0;
+                if ((threadIdx.x & 63u) == 0) // (one lane's loads, then uniform: the decision below must be the wavefront's)
+                {
+                    tickets = __hip_atomic_load(&market[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    given = __hip_atomic_load(&market[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                tickets = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(tickets)));
+                given = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(given)));
+                uint32_t n_paths;
+                const bool path = has_pixel && !retired;
+                const uint32_t path_rank = lane_rank_among(path, n_paths);
+                if (tickets > given && n_paths >= 2u)
+                {
+                    // (a ticket means a wavefront was refused by the counter and its whole workgroup ran out: the counter is dry)
+                    if (!dry)
+                        compact_count[5] = 1u;
+                    uint32_t base = 0xFFFFFFFFu, n_give = 0;
+                    if ((threadIdx.x & 63u) == 0)
+                    {
+                        // `given` never passes `tickets`: every record has a wavefront waiting for it
+                        uint32_t expect = given;
+                        for (uint32_t tries = 0; tries < 4u; ++tries)
+                        {
+                            const uint32_t waiting = __hip_atomic_load(&market[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (waiting <= expect)
+                                break;
+                            const uint32_t want_give = n_paths / 2u < waiting - expect ? n_paths / 2u : waiting - expect;
+                            const uint32_t old = atomicCAS(&market[32], expect, expect + want_give);
+                            if (old == expect)
+                            {
+                                base = expect, n_give = want_give;
+                                break;
+                            }
+                            expect = old;
+                        }
+                    }
+                    base = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(base)));
+                    n_give = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(n_give)));
+                    if (n_give != 0 && path && path_rank >= n_paths - n_give)
+                    {
+                        const uint32_t record = base + (path_rank - (n_paths - n_give)), at = record & (kMarketSlots - 1u);
+                        uint32_t in[kStateWords];
+                        pack_path(in);
+#pragma unroll
+                        for (uint32_t k = 0; k < kStateWords; ++k)
+                            market[kMarketRecordsAt + kMarketRecord * at + k] = in[k];
+                        __threadfence();
+                        __hip_atomic_store(&market[kMarketReadyAt + at], record / kMarketSlots + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        has_pixel = false, st.alive = false, pend.shadow = pend.finish = false;
+                        q = n_work;
+                        retired = true;
+                        atomicAdd(&compact_count[4], 1u);
+                    }
+                }
             }
             if (lanes_where(!retired) == 0)
             {
@@ -427,7 +562,10 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
             // items 0 .. stride-1), or, without a counter, the next of its fixed list
             q = job.work_counter ? kFetchNext : q + stride;
             if (x >= width || y >= height)
+            {
+                finished_item = true;
                 continue; // padding of an edge tile
+            }
             const uint32_t pixel = y * width + x;
             if (job.wave_clock)
             {
@@ -452,6 +590,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
                 if (job.tile_steps)
                     atomicAdd(&job.tile_steps[my_tile], steps);
                 has_pixel = false;
+                finished_item = true;
                 continue;
             }
             start_sample(sc, st, split, independent, job.rng_seed);
@@ -671,9 +810,10 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
     const dim3 grid(static_cast<uint32_t>(blocks)), block(kBlockSize);
     if constexpr (kByPointer)
     {
-        const LaunchRecords *records = StageLaunchRecords(sc, spread_job, stream, &err);
-        if (!records)
+        err = StageLaunchRecords(sc, spread_job, stream);
+        if (err != hipSuccess)
             return err;
+        const LaunchRecords *records = spread_job.launch_records;
         bool probe = false;
         if constexpr (kProbed)
             probe = job.tile_steps != nullptr;
@@ -687,9 +827,7 @@ hipError_t Launch(const DeviceScene &sc, const RenderJob &job, float *out, Trace
         }
         if (!probe)
             hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, (LaunchRecordsPtr)(records), out, counters);
-        err = hipGetLastError();
-        LaunchRecordsInFlight(stream);
-        return err;
+        return hipGetLastError();
     }
     else
     {

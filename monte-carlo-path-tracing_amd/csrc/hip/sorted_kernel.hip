@@ -58,13 +58,11 @@ static hipError_t LaunchSorted(const DeviceScene &sc, const RenderJob &job, floa
     const dim3 grid(static_cast<uint32_t>(blocks)), block(kBlockSize);
     if constexpr (kSortedByPointer)
     {
-        const LaunchRecords *records = StageLaunchRecords(sc, j, stream, &err);
-        if (!records)
+        err = StageLaunchRecords(sc, j, stream);
+        if (err != hipSuccess)
             return err;
-        hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, (LaunchRecordsPtr)(records), out);
-        err = hipGetLastError();
-        LaunchRecordsInFlight(stream);
-        return err;
+        hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, (LaunchRecordsPtr)(j.launch_records), out);
+        return hipGetLastError();
     }
     else
     {

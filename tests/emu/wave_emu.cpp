@@ -445,6 +445,9 @@ struct BodyArgs
     }
 };
 
+// (the path market's words, RenderJob::market: one array per render call of the calling thread)
+thread_local std::vector<uint32_t> t_market;
+
 RenderJob FilmJob(const DeviceScene &sc, const Options &opt, uint32_t *work_counter)
 {
     for (uint32_t i = 0; i < kBands * kBandStride; ++i)
@@ -456,6 +459,11 @@ RenderJob FilmJob(const DeviceScene &sc, const Options &opt, uint32_t *work_coun
     job.work_counter = work_counter;
     job.lane_spread = opt.lane_spread, job.compact = opt.compact, job.tail_spread = opt.compact /* (one switch for both kinds of event) */, job.scatter = opt.xcd_bands ? 0u : opt.scatter, job.pool_walk = 1;
     job.xcd_bands = opt.xcd_bands;
+    if (opt.compact >= 2) // (2: the tail spread with the path market between workgroups)
+    {
+        t_market.assign(kMarketWords, 0u);
+        job.market = t_market.data();
+    }
     return job;
 }
 

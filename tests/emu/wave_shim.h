@@ -129,7 +129,10 @@ static const ::wave_emu::Index3 gridDim{{::wave_emu::grid_blocks}};
 #define __builtin_amdgcn_wave_barrier() static_cast<void>(::wave_emu::collective(::wave_emu::kWaveBarrier, MCPT_WAVE_SITE, 0))
 #define __builtin_amdgcn_s_sleep(n) static_cast<void>(::wave_emu::collective(::wave_emu::kSleep, 0xFFFFFFF8u, 0))
 #define __syncthreads() static_cast<void>(::wave_emu::collective(::wave_emu::kSyncThreads, MCPT_WAVE_SITE, 0))
-#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_RELAXED)
+// (real acquire / release on the host threads that run the workgroups: the path market's records travel between them)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_ACQUIRE)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_RELEASE)
+#define __threadfence() __atomic_thread_fence(__ATOMIC_SEQ_CST)
 #define __builtin_amdgcn_s_getreg(immediate) (::wave_emu::block_index() & 7u) /* HW_REG_XCC_ID: workgroup b runs on XCD b % 8 */
 #define __HIP_MEMORY_SCOPE_AGENT 0
 
@@ -148,6 +151,11 @@ inline float __uint_as_float(uint32_t u)
 // (workgroups run on several host threads: device-memory atomics are real ones; LDS belongs to one thread)
 inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline uint32_t atomicCAS(uint32_t *p, uint32_t expected, uint32_t desired)
+{
+    __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+    return expected; // (the old value, like the device's)
+}
 inline uint32_t atomicMin(uint32_t *p, uint32_t v)
 {
     uint32_t old = __atomic_load_n(p, __ATOMIC_RELAXED);

@@ -253,12 +253,22 @@ def test_dragon_full_film_equals_the_oracle(pkg, oracle, tmp_path):
     cfg = pkg.workloads.config("dragon", w, h, spp)
     path = str(tmp_path / "dragon.mcsd")
     cfg.save_mcsd(path)
-    frame, stats = _draw(pkg, cfg)
+    r = pkg.capi.Renderer(cfg, device=0)
+    try:
+        frame, stats = r.draw()
+        tickets, given, finished = (int(v) for v in r.table("market"))
+        kernel = r.last_kernel()
+    finally:
+        r.close()
     want, info = oracle.render(path)
-    print("dragon full film", (w, h, spp), "GPU kernel ms", stats["kernel_milliseconds"], "oracle seconds", info["seconds"])
+    print("dragon full film", (w, h, spp), "GPU kernel ms", stats["kernel_milliseconds"], "oracle seconds", info["seconds"], "path market: tickets, records given", tickets, given)
     assert frame.shape == want.shape == (h, w, 3)
     differing = int((frame != want).any(axis=2).sum())
     assert differing == 0, f"{differing} of {w * h} pixels differ, max |diff| {np.abs(frame - want).max()}"
+    # (round 6: this frame's last paths travel — through LDS inside a workgroup, through device memory between workgroups, render_kernel_impl.h
+    #  "TAIL SPREAD" / "PATH MARKET" — and the equality above is the equality of a frame in which thousands of them did)
+    assert "most expensive first" in kernel, kernel
+    assert given > 100 and tickets >= given and finished == ((w + 7) // 8) * ((h + 7) // 8) * 64, (tickets, given, finished)
 
 
 @pytest.mark.gpu

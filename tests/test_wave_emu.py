@@ -133,6 +133,19 @@ def test_tail_spread_deals_the_last_paths_out_and_changes_nothing(lockstep, scen
     assert np.array_equal(frame, golden)
 
 
+@pytest.mark.parametrize("blocks,spread,order", [(2, 0, 0), (4, 2, 2), (3, 0, 2), (4, 4, 1)])
+def test_path_market_between_workgroups_changes_nothing(lockstep, scenes, blocks, spread, order):
+    """RenderJob::market (round 6): the wavefronts of a workgroup that is done take tickets and wait; wavefronts of other workgroups that
+    still hold two or more paths give half of them away — records in device memory, release / acquire on the slot's generation word — and
+    every wavefront leaves when the count of finished items reaches the job's.  Several workgroups on several host threads (real
+    atomics between them); how many paths travel depends on their timing (the GPU side pins a frame in which thousands do:
+    test_dragon_full_film_equals_the_oracle), that the frame is the golden and that everybody leaves does not."""
+    for name, features in (("cornell_64_spp8", W.EMITTERS | W.PB), ("terrain_directional", W.EMITTERS | W.PBU)):
+        frame, golden, info = render(lockstep, scenes, name, features, False, order=order, seed=3, poison=0xFFFFFFFF, compact=2, max_blocks=blocks, lane_spread=spread, threads=blocks)  # (one host thread per workgroup: a waiting workgroup needs the others to run)
+        assert info["blocks"] == blocks
+        assert np.array_equal(frame, golden)
+
+
 @pytest.mark.parametrize("name,features", BIG, ids=[f"{n}-{f:#x}" for n, f in BIG])
 def test_pool_walk_kernels_outside_lds_equal_the_golden(lockstep, scenes, name, features):
     """32-bit items, the quantised 4-wide hierarchy, the leaf-box test at the primitive, merged (kPB) and unmerged (kPBU) queries,
