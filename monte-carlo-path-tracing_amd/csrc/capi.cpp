@@ -861,7 +861,9 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
             return e ? std::atoi(e) : 1;
         }();
         job.compact = compact != 0 ? 1u : 0u;
-        job.tail_spread = compact != 0 ? 1u : 0u; // (the same events the other way round, kernels outside LDS: RenderJob::tail_spread)
+        // (the same events the other way round, kernels outside LDS: RenderJob::tail_spread — the reference's stream only: the independent-
+        //  sample modes cut a pixel's chain into short items, there is no tail to spread, and the events cost dragon's throughput mode 6 %)
+        job.tail_spread = compact != 0 && r->rng_mode == 0 ? 1u : 0u;
         static const int sort_classes = []
         {
             const char *e = mcpt::MeasurementEnv("MCPT_SORT"); // (measurements: 0 = render_kernel instead of the class-sorted kernel)

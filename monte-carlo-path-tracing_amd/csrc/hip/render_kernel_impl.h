@@ -223,6 +223,11 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     // (they sit at their 128-register limit, and their tails are what lanes per path by tile cost is for): not there (EXPERIMENTS R6-13).
     constexpr bool kTailSpread = MCPT_TAIL_SPREAD != 0 && C::kPool && C::kPoolBig && !kLdsGeometry && !kCount &&
                                  (kFeatures & (kFeatVolPath | kFeatAnalytic | kFeatMicrofacet | kFeatTextures)) == 0;
+    // (-DMCPT_LDS_MARKET=1, experiment builds: the LDS kernels with the compaction take part in the path market too)
+#ifndef MCPT_LDS_MARKET
+#define MCPT_LDS_MARKET 0
+#endif
+    constexpr bool kMarket = kTailSpread || (kCompact && C::kPool && MCPT_LDS_MARKET != 0);
     constexpr bool kEventsBuilt = kCompact || kTailSpread;
     constexpr uint32_t kEvents = kTailSpread ? 5u : kBlockSize / 64u - 1u;
     // (event k falls due when this many lanes of the workgroup have retired)
@@ -299,13 +304,13 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
         my_lg = (got[4] >> 8) & 3u;
     };
     // PATH MARKET (RenderJob::market; kernels with the tail spread): what the tail spread does inside a workgroup, between workgroups.
-    uint32_t *const market = kTailSpread && events_on ? job.market : nullptr;
+    uint32_t *const market = kMarket && events_on ? job.market : nullptr;
     bool market_mode = false, have_ticket = false, finished_item = false; // (this wavefront's workgroup is done: it waits for paths; its ticket; an item ended on this lane)
     uint32_t ticket = 0, rounds = 0, backoff = 1;
     for (;;)
     {
         MCPT_WAVE_CONVERGE();
-        if (kTailSpread && market != nullptr)
+        if (kMarket && market != nullptr)
         {
             // (items finished since the last time here: the count a waiting wavefront leaves by)
             const unsigned long long fin = __ballot(finished_item);
@@ -344,7 +349,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
         }
         // (pool walk: a lane without work of its own stays in the loop as a HELPER of its wavefront's ray queries)
         bool helper = false;
-        if (kTailSpread && market_mode)
+        if (kMarket && market_mode)
         {
             // ---- this wavefront's workgroup is done: it runs paths other wavefronts give away, one at a time, on its first lane ----
             if (__ballot(has_pixel) == 0)
@@ -409,7 +414,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
             //  wavefront that left early would leave the others waiting at the event's barriers)
             if (n_retired >= kBlockSize && compact_events == kEvents)
             {
-                if (kTailSpread && market != nullptr)
+                if (kMarket && market != nullptr)
                 {
                     market_mode = true; // the workgroup is done: its wavefronts wait for other workgroups' paths
                     continue;
@@ -439,8 +444,18 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
                 // spread: path j goes to wavefront j mod 4, lane j / 4 — which lane of a wavefront carries a path is irrelevant to the
                 // pool walk, every lane is a worker
                 const uint32_t place = before + rank_in_wave;
-                const uint32_t dst = kTailSpread ? (place & 3u) * 64u + (place >> 2) : place;
-                const uint32_t mine = kTailSpread ? (threadIdx.x & 63u) * 4u + (threadIdx.x >> 6) : threadIdx.x; // the place whose path this lane receives
+                // The LDS kernels' events DEAL the paths out too (round 6).  They used to pack them into the workgroup's first wavefronts
+                // (round 3: an instruction of a wavefront with 20 live lanes costs what one with 64 does, +2 % then); since the pool
+                // walk's lanes without a path help their wavefront's queries (round 4) and node steps with few items take 4 / 2 lanes
+                // per item (round 5), four wavefronts with a quarter of the paths each finish them sooner than one full one: cornell
+                // 37.3 (pack) / 37.0 (no events) / 36.9 ms (deal), 16 draws each, same box (EXPERIMENTS R6-15).
+                // -DMCPT_COMPACT_DEALS=<k>: only from the k-th event on (99: always pack).
+#ifndef MCPT_COMPACT_DEALS
+#define MCPT_COMPACT_DEALS 1
+#endif
+                const bool deal = kTailSpread || compact_events >= MCPT_COMPACT_DEALS;
+                const uint32_t dst = deal ? (place & 3u) * 64u + (place >> 2) : place;
+                const uint32_t mine = deal ? (threadIdx.x & 63u) * 4u + (threadIdx.x >> 6) : threadIdx.x; // the place whose path this lane receives
                 uint32_t in[kStateWords], got[kStateWords];
                 pack_path(in);
                 static_assert(!(kCompact && C::kPoolDual), "the compaction does not carry a pending shadow ray");
@@ -469,7 +484,7 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
                 continue;
             }
             // ---- path market, the giving side: a wavefront with two or more paths, while tickets wait ----
-            if (kTailSpread && market != nullptr && (rounds++ & 3u) == 0u)
+            if (kMarket && market != nullptr && (rounds++ & 3u) == 0u)
             {
                 uint32_t tickets = 0, given = 0;
                 if ((threadIdx.x & 63u) == 0) // (one lane's loads, then uniform: the decision below must be the wavefront's)
