@@ -115,7 +115,9 @@ int mcpt_renderer_draw(mcpt_renderer *r, float *frame, mcpt_stats *stats);
  *                floats per tile (pixels outside the image are left untouched).
  * The FIRST draw of a tile range waits on `stream` once or twice even with blocking == 0: it reads the range's statistics
  * (camera-ray hits of the pre-pass, the 2-spp cost probe: mcpt_renderer_set_tile_order, _set_stream_waves) to the host, lays
- * the tiles out and keeps the result; later draws of the same range only enqueue. */
+ * the tiles out and keeps the result; later draws of the same range only enqueue.
+ * The draws of ONE renderer are ordered — enqueue them on one stream at a time: its work counter, the records of the launch in
+ * flight and its path market belong to that launch.  Different renderers may draw at the same time, also on one device. */
 int mcpt_renderer_draw_device(mcpt_renderer *r, float *out_device, const mcpt_tile_range *range,
                               int packed, void *stream, int blocking, mcpt_stats *stats);
 

@@ -86,8 +86,8 @@ struct RenderJob
     // Only with the work counter; packed output keeps the image-order layout.
     const unsigned long long *tile_order;
     // Lane-owns-a-path kernel on LDS-resident scenes: 1 = once the items are handed out, the paths still in flight are
-    // moved into the first wavefronts of their workgroup whenever another 64 of its lanes have retired
-    // (render_kernel_impl.h, "COMPACTION").  The image does not depend on it.
+    // dealt out over the four wavefronts of their workgroup (rounds 3-5: packed into its first ones) whenever another 64 of its
+    // lanes have retired (render_kernel_impl.h, "EVENTS OF A THINNING WORKGROUP").  The image does not depend on it.
     uint32_t compact;
     // Pool-walk kernels OUTSIDE LDS with the work counter (round 6): 1 = once the counter is dry, the paths a workgroup still holds are
     // dealt out evenly over its four wavefronts whenever few enough of them are left (render_kernel_impl.h, "TAIL SPREAD"): a frame
@@ -99,7 +99,8 @@ struct RenderJob
     // that still holds two or more paths after the counter ran dry gives half of them (at most one per waiting ticket) away — state
     // and pending shadow ray through device memory — so that the frame's last paths run one per wavefront, with 63 helper lanes each,
     // on ALL wavefronts of the GPU instead of 32 per wavefront on a few dozen (render_kernel_impl.h, "PATH MARKET").  Words: [0] tickets
-    // taken, [32] records given, [64] items of the job finished (a waiting wavefront leaves when that reaches the job's items),
+    // taken, [32] records given, [64] items of the job finished (a waiting wavefront leaves when that reaches the job's items), [96] workgroups of the launch that
+    // have started (a wavefront waits only when that is all of them: nobody waits for a workgroup that is not resident),
     // [128 + s] generation of slot s, records of 48 words behind them.  The image does not depend on it.
     uint32_t *market;
     // Device memory for the records of a launch (the kernels that read the scene and the job through a pointer: LaunchRecords below,

@@ -200,15 +200,15 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     bool has_pixel = false;
     uint32_t slot = 0; // where this pixel's result goes
     uint32_t steps = 0, my_tile = 0; // cost probe (RenderJob::tile_steps)
-    // COMPACTION (LDS-resident scenes: the kernel is VALU-issue bound there, and an instruction of a wavefront with 20
-    // live lanes costs what one with 64 does).  Once the job's items are handed out, a lane whose pixel is finished has
-    // nothing left to do, and its wavefront thins out while the SIMD's issue slots stay taken.  Whenever another 64 lanes
-    // of the workgroup have retired, the paths still in flight move — through LDS, state word by state word — into the
-    // first wavefronts of the workgroup, which are full again, and the emptied wavefront only sleeps until the next such
-    // event.  A path's state is all that makes its pixel (RNG, sample counter, ray, sums): which lane carries it is
-    // irrelevant, the frame is unchanged.
-    // (measured: cornell 1074 -> 1098 Msamples/s; the full-feature instantiation — volumetric-caustic, 3 wavefronts per
-    //  SIMD, 3.5 pixels per lane from the work counter — 1012 -> 1007, so not there)
+    // EVENTS OF A THINNING WORKGROUP ("COMPACTION": LDS-resident scenes).  Once the job's items are handed out, a lane whose pixel is
+    // finished has nothing left to do.  Whenever another 64 lanes of the workgroup have retired, its four wavefronts meet at a barrier
+    // and the paths still in flight move — through LDS, state word by state word.  Round 3 PACKED them into the first wavefronts of the
+    // workgroup (the kernel is VALU-issue bound, an instruction of a wavefront with 20 live lanes costs what one with 64 does: cornell
+    // 1074 -> 1098 Msamples/s then); since the pool walk's lanes without a path help their wavefront's queries and node steps with few
+    // items take 4 / 2 lanes per item, the opposite wins and the events DEAL the paths out (below, MCPT_COMPACT_DEALS: cornell 37.3 ->
+    // 36.9 ms).  A path's state is all that makes its pixel (RNG, sample counter, ray, sums): which lane carries it is irrelevant,
+    // the frame is unchanged.
+    // (the full-feature instantiation — volumetric-caustic, 3.5 pixels per lane from the work counter — 1012 -> 1007 with packing: not there)
     constexpr bool kCompact = kLdsGeometry && !kCount && C::kOrdered && !(C::kVolPath || C::kAnalytic) && !C::kPoolDual; // (the compaction carries no pending shadow ray)
     // TAIL SPREAD (round 6; pool-walk kernels outside LDS with the work counter: RenderJob::tail_spread).  The same events, the other
     // way round.  dragon/scene.xml's frame ends on a few dozen wavefronts that hold 32 paths of its most expensive tiles each — a tile
@@ -305,6 +305,8 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     };
     // PATH MARKET (RenderJob::market; kernels with the tail spread): what the tail spread does inside a workgroup, between workgroups.
     uint32_t *const market = kMarket && events_on ? job.market : nullptr;
+    if (kMarket && market != nullptr && threadIdx.x == 0)
+        atomicAdd(&market[96], 1u); // workgroups of this launch that have started (see where a wavefront decides to wait)
     bool market_mode = false, have_ticket = false, finished_item = false; // (this wavefront's workgroup is done: it waits for paths; its ticket; an item ended on this lane)
     uint32_t ticket = 0, rounds = 0, backoff = 1;
     for (;;)
@@ -416,7 +418,16 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
             {
                 if (kMarket && market != nullptr)
                 {
-                    market_mode = true; // the workgroup is done: its wavefronts wait for other workgroups' paths
+                    // the workgroup is done: its wavefronts wait for other workgroups' paths — IF every workgroup of the launch has
+                    // started.  A wavefront that waits holds its slot until the job's last item is finished; were some workgroups
+                    // not resident yet (another kernel on the device: a second renderer, another process), they would wait for the
+                    // slots of wavefronts that wait for them.  Then it leaves, like before the market existed.
+                    uint32_t started = 0;
+                    if ((threadIdx.x & 63u) == 0)
+                        started = __hip_atomic_load(&market[96], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(started))) != gridDim.x)
+                        break;
+                    market_mode = true;
                     continue;
                 }
                 break; // the workgroup is done

@@ -271,6 +271,52 @@ def test_dragon_full_film_equals_the_oracle(pkg, oracle, tmp_path):
     assert given > 100 and tickets >= given and finished == ((w + 7) // 8) * ((h + 7) // 8) * 64, (tickets, given, finished)
 
 
+_CONCURRENT_SCRIPT = r"""
+import hashlib, json, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+from _pkg import load_package
+pkg = load_package()
+w, h, spp = 1280, 720, 8
+cfg = pkg.workloads.config("dragon", w, h, spp)
+rs = [pkg.capi.Renderer(cfg, device=0) for _ in range(2)]
+plain, _ = rs[0].draw()
+streams = [torch.cuda.Stream() for _ in rs]
+bufs = [torch.zeros(w * h * 3, dtype=torch.float32, device="cuda:0") for _ in rs]
+for r, s, b in zip(rs, streams, bufs):   # (the first draw of a tile range reads its statistics back: not part of the overlap)
+    r.draw_device(b.data_ptr(), None, packed=False, stream=s.cuda_stream, blocking=True)
+given = []
+for rounds in range(3):
+    for b in bufs:
+        b.zero_()
+    torch.cuda.synchronize()
+    for r, s, b in zip(rs, streams, bufs):
+        r.draw_device(b.data_ptr(), None, packed=False, stream=s.cuda_stream, blocking=False)
+    torch.cuda.synchronize()
+    frames = [b.cpu().numpy().reshape(h, w, 3) for b in bufs]
+    given.append([int(r.table("market")[1]) for r in rs])
+    assert all((f == plain).all() for f in frames), "a frame of two concurrent launches differs from the single launch's"
+print(json.dumps({"records_given": given, "kernel": rs[0].last_kernel()}))
+"""
+
+
+@pytest.mark.gpu
+def test_two_renderers_at_once_neither_waits_for_the_other(pkg):
+    """Two renderers of dragon/scene.xml's class draw AT THE SAME TIME on two streams of one device: each launch is sized for the whole
+    GPU, so neither has all its workgroups resident — and a wavefront of the path market waits (holding its slot) only when every
+    workgroup of its launch has started (RenderJob::market[96], render_kernel_impl.h).  Both frames equal the single launch's, three
+    times; in a subprocess with a time limit (what this guards against is a launch that never ends)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _CONCURRENT_SCRIPT, root], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    print(out)
+    assert "pool-walk" in out["kernel"] and len(out["records_given"]) == 3
+
+
 @pytest.mark.gpu
 def test_walk_check_at_renderer_creation(pkg):
     """MCPT_CHECK_WALKS=<spp>: mcpt_renderer_create renders the film with both walks and reports on stderr; the renderer

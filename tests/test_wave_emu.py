@@ -146,6 +146,16 @@ def test_path_market_between_workgroups_changes_nothing(lockstep, scenes, blocks
         assert np.array_equal(frame, golden)
 
 
+def test_path_market_does_not_wait_for_workgroups_that_have_not_started(lockstep, scenes):
+    """A wavefront that waits in the market holds its slot until the job's last item is finished: it may only wait when every
+    workgroup of the launch has started (the count in RenderJob::market[96]) — otherwise workgroups that are not resident yet (another
+    kernel on the device) would wait for the slots of wavefronts that wait for them.  Here: three workgroups on ONE host thread, one
+    after the other — a workgroup that waited would wait for ever."""
+    frame, golden, info = render(lockstep, scenes, "cornell_64_spp8", W.EMITTERS | W.PB, False, order=2, seed=9, compact=2, max_blocks=3, lane_spread=0, threads=1)
+    assert info["blocks"] == 3
+    assert np.array_equal(frame, golden)
+
+
 @pytest.mark.parametrize("name,features", BIG, ids=[f"{n}-{f:#x}" for n, f in BIG])
 def test_pool_walk_kernels_outside_lds_equal_the_golden(lockstep, scenes, name, features):
     """32-bit items, the quantised 4-wide hierarchy, the leaf-box test at the primitive, merged (kPB) and unmerged (kPBU) queries,
