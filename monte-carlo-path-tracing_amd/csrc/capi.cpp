@@ -772,6 +772,21 @@ std::vector<unsigned long long> CostOrderedTable(const std::vector<uint32_t> &st
             table[g] = order[quarter * simds + ((quarter & 1u) ? simds - 1u - i : i)];
         }
     }
+    else if (layout == 4)
+    {
+        // LATIN SQUARE (round 6; MCPT_COST_LAYOUT=4 in builds with the measurement hooks.  Measured: cornell 46.7 ms against layout 1's
+        // 36.8 — EXPERIMENTS R6-16): every SIMD still holds one wavefront of each cost quarter — and so does every WORKGROUP: wavefront w
+        // of the s-th workgroup of a CU renders a tile of quarter (w + s) mod 4.  When a workgroup's cheap wavefronts run out of
+        // paths, its events deal the expensive wavefronts' paths out over all four (render_kernel_impl.h): the long chains get
+        // helper lanes from the moment the short ones end, in every workgroup of the GPU alike.
+        for (uint32_t quarter = 0; quarter < 4u; ++quarter)
+            for (uint32_t j = 0; j < simds; ++j)
+            {
+                const uint32_t i = (quarter & 1u) ? simds - 1u - j : j; // (odd quarters reversed: the SIMDs' sums even out)
+                const uint32_t cu = j >> 2, slot = j & 3u, wave = (quarter + 4u - slot) & 3u;
+                table[4u * (cu + slot * n_cus) + wave] = order[quarter * simds + i];
+            }
+    }
     else
     {
         std::vector<unsigned long long> load(simds, 0);
