@@ -1047,7 +1047,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         Check(hipMemsetAsync(r->work_counter_dev, 0, kWorkCounterBytes, stream), "clear work counter");
         job.work_counter = r->work_counter_dev;
         // the path market of the tail spread (RenderJob::market; kernels outside LDS, reference and throughput streams alike)
-        if (job.tail_spread != 0 && !small_scene && !counted)
+        if (job.tail_spread != 0 && !small_scene && !counted && mcpt::TailSpreadRuns(r->dev, job))
         {
             if (!r->market_dev)
                 Check(hipMalloc(reinterpret_cast<void **>(&r->market_dev), mcpt::kMarketWords * sizeof(uint32_t)), "allocate path market");
