@@ -1961,6 +1961,8 @@ int mcpt_build_has_formulations(void) { return mcpt::FormulationsBuilt() ? 1 : 0
 
 // TEST HOOK, not part of include/mcpt.h: the scale of the ordered walk's tie radius for scenes committed from now on (1 = production).
 // tests/test_gpu_parity.py builds a scene that lies outside a shrunken radius to see mcpt_renderer_create's self-check catch it.
+// (Round 5's advisor: a process-wide, unsynchronised value that scales a correctness bound — it must not be called while another thread
+//  creates a renderer, and nothing but that test may call it; it stays in the library because the test drives the PRODUCT's create path.)
 void mcpt_testing_set_walk_tie_scale(float scale) { mcpt::SetWalkTieScaleForTesting(scale); }
 
 int mcpt_renderer_set_walk(mcpt_renderer *r, int reference_order)
