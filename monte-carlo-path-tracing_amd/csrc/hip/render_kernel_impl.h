@@ -625,9 +625,9 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
         }
         phase_mark(kPhaseRegenerate, !helper);
         if constexpr (C::kPoolDual)
-            path_step_merged<C>(sc, st, pend, cnt, !helper && st.alive);
+            path_step_merged<C>(sc, st, pend, cnt, !helper && st.alive, SampleStart{split, independent, job.rng_seed});
         else if constexpr (C::kPool)
-            path_step_uniform<C>(sc, st, cnt, !helper);
+            path_step_uniform<C>(sc, st, cnt, !helper, SampleStart{split, independent, job.rng_seed});
         else
             path_step<C>(sc, st, cnt);
         steps += helper ? 0u : 1u;

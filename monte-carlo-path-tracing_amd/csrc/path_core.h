@@ -895,9 +895,52 @@ __device__ __forceinline__ void path_connect_scatter_uniform(const DeviceScene &
     st.dir = -st.wi;
 }
 
+// THE NEXT SAMPLE IN THE SAME STEP (round 6; scenes with the camera-ray pre-pass).  A sample that ends in path_resolve — its ray left
+// the scene, hit a light, was stopped by the roulette — used to leave its lane idle for the rest of the step (connect, shadow query,
+// scatter: half of a step's instructions) and take the whole next step for its successor's FIRST vertex, whose ray query the
+// pre-pass has already answered.  Here the lane starts its pixel's next sample on the spot — the same random stream, the samples still
+// one after the other — reads the camera ray's hit from the pre-pass, resolves it and joins this step's connect / scatter with its
+// first vertex; a camera ray that misses ends that sample too, and the lane tries the next (kRegenerateRounds per step at most: the
+// other lanes wait meanwhile).  matpreview: the lanes that reach connect / scatter were 36-42 of 64.  Nothing a path computes changes.
+#ifndef MCPT_REGENERATE_ROUNDS
+#define MCPT_REGENERATE_ROUNDS 4
+#endif
+constexpr uint32_t kRegenerateRounds = MCPT_REGENERATE_ROUNDS;
+struct SampleStart // start_sample's arguments (RenderJob: sample_split, independent_samples, rng_seed)
+{
+    uint32_t step;
+    bool independent;
+    uint32_t seed;
+};
+template <class C>
+__device__ __forceinline__ void regenerate_in_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt, bool has_path, const SampleStart &how, Ray &ray, HitRaw &raw, Surface &surf)
+{
+    if (kRegenerateRounds == 0 || sc.prehit == nullptr)
+        return;
+#pragma unroll 1
+    for (uint32_t round = 0; round < kRegenerateRounds; ++round)
+    {
+        const bool again = has_path && !st.alive && st.sample < sc.camera.spp;
+        if (__ballot(again) == 0)
+            break;
+        if (again)
+        {
+            start_sample(sc, st, how.step, how.independent, how.seed);
+            if (cnt)
+                ++cnt->samples;
+            ray = make_ray(st.origin, st.dir);
+            const uint32_t *rec = prehit_record(sc, st.pixel, st.sample - sc.prehit_step); // (path_extend_uniform's "known" branch)
+            const bool hit_valid = rec[0] != kNone;
+            if (hit_valid)
+                hit_from_record<C::kAnalytic>(sc, rec[1], rec[0], ray, raw);
+            path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
+        }
+    }
+}
+
 // One step of every lane of the wavefront; `has_path`: the lane's path is alive (st.alive) — the others only help.
 template <class C>
-__device__ __forceinline__ void path_step_uniform(const DeviceScene &sc, PathState &st, LaneCounters *cnt, bool has_path)
+__device__ __forceinline__ void path_step_uniform(const DeviceScene &sc, PathState &st, LaneCounters *cnt, bool has_path, const SampleStart &how = SampleStart{1u, false, 0u})
 {
     static_assert(C::kOrdered, "ordered walk");
     Ray ray;
@@ -909,6 +952,7 @@ __device__ __forceinline__ void path_step_uniform(const DeviceScene &sc, PathSta
     surf.position = surf.normal = surf.tangent = surf.bitangent = V3{0, 0, 0};
     if (has_path)
         path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
+    regenerate_in_step<C>(sc, st, cnt, has_path, how, ray, raw, surf);
     phase_mark(kPhaseResolve, has_path && st.alive);
     path_connect_scatter_uniform<C>(sc, st, cnt, surf, has_path && st.alive);
     phase_mark(kPhaseScatter, has_path && st.alive);
@@ -1030,7 +1074,7 @@ __device__ __forceinline__ void connect_lights_merged(const DeviceScene &sc, uin
 // One step of every lane of the wavefront with merged queries.  `has_path`: the lane's path is alive; a lane may also only have a
 // pending shadow ray (its sample's path ended at the last vertex), or nothing (a helper of the others' rays).
 template <class C>
-__device__ __forceinline__ void path_step_merged(const DeviceScene &sc, PathState &st, PendingShadow &pd, LaneCounters *cnt, bool has_path)
+__device__ __forceinline__ void path_step_merged(const DeviceScene &sc, PathState &st, PendingShadow &pd, LaneCounters *cnt, bool has_path, const SampleStart &how = SampleStart{1u, false, 0u})
 {
     static_assert(C::kOrdered && C::kPoolDual, "merged queries run on the pool walk");
     // ---- the walk: this segment's closest query + the last vertex's pending shadow query ----
@@ -1079,6 +1123,7 @@ __device__ __forceinline__ void path_step_merged(const DeviceScene &sc, PathStat
     surf.position = surf.normal = surf.tangent = surf.bitangent = V3{0, 0, 0};
     if (has_path)
         path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
+    regenerate_in_step<C>(sc, st, cnt, has_path, how, ray, raw, surf); // (the pending ray above has been answered: nothing of the ended sample is open)
     const bool active = has_path && st.alive;
     phase_mark(kPhaseResolve, active);
     connect_lights_merged<C>(sc, st.stack, active, surf, surf.position, st.wo, st.throughput, st.rng, st.L, pd, cnt);
