@@ -1250,7 +1250,14 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
         // first by the same probe (longest-processing-time order): 1280 x 720 spp 1024, one box, 922 / 929 -> 914 / 911 ms, first
         // draw unchanged.
         const bool many_pixels = uint64_t(job.n_items) > uint64_t(r->n_cus) * 1024u && dynamic_work;
-        if (cost_order > 0 && r->tile_order_mode != 0 && r->pixel_order < 0 && small_scene && !counted && !prepass && job.sample_split <= 1 &&
+        // (MCPT_LDS_PREPASS_LAYOUT=1 in builds with the measurement hooks: the layout also when mcpt_renderer_set_prepass(r, 1) switched the
+        //  pre-pass on for an LDS-resident scene — EXPERIMENTS R6-17's question whether the next sample in the same step pays for it)
+        static const bool layout_with_prepass = []
+        {
+            const char *e = mcpt::MeasurementEnv("MCPT_LDS_PREPASS_LAYOUT");
+            return e != nullptr && std::atoi(e) != 0;
+        }();
+        if (cost_order > 0 && r->tile_order_mode != 0 && r->pixel_order < 0 && small_scene && !counted && (!prepass || layout_with_prepass) && job.sample_split <= 1 &&
             n_tiles > 1 && r->rng_mode == 0 && !job.reference_walk && ((one_pixel_per_lane && probed_class) || many_pixels))
         {
             if (n_tiles > r->tile_keys_capacity || n_tiles > r->tile_steps_capacity)
@@ -1277,6 +1284,7 @@ void Draw(mcpt_renderer *r, float *out_device, const mcpt_tile_range &range, boo
                     return e ? static_cast<uint32_t>(std::max(1, std::atoi(e))) : 2u;
                 }();
                 mcpt::DeviceScene probe = r->dev;
+                probe.prehit = nullptr; // (the pre-pass's records are laid out for the draw's spp)
                 probe.camera.spp = std::min(probe.camera.spp, probe_spp);
                 probe.camera.spp_inv = 1.0f / static_cast<float>(probe.camera.spp);
                 mcpt::RenderJob pj = job;
