@@ -457,9 +457,10 @@ RenderJob FilmJob(const DeviceScene &sc, const Options &opt, uint32_t *work_coun
     RenderJob job{};
     job.n_items = tiles_x * tiles_y * 64u, job.tile_first = 0, job.tile_stride = 1, job.tiles_x = tiles_x;
     job.work_counter = work_counter;
-    job.lane_spread = opt.lane_spread, job.compact = opt.compact, job.tail_spread = opt.compact /* (one switch for both kinds of event) */, job.scatter = opt.xcd_bands ? 0u : opt.scatter, job.pool_walk = 1;
+    const uint32_t events = opt.compact & 3u; // (bit 2 of the option: the camera-ray pre-pass, WithPrepass below)
+    job.lane_spread = opt.lane_spread, job.compact = events, job.tail_spread = events /* (one switch for both kinds of event) */, job.scatter = opt.xcd_bands ? 0u : opt.scatter, job.pool_walk = 1;
     job.xcd_bands = opt.xcd_bands;
-    if (opt.compact >= 2) // (2: the tail spread with the path market between workgroups)
+    if (events >= 2) // (2: the tail spread with the path market between workgroups)
     {
         t_market.assign(kMarketWords, 0u);
         job.market = t_market.data();
@@ -469,9 +470,44 @@ RenderJob FilmJob(const DeviceScene &sc, const Options &opt, uint32_t *work_coun
 
 void RunGrid(void (*body)(void *), void *body_arg, uint32_t n_lanes, uint64_t blocks, size_t lds_bytes, const RenderJob &shaped, const Options &opt, Report *report);
 
-template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
-void RenderGrid(const DeviceScene &sc, const Options &opt, float *frame, TraceCounters *counters, Report *report)
+// The camera-ray PRE-PASS on the host (hip/primary_kernel.hip's table, DeviceScene::prehit): the closest hit of every (pixel, sample)'s
+// camera ray by the per-lane ordered walk — so that the lockstep build runs what the kernels do with it: samples that start at their
+// first vertex, and the next sample in the same step (path_core.h regenerate_in_step).
+thread_local std::vector<uint32_t> t_prehit;
+DeviceScene WithPrepass(const DeviceScene &sc_in)
 {
+    DeviceScene sc = sc_in;
+    const uint32_t width = static_cast<uint32_t>(sc.camera.width), height = static_cast<uint32_t>(sc.camera.height), spp = sc.camera.spp;
+    const uint32_t tiles_x = (width + 7u) / 8u, tiles_y = (height + 7u) / 8u;
+    t_prehit.assign(size_t(2) * tiles_x * tiles_y * 64u * spp, 0u);
+    for (uint32_t item = 0; item < tiles_x * tiles_y * 64u; ++item)
+    {
+        const uint32_t tile = item >> 6, r = item & 63u, x = (tile % tiles_x) * 8u + (r & 7u), y = (tile / tiles_x) * 8u + (r >> 3);
+        if (x >= width || y >= height)
+            continue;
+        for (uint32_t s = 0; s < spp; ++s)
+        {
+            PathState st{};
+            st.pixel = y * width + x, st.sample = s;
+            start_sample(sc, st);
+            Ray ray = make_ray(st.origin, st.dir);
+            HitRaw hit;
+            hit.inst = hit.prim = 0, hit.a = hit.b = hit.c = 0.0f, hit.inside = false;
+            TraceStats ts{0, 0, 0, 0};
+            uint32_t stack[kWalkStackMax];
+            const bool found = walk_ordered<false, true, false, true, 1u>(sc, stack, ray, hit, ts);
+            uint32_t *rec = t_prehit.data() + 2 * (size_t(item) * spp + s);
+            rec[0] = found ? hit.prim : kNone, rec[1] = found ? hit.inst : 0u;
+        }
+    }
+    sc.prehit = t_prehit.data(), sc.prehit_step = 1, sc.prehit_tile_first = 0, sc.prehit_tile_stride = 1, sc.prehit_tiles_x = tiles_x;
+    return sc;
+}
+
+template <uint32_t kFeatures, bool kCount, bool kLdsGeometry>
+void RenderGrid(const DeviceScene &sc_in, const Options &opt, float *frame, TraceCounters *counters, Report *report)
+{
+    const DeviceScene sc = (opt.compact & 4u) ? WithPrepass(sc_in) : sc_in;
     uint32_t work_counter[kBands * kBandStride];
     const RenderJob job = FilmJob(sc, opt, work_counter);
     RenderJob shaped;
