@@ -912,28 +912,70 @@ struct SampleStart // start_sample's arguments (RenderJob: sample_split, indepen
     bool independent;
     uint32_t seed;
 };
+// path_resolve for every lane of the step, with the regeneration above around it:
+//   1. lanes whose ray found NOTHING are resolved first — no surface frame to build: the escape's radiance, the sample ends (or stands at a
+//      medium vertex) — and start their next sample, whose camera ray the pre-pass has answered; again while that one misses too;
+//   2. ONE path_resolve for all lanes that stand at a hit — the surface frames (a triangle's: 36 floats from memory) built once, with
+//      the regenerated lanes among them (phase clock, matpreview: that phase ran twice a step at 30 of 64 lanes and was 15 % of the time);
+//   3. lanes that ended THERE (a light, a back face, the roulette) start their next sample and resolve it, as before.
 template <class C>
-__device__ __forceinline__ void regenerate_in_step(const DeviceScene &sc, PathState &st, LaneCounters *cnt, bool has_path, const SampleStart &how, Ray &ray, HitRaw &raw, Surface &surf)
+__device__ __forceinline__ void resolve_and_regenerate(const DeviceScene &sc, PathState &st, LaneCounters *cnt, bool has_path, const SampleStart &how, Ray &ray, HitRaw &raw,
+                                                       bool hit_valid, Surface &surf)
 {
-    if (kRegenerateRounds == 0 || sc.prehit == nullptr)
-        return;
-#pragma unroll 1
-    for (uint32_t round = 0; round < kRegenerateRounds; ++round)
+    const bool regenerate = kRegenerateRounds != 0 && sc.prehit != nullptr; // (uniform)
+    // Step 1 only in the diffuse instantiations (dragon/scene.xml's class: three quarters of its camera rays miss, and a miss costs a
+    // constant): dragon 92.7 -> 90.3 ms.  The surface-material instantiations lose with it — matpreview 374.7 -> 379.3, 639.8 -> 652.4 ms:
+    // their escapes are environment-map lookups, and those first, then the frames, is two latency chains one after the other where one
+    // diverged path_resolve overlaps them (EXPERIMENTS R6-17).
+    constexpr bool kEscapedFirst = !C::kMicrofacet && !C::kTextures;
+    bool resolved = !has_path;
+    auto next_sample = [&]() __attribute__((always_inline))
     {
-        const bool again = has_path && !st.alive && st.sample < sc.camera.spp;
-        if (__ballot(again) == 0)
-            break;
-        if (again)
+        start_sample(sc, st, how.step, how.independent, how.seed);
+        if (cnt)
+            ++cnt->samples;
+        ray = make_ray(st.origin, st.dir);
+        const uint32_t *rec = prehit_record(sc, st.pixel, st.sample - sc.prehit_step); // (path_extend_uniform's "known" branch)
+        hit_valid = rec[0] != kNone;
+        if (hit_valid)
+            hit_from_record<C::kAnalytic>(sc, rec[1], rec[0], ray, raw);
+        resolved = false;
+    };
+    if (kEscapedFirst && regenerate)
+    {
+#pragma unroll 1
+        for (uint32_t round = 0; round < kRegenerateRounds; ++round)
         {
-            start_sample(sc, st, how.step, how.independent, how.seed);
-            if (cnt)
-                ++cnt->samples;
-            ray = make_ray(st.origin, st.dir);
-            const uint32_t *rec = prehit_record(sc, st.pixel, st.sample - sc.prehit_step); // (path_extend_uniform's "known" branch)
-            const bool hit_valid = rec[0] != kNone;
-            if (hit_valid)
-                hit_from_record<C::kAnalytic>(sc, rec[1], rec[0], ray, raw);
-            path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
+            const bool escaped = !resolved && !hit_valid;
+            if (__ballot(escaped) == 0)
+                break;
+            if (escaped)
+            {
+                path_resolve<C>(sc, st, cnt, ray, raw, false, surf);
+                resolved = true;
+                if (!st.alive && st.sample < sc.camera.spp)
+                    next_sample();
+            }
+        }
+    }
+    if (!resolved)
+    {
+        path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
+        resolved = true;
+    }
+    if (regenerate)
+    {
+#pragma unroll 1
+        for (uint32_t round = 0; round < kRegenerateRounds; ++round)
+        {
+            const bool again = has_path && !st.alive && st.sample < sc.camera.spp;
+            if (__ballot(again) == 0)
+                break;
+            if (again)
+            {
+                next_sample();
+                path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
+            }
         }
     }
 }
@@ -950,9 +992,7 @@ __device__ __forceinline__ void path_step_uniform(const DeviceScene &sc, PathSta
     Surface surf;
     surf.inside = false, surf.inst = 0, surf.uv = V2{0, 0};
     surf.position = surf.normal = surf.tangent = surf.bitangent = V3{0, 0, 0};
-    if (has_path)
-        path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
-    regenerate_in_step<C>(sc, st, cnt, has_path, how, ray, raw, surf);
+    resolve_and_regenerate<C>(sc, st, cnt, has_path, how, ray, raw, hit_valid, surf);
     phase_mark(kPhaseResolve, has_path && st.alive);
     path_connect_scatter_uniform<C>(sc, st, cnt, surf, has_path && st.alive);
     phase_mark(kPhaseScatter, has_path && st.alive);
@@ -1121,9 +1161,7 @@ __device__ __forceinline__ void path_step_merged(const DeviceScene &sc, PathStat
     Surface surf;
     surf.inside = false, surf.inst = 0, surf.uv = V2{0, 0};
     surf.position = surf.normal = surf.tangent = surf.bitangent = V3{0, 0, 0};
-    if (has_path)
-        path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
-    regenerate_in_step<C>(sc, st, cnt, has_path, how, ray, raw, surf); // (the pending ray above has been answered: nothing of the ended sample is open)
+    resolve_and_regenerate<C>(sc, st, cnt, has_path, how, ray, raw, hit_valid, surf); // (the pending ray above has been answered: nothing of the ended sample is open)
     const bool active = has_path && st.alive;
     phase_mark(kPhaseResolve, active);
     connect_lights_merged<C>(sc, st.stack, active, surf, surf.position, st.wo, st.throughput, st.rng, st.L, pd, cnt);
