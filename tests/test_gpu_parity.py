@@ -367,6 +367,24 @@ print(json.dumps(out))
 
 
 @pytest.mark.gpu
+def test_tiled_renderer_with_logical_ranks_on_a_mesh_outside_lds(pkg):
+    """The same N-rank host with dragon/scene.xml (1280 x 720 spp 8): 2, 3 and 8 ranks' launches share ONE GPU, each sized for all of it —
+    the kernels of this class hand paths between workgroups (the path market, round 6) and must neither lose one nor wait for a
+    workgroup that is not resident.  Frame == the plain draw, twice, for every N."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shim_dir = os.path.join(root, "tests", "rccl_shim")
+    subprocess.run(["make", "-C", shim_dir], check=True, capture_output=True)
+    env = dict(os.environ, MCPT_RCCL_LIBRARY=os.path.join(shim_dir, "librccl_shim.so"))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "experiments", "tiled_logical_ranks_dragon.py"), root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out == {"2": [True, True], "3": [True, True], "8": [True, True]}, out
+
+
+@pytest.mark.gpu
 def test_tiled_renderer_with_several_logical_ranks_through_the_rccl_shim(pkg):
     """The C++ N-GPU host (capi.cpp: per-rank offsets, ONE grouped ncclSend / ncclRecv gather, per-rank unpack) with
     N = 2, 3, 8 ranks on this box's single GPU: the device is listed N times (MCPT_TILED_LOGICAL_RANKS) and the seven RCCL
