@@ -927,7 +927,12 @@ __device__ __forceinline__ void resolve_and_regenerate(const DeviceScene &sc, Pa
     // constant): dragon 92.7 -> 90.3 ms.  The surface-material instantiations lose with it — matpreview 374.7 -> 379.3, 639.8 -> 652.4 ms:
     // their escapes are environment-map lookups, and those first, then the frames, is two latency chains one after the other where one
     // diverged path_resolve overlaps them (EXPERIMENTS R6-17).
-    constexpr bool kEscapedFirst = !C::kMicrofacet && !C::kTextures;
+    // (-DMCPT_REGEN_FORM=1 / 2, experiment builds: step 1 in every instantiation, with / without step 3)
+#ifndef MCPT_REGEN_FORM
+#define MCPT_REGEN_FORM 0
+#endif
+    constexpr bool kEscapedFirst = MCPT_REGEN_FORM != 0 || (!C::kMicrofacet && !C::kTextures);
+    constexpr bool kAfterwards = MCPT_REGEN_FORM != 2;
     bool resolved = !has_path;
     auto next_sample = [&]() __attribute__((always_inline))
     {
@@ -963,7 +968,7 @@ __device__ __forceinline__ void resolve_and_regenerate(const DeviceScene &sc, Pa
         path_resolve<C>(sc, st, cnt, ray, raw, hit_valid, surf);
         resolved = true;
     }
-    if (regenerate)
+    if (kAfterwards && regenerate)
     {
 #pragma unroll 1
         for (uint32_t round = 0; round < kRegenerateRounds; ++round)
