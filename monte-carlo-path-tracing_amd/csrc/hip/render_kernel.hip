@@ -245,7 +245,7 @@ bool PoolBigSupports(const DeviceScene &sc)
 bool TailSpreadRuns(const DeviceScene &sc, const RenderJob &job)
 {
     return MCPT_TAIL_SPREAD != 0 && !job.reference_walk && !sc.integrator.has_masks && job.pool_walk >= 1 && StagedBytes(sc, true) > kLdsGeometryBytes && PoolBigSupports(sc) &&
-           (sc.features & ~uint32_t(kFeatEmitters)) == 0;
+           (sc.features & ~uint32_t(MCPT_TAIL_SPREAD == 2 ? kSurface : kFeatEmitters)) == 0;
 }
 
 hipError_t LaunchRender(const DeviceScene &sc, const RenderJob &job, float *out, TraceCounters *counters,

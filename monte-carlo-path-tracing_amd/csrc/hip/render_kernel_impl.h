@@ -221,8 +221,9 @@ __device__ __forceinline__ void render_body(const DeviceScene &sc_in, const Rend
     // Built into the diffuse (+ emitters, slivers) kernels outside LDS — dragon/scene.xml's class: 119.4 -> 107.1 ms (108.9-131.6 ->
     // 101.5-115.1 over 24 draws), its 1/8 share 44.5 -> 40.1.  The one-BSDF surface units lose 1.5-1.9 % with the code compiled in
     // (they sit at their 128-register limit, and their tails are what lanes per path by tile cost is for): not there (EXPERIMENTS R6-13).
+    // (-DMCPT_TAIL_SPREAD=2, experiment builds: in every surface instantiation outside LDS — with render_kernel.hip's TailSpreadRuns)
     constexpr bool kTailSpread = MCPT_TAIL_SPREAD != 0 && C::kPool && C::kPoolBig && !kLdsGeometry && !kCount &&
-                                 (kFeatures & (kFeatVolPath | kFeatAnalytic | kFeatMicrofacet | kFeatTextures)) == 0;
+                                 (kFeatures & (kFeatVolPath | kFeatAnalytic | (MCPT_TAIL_SPREAD == 2 ? 0u : kFeatMicrofacet | kFeatTextures))) == 0;
     // (-DMCPT_LDS_MARKET=1, experiment builds: the LDS kernels with the compaction take part in the path market too)
 #ifndef MCPT_LDS_MARKET
 #define MCPT_LDS_MARKET 0
