@@ -2,7 +2,8 @@
 # usage: kinfo.sh obj  -> per kernel: vgpr, sgpr, spills, scratch, lds
 obj=$1
 tmp=$(mktemp -d)
-/opt/rocm/lib/llvm/bin/llvm-objcopy --dump-section .hip_fatbin=$tmp/fb.bin $obj
+cp $obj $tmp/in.o # (llvm-objcopy without an output file rewrites its input: the build's object keeps its time stamp)
+/opt/rocm/lib/llvm/bin/llvm-objcopy --dump-section .hip_fatbin=$tmp/fb.bin $tmp/in.o
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=$tmp/fb.bin --output=$tmp/dev.co --unbundle
 /opt/rocm/lib/llvm/bin/llvm-readelf --notes $tmp/dev.co | python3 -c "
 import sys,re
